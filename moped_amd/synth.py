@@ -1,0 +1,160 @@
+"""Seeded synthetic workloads for the MATCH -> CLUSTER -> POSE path.
+
+Everything is float32/int32 numpy on the host.  Object models are absent from the
+reference tree (moped2/download_models.sh fetches them), so model databases are
+synthesised: SIFT-like descriptors are derived from the real SIFT descriptors of
+the five frames bundled in moped2/test_data/timing.bag (tests/golden/sift_frames.npz,
+extracted once with the reference's own libsiftfast -- oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_FIXTURE = os.path.join(_HERE, "..", "tests", "golden", "sift_frames.npz")
+
+# 640x480, K = (fx, fy, cx, cy), identity camera pose (moped2/moped_test.cpp:187-188)
+K_DEFAULT = np.array([800.0, 800.0, 320.0, 240.0], dtype=np.float32)
+CAM_IDENTITY = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+IMG_W, IMG_H = 640, 480
+
+
+def load_sift_fixture():
+    """Real SIFT descriptors (x512 quantised to u8) + keypoint xy + frame id."""
+    z = np.load(_FIXTURE)
+    desc = z["desc_u8"].astype(np.float32) / np.float32(512.0)
+    return desc, z["xy"].astype(np.float32), z["frame"].astype(np.int32)
+
+
+def l2_normalize(d: np.ndarray) -> np.ndarray:
+    """Plain numpy normalisation used only to *generate* data (the pipeline
+    re-normalises with the reference's arithmetic, MATCH_ANN_CPU.hpp:54-57)."""
+    n = np.sqrt((d.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    n[n == 0] = 1.0
+    return (d / n).astype(np.float32)
+
+
+@dataclass
+class ModelDB:
+    desc: np.ndarray      # [N,128] float32, near unit norm
+    xyz: np.ndarray       # [N,3]  float32 model-frame coordinates (metres)
+    model_of: np.ndarray  # [N]    int32
+    n_models: int
+
+    @property
+    def n(self) -> int:
+        return int(self.desc.shape[0])
+
+
+def make_db(n_models: int, pts_per_model: int = 5000, seed: int = 0xC0FFEE,
+            base: np.ndarray | None = None) -> ModelDB:
+    """SIFT-like model database: base descriptor from the real fixture +
+    N(0, 0.03^2) per dim, clamped at 0, L2-normalised; 3-D points uniform in a
+    0.10 x 0.10 x 0.20 m box."""
+    if base is None:
+        base, _, _ = load_sift_fixture()
+    descs, xyzs, owners = [], [], []
+    for m in range(n_models):
+        rng = np.random.default_rng([seed, m])
+        pick = rng.integers(0, base.shape[0], size=pts_per_model)
+        d = base[pick] + rng.normal(0.0, 0.03, size=(pts_per_model, 128)).astype(np.float32)
+        d = l2_normalize(np.maximum(d, 0.0).astype(np.float32))
+        x = (rng.random((pts_per_model, 3)) - 0.5) * np.array([0.10, 0.10, 0.20])
+        descs.append(d)
+        xyzs.append(x.astype(np.float32))
+        owners.append(np.full(pts_per_model, m, dtype=np.int32))
+    return ModelDB(np.ascontiguousarray(np.concatenate(descs)),
+                   np.ascontiguousarray(np.concatenate(xyzs)),
+                   np.concatenate(owners), n_models)
+
+
+def random_quat(rng) -> np.ndarray:
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return q.astype(np.float32)  # (x, y, z, w)
+
+
+def quat_to_R(q) -> np.ndarray:
+    x, y, z, w = [float(v) for v in q]
+    return np.array([
+        [1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+        [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+        [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def project_np(pose7, xyz, K=K_DEFAULT):
+    """float64 pinhole projection with an identity camera (generation only)."""
+    R = quat_to_R(pose7[:4])
+    p = xyz.astype(np.float64) @ R.T + np.asarray(pose7[4:7], dtype=np.float64)
+    u = p[:, 0] / p[:, 2] * float(K[0]) + float(K[2])
+    v = p[:, 1] / p[:, 2] * float(K[1]) + float(K[3])
+    return np.stack([u, v], axis=1), p[:, 2]
+
+
+@dataclass
+class Frame:
+    desc: np.ndarray       # [Q,128] float32 query descriptors (un-normalised is fine)
+    uv: np.ndarray         # [Q,2]   float32 pixel coordinates
+    visible: np.ndarray    # [n_vis] int32 model ids planted in this frame
+    poses: np.ndarray      # [n_vis,7] float32 planted poses (qx,qy,qz,qw,tx,ty,tz)
+    src_point: np.ndarray  # [Q] int32 DB row a planted feature came from, -1 = clutter
+    is_outlier: np.ndarray # [Q] bool planted feature with a wrong 2-D location
+
+
+def make_frame(db: ModelDB, n_vis: int = 2, seed: int = 0, Q: int = 3000,
+               pts_per_obj: int = 150, outlier_frac: float = 0.2,
+               pix_noise: float = 0.5, K=K_DEFAULT,
+               base: np.ndarray | None = None) -> Frame:
+    """One 640x480 frame: n_vis planted objects x pts_per_obj features (+/-0.5 px
+    uniform noise, descriptor = model descriptor + N(0, 0.01^2) renormalised,
+    outlier_frac of them at a wrong pixel), the rest clutter (real fixture
+    descriptors at uniform pixel positions), shuffled."""
+    if base is None:
+        base, _, _ = load_sift_fixture()
+    rng = np.random.default_rng([0xF4A3E, seed])
+    n_vis = min(n_vis, db.n_models)
+    visible = rng.choice(db.n_models, size=n_vis, replace=False).astype(np.int32)
+    descs, uvs, srcs, outl, poses = [], [], [], [], []
+    for m in visible:
+        rows = np.nonzero(db.model_of == m)[0]
+        for _ in range(100):
+            q = random_quat(rng)
+            z = rng.uniform(0.5, 1.0)
+            u0 = rng.uniform(120, IMG_W - 120)
+            v0 = rng.uniform(100, IMG_H - 100)
+            t = np.array([(u0 - K[2]) / K[0] * z, (v0 - K[3]) / K[1] * z, z])
+            pose = np.concatenate([q, t]).astype(np.float32)
+            uv_all, zc = project_np(pose, db.xyz[rows], K)
+            ok = (zc > 0.05) & (uv_all[:, 0] >= 0) & (uv_all[:, 0] < IMG_W) & \
+                 (uv_all[:, 1] >= 0) & (uv_all[:, 1] < IMG_H)
+            if ok.sum() >= pts_per_obj:
+                break
+        sel = rng.choice(np.nonzero(ok)[0], size=pts_per_obj, replace=False)
+        uv = uv_all[sel] + rng.uniform(-pix_noise, pix_noise, size=(pts_per_obj, 2))
+        bad = rng.random(pts_per_obj) < outlier_frac
+        uv[bad] = rng.uniform([0, 0], [IMG_W, IMG_H], size=(int(bad.sum()), 2))
+        d = db.desc[rows[sel]] + rng.normal(0, 0.01, size=(pts_per_obj, 128)).astype(np.float32)
+        descs.append(l2_normalize(np.maximum(d, 0).astype(np.float32)))
+        uvs.append(uv.astype(np.float32))
+        srcs.append(rows[sel].astype(np.int32))
+        outl.append(bad)
+        poses.append(pose)
+    n_planted = n_vis * pts_per_obj
+    n_clutter = max(Q - n_planted, 0)
+    pick = rng.integers(0, base.shape[0], size=n_clutter)
+    descs.append(base[pick])
+    uvs.append(rng.uniform([0, 0], [IMG_W, IMG_H], size=(n_clutter, 2)).astype(np.float32))
+    srcs.append(np.full(n_clutter, -1, dtype=np.int32))
+    outl.append(np.zeros(n_clutter, dtype=bool))
+    desc = np.concatenate(descs)
+    uv = np.concatenate(uvs)
+    src = np.concatenate(srcs)
+    bad = np.concatenate(outl)
+    perm = rng.permutation(desc.shape[0])
+    return Frame(np.ascontiguousarray(desc[perm], dtype=np.float32),
+                 np.ascontiguousarray(uv[perm], dtype=np.float32),
+                 visible, np.asarray(poses, dtype=np.float32).reshape(-1, 7),
+                 src[perm], bad[perm])

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own libraries (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference for
+the bag file and a built oracle/_ref); the .npz outputs are data -- inputs and the
+reference's outputs -- and are committed so the GPU box can check against them
+without the reference.
+
+  sift_frames.npz   real SIFT descriptors of the 5 frames in
+                    moped2/test_data/timing.bag, extracted with the reference's
+                    libsiftfast the way FEAT_SIFT_CPU.hpp:78-112 calls it;
+                    descriptors quantised x512 to uint8 (values are defined as u8/512)
+  match_ann_*.npz   ANN 1.1.1 kd-tree 2-NN at eps=0 (exact) and eps=5 (shipped
+                    default, config.hpp:83) for fixture queries vs seeded DBs
+  pose_ref.npz      project() / lmFuncQuat residual tables and slevmar_dif end
+                    states for seeded 5/6-point and inlier-set problems
+"""
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import orclib  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+BAG = "/root/reference/moped2/test_data/timing.bag"
+
+
+def make_sift_fixture():
+    from PIL import Image
+    bag = open(BAG, "rb").read()
+    R = orclib.ref()
+    descs, xys, frames = [], [], []
+    pos, f = 0, 0
+    while True:
+        pos = bag.find(b"\xff\xd8\xff", pos)
+        if pos < 0:
+            break
+        img = Image.open(io.BytesIO(bag[pos:]))
+        img.load()
+        g = np.ascontiguousarray(np.array(img.convert("L")), dtype=np.uint8)
+        h, w = g.shape
+        xy = np.zeros((8192, 2), np.float32)
+        d = np.zeros((8192, 128), np.float32)
+        n = R.ref_sift(g.reshape(-1), w, h, xy.reshape(-1), d.reshape(-1), 8192)
+        descs.append(d[:n])
+        xys.append(xy[:n])
+        frames.append(np.full(n, f, np.int32))
+        print(f"frame {f}: {w}x{h} -> {n} keypoints")
+        pos += 3
+        f += 1
+    d = np.concatenate(descs)
+    u8 = np.clip(np.rint(d * 512.0), 0, 255).astype(np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "sift_frames.npz"), desc_u8=u8,
+                        xy=np.concatenate(xys), frame=np.concatenate(frames))
+    print("sift_frames.npz:", u8.shape)
+
+
+def make_match_golden():
+    from moped_amd import synth
+    base, _, _ = synth.load_sift_fixture()
+    q = orclib.normalize(base)  # MATCH_ANN_CPU.hpp:157
+    for tag, n_models, ppm in (("1k", 1, 1000), ("10k", 2, 5000), ("100k", 20, 5000)):
+        db = synth.make_db(n_models, ppm)
+        dbn = orclib.normalize(db.desc)  # MATCH_ANN_CPU.hpp:94
+        ann = orclib.RefAnn(dbn)
+        idx0, dist0 = ann.search2(q, 0.0)
+        idx5, dist5 = ann.search2(q, 5.0)
+        ann.close()
+        np.savez_compressed(os.path.join(GOLD, f"match_ann_{tag}.npz"),
+                            n_models=n_models, pts_per_model=ppm,
+                            idx_eps0=idx0, dist_eps0=dist0, idx_eps5=idx5, dist_eps5=dist5)
+        acc0 = (dist0[:, 0] / dist0[:, 1] < 0.8).sum()
+        acc5 = (dist5[:, 0] / dist5[:, 1] < 0.8).sum()
+        print(f"match_ann_{tag}: N={db.n} accepted eps0={acc0} eps5={acc5}")
+
+
+def make_pose_golden():
+    from moped_amd import synth
+    rng = np.random.default_rng(20240607)
+    K = synth.K_DEFAULT
+    cams = [synth.CAM_IDENTITY,
+            np.concatenate([synth.random_quat(rng), [0.05, -0.02, 0.1]]).astype(np.float32)]
+    out = {}
+    cases = []
+    for ci in range(24):
+        cam = cams[ci % 2]
+        n = [5, 6, 12, 40][ci % 4]
+        xyz = ((rng.random((n, 3)) - 0.5) * [0.1, 0.1, 0.2]).astype(np.float32)
+        q = synth.random_quat(rng)
+        t = np.array([rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(0.5, 1.0)])
+        pose = np.concatenate([q, t]).astype(np.float32)
+        uv = orclib.ref_project(pose, xyz, K, cam)
+        uv = (uv + rng.uniform(-0.5, 0.5, uv.shape)).astype(np.float32)
+        # start: perturbed truth (refine-like) for even cases, the reference's
+        # initPose-style random quaternion + (0,0,0.5) for odd ones
+        if ci % 2 == 0:
+            start = pose + rng.normal(0, 0.02, 7).astype(np.float32)
+        else:
+            start = np.array([rng.integers(0, 256) / 256., rng.integers(0, 256) / 256.,
+                              rng.integers(0, 256) / 256., rng.integers(0, 256) / 256.,
+                              0, 0, 0.5], np.float32)
+        itmax = 200 if ci % 4 < 2 else 500
+        hx = orclib.ref_residuals(start, uv, xyz, K, cam)
+        ret, p_end, info = orclib.ref_optimize_camera(start, uv, xyz, K, cam, itmax)
+        uv_end = orclib.ref_project(p_end, xyz, K, cam)
+        cases.append(dict(cam=cam, xyz=xyz, uv=uv, pose_true=pose, start=start, itmax=itmax,
+                          hx_start=hx, ret=ret, pose_end=p_end, info=info, uv_end=uv_end))
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            out[f"c{i}_{k}"] = np.asarray(v)
+    out["n_cases"] = len(cases)
+    out["K"] = K
+    # behind-the-camera / near-plane table for project() and the residual branch
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0], np.float32)
+    xyz = np.array([[0, 0, 1], [0.1, -0.1, 0.5], [0, 0, 0.0005], [0, 0, -0.3], [0.2, 0.1, 0.001],
+                    [0.05, 0.05, 0.00099]], np.float32)
+    out["edge_xyz"] = xyz
+    out["edge_uv"] = orclib.ref_project(pose, xyz, K, synth.CAM_IDENTITY)
+    out["edge_hx"] = orclib.ref_residuals(pose, np.zeros((6, 2), np.float32), xyz, K, synth.CAM_IDENTITY)
+    np.savez_compressed(os.path.join(GOLD, "pose_ref.npz"), **out)
+    print("pose_ref.npz:", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["sift", "match", "pose"]
+    if "sift" in what:
+        make_sift_fixture()
+    if "match" in what:
+        make_match_golden()
+    if "pose" in what:
+        make_pose_golden()

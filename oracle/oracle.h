@@ -1,0 +1,123 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of libmoped's per-frame hot path (MATCH -> CLUSTER -> POSE
+ * [-> FILTER]) in plain C++ with a C ABI, used as the parity checker for the
+ * HIP path and as the "port" CPU baseline in bench.py.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (moped_amd/) never does.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/moped2/libmoped/).  Pinning status (see DESIGN.md "Oracle"):
+ *   match      pinned against the reference's own ANN 1.1.1 library at eps=0
+ *              (oracle/_ref, tests/golden/match_*.npz)
+ *   project /  pinned against the reference's project()/TransformMatrix and
+ *   LM refine  levmar slevmar_dif (oracle/_ref, tests/golden/pose_*.npz)
+ *   mean shift PARITY UNPINNED: the algorithm lives wholly inside
+ *              CLUSTER_MEAN_SHIFT_CPU.hpp, which cannot be compiled here
+ *              (needs util.hpp -> OpenCV headers) and the reference holds no
+ *              fixture for it; restated from the source text only.
+ *   RANSAC skeleton / FILTER: restated from the source text; the numerical
+ *              kernels they call are the pinned ones above.
+ */
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A1  MATCH_ANN_CPU::norm (match/MATCH_ANN_CPU.hpp:54-57): in-place L2
+ * normalisation, sequential fp32 sum, scale = (float)(1.0 / sqrtf(sum)). */
+void orc_normalize(float* desc, int n, int dim);
+
+/* A3  exact 2-NN by squared L2 over the whole DB (MATCH_ANN_CPU.hpp:155-162 with
+ * Quality = 0).  Canonical arithmetic shared bit-for-bit with the HIP kernel:
+ *   dot(a,b) = fmaf chain over k = 0..dim-1 starting from 0
+ *   dist(q,d) = max(0, fmaf(-2, dot(q,d), dot(q,q) + dot(d,d)))
+ * ties on distance -> lower DB index.  idx1[i] = -1 when N == 0; d2 = +inf
+ * when N < 2.  n_threads <= 0 -> all OpenMP threads. */
+void orc_match_2nn(const float* db, int N, const float* q, int Q, int dim,
+                   int32_t* idx1, float* d1, float* d2, int n_threads);
+
+/* A3  ratio test + scatter (MATCH_ANN_CPU.hpp:165-176): accept query i when
+ * d1[i] / d2[i] < ratio (squared distances, fp32 division); matches are
+ * grouped by model_of[idx1] and kept in ascending query order inside a model.
+ * out_q[m] = query index of the m-th match in (model, query) order,
+ * model_off[n_models + 1] = CSR offsets.  Returns the match count. */
+int orc_match_accept(const int32_t* idx1, const float* d1, const float* d2, int Q,
+                     float ratio, const int32_t* model_of, int n_models,
+                     int32_t* out_q, int32_t* model_off);
+
+/* Exchange-1 merge for a model-sharded DB (new design; the
+ * reference builds one kd-tree over all models, MATCH_ANN_CPU.hpp:76-107):
+ * per shard s the local (idx1 [global index], d1, d2) of every query, laid out
+ * [s][Q]; result = the global top-2. */
+void orc_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s,
+                     int n_shards, int Q, int32_t* idx1, float* d1, float* d2);
+
+/* A6  CLUSTER_MEAN_SHIFT_CPU::MeanShift (cluster/CLUSTER_MEAN_SHIFT_CPU.hpp:80-158)
+ * on n points of `dim` (2 or 3) floats.  members[] receives the point indices
+ * of every emitted cluster (size >= min_pts) in emission order and, inside a
+ * cluster, in the reference's splice order; cluster_off[] the CSR offsets
+ * (capacity n + 1).  Returns the number of clusters; *n_iter (optional) the
+ * iterations run. */
+int orc_meanshift(const float* pts, int n, int dim, float radius, float merge,
+                  int min_pts, int max_iter, int32_t* members, int32_t* cluster_off,
+                  int* n_iter);
+
+/* A12 project() (include/moped.hpp:330-354) for n points: pose/cam are
+ * (qx,qy,qz,qw,tx,ty,tz), K = (fx,fy,cx,cy); z < 0.001 -> (FLT_MAX,FLT_MAX). */
+void orc_project(const float pose7[7], const float* xyz, int n, const float K[4],
+                 const float cam[7], float* uv);
+
+/* A10 lmFuncQuat (pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:100-138):
+ * hx[2n] squared pixel residuals, (-z + 10) twice when z < 0. */
+void orc_residuals(const float pose7[7], const float* uv, const float* xyz, int n,
+                   const float K[4], const float cam[7], float* hx);
+
+/* A12 testAllPoints (…REPROJECTION_CPU.hpp:166-180): inlier[i] = squared
+ * reprojection error < thr.  Returns the inlier count. */
+int orc_test_all_points(const float pose7[7], const float* uv, const float* xyz, int n,
+                        const float K[4], const float cam[7], float thr, uint8_t* inlier);
+
+/* A11 optimizeCamera (…REPROJECTION_CPU.hpp:140-164): Levenberg-Marquardt with a
+ * forward-difference Jacobian and Broyden rank-one updates, restating the
+ * published algorithm of levmar 2.4 slevmar_dif (lm_core.c:427-825; defaults
+ * lm.h:83-85).  Returns iterations (>= 0) or -1; pose7 updated with the
+ * quaternion re-normalised; info[0] = initial ||e||^2, info[1] = final ||e||^2,
+ * info[2] = stop reason. */
+int orc_optimize_camera(float pose7[7], const float* uv, const float* xyz, int n,
+                        const float K[4], const float cam[7], int itmax, float* info);
+
+typedef struct {
+  int max_ransac_tests;       /* 600 POSE / 100 POSE2 (config.hpp:110,118) */
+  int max_lm_tests;           /* 200 / 500 */
+  int max_objects_per_cluster;/* 4 */
+  int n_pts_align;            /* 5 / 6 */
+  int min_n_pts_object;       /* 6 / 8 */
+  float error_threshold;      /* 10 / 5 (px^2) */
+} orc_pose_params;
+
+/* A8+A9+A13 RANSAC (…REPROJECTION_CPU.hpp:76-98,182-211) on one cluster of k
+ * correspondences (single image), libc rand() as the reference uses.
+ * Returns 1 and the refined pose when a hypothesis with more than
+ * min_n_pts_object inliers was found, else 0. */
+int orc_ransac(const float* uv, const float* xyz, int k, const float K[4],
+               const float cam[7], const orc_pose_params* prm, float pose7[7]);
+
+/* N1  FILTER_PROJECTION_CPU::process (filter/FILTER_PROJECTION_CPU.hpp:80-162)
+ * for one image.  Matches in (model, query) order with CSR model_off; objects
+ * given as (model, pose) in list order.  Outputs: score per object, keep flag
+ * per object, and the rewritten clusters (match indices inside the model) as
+ * CSR over kept objects in output order (model-major, list order inside).
+ * Returns the number of kept objects. */
+int orc_filter(const float* uv, const float* xyz, const int32_t* model_off, int n_models,
+               const int32_t* obj_model, const float* obj_pose, int n_obj,
+               const float K[4], const float cam[7],
+               int min_points, float feature_distance, float min_score,
+               float* score, uint8_t* keep, int32_t* out_order,
+               int32_t* cl_members, int32_t* cl_off);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,263 @@
+"""ctypes bindings for the CPU oracle (liboracle.so) and, where it was built, the
+reference's own libraries (oracle/_ref/libmoped_ref*.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  moped_amd/ never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+class PoseParams(C.Structure):
+    _fields_ = [("max_ransac_tests", C.c_int), ("max_lm_tests", C.c_int),
+                ("max_objects_per_cluster", C.c_int), ("n_pts_align", C.c_int),
+                ("min_n_pts_object", C.c_int), ("error_threshold", C.c_float)]
+
+
+POSE1 = dict(max_ransac_tests=600, max_lm_tests=200, max_objects_per_cluster=4,
+             n_pts_align=5, min_n_pts_object=6, error_threshold=10.0)   # config.hpp:110
+POSE2 = dict(max_ransac_tests=100, max_lm_tests=500, max_objects_per_cluster=4,
+             n_pts_align=6, min_n_pts_object=8, error_threshold=5.0)    # config.hpp:118
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.orc_normalize.argtypes = [_f32p, C.c_int, C.c_int]
+        L.orc_match_2nn.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _i32p, _f32p, _f32p, C.c_int]
+        L.orc_match_accept.argtypes = [_i32p, _f32p, _f32p, C.c_int, C.c_float, _i32p, C.c_int, _i32p, _i32p]
+        L.orc_match_accept.restype = C.c_int
+        L.orc_match_merge.argtypes = [_i32p, _f32p, _f32p, C.c_int, C.c_int, _i32p, _f32p, _f32p]
+        L.orc_meanshift.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                    _i32p, _i32p, C.POINTER(C.c_int)]
+        L.orc_meanshift.restype = C.c_int
+        L.orc_project.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        L.orc_residuals.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        L.orc_test_all_points.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_float, _u8p]
+        L.orc_test_all_points.restype = C.c_int
+        L.orc_optimize_camera.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p]
+        L.orc_optimize_camera.restype = C.c_int
+        L.orc_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, C.POINTER(PoseParams), _f32p]
+        L.orc_ransac.restype = C.c_int
+        L.orc_filter.argtypes = [_f32p, _f32p, _i32p, C.c_int, _i32p, _f32p, C.c_int, _f32p, _f32p,
+                                 C.c_int, C.c_float, C.c_float, _f32p, _u8p, _i32p, _i32p, _i32p]
+        L.orc_filter.restype = C.c_int
+        L.srand = C.CDLL(None).srand
+        _lib = L
+    return _lib
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ---- thin numpy-level wrappers ------------------------------------------------
+
+def normalize(desc):
+    d = _c(desc, np.float32).copy()
+    lib().orc_normalize(d, d.shape[0], d.shape[1])
+    return d
+
+
+def match_2nn(db, q, n_threads=0):
+    db = _c(db, np.float32)
+    q = _c(q, np.float32)
+    Q = q.shape[0]
+    idx = np.empty(Q, np.int32)
+    d1 = np.empty(Q, np.float32)
+    d2 = np.empty(Q, np.float32)
+    dim = db.shape[1] if db.ndim == 2 and db.shape[0] else q.shape[1]
+    lib().orc_match_2nn(db.reshape(-1), db.shape[0], q.reshape(-1), Q, dim, idx, d1, d2, n_threads)
+    return idx, d1, d2
+
+
+def match_accept(idx, d1, d2, ratio, model_of, n_models):
+    Q = idx.shape[0]
+    out_q = np.empty(max(Q, 1), np.int32)
+    off = np.empty(n_models + 1, np.int32)
+    m = lib().orc_match_accept(_c(idx, np.int32), _c(d1, np.float32), _c(d2, np.float32), Q,
+                               ratio, _c(model_of, np.int32), n_models, out_q, off)
+    return out_q[:m].copy(), off
+
+
+def match_merge(idx_s, d1_s, d2_s):
+    S, Q = idx_s.shape
+    idx = np.empty(Q, np.int32)
+    d1 = np.empty(Q, np.float32)
+    d2 = np.empty(Q, np.float32)
+    lib().orc_match_merge(_c(idx_s, np.int32).reshape(-1), _c(d1_s, np.float32).reshape(-1),
+                          _c(d2_s, np.float32).reshape(-1), S, Q, idx, d1, d2)
+    return idx, d1, d2
+
+
+def meanshift(pts, radius=200.0, merge=20.0, min_pts=7, max_iter=100):
+    """-> (list of member-index arrays in emission/splice order, iterations)."""
+    pts = _c(pts, np.float32)
+    n, dim = (pts.shape[0], pts.shape[1]) if pts.ndim == 2 else (0, 2)
+    members = np.empty(max(n, 1), np.int32)
+    off = np.empty(n + 2, np.int32)
+    it = C.c_int(0)
+    k = lib().orc_meanshift(pts.reshape(-1), n, dim, radius, merge, min_pts, max_iter,
+                            members, off, C.byref(it))
+    return [members[off[i]:off[i + 1]].copy() for i in range(k)], it.value
+
+
+def project(pose7, xyz, K, cam):
+    xyz = _c(xyz, np.float32)
+    uv = np.empty((xyz.shape[0], 2), np.float32)
+    lib().orc_project(_c(pose7, np.float32), xyz.reshape(-1), xyz.shape[0], _c(K, np.float32),
+                      _c(cam, np.float32), uv.reshape(-1))
+    return uv
+
+
+def residuals(pose7, uv, xyz, K, cam):
+    n = uv.shape[0]
+    hx = np.empty(2 * n, np.float32)
+    lib().orc_residuals(_c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
+                        _c(xyz, np.float32).reshape(-1), n, _c(K, np.float32),
+                        _c(cam, np.float32), hx)
+    return hx
+
+
+def test_all_points(pose7, uv, xyz, K, cam, thr):
+    n = uv.shape[0]
+    inl = np.zeros(max(n, 1), np.uint8)
+    c = lib().orc_test_all_points(_c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
+                                  _c(xyz, np.float32).reshape(-1), n, _c(K, np.float32),
+                                  _c(cam, np.float32), thr, inl)
+    return c, inl[:n].astype(bool)
+
+
+test_all_points.__test__ = False  # not a pytest test
+
+
+def optimize_camera(pose7, uv, xyz, K, cam, itmax):
+    p = _c(pose7, np.float32).copy()
+    info = np.zeros(3, np.float32)
+    ret = lib().orc_optimize_camera(p, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                                    uv.shape[0], _c(K, np.float32), _c(cam, np.float32), itmax, info)
+    return ret, p, info
+
+
+def ransac(uv, xyz, K, cam, params=POSE1, seed=None):
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    prm = PoseParams(**params)
+    p = np.zeros(7, np.float32)
+    ok = lib().orc_ransac(_c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                          uv.shape[0], _c(K, np.float32), _c(cam, np.float32), C.byref(prm), p)
+    return bool(ok), p
+
+
+def filter_projection(uv, xyz, model_off, obj_model, obj_pose, K, cam, min_points,
+                      feature_distance, min_score):
+    n_models = len(model_off) - 1
+    n_obj = len(obj_model)
+    M = uv.shape[0]
+    score = np.zeros(max(n_obj, 1), np.float32)
+    keep = np.zeros(max(n_obj, 1), np.uint8)
+    order = np.zeros(max(n_obj, 1), np.int32)
+    members = np.zeros(max(M, 1), np.int32)
+    off = np.zeros(n_obj + 2, np.int32)
+    k = lib().orc_filter(_c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                         _c(model_off, np.int32), n_models, _c(obj_model, np.int32),
+                         _c(obj_pose, np.float32).reshape(-1), n_obj, _c(K, np.float32),
+                         _c(cam, np.float32), min_points, feature_distance, min_score,
+                         score, keep, order, members, off)
+    clusters = [members[off[i]:off[i + 1]].copy() for i in range(k)]
+    return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters
+
+
+# ---- the reference's own libraries (only where oracle/_ref was built) ----------
+
+_ref = {}
+
+
+def ref_available(fast=False):
+    return os.path.exists(os.path.join(HERE, "_ref", "libmoped_ref_fast.so" if fast else "libmoped_ref.so"))
+
+
+def ref(fast=False):
+    key = bool(fast)
+    if key not in _ref:
+        path = os.path.join(HERE, "_ref", "libmoped_ref_fast.so" if fast else "libmoped_ref.so")
+        R = C.CDLL(path)
+        R.ref_ann_build.argtypes = [_f32p, C.c_int, C.c_int]
+        R.ref_ann_build.restype = C.c_void_p
+        R.ref_ann_search2.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_float, _i32p, _f32p]
+        R.ref_ann_free.argtypes = [C.c_void_p]
+        R.ref_project.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        R.ref_residuals.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        R.ref_optimize_camera.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p]
+        R.ref_optimize_camera.restype = C.c_int
+        R.ref_sift.argtypes = [_u8p, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
+        R.ref_sift.restype = C.c_int
+        _ref[key] = R
+    return _ref[key]
+
+
+class RefAnn:
+    """ANN kd-tree over a DB, searched the way MATCH_ANN_CPU does."""
+
+    def __init__(self, db, fast=False):
+        self.R = ref(fast)
+        db = _c(db, np.float32)
+        self.h = self.R.ref_ann_build(db.reshape(-1), db.shape[0], db.shape[1])
+
+    def search2(self, q, eps):
+        q = _c(q, np.float32)
+        idx = np.empty((q.shape[0], 2), np.int32)
+        dist = np.empty((q.shape[0], 2), np.float32)
+        self.R.ref_ann_search2(self.h, q.reshape(-1), q.shape[0], eps, idx.reshape(-1), dist.reshape(-1))
+        return idx, dist
+
+    def close(self):
+        if self.h:
+            self.R.ref_ann_free(self.h)
+            self.h = None
+
+
+def ref_project(pose7, xyz, K, cam):
+    xyz = _c(xyz, np.float32)
+    uv = np.empty((xyz.shape[0], 2), np.float32)
+    ref().ref_project(_c(pose7, np.float32), xyz.reshape(-1), xyz.shape[0], _c(K, np.float32),
+                      _c(cam, np.float32), uv.reshape(-1))
+    return uv
+
+
+def ref_residuals(pose7, uv, xyz, K, cam):
+    n = uv.shape[0]
+    hx = np.empty(2 * n, np.float32)
+    ref().ref_residuals(_c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
+                        _c(xyz, np.float32).reshape(-1), n, _c(K, np.float32), _c(cam, np.float32), hx)
+    return hx
+
+
+def ref_optimize_camera(pose7, uv, xyz, K, cam, itmax):
+    p = _c(pose7, np.float32).copy()
+    info = np.zeros(10, np.float32)
+    ret = ref().ref_optimize_camera(p, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                                    uv.shape[0], _c(K, np.float32), _c(cam, np.float32), itmax, info)
+    return ret, p, info

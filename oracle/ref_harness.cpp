@@ -1,0 +1,233 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin C-ABI wrapper over the parts of the reference hot path that compile
+// from the reference's own sources without any external library:
+//
+//   * ANN 1.1.1 (float build) kd-tree 2-NN search -- the arithmetic under
+//     MATCH_ANN_CPU (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:83-107,150-162;
+//     libs.tgz -> ann_1.1.1/kd_search.cpp:89-119,172-210)
+//   * levmar 2.4 slevmar_dif -- the optimiser under
+//     POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::optimizeCamera
+//     (moped2/libmoped/src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:140-164;
+//     libs.tgz -> levmar-2.4/lm_core.c:427-825)
+//   * include/moped.hpp: Pt<N>, Pose, TransformMatrix, project()
+//     (moped2/libmoped/include/moped.hpp:84-203,330-354)
+//   * libsiftfast 1.1 GetKeypoints -- only to produce real SIFT descriptors
+//     for fixtures, called the way FEAT_SIFT_CPU does
+//     (moped2/libmoped/src/feat/FEAT_SIFT_CPU.hpp:78-112).
+//
+// It is built by oracle/build_ref.sh from the sources where they lie under
+// /root/reference (the vendored tarball is unpacked into a temp dir outside
+// the repo) and the only output is oracle/_ref/libmoped_ref.so.
+//
+// NOT built from the reference: the STEP classes themselves
+// (MATCH_ANN_CPU / CLUSTER_MEAN_SHIFT_CPU / POSE_RANSAC_* / FILTER_*). They
+// need src/util.hpp, which includes OpenCV headers this image does not have
+// (util.hpp:51-52); no stand-in headers are written, so those classes are
+// treated as unbuildable here (see DESIGN.md "Oracle").  The small amount of
+// glue this file adds around the libraries (the residual callback, the
+// search loop) is our own restatement and says so where it appears.
+//
+// Build flags (see build_ref.sh): -std=gnu++98 (moped.hpp pulls std and
+// tr1 into one namespace) and -fno-delete-null-pointer-checks (project()
+// tests the address of a reference against NULL, moped.hpp:245,338).
+
+#include <moped.hpp>
+#include <ANN.h>
+#include <lm.h>
+#include <siftfast.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace MopedNS;
+
+extern int DoubleImSize;  // libsiftfast.cpp:107 (FEAT_SIFT_CPU.hpp:50)
+
+namespace {
+
+struct AnnIndex {
+  ANNpointArray pts;
+  ANNkd_tree* tree;
+  int n, dim;
+};
+
+// One correspondence as POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::LmData holds it
+// (…REPROJECTION_CPU.hpp:66-72): image (intrinsics + camera TM), 2-D, 3-D.
+struct Corr {
+  Image* image;
+  Pt<2> coord2D;
+  Pt<3> coord3D;
+};
+
+// Restatement of lmFuncQuat (…REPROJECTION_CPU.hpp:100-138) on top of the
+// reference's own Pose / TransformMatrix arithmetic: squared pixel residuals,
+// (-z+10) for points behind the camera.
+void residual_cb(float* p, float* hx, int /*m*/, int n, void* adata) {
+  std::vector<Corr>& c = *(std::vector<Corr>*)adata;
+  Pose pose;
+  pose.rotation.init(p);
+  pose.rotation.norm();
+  pose.translation.init(p + 4);
+  TransformMatrix tm;
+  tm.init(pose);
+  for (int i = 0; i < n / 2; i++) {
+    Pt<3> x;
+    tm.transform(x, c[i].coord3D);
+    c[i].image->TM.inverseTransform(x, x);
+    const Pt<4>& K = c[i].image->intrinsicLinearCalibration;
+    float u = x[0] / x[2] * K[0] + K[2];
+    float v = x[1] / x[2] * K[1] + K[3];
+    if (x[2] < 0) {
+      hx[2 * i] = -x[2] + 10;
+      hx[2 * i + 1] = -x[2] + 10;
+    } else {
+      float du = u - c[i].coord2D[0];
+      float dv = v - c[i].coord2D[1];
+      hx[2 * i] = du * du;
+      hx[2 * i + 1] = dv * dv;
+    }
+  }
+}
+
+void fill_image(Image& img, const float K[4], const float cam[7]) {
+  img.width = 640;
+  img.height = 480;
+  img.intrinsicLinearCalibration.init(K[0], K[1], K[2], K[3]);
+  img.intrinsicNonlinearCalibration.init(0.f, 0.f, 0.f, 0.f);
+  img.cameraPose.rotation.init(cam[0], cam[1], cam[2], cam[3]);
+  img.cameraPose.translation.init(cam[4], cam[5], cam[6]);
+  img.TM.init(img.cameraPose);  // as MopedPimpl::processImages does (moped.cpp:168-169)
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- ANN -------------------------------------------------------------------
+
+// db: n x dim row-major, used as given (caller normalises like Update() :94).
+void* ref_ann_build(const float* db, int n, int dim) {
+  AnnIndex* ix = new AnnIndex;
+  ix->n = n;
+  ix->dim = dim;
+  ix->pts = annAllocPts(n, dim);
+  for (int i = 0; i < n; i++) memcpy(ix->pts[i], db + (size_t)i * dim, dim * sizeof(float));
+  ix->tree = new ANNkd_tree(ix->pts, n, dim);  // defaults: bucket 1, ANN_KD_SUGGEST
+  return ix;
+}
+
+// 2-NN per query with error bound eps (MATCH_ANN_CPU's Quality); squared
+// distances out (ANN never takes the root).  idx/dist: 2 per query.
+void ref_ann_search2(void* h, const float* q, int nq, float eps, int* idx, float* dist) {
+  AnnIndex* ix = (AnnIndex*)h;
+  ANNpoint pt = annAllocPt(ix->dim);
+  ANNidx nx[2];
+  ANNdist ds[2];
+  for (int i = 0; i < nq; i++) {
+    memcpy(pt, q + (size_t)i * ix->dim, ix->dim * sizeof(float));
+    ix->tree->annkSearch(pt, 2, nx, ds, eps);
+    idx[2 * i] = nx[0];
+    idx[2 * i + 1] = nx[1];
+    dist[2 * i] = ds[0];
+    dist[2 * i + 1] = ds[1];
+  }
+  annDeallocPt(pt);
+}
+
+void ref_ann_free(void* h) {
+  AnnIndex* ix = (AnnIndex*)h;
+  delete ix->tree;
+  annDeallocPts(ix->pts);
+  delete ix;
+  annClose();
+}
+
+// ---- project() / levmar ------------------------------------------------------
+
+// Reference project() (moped.hpp:330-354).  pose/cam = (qx,qy,qz,qw,tx,ty,tz).
+void ref_project(const float pose7[7], const float* xyz, int n, const float K[4],
+                 const float cam[7], float* uv) {
+  Image img;
+  fill_image(img, K, cam);
+  Pose pose;
+  pose.rotation.init(pose7[0], pose7[1], pose7[2], pose7[3]);
+  pose.translation.init(pose7[4], pose7[5], pose7[6]);
+  for (int i = 0; i < n; i++) {
+    Pt<3> X;
+    X.init(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    Pt<2> p = project(pose, X, img);
+    uv[2 * i] = p[0];
+    uv[2 * i + 1] = p[1];
+  }
+}
+
+// The residual vector lmFuncQuat would produce for (pose7, correspondences).
+void ref_residuals(const float pose7[7], const float* uv, const float* xyz, int n,
+                   const float K[4], const float cam[7], float* hx) {
+  Image img;
+  fill_image(img, K, cam);
+  std::vector<Corr> c(n);
+  for (int i = 0; i < n; i++) {
+    c[i].image = &img;
+    c[i].coord2D.init(uv[2 * i], uv[2 * i + 1]);
+    c[i].coord3D.init(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  }
+  float p[7];
+  memcpy(p, pose7, sizeof p);
+  residual_cb(p, hx, 7, 2 * n, &c);
+}
+
+// optimizeCamera (…REPROJECTION_CPU.hpp:140-164): slevmar_dif on 7 params with
+// zero targets and default options; pose7 updated in place with the
+// quaternion re-normalised; returns slevmar_dif's return value (iterations,
+// or -1 on LM_ERROR) and info[LM_INFO_SZ].
+int ref_optimize_camera(float pose7[7], const float* uv, const float* xyz, int n,
+                        const float K[4], const float cam[7], int itmax, float* info) {
+  Image img;
+  fill_image(img, K, cam);
+  std::vector<Corr> c(n);
+  for (int i = 0; i < n; i++) {
+    c[i].image = &img;
+    c[i].coord2D.init(uv[2 * i], uv[2 * i + 1]);
+    c[i].coord3D.init(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  }
+  std::vector<float> target(2 * n, 0.f);
+  float linfo[LM_INFO_SZ];
+  int ret = slevmar_dif(residual_cb, pose7, &target[0], 7, 2 * n, itmax, NULL, linfo, NULL, NULL,
+                        (void*)&c);
+  if (info) memcpy(info, linfo, sizeof linfo);
+  if (ret < 0) return ret;
+  Quat q;
+  q.init(pose7[0], pose7[1], pose7[2], pose7[3]);
+  q.norm();
+  for (int i = 0; i < 4; i++) pose7[i] = q[i];
+  return ret;
+}
+
+// ---- libsiftfast -------------------------------------------------------------
+
+// gray: h x w bytes.  Keypoints in list order as FEAT_SIFT_CPU emits them:
+// xy = (col,row), 128 floats each.  Returns the keypoint count (may exceed
+// max_kp; only max_kp are written).
+int ref_sift(const unsigned char* gray, int w, int h, float* xy, float* desc, int max_kp) {
+  DoubleImSize = 1;  // ScaleOrigin "-1" (config.hpp:69, FEAT_SIFT_CPU.hpp:72-73)
+  SFImage image = CreateImage(h, w);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)
+      image->pixels[y * image->stride + x] = ((float)gray[w * y + x]) * 1. / 255.;
+  Keypoint keypts = GetKeypoints(image);
+  int n = 0;
+  for (Keypoint k = keypts; k; k = k->next, n++) {
+    if (n >= max_kp) continue;
+    xy[2 * n] = k->col;
+    xy[2 * n + 1] = k->row;
+    memcpy(desc + (size_t)n * 128, k->descrip, 128 * sizeof(float));
+  }
+  FreeKeypoints(keypts);
+  DestroyAllImages();
+  return n;
+}
+
+}  // extern "C"
