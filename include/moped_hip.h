@@ -1,0 +1,230 @@
+/* include/moped_hip.h -- C ABI of libmoped_hip.so
+ *
+ * MI355X (gfx950) implementation of libmoped's per-frame hot path
+ *   MATCH (brute-force 2-NN + ratio) -> CLUSTER (mean shift) -> POSE (RANSAC + LM)
+ *   [-> FILTER -> POSE2 -> FILTER2]
+ * behind plain C entry points: opaque context, plain pointers and sizes, int
+ * status (0 = ok, < 0 = error, text via mh_last_error), never aborts, never
+ * throws.  One context per pipeline; calls on one context are serialised by the
+ * caller (libmoped calls its steps from one thread, src/moped.cpp:184-191).
+ *
+ * What each entry point replaces (paths relative to moped2/libmoped/):
+ *   mh_db_upload        MATCH_ANN_CPU::Update            src/match/MATCH_ANN_CPU.hpp:72-109
+ *   mh_normalize        MATCH_ANN_CPU::norm              src/match/MATCH_ANN_CPU.hpp:54-57
+ *   mh_match            MATCH_ANN_CPU::process search    src/match/MATCH_ANN_CPU.hpp:155-165
+ *                       (= MATCH_FLANN_CPU::process      src/match/MATCH_FLANN_CPU.hpp:133-191)
+ *   mh_match_local /    the same search on one model shard + the cross-shard
+ *   mh_match_merge      top-2 merge (new: the reference has one kd-tree over all
+ *                       models, MATCH_ANN_CPU.hpp:76-107)
+ *   mh_meanshift        CLUSTER_MEAN_SHIFT_CPU::MeanShift src/cluster/CLUSTER_MEAN_SHIFT_CPU.hpp:80-158
+ *   mh_pose_ransac      POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::RANSAC/process
+ *                                                        src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:76-211,264-307
+ *   mh_project_test     testAllPoints / project()        …REPROJECTION_CPU.hpp:166-180, include/moped.hpp:330-354
+ *   mh_filter           FILTER_PROJECTION_CPU::process   src/filter/FILTER_PROJECTION_CPU.hpp:80-162
+ *   mh_frame_*          the per-frame loop over those steps, MopedPimpl::processImages
+ *                                                        src/moped.cpp:166-194 (device-resident form)
+ *
+ * Pointer arguments named *_host are host memory; *_dev are device (HBM)
+ * pointers on the context's device.  Poses are (qx,qy,qz,qw,tx,ty,tz) as in
+ * MopedNS::Pose (include/moped.hpp:136-164); intrinsics K = (fx,fy,cx,cy) as in
+ * Image::intrinsicLinearCalibration (include/moped.hpp:233).
+ */
+#ifndef MOPED_HIP_H
+#define MOPED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_DESC_DIM 128
+#define MH_OK 0
+#define MH_ERR_ARG (-1)
+#define MH_ERR_HIP (-2)
+#define MH_ERR_CAPACITY (-3)
+#define MH_ERR_NODEVICE (-4)
+
+typedef struct mh_ctx mh_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Selects `device`, checks it is a gfx950 part, creates the context's stream.
+ * Failure is the signal for a STEP plugin to set capable = false
+ * (src/util.hpp:151-159). */
+int mh_create(int device, mh_ctx** out);
+void mh_destroy(mh_ctx* ctx);
+const char* mh_last_error(const mh_ctx* ctx);
+/* Run subsequent work on a caller-owned hipStream_t (e.g. the stream a
+ * framework uses); NULL restores the context's own stream. */
+int mh_set_stream(mh_ctx* ctx, void* hip_stream);
+int mh_synchronize(mh_ctx* ctx);
+/* Capacities of the per-frame device buffers (defaults: 16384 queries, 16384
+ * matches, 1024 clusters, 4096 objects). Call before the first frame. */
+int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects);
+
+/* ---- model database (A2) -------------------------------------------------- */
+
+/* desc_host: N x 128 row-major, ALREADY L2-normalised by the caller (the
+ * reference normalises model descriptors in place in Update(), :94);
+ * model_of_host[N]: model index of each row (local to this context, 0..n_models-1);
+ * xyz_host: N x 3 model coordinates.  index_base: value added to row numbers in
+ * every index this context reports (global row id of row 0 when the DB is a
+ * shard).  Re-upload after modelsUpdated(). */
+int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
+                 const float* xyz_host, int N, int n_models, int32_t index_base);
+int mh_db_size(const mh_ctx* ctx, int* N, int* n_models);
+
+/* ---- MATCH ---------------------------------------------------------------- */
+
+/* A1: in-place L2 normalisation of n descriptors on the device, bit-identical
+ * to MATCH_ANN_CPU::norm.  Host round trip. */
+int mh_normalize(mh_ctx* ctx, float* desc_host, int n);
+
+/* A3: exact 2-NN of Q normalised queries against the uploaded DB, squared L2.
+ * nn_idx[i] = row (index_base applied) of the nearest descriptor if
+ * d1/d2 < ratio, else -1; nn_raw (optional) = the nearest row regardless of the
+ * ratio test; d1/d2 (optional) = best / second-best squared distance. */
+int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio,
+             int32_t* nn_idx, int32_t* nn_raw, float* d1, float* d2);
+
+/* Device-pointer forms for a model-sharded DB: local top-2 of this shard
+ * (idx carries index_base; -1 when the shard is empty), then the merge of S
+ * shards' results laid out [S][Q] (e.g. the output of an all-gather). All
+ * pointers are device memory; work is enqueued on the context's stream. */
+int mh_match_local_dev(mh_ctx* ctx, const float* qn_dev, const float* qnorm_dev, int Q,
+                       int32_t* idx1_dev, float* d1_dev, float* d2_dev);
+int mh_match_merge_dev(mh_ctx* ctx, const int32_t* idx1_s_dev, const float* d1_s_dev,
+                       const float* d2_s_dev, int n_shards, int Q,
+                       int32_t* idx1_dev, float* d1_dev, float* d2_dev);
+/* Normalise on device: q_dev [Q x 128] in place, qnorm_dev[Q] = dot(q,q) of the
+ * normalised rows (the norm term of the distance). */
+int mh_normalize_dev(mh_ctx* ctx, float* q_dev, float* qnorm_dev, int Q);
+
+/* ---- CLUSTER (A6) ----------------------------------------------------------- */
+
+/* Mean shift of n points (dim 2 or 3) exactly as MeanShift<T,N>: label[i] =
+ * cluster number in the reference's emission order, -1 for points whose canopy
+ * ended below min_pts; order[] (optional, n entries) = point indices grouped by
+ * cluster, in the reference's within-cluster (splice) order; n_clusters out. */
+int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radius,
+                 float merge, int min_pts, int max_iter, int32_t* label,
+                 int32_t* order, int32_t* n_clusters);
+
+/* ---- POSE (A8-A13) ---------------------------------------------------------- */
+
+typedef struct {
+  float u, v;    /* image coordinates of the matched keypoint */
+  float x, y, z; /* model coordinates of the matched point */
+} mh_corr;
+
+typedef struct {
+  float K[4];    /* fx, fy, cx, cy */
+  float cam[7];  /* camera pose (qx,qy,qz,qw,tx,ty,tz) */
+} mh_cam;
+
+typedef struct {
+  int n_hypotheses;        /* P3P hypotheses per (cluster, replica); 0 -> 1024 */
+  int max_objects_per_cluster; /* replicas per cluster (reference: 4) */
+  int n_pts_align;         /* distinct 2-D points a cluster needs (5 POSE / 6 POSE2) */
+  int min_n_pts_object;    /* a hypothesis needs MORE inliers than this (6 / 8) */
+  float error_threshold;   /* squared pixel error of an inlier (10 / 5) */
+  int lm_iters_l2;         /* LM iterations on plain pixel residuals */
+  int lm_iters_l4;         /* then on the reference's squared residuals */
+} mh_pose_params;
+
+typedef struct {
+  float pose[7];
+  int32_t cluster;     /* input cluster this object came from */
+  int32_t n_inliers;   /* inliers of the winning hypothesis */
+  float err;           /* final sum of squared residuals of the refine */
+} mh_pose_out;
+
+/* RANSAC on n_clusters clusters: corr_host[cluster_off[c] .. cluster_off[c+1]).
+ * out_host has capacity n_clusters * max_objects_per_cluster; *n_out = objects
+ * found (cluster-major, replica order).  Deterministic for a given seed. */
+int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster_off,
+                   int n_clusters, const mh_cam* cam, const mh_pose_params* prm,
+                   uint64_t seed, mh_pose_out* out_host, int32_t* n_out);
+
+/* testAllPoints: inlier_host[i] = squared reprojection error < thr; err2_host
+ * (optional) the squared error (FLT_MAX-based for z < 0.001 like project()). */
+int mh_project_test(mh_ctx* ctx, const float pose[7], const mh_corr* corr_host, int n,
+                    const mh_cam* cam, float thr, uint8_t* inlier_host, float* err2_host,
+                    int32_t* n_inliers);
+
+/* ---- FILTER (N1) ------------------------------------------------------------- */
+
+/* FILTER_PROJECTION_CPU::process for one image.  corr_host: all matches in
+ * (model, query) order, model_off[n_models+1]; objects (model, pose) in list
+ * order.  score[n_obj], keep[n_obj]; the rewritten clusters of kept objects in
+ * (model, list) order: out_order[kept] object indices, cl_off[kept+1] /
+ * cl_members (match index inside its model). */
+int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, int n_models,
+              const int32_t* obj_model, const float* obj_pose, int n_obj, const mh_cam* cam,
+              int min_points, float feature_distance, float min_score,
+              float* score, uint8_t* keep, int32_t* out_order, int32_t* cl_members,
+              int32_t* cl_off, int32_t* n_kept);
+
+/* ---- whole frame, device resident --------------------------------------------- */
+
+typedef struct {
+  float ratio;               /* 0.8  (config.hpp:83) */
+  float ms_radius, ms_merge; /* 200, 20 (config.hpp:101) */
+  int ms_min_pts, ms_max_iter; /* 7, 100 */
+  mh_pose_params pose1;      /* (.., 4, 5, 6, 10)  config.hpp:110 */
+  int f1_min_points; float f1_feature_distance, f1_min_score; /* 5, 4096, 2  config.hpp:115 */
+  mh_pose_params pose2;      /* (.., 4, 6, 8, 5)   config.hpp:118 */
+  int f2_min_points; float f2_feature_distance, f2_min_score; /* 7, 4096, 3  config.hpp:120 */
+  int run_stage2;            /* 0: stop after POSE (objects unscored) */
+} mh_frame_params;
+
+void mh_frame_default_params(mh_frame_params* p);
+
+typedef struct {
+  int32_t model;   /* model index (local to the context) */
+  float pose[7];
+  float score;
+  int32_t n_points; /* size of the object's final cluster */
+} mh_object;
+
+/* One frame from device-resident inputs: q_desc_dev [Q x 128] raw descriptors
+ * (normalised in place, as the reference mutates detectedFeatures), q_uv_dev
+ * [Q x 2].  Everything is enqueued on the context's stream; no host
+ * synchronisation.  Results stay on the device until mh_frame_fetch. */
+int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
+                     const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* The two halves around exchange 1 when the DB is sharded over ranks:
+ *   mh_frame_enqueue_match_local : normalise + local top-2 -> ctx-owned
+ *       device arrays (pointers returned for the all-gather)
+ *   mh_frame_enqueue_rest        : merge gathered [S][Q] top-2, keep matches of
+ *       models this context owns, then CLUSTER..FILTER2 as above. */
+int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q,
+                                 int32_t** idx1_dev, float** d1_dev, float** d2_dev);
+int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q,
+                          const int32_t* idx1_s_dev, const float* d1_s_dev,
+                          const float* d2_s_dev, int n_shards,
+                          const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* Synchronises the stream and copies the frame's objects out (capacity
+ * max_objects); *n_objects = count.  counts (optional, 4 ints): accepted
+ * matches, clusters, objects after POSE, objects after FILTER. */
+int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
+                   int32_t* n_objects, int32_t* counts);
+/* Device address of the frame's packed result block {int32 n; mh_object[cap]}
+ * for exchange 2 (gather of per-rank objects); *bytes = its size. */
+int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);
+
+/* ---- timing --------------------------------------------------------------------- */
+
+typedef struct {
+  float match_ms, group_ms, cluster_ms, pose1_ms, filter1_ms, pose2_ms, filter2_ms, total_ms;
+} mh_times;
+/* GPU time of each stage of the last frame (hipEvents on the context's stream;
+ * collected only after mh_enable_timing(ctx, 1)). */
+int mh_enable_timing(mh_ctx* ctx, int on);
+int mh_timing(mh_ctx* ctx, mh_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPED_HIP_H */

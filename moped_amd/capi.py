@@ -1,0 +1,328 @@
+"""ctypes binding of libmoped_hip.so (include/moped_hip.h).
+
+This is plumbing for tests/ and bench.py: it adds no computation of its own.
+There is no CPU fallback -- if the HIP library is missing or no gfx950 device is
+present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoped_hip.so")
+
+MH_OK = 0
+
+
+class MhError(RuntimeError):
+    pass
+
+
+class mh_corr(C.Structure):
+    _fields_ = [("u", C.c_float), ("v", C.c_float), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class mh_cam(C.Structure):
+    _fields_ = [("K", C.c_float * 4), ("cam", C.c_float * 7)]
+
+
+class mh_pose_params(C.Structure):
+    _fields_ = [("n_hypotheses", C.c_int), ("max_objects_per_cluster", C.c_int),
+                ("n_pts_align", C.c_int), ("min_n_pts_object", C.c_int),
+                ("error_threshold", C.c_float), ("lm_iters_l2", C.c_int), ("lm_iters_l4", C.c_int)]
+
+
+class mh_pose_out(C.Structure):
+    _fields_ = [("pose", C.c_float * 7), ("cluster", C.c_int32), ("n_inliers", C.c_int32),
+                ("err", C.c_float)]
+
+
+class mh_frame_params(C.Structure):
+    _fields_ = [("ratio", C.c_float), ("ms_radius", C.c_float), ("ms_merge", C.c_float),
+                ("ms_min_pts", C.c_int), ("ms_max_iter", C.c_int), ("pose1", mh_pose_params),
+                ("f1_min_points", C.c_int), ("f1_feature_distance", C.c_float),
+                ("f1_min_score", C.c_float), ("pose2", mh_pose_params),
+                ("f2_min_points", C.c_int), ("f2_feature_distance", C.c_float),
+                ("f2_min_score", C.c_float), ("run_stage2", C.c_int)]
+
+
+class mh_object(C.Structure):
+    _fields_ = [("model", C.c_int32), ("pose", C.c_float * 7), ("score", C.c_float),
+                ("n_points", C.c_int32)]
+
+
+class mh_times(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("match_ms", "group_ms", "cluster_ms", "pose1_ms",
+                                         "filter1_ms", "pose2_ms", "filter2_ms", "total_ms")]
+
+
+CORR_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
+OBJECT_DTYPE = np.dtype([("model", "<i4"), ("pose", "<f4", (7,)), ("score", "<f4"), ("n_points", "<i4")])
+POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
+
+# every symbol include/moped_hip.h declares
+EXPORTS = [
+    "mh_create", "mh_destroy", "mh_last_error", "mh_set_stream", "mh_synchronize", "mh_reserve",
+    "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
+    "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_pose_ransac", "mh_project_test",
+    "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_enqueue_match_local",
+    "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and declare prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MhError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.mh_create.argtypes = [i32, C.POINTER(vp)]
+    L.mh_destroy.argtypes = [vp]
+    L.mh_destroy.restype = None
+    L.mh_last_error.argtypes = [vp]
+    L.mh_last_error.restype = C.c_char_p
+    L.mh_set_stream.argtypes = [vp, vp]
+    L.mh_synchronize.argtypes = [vp]
+    L.mh_reserve.argtypes = [vp, i32, i32, i32]
+    L.mh_db_upload.argtypes = [vp, vp, vp, vp, i32, i32, C.c_int32]
+    L.mh_db_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.mh_normalize.argtypes = [vp, vp, i32]
+    L.mh_match.argtypes = [vp, vp, i32, f32, vp, vp, vp, vp]
+    L.mh_match_local_dev.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.mh_match_merge_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.mh_normalize_dev.argtypes = [vp, vp, vp, i32]
+    L.mh_meanshift.argtypes = [vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, C.POINTER(C.c_int32)]
+    L.mh_pose_ransac.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_pose_params),
+                                 C.c_uint64, vp, C.POINTER(C.c_int32)]
+    L.mh_project_test.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, vp, vp, C.POINTER(C.c_int32)]
+    L.mh_filter.argtypes = [vp, vp, vp, i32, vp, vp, i32, C.POINTER(mh_cam), i32, f32, f32,
+                            vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.mh_frame_default_params.argtypes = [C.POINTER(mh_frame_params)]
+    L.mh_frame_default_params.restype = None
+    L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_enqueue_match_local.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mh_frame_enqueue_rest.argtypes = [vp, vp, i32, vp, vp, vp, i32, C.POINTER(mh_cam),
+                                        C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_fetch.argtypes = [vp, vp, i32, C.POINTER(C.c_int32), vp]
+    L.mh_frame_result_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.mh_enable_timing.argtypes = [vp, i32]
+    L.mh_timing.argtypes = [vp, C.POINTER(mh_times)]
+    _lib = L
+    return L
+
+
+def make_cam(K, cam) -> mh_cam:
+    c = mh_cam()
+    c.K[:] = [float(x) for x in K]
+    c.cam[:] = [float(x) for x in cam]
+    return c
+
+
+def make_pose_params(n_hypotheses=1024, max_objects_per_cluster=4, n_pts_align=5,
+                     min_n_pts_object=6, error_threshold=10.0, lm_iters_l2=10, lm_iters_l4=10):
+    return mh_pose_params(n_hypotheses, max_objects_per_cluster, n_pts_align, min_n_pts_object,
+                          error_threshold, lm_iters_l2, lm_iters_l4)
+
+
+def default_frame_params() -> mh_frame_params:
+    p = mh_frame_params()
+    load().mh_frame_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack_corr(uv, xyz) -> np.ndarray:
+    n = len(uv)
+    c = np.zeros(n, CORR_DTYPE)
+    if n:
+        uv = np.asarray(uv, np.float32)
+        xyz = np.asarray(xyz, np.float32)
+        c["u"], c["v"] = uv[:, 0], uv[:, 1]
+        c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    return c
+
+
+class Context:
+    """One mh_ctx.  Host-array methods mirror the per-step C entry points."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.mh_create(device, C.byref(h))
+        if rc != MH_OK:
+            raise MhError(f"mh_create(device={device}) failed with {rc}: no gfx950 device?")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mh_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc, what):
+        if rc != MH_OK:
+            raise MhError(f"{what} -> {rc}: {self.L.mh_last_error(self.h).decode()}")
+
+    # ---- context ----
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.mh_set_stream(self.h, C.c_void_p(stream_ptr)), "mh_set_stream")
+
+    def synchronize(self):
+        self._ck(self.L.mh_synchronize(self.h), "mh_synchronize")
+
+    def reserve(self, max_queries, max_clusters=1024, max_objects=4096):
+        self._ck(self.L.mh_reserve(self.h, max_queries, max_clusters, max_objects), "mh_reserve")
+
+    def enable_timing(self, on=True):
+        self._ck(self.L.mh_enable_timing(self.h, int(on)), "mh_enable_timing")
+
+    def timing(self) -> dict:
+        t = mh_times()
+        self._ck(self.L.mh_timing(self.h, C.byref(t)), "mh_timing")
+        return {n: getattr(t, n) for n, _ in mh_times._fields_}
+
+    # ---- DB / MATCH ----
+    def db_upload(self, desc, model_of, xyz, n_models, index_base=0):
+        desc = np.ascontiguousarray(desc, np.float32)
+        model_of = np.ascontiguousarray(model_of, np.int32)
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self._ck(self.L.mh_db_upload(self.h, _ptr(desc), _ptr(model_of), _ptr(xyz), desc.shape[0],
+                                     n_models, index_base), "mh_db_upload")
+
+    def normalize(self, desc):
+        d = np.ascontiguousarray(desc, np.float32).copy()
+        self._ck(self.L.mh_normalize(self.h, _ptr(d), d.shape[0]), "mh_normalize")
+        return d
+
+    def match(self, q, ratio=0.8):
+        q = np.ascontiguousarray(q, np.float32)
+        Q = q.shape[0]
+        acc = np.full(Q, -1, np.int32)
+        raw = np.full(Q, -1, np.int32)
+        d1 = np.zeros(Q, np.float32)
+        d2 = np.zeros(Q, np.float32)
+        self._ck(self.L.mh_match(self.h, _ptr(q), Q, ratio, _ptr(acc), _ptr(raw), _ptr(d1), _ptr(d2)), "mh_match")
+        return acc, raw, d1, d2
+
+    # ---- CLUSTER ----
+    def meanshift(self, pts, radius=200.0, merge=20.0, min_pts=7, max_iter=100):
+        pts = np.ascontiguousarray(pts, np.float32)
+        n = pts.shape[0]
+        dim = pts.shape[1] if pts.ndim == 2 else 2
+        label = np.full(max(n, 1), -1, np.int32)
+        order = np.full(max(n, 1), -1, np.int32)
+        ncl = C.c_int32(0)
+        self._ck(self.L.mh_meanshift(self.h, _ptr(pts), n, dim, radius, merge, min_pts, max_iter,
+                                     _ptr(label), _ptr(order), C.byref(ncl)), "mh_meanshift")
+        label = label[:n]
+        clusters, pos = [], 0
+        for c in range(ncl.value):
+            sz = int((label == c).sum())
+            clusters.append(order[pos:pos + sz].copy())
+            pos += sz
+        return clusters, label
+
+    # ---- POSE ----
+    def pose_ransac(self, corr, cluster_off, K, cam, params: mh_pose_params, seed=1):
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        cluster_off = np.ascontiguousarray(cluster_off, np.int32)
+        ncl = len(cluster_off) - 1
+        R = max(params.max_objects_per_cluster, 1)
+        out = np.zeros(max(ncl * R, 1), POSE_OUT_DTYPE)
+        n_out = C.c_int32(0)
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_pose_ransac(self.h, _ptr(corr), _ptr(cluster_off), ncl, C.byref(c),
+                                       C.byref(params), seed, _ptr(out), C.byref(n_out)), "mh_pose_ransac")
+        return out[:n_out.value].copy()
+
+    def project_test(self, pose7, corr, K, cam, thr):
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        n = corr.shape[0]
+        inl = np.zeros(max(n, 1), np.uint8)
+        e2 = np.zeros(max(n, 1), np.float32)
+        cnt = C.c_int32(0)
+        p = np.ascontiguousarray(pose7, np.float32)
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_project_test(self.h, _ptr(p), _ptr(corr), n, C.byref(c), thr, _ptr(inl),
+                                        _ptr(e2), C.byref(cnt)), "mh_project_test")
+        return cnt.value, inl[:n].astype(bool), e2[:n]
+
+    # ---- FILTER ----
+    def filter(self, corr, model_off, obj_model, obj_pose, K, cam, min_points, feature_distance, min_score):
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        model_off = np.ascontiguousarray(model_off, np.int32)
+        obj_model = np.ascontiguousarray(obj_model, np.int32)
+        obj_pose = np.ascontiguousarray(obj_pose, np.float32)
+        n_obj = obj_model.shape[0]
+        M = corr.shape[0]
+        score = np.zeros(max(n_obj, 1), np.float32)
+        keep = np.zeros(max(n_obj, 1), np.uint8)
+        order = np.zeros(max(n_obj, 1), np.int32)
+        members = np.zeros(max(M, 1), np.int32)
+        off = np.zeros(n_obj + 2, np.int32)
+        kept = C.c_int32(0)
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_filter(self.h, _ptr(corr), _ptr(model_off), len(model_off) - 1, _ptr(obj_model),
+                                  _ptr(obj_pose), n_obj, C.byref(c), min_points, feature_distance,
+                                  min_score, _ptr(score), _ptr(keep), _ptr(order), _ptr(members),
+                                  _ptr(off), C.byref(kept)), "mh_filter")
+        k = kept.value
+        clusters = [members[off[i]:off[i + 1]].copy() for i in range(k)]
+        return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters
+
+    # ---- frame (device pointers as ints) ----
+    def frame_enqueue(self, q_desc_ptr, q_uv_ptr, Q, K, cam, params: mh_frame_params, seed=1):
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue(self.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q,
+                                         C.byref(c), C.byref(params), seed), "mh_frame_enqueue")
+
+    def frame_enqueue_match_local(self, q_desc_ptr, Q):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.L.mh_frame_enqueue_match_local(self.h, C.c_void_p(q_desc_ptr), Q, C.byref(a),
+                                                     C.byref(b), C.byref(c)), "mh_frame_enqueue_match_local")
+        return a.value, b.value, c.value
+
+    def frame_enqueue_rest(self, q_uv_ptr, Q, idx_ptr, d1_ptr, d2_ptr, n_shards, K, cam,
+                           params: mh_frame_params, seed=1):
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_rest(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(idx_ptr),
+                                              C.c_void_p(d1_ptr), C.c_void_p(d2_ptr), n_shards,
+                                              C.byref(c), C.byref(params), seed), "mh_frame_enqueue_rest")
+
+    def frame_fetch(self, max_objects=4096):
+        objs = np.zeros(max_objects, OBJECT_DTYPE)
+        n = C.c_int32(0)
+        counts = np.zeros(4, np.int32)
+        self._ck(self.L.mh_frame_fetch(self.h, _ptr(objs), max_objects, C.byref(n), _ptr(counts)), "mh_frame_fetch")
+        return objs[:min(n.value, max_objects)].copy(), counts
+
+    def frame_result_dev(self):
+        p = C.c_void_p()
+        b = C.c_int64(0)
+        self._ck(self.L.mh_frame_result_dev(self.h, C.byref(p), C.byref(b)), "mh_frame_result_dev")
+        return p.value, b.value
+
+    def match_local_dev(self, qn_ptr, qnorm_ptr, Q, idx_ptr, d1_ptr, d2_ptr):
+        self._ck(self.L.mh_match_local_dev(self.h, C.c_void_p(qn_ptr), C.c_void_p(qnorm_ptr), Q,
+                                           C.c_void_p(idx_ptr), C.c_void_p(d1_ptr), C.c_void_p(d2_ptr)),
+                 "mh_match_local_dev")
+
+    def match_merge_dev(self, idx_s_ptr, d1_s_ptr, d2_s_ptr, n_shards, Q, idx_ptr, d1_ptr, d2_ptr):
+        self._ck(self.L.mh_match_merge_dev(self.h, C.c_void_p(idx_s_ptr), C.c_void_p(d1_s_ptr),
+                                           C.c_void_p(d2_s_ptr), n_shards, Q, C.c_void_p(idx_ptr),
+                                           C.c_void_p(d1_ptr), C.c_void_p(d2_ptr)), "mh_match_merge_dev")
+
+    def normalize_dev(self, q_ptr, qnorm_ptr, Q):
+        self._ck(self.L.mh_normalize_dev(self.h, C.c_void_p(q_ptr), C.c_void_p(qnorm_ptr), Q), "mh_normalize_dev")

@@ -1,0 +1,263 @@
+// C ABI of libmoped_hip.so: context, model database, MATCH entry points.
+// (CLUSTER / POSE / FILTER / frame entry points live in api_steps.hip.)
+#include <cstring>
+#include <new>
+
+#include "context.h"
+#include "steps.h"
+
+using namespace mh;
+
+namespace mh {
+
+int ensure_scratch(mh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_cap) return MH_OK;
+  if (ctx->scratch) MH_HIP(ctx, hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_cap = 0;
+  size_t cap = bytes + bytes / 4 + 4096;
+  MH_HIP(ctx, hipMalloc(&ctx->scratch, cap));
+  ctx->scratch_cap = cap;
+  return MH_OK;
+}
+
+int ensure_pinned(mh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_cap) return MH_OK;
+  if (ctx->pinned) MH_HIP(ctx, hipHostFree(ctx->pinned));
+  ctx->pinned = nullptr;
+  ctx->pinned_cap = 0;
+  size_t cap = bytes + bytes / 4 + 4096;
+  MH_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+  ctx->pinned_cap = cap;
+  return MH_OK;
+}
+
+int ensure_match_scratch(mh_ctx* ctx, int Q) {
+  size_t need = match_scratch_elems(Q, ctx->N > 0 ? ctx->N : 1);
+  if (need <= ctx->match_scratch_cap) return MH_OK;
+  if (ctx->match_scratch) MH_HIP(ctx, hipFree(ctx->match_scratch));
+  ctx->match_scratch = nullptr;
+  ctx->match_scratch_cap = 0;
+  MH_HIP(ctx, hipMalloc(&ctx->match_scratch, need * sizeof(Top2)));
+  ctx->match_scratch_cap = need;
+  return MH_OK;
+}
+
+template <typename T>
+static int realloc_dev(mh_ctx* ctx, T*& p, size_t n) {
+  if (p) MH_HIP(ctx, hipFree(p));
+  p = nullptr;
+  MH_HIP(ctx, hipMalloc(&p, (n > 0 ? n : 1) * sizeof(T)));
+  return MH_OK;
+}
+
+int ensure_frame_buffers(mh_ctx* ctx, int Q) {
+  if (Q <= ctx->max_q) return MH_OK;
+  int cap = ctx->max_q > 0 ? ctx->max_q : 4096;
+  while (cap < Q) cap *= 2;
+  int rc;
+  if ((rc = realloc_dev(ctx, ctx->q_desc, (size_t)cap * DIM))) return rc;
+  if ((rc = realloc_dev(ctx, ctx->q_norm, cap))) return rc;
+  if ((rc = realloc_dev(ctx, ctx->q_uv, (size_t)cap * 2))) return rc;
+  if ((rc = realloc_dev(ctx, ctx->nn_idx, cap))) return rc;
+  if ((rc = realloc_dev(ctx, ctx->nn_d1, cap))) return rc;
+  if ((rc = realloc_dev(ctx, ctx->nn_d2, cap))) return rc;
+  ctx->max_q = cap;
+  return MH_OK;
+}
+
+}  // namespace mh
+
+extern "C" {
+
+int mh_create(int device, mh_ctx** out) {
+  if (!out) return MH_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return MH_ERR_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MH_ERR_NODEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MH_ERR_NODEVICE;  // gfx950 code objects only
+  if (hipSetDevice(device) != hipSuccess) return MH_ERR_HIP;
+  mh_ctx* ctx = new (std::nothrow) mh_ctx;
+  if (!ctx) return MH_ERR_HIP;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return MH_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return MH_OK;
+}
+
+void mh_free_frame_state(mh_ctx* ctx);  // api_steps.hip
+
+void mh_destroy(mh_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  mh_free_frame_state(ctx);
+  void* ptrs[] = {ctx->db_desc, ctx->db_norm, ctx->db_xyz, ctx->db_model, ctx->q_desc, ctx->q_norm,
+                  ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
+                  ctx->scratch};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->ev_made)
+    for (auto& e : ctx->ev) hipEventDestroy(e);
+  hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* mh_last_error(const mh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mh_set_stream(mh_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MH_ERR_ARG;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return MH_OK;
+}
+
+int mh_synchronize(mh_ctx* ctx) {
+  if (!ctx) return MH_ERR_ARG;
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
+                 const float* xyz_host, int N, int n_models, int32_t index_base) {
+  if (!ctx || N < 0 || n_models < 0 || (N > 0 && (!desc_host || !model_of_host || !xyz_host))) {
+    if (ctx) ctx->err = "mh_db_upload: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((size_t)N > ctx->db_cap) {
+    int rc;
+    if ((rc = realloc_dev(ctx, ctx->db_desc, (size_t)N * DIM))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_norm, N))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_xyz, (size_t)N * 3))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_model, N))) return rc;
+    ctx->db_cap = N;
+  }
+  ctx->N = N;
+  ctx->n_models = n_models;
+  ctx->index_base = index_base;
+  if (N > 0) {
+    MH_HIP(ctx, hipMemcpyAsync(ctx->db_desc, desc_host, (size_t)N * DIM * sizeof(float),
+                               hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(ctx->db_xyz, xyz_host, (size_t)N * 3 * sizeof(float),
+                               hipMemcpyHostToDevice, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(ctx->db_model, model_of_host, (size_t)N * sizeof(int32_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    launch_row_norms(ctx->db_desc, ctx->db_norm, N, ctx->stream);
+    MH_HIP(ctx, hipGetLastError());
+  }
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_db_size(const mh_ctx* ctx, int* N, int* n_models) {
+  if (!ctx) return MH_ERR_ARG;
+  if (N) *N = ctx->N;
+  if (n_models) *n_models = ctx->n_models;
+  return MH_OK;
+}
+
+int mh_normalize(mh_ctx* ctx, float* desc_host, int n) {
+  if (!ctx || n < 0 || (n > 0 && !desc_host)) return MH_ERR_ARG;
+  if (n == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_frame_buffers(ctx, n);
+  if (rc) return rc;
+  const size_t bytes = (size_t)n * DIM * sizeof(float);
+  MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, desc_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  launch_normalize(ctx->q_desc, ctx->q_norm, n, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  MH_HIP(ctx, hipMemcpyAsync(desc_host, ctx->q_desc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
+int mh_normalize_dev(mh_ctx* ctx, float* q_dev, float* qnorm_dev, int Q) {
+  if (!ctx || Q < 0 || (Q > 0 && (!q_dev || !qnorm_dev))) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  launch_normalize(q_dev, qnorm_dev, Q, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
+}
+
+int mh_match_local_dev(mh_ctx* ctx, const float* qn_dev, const float* qnorm_dev, int Q,
+                       int32_t* idx1_dev, float* d1_dev, float* d2_dev) {
+  if (!ctx || Q < 0 || (Q > 0 && (!qn_dev || !qnorm_dev || !idx1_dev || !d1_dev || !d2_dev)))
+    return MH_ERR_ARG;
+  if (Q == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_match_scratch(ctx, Q);
+  if (rc) return rc;
+  launch_match(qn_dev, qnorm_dev, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+               ctx->match_scratch, idx1_dev, d1_dev, d2_dev, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
+}
+
+int mh_match_merge_dev(mh_ctx* ctx, const int32_t* idx1_s_dev, const float* d1_s_dev,
+                       const float* d2_s_dev, int n_shards, int Q, int32_t* idx1_dev,
+                       float* d1_dev, float* d2_dev) {
+  if (!ctx || Q < 0 || n_shards < 0) return MH_ERR_ARG;
+  if (Q == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, idx1_dev, d1_dev, d2_dev,
+                     ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
+}
+
+int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_idx,
+             int32_t* nn_raw, float* d1, float* d2) {
+  if (!ctx || Q < 0 || (Q > 0 && (!q_host || !nn_idx))) return MH_ERR_ARG;
+  if (Q == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_frame_buffers(ctx, Q);
+  if (rc) return rc;
+  if ((rc = ensure_match_scratch(ctx, Q))) return rc;
+  if ((rc = ensure_pinned(ctx, (size_t)Q * 16))) return rc;
+  if ((rc = ensure_scratch(ctx, (size_t)Q * 4))) return rc;
+  MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_host, (size_t)Q * DIM * sizeof(float),
+                             hipMemcpyHostToDevice, ctx->stream));
+  launch_row_norms(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
+  launch_match(ctx->q_desc, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+  // the reference's acceptance test on squared distances (MATCH_ANN_CPU.hpp:165)
+  int32_t* d_acc = (int32_t*)ctx->scratch;
+  launch_accept(ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, ratio, d_acc, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t* h_acc = (int32_t*)ctx->pinned;
+  int32_t* h_raw = h_acc + Q;
+  float* h_d1 = (float*)(h_raw + Q);
+  float* h_d2 = h_d1 + Q;
+  MH_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(h_raw, ctx->nn_idx, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(h_d1, ctx->nn_d1, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(h_d2, ctx->nn_d2, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(nn_idx, h_acc, (size_t)Q * 4);
+  if (nn_raw) std::memcpy(nn_raw, h_raw, (size_t)Q * 4);
+  if (d1) std::memcpy(d1, h_d1, (size_t)Q * 4);
+  if (d2) std::memcpy(d2, h_d2, (size_t)Q * 4);
+  return MH_OK;
+}
+
+int mh_enable_timing(mh_ctx* ctx, int on) {
+  if (!ctx) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (on && !ctx->ev_made) {
+    for (auto& e : ctx->ev) MH_HIP(ctx, hipEventCreate(&e));
+    ctx->ev_made = true;
+  }
+  ctx->timing = on != 0;
+  return MH_OK;
+}
+
+}  // extern "C"

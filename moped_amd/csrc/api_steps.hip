@@ -1,0 +1,581 @@
+// C ABI: CLUSTER / POSE / FILTER entry points and the device-resident frame.
+#include <cstring>
+#include <vector>
+
+#include "context.h"
+#include "steps.h"
+
+using namespace mh;
+
+// Device buffers of one frame.  Match records are kept sorted by (model, query):
+// matches[model] of the reference is the slice [model_off[m], model_off[m+1]).
+struct FrameState {
+  int max_m = 0, max_clusters = 0, max_objects = 0, n_models_cap = 0;
+  FrameCounts* counts = nullptr;
+  int32_t* n_slots = nullptr;      // object slots in use (device scalar)
+  int32_t* n_clusters = nullptr;   // rows of the current cluster table (device scalar)
+  // group
+  int32_t *acc_q = nullptr, *acc_model = nullptr, *m_q = nullptr, *m_model = nullptr, *m_rep = nullptr;
+  mh_corr* m_corr = nullptr;
+  int32_t* model_off = nullptr;
+  // cluster
+  int32_t *ms_members = nullptr, *ms_cl_start = nullptr, *ms_ncl = nullptr;
+  int32_t *cl_model = nullptr, *cl_begin = nullptr, *cl_count = nullptr;
+  // objects
+  int32_t *obj_model = nullptr, *obj_ninl = nullptr, *obj_cluster = nullptr, *obj_valid = nullptr,
+          *obj_npts = nullptr, *obj_clsize = nullptr;
+  float *obj_pose = nullptr, *obj_err = nullptr, *obj_score = nullptr, *obj_score_raw = nullptr;
+  // filter
+  unsigned long long* best = nullptr;
+  int32_t* new_members = nullptr;
+  // packed result {int32 n; int32 pad[3]; mh_object[max_objects]}
+  unsigned char* result = nullptr;
+  size_t result_bytes = 0;
+  int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mh_ctx* ctx, T*& p, size_t n) {
+  MH_HIP(ctx, hipMalloc(&p, (n > 0 ? n : 1) * sizeof(T)));
+  return MH_OK;
+}
+
+void free_fs(FrameState* fs) {
+  if (!fs) return;
+  void* ptrs[] = {fs->counts,     fs->n_slots,   fs->n_clusters, fs->acc_q,      fs->acc_model,
+                  fs->m_q,        fs->m_model,   fs->m_rep,      fs->m_corr,     fs->model_off,
+                  fs->ms_members, fs->ms_cl_start, fs->ms_ncl,   fs->cl_model,   fs->cl_begin,
+                  fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
+                  fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
+                  fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete fs;
+}
+
+int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_models) {
+  FrameState* fs = ctx->fs;
+  if (fs && fs->max_m >= max_m && fs->max_clusters >= max_clusters &&
+      fs->max_objects >= max_objects && fs->n_models_cap >= n_models)
+    return MH_OK;
+  if (fs) {
+    max_m = std::max(max_m, fs->max_m);
+    max_clusters = std::max(max_clusters, fs->max_clusters);
+    max_objects = std::max(max_objects, fs->max_objects);
+    n_models = std::max(n_models, fs->n_models_cap);
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_fs(fs);
+    ctx->fs = nullptr;
+  }
+  fs = new FrameState;
+  ctx->fs = fs;
+  fs->max_m = max_m;
+  fs->max_clusters = max_clusters;
+  fs->max_objects = max_objects;
+  fs->n_models_cap = n_models;
+  int rc = 0;
+  rc |= dev_alloc(ctx, fs->counts, 1);
+  rc |= dev_alloc(ctx, fs->n_slots, 1);
+  rc |= dev_alloc(ctx, fs->n_clusters, 1);
+  rc |= dev_alloc(ctx, fs->acc_q, max_m);
+  rc |= dev_alloc(ctx, fs->acc_model, max_m);
+  rc |= dev_alloc(ctx, fs->m_q, max_m);
+  rc |= dev_alloc(ctx, fs->m_model, max_m);
+  rc |= dev_alloc(ctx, fs->m_rep, max_m);
+  rc |= dev_alloc(ctx, fs->m_corr, max_m);
+  rc |= dev_alloc(ctx, fs->model_off, (size_t)n_models + 1);
+  rc |= dev_alloc(ctx, fs->ms_members, max_m);
+  rc |= dev_alloc(ctx, fs->ms_cl_start, (size_t)max_m + n_models + 1);
+  rc |= dev_alloc(ctx, fs->ms_ncl, (size_t)n_models + 1);
+  rc |= dev_alloc(ctx, fs->cl_model, max_clusters);
+  rc |= dev_alloc(ctx, fs->cl_begin, max_clusters);
+  rc |= dev_alloc(ctx, fs->cl_count, max_clusters);
+  rc |= dev_alloc(ctx, fs->obj_model, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_ninl, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_cluster, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_valid, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_npts, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_clsize, (size_t)2 * max_objects);
+  rc |= dev_alloc(ctx, fs->obj_pose, (size_t)7 * max_objects);
+  rc |= dev_alloc(ctx, fs->obj_err, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_score, max_objects);
+  rc |= dev_alloc(ctx, fs->obj_score_raw, max_objects);
+  rc |= dev_alloc(ctx, fs->best, max_m);
+  rc |= dev_alloc(ctx, fs->new_members, max_m);
+  fs->result_bytes = 16 + sizeof(mh_object) * (size_t)max_objects;
+  rc |= dev_alloc(ctx, fs->result, fs->result_bytes);
+  rc |= dev_alloc(ctx, fs->snap, 4);
+  if (rc) return MH_ERR_HIP;
+  MH_HIP(ctx, hipMemsetAsync(fs->obj_valid, 0, sizeof(int32_t) * max_objects, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fs->obj_score, 0, sizeof(float) * max_objects, ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fs->obj_npts, 0, sizeof(int32_t) * max_objects, ctx->stream));
+  return MH_OK;
+}
+
+FilterBuffers make_fb(const mh_ctx* ctx, const FrameState* fs, int n_models) {
+  (void)ctx;
+  FilterBuffers fb;
+  fb.corr = fs->m_corr;
+  fb.m_rep = fs->m_rep;
+  fb.model_off = fs->model_off;
+  fb.n_models = n_models;
+  fb.max_m = fs->max_m;
+  fb.obj_model = fs->obj_model;
+  fb.obj_pose = fs->obj_pose;
+  fb.obj_score = fs->obj_score;
+  fb.obj_score_raw = fs->obj_score_raw;
+  fb.obj_valid = fs->obj_valid;
+  fb.obj_npts = fs->obj_npts;
+  fb.max_objects = fs->max_objects;
+  fb.best = fs->best;
+  fb.obj_clsize = fs->obj_clsize;
+  fb.new_members = fs->new_members;
+  fb.cl_model = fs->cl_model;
+  fb.cl_begin = fs->cl_begin;
+  fb.cl_count = fs->cl_count;
+  fb.max_clusters = fs->max_clusters;
+  return fb;
+}
+
+// n_slots += n_clusters * R after a POSE launch; optional snapshot of a counter.
+__global__ void advance_slots_kernel(int32_t* n_slots, const int32_t* n_clusters, int R, int max_objects) {
+  int v = *n_slots + *n_clusters * R;
+  *n_slots = v > max_objects ? max_objects : v;
+}
+__global__ void set_scalar_kernel(int32_t* p, int32_t v) { *p = v; }
+__global__ void snapshot_kernel(int32_t* dst, const int32_t* src) { *dst = *src; }
+__global__ void count_valid_kernel(int32_t* dst, const int32_t* valid, const int32_t* n_slots) {
+  int c = 0;
+  for (int i = 0; i < *n_slots; ++i) c += valid[i] != 0;
+  *dst = c;
+}
+
+// Pack the valid objects (list order) into the result block.
+__global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots,
+                                   const int32_t* obj_valid, const int32_t* obj_model,
+                                   const float* obj_pose, const float* obj_score,
+                                   const int32_t* obj_npts, int max_objects) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  mh_object* out = reinterpret_cast<mh_object*>(result + 16);
+  int k = 0;
+  const int n = *n_slots;
+  for (int o = 0; o < n && k < max_objects; ++o) {
+    if (!obj_valid[o]) continue;
+    mh_object ob;
+    ob.model = obj_model[o];
+    for (int j = 0; j < 7; ++j) ob.pose[j] = obj_pose[7 * o + j];
+    ob.score = obj_score[o];
+    ob.n_points = obj_npts[o];
+    out[k++] = ob;
+  }
+  reinterpret_cast<int32_t*>(result)[0] = k;
+}
+
+void stamp(mh_ctx* ctx, int i) {
+  if (ctx->timing) hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, const float* d1,
+               const float* d2, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  const DevCam dc = make_devcam(*cam);
+  const int nm = ctx->n_models;
+  MH_HIP(ctx, hipMemsetAsync(fs->counts, 0, sizeof(FrameCounts), s));
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
+  // MATCH tail: ratio test + per-model lists
+  launch_group(idx1, d1, d2, Q, prm->ratio, q_uv_dev, ctx->db_model, ctx->db_xyz, ctx->N,
+               ctx->index_base, nm, fs->max_m, fs->acc_q, fs->acc_model, fs->m_q, fs->m_model,
+               fs->m_corr, fs->m_rep, fs->model_off, fs->counts, s);
+  stamp(ctx, 2);
+  // CLUSTER
+  launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
+                          prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
+                          fs->ms_ncl, fs->counts, s);
+  launch_cluster_table(fs->model_off, fs->ms_cl_start, fs->ms_ncl, nm, fs->max_clusters,
+                       fs->cl_model, fs->cl_begin, fs->cl_count, fs->counts, s);
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->n_clusters, &fs->counts->n_clusters);
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 0, &fs->counts->n_matches);
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 1, &fs->counts->n_clusters);
+  stamp(ctx, 3);
+  // POSE
+  launch_pose(fs->m_corr, fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
+              fs->max_clusters, dc, prm->pose1, seed, fs->n_slots, fs->max_objects, fs->obj_model,
+              fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
+  hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
+                     prm->pose1.max_objects_per_cluster > 0 ? prm->pose1.max_objects_per_cluster : 1,
+                     fs->max_objects);
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1), 0, s, fs->snap + 2, fs->obj_valid, fs->n_slots);
+  stamp(ctx, 4);
+  if (prm->run_stage2) {
+    FilterBuffers fb = make_fb(ctx, fs, nm);
+    // FILTER
+    launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
+                  fs->n_slots, fs->n_clusters, fs->counts, s);
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 3, fs->n_slots);
+    stamp(ctx, 5);
+    // POSE2 on the rewritten clusters, objects appended after the kept ones
+    launch_pose(fs->m_corr, fs->new_members, fs->cl_model, fs->cl_begin, fs->cl_count,
+                fs->n_clusters, fs->max_clusters, dc, prm->pose2, seed ^ 0x5DEECE66Dull, fs->n_slots,
+                fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err,
+                fs->obj_cluster, fs->obj_valid, fs->counts, s);
+    hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
+                       prm->pose2.max_objects_per_cluster > 0 ? prm->pose2.max_objects_per_cluster : 1,
+                       fs->max_objects);
+    stamp(ctx, 6);
+    // FILTER2
+    launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
+                  fs->n_slots, fs->n_clusters, fs->counts, s);
+    stamp(ctx, 7);
+  } else {
+    for (int i = 5; i <= 7; ++i) stamp(ctx, i);
+  }
+  hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, fs->result, fs->n_slots,
+                     fs->obj_valid, fs->obj_model, fs->obj_pose, fs->obj_score, fs->obj_npts,
+                     fs->max_objects);
+  stamp(ctx, 8);
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
+}
+
+int prepare_frame(mh_ctx* ctx, int Q) {
+  int rc = ensure_frame_buffers(ctx, Q);
+  if (rc) return rc;
+  if ((rc = ensure_match_scratch(ctx, Q))) return rc;
+  const int want_m = ctx->fs ? ctx->fs->max_m : 0;
+  const int mc = ctx->fs ? ctx->fs->max_clusters : 1024;
+  const int mo = ctx->fs ? ctx->fs->max_objects : 4096;
+  return ensure_fs(ctx, std::max(want_m, ctx->max_q), mc, mo, ctx->n_models);
+}
+
+}  // namespace
+
+extern "C" {
+
+void mh_free_frame_state(mh_ctx* ctx) {
+  free_fs(ctx->fs);
+  ctx->fs = nullptr;
+}
+
+int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects) {
+  if (!ctx || max_queries <= 0 || max_clusters <= 0 || max_objects <= 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_frame_buffers(ctx, max_queries);
+  if (rc) return rc;
+  return ensure_fs(ctx, ctx->max_q, max_clusters, max_objects, ctx->n_models);
+}
+
+void mh_frame_default_params(mh_frame_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  p->ratio = 0.8f;            // config.hpp:83
+  p->ms_radius = 200.f;       // config.hpp:101
+  p->ms_merge = 20.f;
+  p->ms_min_pts = 7;
+  p->ms_max_iter = 100;
+  p->pose1 = {1024, 4, 5, 6, 10.f, 10, 10};  // config.hpp:110 (…, 4, 5, 6, 10)
+  p->f1_min_points = 5;       // config.hpp:115
+  p->f1_feature_distance = 4096.f;
+  p->f1_min_score = 2.f;
+  p->pose2 = {1024, 4, 6, 8, 5.f, 10, 10};   // config.hpp:118 (…, 4, 6, 8, 5)
+  p->f2_min_points = 7;       // config.hpp:120
+  p->f2_feature_distance = 4096.f;
+  p->f2_min_score = 3.f;
+  p->run_stage2 = 1;
+}
+
+int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radius, float merge,
+                 int min_pts, int max_iter, int32_t* label, int32_t* order, int32_t* n_clusters) {
+  if (!ctx || n < 0 || (dim != 2 && dim != 3) || !n_clusters || (n > 0 && (!pts_host || !label))) {
+    if (ctx) ctx->err = "mh_meanshift: bad argument";
+    return MH_ERR_ARG;
+  }
+  *n_clusters = 0;
+  if (n == 0) return MH_OK;
+  if (n > MS_CAP) {
+    ctx->err = "mh_meanshift: more than 2048 points";
+    return MH_ERR_CAPACITY;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_pts = (size_t)n * dim * sizeof(float);
+  const size_t b_i = (size_t)(n + 2) * sizeof(int32_t);
+  int rc = ensure_scratch(ctx, b_pts + 4 * b_i + 64);
+  if (rc) return rc;
+  unsigned char* base = (unsigned char*)ctx->scratch;
+  float* d_pts = (float*)base;
+  int32_t* d_members = (int32_t*)(base + ((b_pts + 15) & ~(size_t)15));
+  int32_t* d_start = d_members + (n + 2);
+  int32_t* d_label = d_start + (n + 2);
+  int32_t* d_misc = d_label + (n + 2);  // [0] ncl, [1] iterations
+  MH_HIP(ctx, hipMemcpyAsync(d_pts, pts_host, b_pts, hipMemcpyHostToDevice, ctx->stream));
+  launch_meanshift_single(d_pts, n, dim, radius, merge, min_pts, max_iter, d_members, d_start,
+                          d_misc, d_label, d_misc + 1, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t misc[2];
+  MH_HIP(ctx, hipMemcpyAsync(misc, d_misc, sizeof misc, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(label, d_label, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_clusters = misc[0];
+  if (order) {
+    std::vector<int32_t> st(misc[0] + 1);
+    MH_HIP(ctx, hipMemcpy(st.data(), d_start, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int total = st[misc[0]];
+    for (int i = 0; i < n; ++i) order[i] = -1;
+    if (total > 0)
+      MH_HIP(ctx, hipMemcpy(order, d_members, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return MH_OK;
+}
+
+int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster_off,
+                   int n_clusters, const mh_cam* cam, const mh_pose_params* prm, uint64_t seed,
+                   mh_pose_out* out_host, int32_t* n_out) {
+  if (!ctx || n_clusters < 0 || !cam || !prm || !n_out || (n_clusters > 0 && (!corr_host || !cluster_off || !out_host))) {
+    if (ctx) ctx->err = "mh_pose_ransac: bad argument";
+    return MH_ERR_ARG;
+  }
+  *n_out = 0;
+  if (n_clusters == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const int R_ = prm->max_objects_per_cluster > 0 ? prm->max_objects_per_cluster : 1;
+  const int total = cluster_off[n_clusters];
+  const int n_obj = n_clusters * R_;
+  int rc = ensure_fs(ctx, std::max(total, 1), n_clusters, n_obj, std::max(ctx->n_models, 1));
+  if (rc) return rc;
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  std::vector<int32_t> h_members(std::max(total, 1)), h_model(n_clusters, 0), h_begin(n_clusters), h_count(n_clusters);
+  for (int i = 0; i < total; ++i) h_members[i] = i;
+  for (int c = 0; c < n_clusters; ++c) {
+    h_begin[c] = cluster_off[c];
+    h_count[c] = cluster_off[c + 1] - cluster_off[c];
+  }
+  MH_HIP(ctx, hipMemcpyAsync(fs->m_corr, corr_host, (size_t)total * sizeof(mh_corr), hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->ms_members, h_members.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->cl_model, h_model.data(), (size_t)n_clusters * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->cl_begin, h_begin.data(), (size_t)n_clusters * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->cl_count, h_count.data(), (size_t)n_clusters * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemsetAsync(fs->counts, 0, sizeof(FrameCounts), s));
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_clusters, n_clusters);
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
+  const DevCam dc = make_devcam(*cam);
+  launch_pose(fs->m_corr, fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
+              n_clusters, dc, *prm, seed, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
+  MH_HIP(ctx, hipGetLastError());
+  std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
+  std::vector<float> pose((size_t)7 * n_obj), err(n_obj);
+  MH_HIP(ctx, hipMemcpyAsync(valid.data(), fs->obj_valid, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(ninl.data(), fs->obj_ninl, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(ocl.data(), fs->obj_cluster, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(pose.data(), fs->obj_pose, (size_t)n_obj * 28, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(err.data(), fs->obj_err, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  int k = 0;
+  for (int o = 0; o < n_obj; ++o) {
+    if (!valid[o]) continue;
+    mh_pose_out& po = out_host[k++];
+    std::memcpy(po.pose, &pose[(size_t)7 * o], 28);
+    po.cluster = ocl[o];
+    po.n_inliers = ninl[o];
+    po.err = err[o];
+  }
+  *n_out = k;
+  return MH_OK;
+}
+
+int mh_project_test(mh_ctx* ctx, const float pose[7], const mh_corr* corr_host, int n,
+                    const mh_cam* cam, float thr, uint8_t* inlier_host, float* err2_host,
+                    int32_t* n_inliers) {
+  if (!ctx || !pose || !cam || n < 0 || (n > 0 && !corr_host)) return MH_ERR_ARG;
+  if (n_inliers) *n_inliers = 0;
+  if (n == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_c = (size_t)n * sizeof(mh_corr);
+  int rc = ensure_scratch(ctx, b_c + (size_t)n * 5 + 256);
+  if (rc) return rc;
+  unsigned char* base = (unsigned char*)ctx->scratch;
+  mh_corr* d_c = (mh_corr*)base;
+  float* d_e = (float*)(base + ((b_c + 15) & ~(size_t)15));
+  float* d_pose = d_e + n;
+  int32_t* d_cnt = (int32_t*)(d_pose + 8);
+  uint8_t* d_in = (uint8_t*)(d_cnt + 4);
+  hipStream_t s = ctx->stream;
+  MH_HIP(ctx, hipMemcpyAsync(d_c, corr_host, b_c, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(d_pose, pose, 28, hipMemcpyHostToDevice, s));
+  launch_project_test(d_pose, d_c, n, make_devcam(*cam), thr, d_in, d_e, d_cnt, s);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t cnt = 0;
+  MH_HIP(ctx, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, s));
+  if (inlier_host) MH_HIP(ctx, hipMemcpyAsync(inlier_host, d_in, n, hipMemcpyDeviceToHost, s));
+  if (err2_host) MH_HIP(ctx, hipMemcpyAsync(err2_host, d_e, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  if (n_inliers) *n_inliers = cnt;
+  return MH_OK;
+}
+
+int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, int n_models,
+              const int32_t* obj_model, const float* obj_pose, int n_obj, const mh_cam* cam,
+              int min_points, float feature_distance, float min_score, float* score,
+              uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off,
+              int32_t* n_kept) {
+  if (!ctx || !model_off || n_models <= 0 || n_obj < 0 || !cam || !n_kept) return MH_ERR_ARG;
+  *n_kept = 0;
+  if (cl_off) cl_off[0] = 0;
+  if (n_obj == 0) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const int M = model_off[n_models];
+  int rc = ensure_fs(ctx, std::max(M, 1), std::max(n_obj, 1), std::max(n_obj, 1), n_models);
+  if (rc) return rc;
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  std::vector<int32_t> ones(n_obj, 1);
+  MH_HIP(ctx, hipMemcpyAsync(fs->m_corr, corr_host, (size_t)M * sizeof(mh_corr), hipMemcpyHostToDevice, s));
+  launch_rep(fs->m_corr, M, fs->m_rep, s);
+  MH_HIP(ctx, hipMemcpyAsync(fs->model_off, model_off, (size_t)(n_models + 1) * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->obj_model, obj_model, (size_t)n_obj * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->obj_pose, obj_pose, (size_t)n_obj * 28, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(fs->obj_valid, ones.data(), (size_t)n_obj * 4, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemsetAsync(fs->counts, 0, sizeof(FrameCounts), s));
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, n_obj);
+  FilterBuffers fb = make_fb(ctx, fs, n_models);
+  fb.max_objects = n_obj;  // grid size; arrays are at least this large
+  launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
+                fs->n_clusters, fs->counts, s);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t kept = 0;
+  MH_HIP(ctx, hipMemcpyAsync(&kept, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  std::vector<int32_t> old_of(std::max(kept, 1)), begin(std::max(kept, 1)), count(std::max(kept, 1));
+  std::vector<float> sc(n_obj);
+  MH_HIP(ctx, hipMemcpy(sc.data(), fs->obj_score_raw, (size_t)n_obj * 4, hipMemcpyDeviceToHost));
+  if (kept > 0) {
+    MH_HIP(ctx, hipMemcpy(old_of.data(), fs->obj_clsize + n_obj, (size_t)kept * 4, hipMemcpyDeviceToHost));
+    MH_HIP(ctx, hipMemcpy(begin.data(), fs->cl_begin, (size_t)kept * 4, hipMemcpyDeviceToHost));
+    MH_HIP(ctx, hipMemcpy(count.data(), fs->cl_count, (size_t)kept * 4, hipMemcpyDeviceToHost));
+  }
+  if (keep) std::memset(keep, 0, n_obj);
+  if (score)
+    for (int o = 0; o < n_obj; ++o) score[o] = sc[o];
+  int w = 0;
+  std::vector<int32_t> mem(std::max(M, 1));
+  if (M > 0) MH_HIP(ctx, hipMemcpy(mem.data(), fs->new_members, (size_t)M * 4, hipMemcpyDeviceToHost));
+  for (int k = 0; k < kept; ++k) {
+    const int o = old_of[k];
+    if (keep) keep[o] = 1;
+    if (out_order) out_order[k] = o;
+    if (cl_off) cl_off[k] = w;
+    const int b = model_off[obj_model[o]];
+    for (int j = 0; j < count[k]; ++j, ++w)
+      if (cl_members) cl_members[w] = mem[begin[k] + j] - b;  // index inside the model
+  }
+  if (cl_off) cl_off[kept] = w;
+  *n_kept = kept;
+  return MH_OK;
+}
+
+int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
+                     const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || Q <= 0 || !q_desc_dev || !q_uv_dev || !cam || !prm) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->n_models > 8192) {
+    ctx->err = "more than 8192 models per context";
+    return MH_ERR_CAPACITY;
+  }
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  stamp(ctx, 0);
+  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+  launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+  stamp(ctx, 1);
+  return frame_rest(ctx, q_uv_dev, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, cam, prm, seed);
+}
+
+int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t** idx1_dev,
+                                 float** d1_dev, float** d2_dev) {
+  if (!ctx || Q <= 0 || !q_desc_dev || !idx1_dev || !d1_dev || !d2_dev) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  stamp(ctx, 0);
+  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+  launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  *idx1_dev = ctx->nn_idx;
+  *d1_dev = ctx->nn_d1;
+  *d2_dev = ctx->nn_d2;
+  return MH_OK;
+}
+
+int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1_s_dev,
+                          const float* d1_s_dev, const float* d2_s_dev, int n_shards,
+                          const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || Q <= 0 || !q_uv_dev || !idx1_s_dev || !d1_s_dev || !d2_s_dev || n_shards <= 0 || !cam || !prm)
+    return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  // merged top-2 goes to scratch so the local arrays handed to the all-gather stay intact
+  if ((rc = ensure_scratch(ctx, (size_t)Q * 12 + 64))) return rc;
+  int32_t* g_idx = (int32_t*)ctx->scratch;
+  float* g_d1 = (float*)(g_idx + Q);
+  float* g_d2 = g_d1 + Q;
+  launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, g_idx, g_d1, g_d2, ctx->stream);
+  stamp(ctx, 1);
+  return frame_rest(ctx, q_uv_dev, Q, g_idx, g_d1, g_d2, cam, prm, seed);
+}
+
+int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_t* n_objects,
+                   int32_t* counts) {
+  if (!ctx || !n_objects || !ctx->fs) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  FrameState* fs = ctx->fs;
+  int32_t head[4];
+  MH_HIP(ctx, hipMemcpyAsync(head, fs->result, sizeof head, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t snap[4] = {0, 0, 0, 0};
+  FrameCounts fc;
+  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(&fc, fs->counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = head[0];
+  *n_objects = n;
+  if (counts) std::memcpy(counts, snap, sizeof snap);
+  const int take = n < max_objects ? n : max_objects;
+  if (take > 0 && objects_host)
+    MH_HIP(ctx, hipMemcpy(objects_host, fs->result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
+  if (fc.error) {
+    ctx->err = "frame: capacity exceeded (flags " + std::to_string(fc.error) + ")";
+    return MH_ERR_CAPACITY;
+  }
+  return MH_OK;
+}
+
+int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes) {
+  if (!ctx || !ctx->fs || !block_dev || !bytes) return MH_ERR_ARG;
+  *block_dev = ctx->fs->result;
+  *bytes = (int64_t)ctx->fs->result_bytes;
+  return MH_OK;
+}
+
+int mh_timing(mh_ctx* ctx, mh_times* out) {
+  if (!ctx || !out || !ctx->timing || !ctx->ev_made) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipEventSynchronize(ctx->ev[8]));
+  float* dst[8] = {&out->match_ms, &out->group_ms, &out->cluster_ms, &out->pose1_ms,
+                   &out->filter1_ms, &out->pose2_ms, &out->filter2_ms, nullptr};
+  for (int i = 0; i < 7; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
+    *dst[i] = ms;
+  }
+  float tot = 0.f;
+  hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[8]);
+  out->total_ms = tot;
+  return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// mh_ctx: device state kept across frames (the analogue of the kd-tree
+// MATCH_ANN_CPU keeps between frames, MATCH_ANN_CPU.hpp:70) plus the per-frame
+// device buffers.  Everything lives in HBM; host pointers only at the C ABI.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct mh_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- model database (resident) ----
+  int N = 0, n_models = 0;
+  int32_t index_base = 0;
+  float* db_desc = nullptr;      // [N][128]
+  float* db_norm = nullptr;      // [N]
+  float* db_xyz = nullptr;       // [N][3]
+  int32_t* db_model = nullptr;   // [N]
+  size_t db_cap = 0;
+
+  // ---- per-frame buffers ----
+  int max_q = 0, max_clusters = 0, max_objects = 0;
+  float* q_desc = nullptr;       // [max_q][128] staging for host-pointer entry points
+  float* q_norm = nullptr;       // [max_q]
+  float* q_uv = nullptr;         // [max_q][2]
+  int32_t* nn_idx = nullptr;     // [max_q]
+  float* nn_d1 = nullptr;        // [max_q]
+  float* nn_d2 = nullptr;        // [max_q]
+  mh::Top2* match_scratch = nullptr;
+  size_t match_scratch_cap = 0;
+
+  // generic byte scratch for host-pointer entry points
+  void* scratch = nullptr;
+  size_t scratch_cap = 0;
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+
+  // frame state (group / cluster / pose / filter); defined in frame.h
+  struct FrameState* fs = nullptr;
+
+  bool timing = false;
+  hipEvent_t ev[10] = {};
+  bool ev_made = false;
+};
+
+namespace mh {
+
+#define MH_HIP(ctx, call)                                                         \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      return MH_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+int ensure_frame_buffers(mh_ctx* ctx, int Q);
+int ensure_scratch(mh_ctx* ctx, size_t bytes);
+int ensure_pinned(mh_ctx* ctx, size_t bytes);
+int ensure_match_scratch(mh_ctx* ctx, int Q);
+
+}  // namespace mh

@@ -1,0 +1,199 @@
+// Ratio test + grouping of accepted matches by model in ascending query order:
+// the tail of MATCH_ANN_CPU::process
+// (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:165-176), plus the small
+// bookkeeping kernels between the steps of a device-resident frame.
+#include "steps.h"
+
+namespace mh {
+
+namespace {
+
+constexpr int GROUP_THREADS = 1024;
+constexpr int GROUP_MAX_MODELS = 8192;  // LDS histogram
+
+__device__ __forceinline__ bool accepted(int32_t idx, float d1, float d2, float ratio) {
+  // squared distances, fp32 division, exactly `ds[0]/ds[1] < Ratio` (:165)
+  return idx >= 0 && (__fdiv_rn(d1, d2) < ratio);
+}
+
+__global__ void accept_kernel(const int32_t* __restrict__ idx1, const float* __restrict__ d1,
+                              const float* __restrict__ d2, int Q, float ratio,
+                              int32_t* __restrict__ out_idx) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < Q) out_idx[q] = accepted(idx1[q], d1[q], d2[q], ratio) ? idx1[q] : -1;
+}
+
+// Single workgroup.  (a) ordered compaction of the accepted queries whose winning
+// row belongs to this shard, (b) per-model histogram + exclusive scan, (c) stable
+// placement by model, (d) m_rep: first match with the same image coordinate (the
+// key of FILTER's bestPoints map, FILTER_PROJECTION_CPU.hpp:89).
+__global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
+    const int32_t* __restrict__ idx1, const float* __restrict__ d1, const float* __restrict__ d2,
+    int Q, float ratio, const float* __restrict__ q_uv, const int32_t* __restrict__ db_model,
+    const float* __restrict__ db_xyz, int N, int32_t index_base, int n_models, int max_m,
+    int32_t* __restrict__ acc_q, int32_t* __restrict__ acc_model, int32_t* __restrict__ m_q,
+    int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
+    int32_t* __restrict__ model_off, FrameCounts* counts) {
+  __shared__ int hist[GROUP_MAX_MODELS + 1];
+  __shared__ int wave_cnt[GROUP_THREADS / 64];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int m = tid; m <= n_models; m += GROUP_THREADS) hist[m] = 0;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+
+  // (a) ordered compaction, 1024 queries per pass
+  for (int q0 = 0; q0 < Q; q0 += GROUP_THREADS) {
+    const int q = q0 + tid;
+    bool ok = false;
+    int model = 0;
+    if (q < Q) {
+      const int32_t gi = idx1[q];
+      const int32_t li = gi - index_base;
+      if (accepted(gi, d1[q], d2[q], ratio) && li >= 0 && li < N) {
+        ok = true;
+        model = db_model[li];
+      }
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = base_s;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok && pos < max_m) {
+      acc_q[pos] = q;
+      acc_model[pos] = model;
+      atomicAdd(&hist[model], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < GROUP_THREADS / 64; ++w) tot += wave_cnt[w];
+      base_s += tot;
+    }
+    __syncthreads();
+  }
+  int M = base_s;
+  if (M > max_m) M = max_m;
+
+  // (b) exclusive scan of the histogram (single thread: n_models is small)
+  if (tid == 0) {
+    int run = 0;
+    for (int m = 0; m < n_models; ++m) {
+      const int c = hist[m];
+      hist[m] = run;
+      model_off[m] = run;
+      run += c;
+    }
+    hist[n_models] = run;
+    model_off[n_models] = run;
+    counts->n_matches = M;
+  }
+  __syncthreads();
+
+  // (c) stable placement: rank among earlier accepted entries of the same model
+  for (int i = tid; i < M; i += GROUP_THREADS) {
+    const int model = acc_model[i];
+    int rank = 0;
+    for (int j = 0; j < i; ++j) rank += (acc_model[j] == model);
+    const int dst = hist[model] + rank;
+    const int q = acc_q[i];
+    const int32_t li = idx1[q] - index_base;
+    m_q[dst] = q;
+    m_model[dst] = model;
+    mh_corr c;
+    c.u = q_uv[2 * q];
+    c.v = q_uv[2 * q + 1];
+    c.x = db_xyz[3 * (size_t)li];
+    c.y = db_xyz[3 * (size_t)li + 1];
+    c.z = db_xyz[3 * (size_t)li + 2];
+    m_corr[dst] = c;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // (d) representative of each image coordinate
+  for (int i = tid; i < M; i += GROUP_THREADS) {
+    const float u = m_corr[i].u, v = m_corr[i].v;
+    int rep = i;
+    for (int j = 0; j < i; ++j)
+      if (m_corr[j].u == u && m_corr[j].v == v) {
+        rep = j;
+        break;
+      }
+    m_rep[i] = rep;
+  }
+}
+
+// m_rep for caller-provided match lists (per-step FILTER entry point).
+__global__ void rep_kernel(const mh_corr* __restrict__ corr, int M, int32_t* __restrict__ rep_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float u = corr[i].u, v = corr[i].v;
+  int rep = i;
+  for (int j = 0; j < i; ++j)
+    if (corr[j].u == u && corr[j].v == v) {
+      rep = j;
+      break;
+    }
+  rep_out[i] = rep;
+}
+
+// Per-model cluster lists -> flat table in (model, emission) order.
+__global__ void cluster_table_kernel(const int32_t* __restrict__ model_off,
+                                     const int32_t* __restrict__ cl_start,
+                                     const int32_t* __restrict__ ncl, int n_models, int max_clusters,
+                                     int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
+                                     int32_t* __restrict__ cl_count, FrameCounts* counts) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int k = 0;
+  for (int m = 0; m < n_models; ++m) {
+    const int b = model_off[m];
+    const int32_t* st = cl_start + b + m;
+    for (int c = 0; c < ncl[m]; ++c) {
+      if (k >= max_clusters) {
+        atomicOr(&counts->error, ERR_CLUSTER_CAP);
+        break;
+      }
+      cl_model[k] = m;
+      cl_begin[k] = b + st[c];
+      cl_count[k] = st[c + 1] - st[c];
+      ++k;
+    }
+  }
+  counts->n_clusters = k;
+}
+
+}  // namespace
+
+void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
+                   int32_t* out_idx, hipStream_t s) {
+  if (Q <= 0) return;
+  hipLaunchKernelGGL(accept_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, idx1, d1, d2, Q, ratio,
+                     out_idx);
+}
+
+void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
+                  const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
+                  int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
+                  int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
+                  int32_t* model_off, FrameCounts* counts, hipStream_t s) {
+  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, idx1, d1, d2, Q, ratio, q_uv,
+                     db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model, m_q,
+                     m_model, m_corr, m_rep, model_off, counts);
+}
+
+void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(rep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, corr, M, rep);
+}
+
+void launch_cluster_table(const int32_t* model_off, const int32_t* cl_start, const int32_t* ncl,
+                          int n_models, int max_clusters, int32_t* cl_model, int32_t* cl_begin,
+                          int32_t* cl_count, FrameCounts* counts, hipStream_t s) {
+  hipLaunchKernelGGL(cluster_table_kernel, dim3(1), dim3(64), 0, s, model_off, cl_start, ncl,
+                     n_models, max_clusters, cl_model, cl_begin, cl_count, counts);
+}
+
+}  // namespace mh

@@ -1,0 +1,727 @@
+// POSE: many-hypotheses RANSAC + LM refine on gfx950.
+//
+// Replaces POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::process / RANSAC
+// (moped2/libmoped/src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:76-211,264-307).
+// The reference draws 5 points, starts levmar from a random quaternion and keeps
+// the FIRST hypothesis with enough inliers (up to 600 x 200 LM iterations per
+// replica).  Here every (cluster, replica) gets one 1024-thread workgroup that
+// evaluates n_hypotheses minimal samples at once, one hypothesis per lane:
+//   sample 3 (+1) points with distinct image coordinates (:76-98)
+//   -> P3P (Grunert's quartic, built by polynomial arithmetic, fp64)
+//   -> pick the root that best reprojects the 4th point
+//   -> count inliers against the LDS-cached cluster with the reference's exact
+//      project()/testAllPoints arithmetic (:166-180)
+// then a workgroup arg-max, and one wavefront refines the winner on its inliers
+// with Levenberg-Marquardt: first on plain pixel residuals (fast convergence),
+// then on the reference's squared-pixel residuals (lmFuncQuat, :100-138) so the
+// refined pose sits at the minimiser optimizeCamera (:140-164) converges to.
+// Parity with the reference is therefore at final-pose level.
+#include "geom.h"
+
+namespace mh {
+
+DevCam make_devcam(const mh_cam& cam) {
+  DevCam d;
+  for (int i = 0; i < 4; ++i) d.K[i] = cam.K[i];
+  TM T;
+  tm_from_pose(T, cam.cam, cam.cam + 4);  // image->TM.init(cameraPose), src/moped.cpp:168-169
+  for (int i = 0; i < 9; ++i) d.Rc[i] = T.r[i];
+  for (int i = 0; i < 3; ++i) d.tc[i] = T.t[i];
+  return d;
+}
+
+namespace {
+
+constexpr int POSE_THREADS = 1024;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// ---- quartic / cubic roots (fp64) ------------------------------------------------
+// Real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 in four fixed slots
+// (NaN = no root) so every access is statically indexed (registers, no scratch).
+__device__ void solve_quartic(const double* c, double& r0, double& r1, double& r2, double& r3) {
+  const double nan = __builtin_nan("");
+  r0 = r1 = r2 = r3 = nan;
+  if (!(fabs(c[4]) > 1e-300)) return;
+  const double a = c[3] / c[4], b = c[2] / c[4], cc = c[1] / c[4], d = c[0] / c[4];
+  const double a2 = a * a;
+  const double p = b - 0.375 * a2;
+  const double q = cc - 0.5 * a * b + 0.125 * a2 * a;
+  const double r = d - 0.25 * a * cc + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+  // resolvent cubic z^3 + 2p z^2 + (p^2 - 4r) z - q^2 = 0, take its largest real root
+  const double A = 2.0 * p, B = p * p - 4.0 * r, C = -q * q;
+  const double Q = (A * A - 3.0 * B) / 9.0;
+  const double R = (2.0 * A * A * A - 9.0 * A * B + 27.0 * C) / 54.0;
+  double z;
+  if (R * R < Q * Q * Q) {
+    const double sq = sqrt(Q);
+    double ct = R / (sq * sq * sq);
+    ct = fmin(1.0, fmax(-1.0, ct));
+    const double th = acos(ct);
+    const double z0 = -2.0 * sq * cos(th / 3.0) - A / 3.0;
+    const double z1 = -2.0 * sq * cos((th + 6.283185307179586) / 3.0) - A / 3.0;
+    const double z2 = -2.0 * sq * cos((th - 6.283185307179586) / 3.0) - A / 3.0;
+    z = fmax(z0, fmax(z1, z2));
+  } else {
+    const double S = -copysign(cbrt(fabs(R) + sqrt(fmax(R * R - Q * Q * Q, 0.0))), R);
+    const double T = (S != 0.0) ? Q / S : 0.0;
+    z = S + T - A / 3.0;
+  }
+  const double shift = -0.25 * a;
+  if (z > 1e-14 * (1.0 + fabs(p))) {
+    const double s = sqrt(z);
+    const double t1 = 0.5 * (p + z - q / s), t2 = 0.5 * (p + z + q / s);
+    double disc = z - 4.0 * t1;  // y^2 + s y + t1
+    if (disc >= 0.0) {
+      const double sd = sqrt(disc);
+      r0 = 0.5 * (-s + sd) + shift;
+      r1 = 0.5 * (-s - sd) + shift;
+    }
+    disc = z - 4.0 * t2;         // y^2 - s y + t2
+    if (disc >= 0.0) {
+      const double sd = sqrt(disc);
+      r2 = 0.5 * (s + sd) + shift;
+      r3 = 0.5 * (s - sd) + shift;
+    }
+  } else {  // q ~ 0: biquadratic in y
+    const double disc = p * p - 4.0 * r;
+    if (disc >= 0.0) {
+      const double sd = sqrt(disc);
+      const double y2a = 0.5 * (-p + sd), y2b = 0.5 * (-p - sd);
+      if (y2a >= 0.0) {
+        r0 = sqrt(y2a) + shift;
+        r1 = -sqrt(y2a) + shift;
+      }
+      if (y2b >= 0.0) {
+        r2 = sqrt(y2b) + shift;
+        r3 = -sqrt(y2b) + shift;
+      }
+    }
+  }
+  // two Newton steps on the original polynomial (NaN stays NaN)
+  auto polish = [&](double x) {
+    for (int it = 0; it < 2; ++it) {
+      const double f = (((c[4] * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
+      const double df = ((4.0 * c[4] * x + 3.0 * c[3]) * x + 2.0 * c[2]) * x + c[1];
+      if (fabs(df) > 1e-300) x -= f / df;
+    }
+    return x;
+  };
+  r0 = polish(r0);
+  r1 = polish(r1);
+  r2 = polish(r2);
+  r3 = polish(r3);
+}
+
+struct Pose34 {
+  float r[9];
+  float t[3];
+};
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+__device__ __forceinline__ bool normalize3(double* a) {
+  const double n = sqrt(dot3(a, a));
+  if (!(n > 1e-12)) return false;
+  a[0] /= n;
+  a[1] /= n;
+  a[2] /= n;
+  return true;
+}
+
+// Orthonormal frame from two edge vectors (columns e1,e2,e3).
+__device__ __forceinline__ bool frame_from(const double* v12, const double* v13, double* F) {
+  double e1[3] = {v12[0], v12[1], v12[2]}, e3[3], e2[3];
+  if (!normalize3(e1)) return false;
+  cross3(e1, v13, e3);
+  if (!normalize3(e3)) return false;
+  cross3(e3, e1, e2);
+  for (int i = 0; i < 3; ++i) {
+    F[i * 3 + 0] = e1[i];
+    F[i * 3 + 1] = e2[i];
+    F[i * 3 + 2] = e3[i];
+  }
+  return true;
+}
+
+// P3P: model points X[3], unit bearings y[3] (camera frame).  Calls
+// consider(R, t) for each of the up to 4 poses (model -> camera frame).
+// Grunert's formulation: with s2 = u s1, s3 = v s1 the three law-of-cosines
+// equations reduce to u = N(v)/D(v) and the quartic
+//   N^2 - 2 cos(gamma) N D + E D^2 = 0   (lengths normalised by b = |X1 X3|).
+template <typename F>
+__device__ void p3p(const double (&X)[3][3], const double (&y)[3][3], F&& consider) {
+  double d12[3], d13[3], d23[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    d12[i] = X[1][i] - X[0][i];
+    d13[i] = X[2][i] - X[0][i];
+    d23[i] = X[2][i] - X[1][i];
+  }
+  const double a2 = dot3(d23, d23), b2 = dot3(d13, d13), c2 = dot3(d12, d12);
+  if (!(b2 > 1e-18) || !(a2 > 1e-18) || !(c2 > 1e-18)) return;
+  const double ca = dot3(y[1], y[2]), cb = dot3(y[0], y[2]), cg = dot3(y[0], y[1]);
+  const double A = a2 / b2, C = c2 / b2, k = C - A;
+  // p(v) = 1 - 2 cb v + v^2 ; N = (v^2 - 1) + k p ; D = 2 (ca v - cg) ; E = 1 - C p
+  const double n0 = -1.0 + k, n1 = -2.0 * k * cb, n2 = 1.0 + k;
+  const double d0 = -2.0 * cg, d1 = 2.0 * ca;
+  const double e0 = 1.0 - C, e1 = 2.0 * C * cb, e2 = -C;
+  const double dd0 = d0 * d0, dd1 = 2 * d0 * d1, dd2 = d1 * d1;  // D^2
+  double c[5];
+  c[0] = n0 * n0 + e0 * dd0 - 2.0 * cg * (n0 * d0);
+  c[1] = 2 * n0 * n1 + (e0 * dd1 + e1 * dd0) - 2.0 * cg * (n0 * d1 + n1 * d0);
+  c[2] = 2 * n0 * n2 + n1 * n1 + (e0 * dd2 + e1 * dd1 + e2 * dd0) - 2.0 * cg * (n1 * d1 + n2 * d0);
+  c[3] = 2 * n1 * n2 + (e1 * dd2 + e2 * dd1) - 2.0 * cg * (n2 * d1);
+  c[4] = n2 * n2 + e2 * dd2;
+  double rt[4];
+  solve_quartic(c, rt[0], rt[1], rt[2], rt[3]);
+  double Fx[9];
+  if (!frame_from(d12, d13, Fx)) return;
+  const double b = sqrt(b2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double v = rt[i];
+    if (!(v > 0.0)) continue;
+    const double pv = 1.0 - 2.0 * cb * v + v * v;
+    const double D = d0 + d1 * v;
+    if (!(pv > 1e-14) || !(fabs(D) > 1e-12)) continue;
+    const double u = (n0 + n1 * v + n2 * v * v) / D;
+    if (!(u > 0.0)) continue;
+    const double s1 = b / sqrt(pv), s2 = u * s1, s3 = v * s1;
+    double p12[3], p13[3], P0[3], Fp[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      P0[j] = s1 * y[0][j];
+      p12[j] = s2 * y[1][j] - P0[j];
+      p13[j] = s3 * y[2][j] - P0[j];
+    }
+    if (!frame_from(p12, p13, Fp)) continue;
+    double R[9], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cidx = 0; cidx < 3; ++cidx)
+        R[r * 3 + cidx] = Fp[r * 3 + 0] * Fx[cidx * 3 + 0] + Fp[r * 3 + 1] * Fx[cidx * 3 + 1] +
+                          Fp[r * 3 + 2] * Fx[cidx * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      t[r] = P0[r] - (R[r * 3 + 0] * X[0][0] + R[r * 3 + 1] * X[0][1] + R[r * 3 + 2] * X[0][2]);
+    consider(R, t);
+  }
+}
+
+// camera-frame pose (R,t) -> world pose: Rw = Rc R, tw = Rc t + tc
+__device__ __forceinline__ void to_world(const DevCam& cam, const double* R, const double* t, Pose34& o) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      o.r[r * 3 + c] = (float)((double)cam.Rc[r * 3 + 0] * R[0 * 3 + c] + (double)cam.Rc[r * 3 + 1] * R[1 * 3 + c] +
+                               (double)cam.Rc[r * 3 + 2] * R[2 * 3 + c]);
+    o.t[r] = (float)((double)cam.Rc[r * 3 + 0] * t[0] + (double)cam.Rc[r * 3 + 1] * t[1] +
+                     (double)cam.Rc[r * 3 + 2] * t[2] + (double)cam.tc[r]);
+  }
+}
+
+// rotation matrix -> quaternion (x,y,z,w), normalised
+__device__ void rot_to_quat(const float* r, float* q) {
+  const float tr = r[0] + r[4] + r[8];
+  float x, y, z, w;
+  if (tr > 0.f) {
+    const float s = sqrtf(tr + 1.f) * 2.f;
+    w = 0.25f * s;
+    x = (r[7] - r[5]) / s;
+    y = (r[2] - r[6]) / s;
+    z = (r[3] - r[1]) / s;
+  } else if (r[0] > r[4] && r[0] > r[8]) {
+    const float s = sqrtf(1.f + r[0] - r[4] - r[8]) * 2.f;
+    w = (r[7] - r[5]) / s;
+    x = 0.25f * s;
+    y = (r[1] + r[3]) / s;
+    z = (r[2] + r[6]) / s;
+  } else if (r[4] > r[8]) {
+    const float s = sqrtf(1.f + r[4] - r[0] - r[8]) * 2.f;
+    w = (r[2] - r[6]) / s;
+    x = (r[1] + r[3]) / s;
+    y = 0.25f * s;
+    z = (r[5] + r[7]) / s;
+  } else {
+    const float s = sqrtf(1.f + r[8] - r[0] - r[4]) * 2.f;
+    w = (r[3] - r[1]) / s;
+    x = (r[2] + r[6]) / s;
+    y = (r[5] + r[7]) / s;
+    z = 0.25f * s;
+  }
+  const float n = 1.f / sqrtf(x * x + y * y + z * z + w * w);
+  q[0] = x * n;
+  q[1] = y * n;
+  q[2] = z * n;
+  q[3] = w * n;
+}
+
+// ---- LM refine, one wavefront ----------------------------------------------------
+// 6-DoF local update (omega, dt): R <- exp(omega) R, t <- t + dt.
+// mode 0: residual (du, dv); mode 1: residual (du^2, dv^2) as lmFuncQuat.
+struct Accum {
+  float H[21];  // upper triangle of J^T J
+  float g[6];   // J^T r
+  float cost;
+};
+
+__device__ __forceinline__ void residual_point(const float* R, const float* t, const DevCam& cam,
+                                               const float* p /*u,v,x,y,z*/, int mode, float* r2,
+                                               float J[2][6], bool want_j) {
+  const float X = p[2], Y = p[3], Z = p[4];
+  const float yx = R[0] * X + R[1] * Y + R[2] * Z;  // rotated model point
+  const float yy = R[3] * X + R[4] * Y + R[5] * Z;
+  const float yz = R[6] * X + R[7] * Y + R[8] * Z;
+  const float wx = yx + t[0] - cam.tc[0], wy = yy + t[1] - cam.tc[1], wz = yz + t[2] - cam.tc[2];
+  const float cx = wx * cam.Rc[0] + wy * cam.Rc[3] + wz * cam.Rc[6];
+  const float cy = wx * cam.Rc[1] + wy * cam.Rc[4] + wz * cam.Rc[7];
+  const float cz = wx * cam.Rc[2] + wy * cam.Rc[5] + wz * cam.Rc[8];
+  if (cz < 0.f || !(fabsf(cz) > 1e-9f)) {  // behind the camera: lmFuncQuat's penalty, no gradient
+    r2[0] = -cz + 10.f;
+    r2[1] = -cz + 10.f;
+    if (want_j)
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 6; ++b) J[a][b] = 0.f;
+    return;
+  }
+  const float iz = 1.f / cz;
+  const float du = cx * iz * cam.K[0] + cam.K[2] - p[0];
+  const float dv = cy * iz * cam.K[1] + cam.K[3] - p[1];
+  if (want_j) {
+    // d(u,v)/d(c) rows
+    const float ju[3] = {cam.K[0] * iz, 0.f, -cam.K[0] * cx * iz * iz};
+    const float jv[3] = {0.f, cam.K[1] * iz, -cam.K[1] * cy * iz * iz};
+    // dc/dw = Rc^T : row i of Rc^T is column i of Rc
+    float gu[3], gv[3];  // gradients w.r.t. world point
+    for (int k = 0; k < 3; ++k) {
+      gu[k] = ju[0] * cam.Rc[k * 3 + 0] + ju[1] * cam.Rc[k * 3 + 1] + ju[2] * cam.Rc[k * 3 + 2];
+      gv[k] = jv[0] * cam.Rc[k * 3 + 0] + jv[1] * cam.Rc[k * 3 + 1] + jv[2] * cam.Rc[k * 3 + 2];
+    }
+    // dw/domega = -[y]_x  ->  g . (omega x y) = omega . (y x g)
+    J[0][0] = yy * gu[2] - yz * gu[1];
+    J[0][1] = yz * gu[0] - yx * gu[2];
+    J[0][2] = yx * gu[1] - yy * gu[0];
+    J[1][0] = yy * gv[2] - yz * gv[1];
+    J[1][1] = yz * gv[0] - yx * gv[2];
+    J[1][2] = yx * gv[1] - yy * gv[0];
+    for (int k = 0; k < 3; ++k) {
+      J[0][3 + k] = gu[k];
+      J[1][3 + k] = gv[k];
+    }
+  }
+  if (mode == 0) {
+    r2[0] = du;
+    r2[1] = dv;
+  } else {
+    r2[0] = du * du;
+    r2[1] = dv * dv;
+    if (want_j)
+      for (int b = 0; b < 6; ++b) {
+        J[0][b] *= 2.f * du;
+        J[1][b] *= 2.f * dv;
+      }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Sum of squared residuals over the inlier list at pose (R,t); all 64 lanes return it.
+__device__ float lm_cost(const float* R, const float* t, const DevCam& cam, const float* pts,
+                         const int* list, int n, int mode, int lane) {
+  float c = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    float r2[2], J[2][6];
+    residual_point(R, t, cam, pts + 5 * list[i], mode, r2, J, false);
+    c += r2[0] * r2[0] + r2[1] * r2[1];
+  }
+  return wave_sum(c);
+}
+
+// exp(omega) R
+__device__ void rotate_left(const float* w, const float* R, float* out) {
+  const float th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const float th = sqrtf(th2);
+  float a, b;  // exp = I + a [w]x + b [w]x^2
+  if (th < 1e-4f) {
+    a = 1.f - th2 / 6.f;
+    b = 0.5f - th2 / 24.f;
+  } else {
+    a = sinf(th) / th;
+    b = (1.f - cosf(th)) / th2;
+  }
+  const float K[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+  float K2[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) K2[r * 3 + c] = K[r * 3] * K[c] + K[r * 3 + 1] * K[3 + c] + K[r * 3 + 2] * K[6 + c];
+  float E[9];
+  for (int i = 0; i < 9; ++i) E[i] = a * K[i] + b * K2[i];
+  E[0] += 1.f;
+  E[4] += 1.f;
+  E[8] += 1.f;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out[r * 3 + c] = E[r * 3] * R[c] + E[r * 3 + 1] * R[3 + c] + E[r * 3 + 2] * R[6 + c];
+}
+
+// Solve (H + mu I) x = -g for symmetric positive H (6x6, upper triangle packed) by Cholesky.
+__device__ bool solve6(const float* Hp, const float* g, float mu, float* x) {
+  float A[6][6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      A[i][j] = Hp[k];
+      A[j][i] = Hp[k];
+      ++k;
+    }
+  for (int i = 0; i < 6; ++i) A[i][i] += mu;
+  float Lm[6][6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      float s = A[i][j];
+      for (int m = 0; m < j; ++m) s -= Lm[i][m] * Lm[j][m];
+      if (i == j) {
+        if (!(s > 0.f)) return false;
+        Lm[i][i] = sqrtf(s);
+      } else {
+        Lm[i][j] = s / Lm[j][j];
+      }
+    }
+  float y[6];
+  for (int i = 0; i < 6; ++i) {
+    float s = -g[i];
+    for (int m = 0; m < i; ++m) s -= Lm[i][m] * y[m];
+    y[i] = s / Lm[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    float s = y[i];
+    for (int m = i + 1; m < 6; ++m) s -= Lm[m][i] * x[m];
+    x[i] = s / Lm[i][i];
+  }
+  return true;
+}
+
+// Runs on one full wavefront; pose in/out is wave-uniform.
+__device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* pts, const int* list,
+                           int n, int mode, int iters, int lane) {
+  float cost = lm_cost(R, t, cam, pts, list, n, mode, lane);
+  float mu = -1.f, nu = 2.f;
+  for (int it = 0; it < iters; ++it) {
+    Accum acc;
+    for (int i = 0; i < 21; ++i) acc.H[i] = 0.f;
+    for (int i = 0; i < 6; ++i) acc.g[i] = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      float r2[2], J[2][6];
+      residual_point(R, t, cam, pts + 5 * list[i], mode, r2, J, true);
+      int k = 0;
+      for (int a = 0; a < 6; ++a) {
+        for (int b = a; b < 6; ++b) acc.H[k++] += J[0][a] * J[0][b] + J[1][a] * J[1][b];
+        acc.g[a] += J[0][a] * r2[0] + J[1][a] * r2[1];
+      }
+    }
+    for (int i = 0; i < 21; ++i) acc.H[i] = wave_sum(acc.H[i]);
+    for (int i = 0; i < 6; ++i) acc.g[i] = wave_sum(acc.g[i]);
+    if (mu < 0.f) {  // tau * max diagonal (lm_core.c:672-676)
+      float mx = 0.f;
+      const int di[6] = {0, 6, 11, 15, 18, 20};
+      for (int i = 0; i < 6; ++i) mx = fmaxf(mx, acc.H[di[i]]);
+      mu = 1e-3f * mx;
+    }
+    float ginf = 0.f;
+    for (int i = 0; i < 6; ++i) ginf = fmaxf(ginf, fabsf(acc.g[i]));
+    if (!(ginf > 1e-12f)) break;
+    bool accepted = false;
+    for (int attempt = 0; attempt < 8 && !accepted; ++attempt) {
+      float dx[6];
+      if (solve6(acc.H, acc.g, mu, dx)) {
+        float Rn[9], tn[3];
+        rotate_left(dx, R, Rn);
+        for (int i = 0; i < 3; ++i) tn[i] = t[i] + dx[3 + i];
+        const float c2 = lm_cost(Rn, tn, cam, pts, list, n, mode, lane);
+        float dL = 0.f;
+        for (int i = 0; i < 6; ++i) dL += dx[i] * (mu * dx[i] - acc.g[i]);
+        const float dF = cost - c2;
+        if (dF > 0.f && dL > 0.f) {
+          for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+          for (int i = 0; i < 3; ++i) t[i] = tn[i];
+          cost = c2;
+          float tt = 2.f * dF / dL - 1.f;
+          tt = 1.f - tt * tt * tt;
+          mu *= fmaxf(tt, 1.f / 3.f);
+          nu = 2.f;
+          accepted = true;
+          break;
+        }
+      }
+      mu *= nu;
+      nu *= 2.f;
+    }
+    if (!accepted) break;
+  }
+  return cost;
+}
+
+struct PoseLds {
+  float pts[POSE_MAX_PTS * 5];      // u,v,x,y,z of the cluster
+  int list[POSE_MAX_PTS];           // inlier list of the winner
+  unsigned long long wave_best[POSE_THREADS / 64];
+  float best_pose[12];
+  int n_distinct;
+  int n_inl;
+};
+
+__global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
+    const mh_corr* __restrict__ corr, const int32_t* __restrict__ members,
+    const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
+    const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
+    mh_pose_params prm, uint64_t seed, const int32_t* __restrict__ obj_base_dev, int max_objects,
+    int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
+    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
+    FrameCounts* counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PoseLds& L = *reinterpret_cast<PoseLds*>(smem);
+  const int R_ = prm.max_objects_per_cluster;
+  const int cluster = blockIdx.x / R_;
+  const int replica = blockIdx.x % R_;
+  const int ncl = *n_clusters_dev;
+  if (cluster >= ncl) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = (obj_base_dev ? *obj_base_dev : 0) + cluster * R_ + replica;
+  if (slot >= max_objects) {
+    if (tid == 0) atomicOr(&counts->error, ERR_OBJECT_CAP);
+    return;
+  }
+  int k = cl_count[cluster];
+  const int begin = cl_begin[cluster];
+  if (k > POSE_MAX_PTS) {
+    if (tid == 0) atomicOr(&counts->error, ERR_POSE_CAP);
+    k = POSE_MAX_PTS;
+  }
+  for (int i = tid; i < k; i += POSE_THREADS) {
+    const mh_corr c = corr[members[begin + i]];
+    float* p = L.pts + 5 * i;
+    p[0] = c.u;
+    p[1] = c.v;
+    p[2] = c.x;
+    p[3] = c.y;
+    p[4] = c.z;
+  }
+  if (tid == 0) {
+    L.n_distinct = 0;
+    L.n_inl = 0;
+  }
+  __syncthreads();
+  // randSample needs n_pts_align correspondences with distinct image coordinates (:76-98)
+  {
+    int mine = 0;
+    for (int i = tid; i < k; i += POSE_THREADS) {
+      bool first = true;
+      for (int j = 0; j < i; ++j)
+        if (L.pts[5 * j] == L.pts[5 * i] && L.pts[5 * j + 1] == L.pts[5 * i + 1]) {
+          first = false;
+          break;
+        }
+      mine += first;
+    }
+    if (mine) atomicAdd(&L.n_distinct, mine);
+  }
+  __syncthreads();
+  const bool enough = L.n_distinct >= prm.n_pts_align && L.n_distinct >= 4;
+  if (tid == 0) {
+    obj_valid[slot] = 0;
+    obj_cluster[slot] = cluster;
+    obj_model[slot] = cl_model[cluster];
+  }
+  if (!enough) return;
+
+  // ---- hypotheses: one per lane ------------------------------------------------------
+  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : POSE_THREADS;
+  unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
+  Pose34 best_pose;
+  for (int h = tid; h < H; h += POSE_THREADS) {
+    uint64_t st = seed ^ ((uint64_t)(cluster + 1) << 40) ^ ((uint64_t)(replica + 1) << 32) ^ (uint64_t)h;
+    splitmix64(st);
+    // 4 correspondences with pairwise distinct image coordinates (:76-98)
+    int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+    auto same_uv = [&](int a, int b) {
+      return L.pts[5 * a] == L.pts[5 * b] && L.pts[5 * a + 1] == L.pts[5 * b + 1];
+    };
+    i0 = (int)(splitmix64(st) % (uint64_t)k);
+    for (int tries = 0; tries < 16 && i1 < 0; ++tries) {
+      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      if (!same_uv(c, i0)) i1 = c;
+    }
+    if (i1 < 0) continue;
+    for (int tries = 0; tries < 16 && i2 < 0; ++tries) {
+      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      if (!same_uv(c, i0) && !same_uv(c, i1)) i2 = c;
+    }
+    if (i2 < 0) continue;
+    for (int tries = 0; tries < 16 && i3 < 0; ++tries) {
+      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      if (!same_uv(c, i0) && !same_uv(c, i1) && !same_uv(c, i2)) i3 = c;
+    }
+    if (i3 < 0) continue;
+    double X[3][3], y[3][3];
+    auto load = [&](int s, int pi) {
+      const float* p = L.pts + 5 * pi;
+      X[s][0] = p[2];
+      X[s][1] = p[3];
+      X[s][2] = p[4];
+      y[s][0] = ((double)p[0] - cam.K[2]) / cam.K[0];
+      y[s][1] = ((double)p[1] - cam.K[3]) / cam.K[1];
+      y[s][2] = 1.0;
+      normalize3(y[s]);
+    };
+    load(0, i0);
+    load(1, i1);
+    load(2, i2);
+    // disambiguate the P3P roots with the 4th point
+    Pose34 cand;
+    float best4 = __builtin_inff();
+    bool have = false;
+    const float* p4 = L.pts + 5 * i3;
+    p3p(X, y, [&](const double* Rc_, const double* tc_) {
+      Pose34 w;
+      to_world(cam, Rc_, tc_, w);
+      const float e = reproj_err2(w.r, w.t, cam, p4[2], p4[3], p4[4], p4[0], p4[1]);
+      if (e < best4) {
+        best4 = e;
+        cand = w;
+        have = true;
+      }
+    });
+    if (!have) continue;
+    int cnt = 0;
+    for (int i = 0; i < k; ++i) {
+      const float* p = L.pts + 5 * i;
+      cnt += reproj_err2(cand.r, cand.t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
+    }
+    const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)h);
+    if (key > best_key) {
+      best_key = key;
+      best_pose = cand;
+    }
+  }
+  // ---- workgroup arg-max ---------------------------------------------------------------
+  unsigned long long wkey = best_key;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(wkey, off);
+    wkey = o > wkey ? o : wkey;
+  }
+  if (lane == 0) L.wave_best[wave] = wkey;
+  __syncthreads();
+  unsigned long long gkey = 0ull;
+  for (int w = 0; w < POSE_THREADS / 64; ++w) gkey = L.wave_best[w] > gkey ? L.wave_best[w] : gkey;
+  const int best_cnt = (int)(gkey >> 32);
+  if (best_cnt <= prm.min_n_pts_object) return;  // needs MORE than MinNPtsObject inliers (:204)
+  if (best_key == gkey) {                        // unique: the key embeds the hypothesis id
+    for (int i = 0; i < 9; ++i) L.best_pose[i] = best_pose.r[i];
+    for (int i = 0; i < 3; ++i) L.best_pose[9 + i] = best_pose.t[i];
+  }
+  __syncthreads();
+
+  // ---- refine on the winner's inliers, wavefront 0 ----------------------------------------
+  if (wave != 0) return;
+  float R[9], t[3];
+  for (int i = 0; i < 9; ++i) R[i] = L.best_pose[i];
+  for (int i = 0; i < 3; ++i) t[i] = L.best_pose[9 + i];
+  int n_inl = 0;
+  for (int base = 0; base < k; base += 64) {
+    const int i = base + lane;
+    bool in = false;
+    if (i < k) {
+      const float* p = L.pts + 5 * i;
+      in = reproj_err2(R, t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
+    }
+    const unsigned long long m = __ballot(in);
+    if (in) L.list[n_inl + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    n_inl += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  lm_refine(R, t, cam, L.pts, L.list, n_inl, 0, prm.lm_iters_l2, lane);
+  const float err = lm_refine(R, t, cam, L.pts, L.list, n_inl, 1, prm.lm_iters_l4, lane);
+  if (lane == 0) {
+    float q[4];
+    rot_to_quat(R, q);
+    float* o = obj_pose + 7 * (size_t)slot;
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+    o[3] = q[3];
+    o[4] = t[0];
+    o[5] = t[1];
+    o[6] = t[2];
+    obj_ninl[slot] = n_inl;
+    obj_err[slot] = err;
+    obj_valid[slot] = 1;
+  }
+}
+
+__global__ void project_test_kernel(const float* __restrict__ pose7, const mh_corr* __restrict__ corr,
+                                    int n, DevCam cam, float thr, uint8_t* __restrict__ inlier,
+                                    float* __restrict__ err2, int32_t* __restrict__ n_inliers) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  TM T;
+  tm_from_pose(T, pose7, pose7 + 4);
+  bool in = false;
+  if (i < n) {
+    const mh_corr c = corr[i];
+    const float e = reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v);
+    in = e < thr;
+    if (inlier) inlier[i] = in;
+    if (err2) err2[i] = e;
+  }
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inliers, __popcll(m));
+}
+
+}  // namespace
+
+void launch_pose(const mh_corr* corr, const int32_t* members, const int32_t* cl_model,
+                 const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
+                 int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
+                 const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
+                 int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
+                 FrameCounts* counts, hipStream_t s) {
+  if (max_clusters <= 0) return;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pose_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds));
+    once = true;
+  }
+  const int R_ = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
+  mh_pose_params p = prm;
+  p.max_objects_per_cluster = R_;
+  hipLaunchKernelGGL(pose_kernel, dim3(max_clusters * R_), dim3(POSE_THREADS), sizeof(PoseLds), s,
+                     corr, members, cl_model, cl_begin, cl_count, n_clusters_dev, cam, p, seed,
+                     obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err, obj_cluster,
+                     obj_valid, counts);
+}
+
+void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
+                         float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
+                         hipStream_t s) {
+  hipMemsetAsync(n_inliers, 0, sizeof(int32_t), s);
+  if (n <= 0) return;
+  hipLaunchKernelGGL(project_test_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pose7, corr, n,
+                     cam, thr, inlier, err2, n_inliers);
+}
+
+}  // namespace mh

@@ -1,0 +1,94 @@
+// Kernels behind the CLUSTER / POSE / FILTER steps and the device-resident frame.
+#pragma once
+#include "common.h"
+
+namespace mh {
+
+constexpr int MS_CAP = 2048;         // points per mean-shift problem (LDS resident)
+constexpr int POSE_MAX_PTS = 2048;   // correspondences of one cluster cached in LDS
+
+enum : int32_t {
+  ERR_MS_CAP = 1,        // a model had more than MS_CAP matches (truncated)
+  ERR_CLUSTER_CAP = 2,   // more clusters than reserved
+  ERR_OBJECT_CAP = 4,    // more objects than reserved
+  ERR_POSE_CAP = 8,      // a cluster had more than POSE_MAX_PTS points (truncated)
+};
+
+// ---- group -------------------------------------------------------------------
+// Ratio test + grouping by model in ascending query order (MATCH_ANN_CPU.hpp:165-176).
+// Rows outside [index_base, index_base+N) belong to another shard and are dropped.
+void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
+                  const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
+                  int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
+                  int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
+                  int32_t* model_off, FrameCounts* counts, hipStream_t s);
+void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
+void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
+                   int32_t* out_idx, hipStream_t s);
+
+// ---- mean shift ----------------------------------------------------------------
+void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
+                             float radius, float merge, int min_pts, int max_iter, int32_t* members,
+                             int32_t* cl_start, int32_t* ncl, FrameCounts* counts, hipStream_t s);
+void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,
+                             int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
+                             int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s);
+// Per-model cluster lists -> flat cluster table in (model, emission) order.
+void launch_cluster_table(const int32_t* model_off, const int32_t* cl_start, const int32_t* ncl,
+                          int n_models, int max_clusters, int32_t* cl_model, int32_t* cl_begin,
+                          int32_t* cl_count, FrameCounts* counts, hipStream_t s);
+
+// ---- pose ----------------------------------------------------------------------
+struct DevCam {
+  float K[4];
+  float Rc[9];  // camera rotation (row-major), TransformMatrix::init of cameraPose
+  float tc[3];
+};
+DevCam make_devcam(const mh_cam& cam);
+
+// One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
+// n_clusters_dev: device count (grid is launched for max_clusters).
+void launch_pose(const mh_corr* corr, const int32_t* members, const int32_t* cl_model,
+                 const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
+                 int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
+                 const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
+                 int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
+                 FrameCounts* counts, hipStream_t s);
+void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
+                         float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
+                         hipStream_t s);
+
+// ---- filter ---------------------------------------------------------------------
+struct FilterBuffers {
+  // inputs
+  const mh_corr* corr;        // matches in (model, query) order
+  const int32_t* m_rep;       // first match with the same (u,v)
+  const int32_t* model_off;
+  int n_models;
+  int max_m;
+  // object list (slots [0, n_slots), valid flag)
+  int32_t* obj_model;
+  float* obj_pose;
+  float* obj_score;
+  float* obj_score_raw;       // score of every slot before the erase/compaction
+  int32_t* obj_valid;
+  int32_t* obj_npts;
+  int max_objects;
+  // scratch
+  unsigned long long* best;   // [max_m] packed (score bits, ~object)
+  int32_t* obj_clsize;        // [2*max_objects]: cluster size, then old slot of each kept object
+  // outputs: compacted objects + cluster table 2
+  int32_t* new_members;       // [max_objects-bounded] CSR members (sorted match index)
+  int32_t* cl_model;
+  int32_t* cl_begin;
+  int32_t* cl_count;
+  int max_clusters;
+};
+// n_slots_dev: number of object slots in use; after the call the kept objects are
+// compacted to slots [0, kept) in list order, *n_slots_dev = kept, and the cluster
+// table holds their rewritten clusters.
+void launch_filter(const FilterBuffers& fb, const DevCam& cam, int min_points,
+                   float feature_distance, float min_score, int32_t* n_slots_dev,
+                   int32_t* n_clusters_dev, FrameCounts* counts, hipStream_t s);
+
+}  // namespace mh

@@ -367,6 +367,10 @@ static inline float dot_chain(const float* a, const float* b, int dim) {
   return s;
 }
 
+void orc_row_norms(const float* desc, int n, int dim, float* out) {
+  for (int i = 0; i < n; i++) out[i] = dot_chain(desc + (size_t)i * dim, desc + (size_t)i * dim, dim);
+}
+
 void orc_match_2nn(const float* db, int N, const float* q, int Q, int dim, int32_t* idx1,
                    float* d1, float* d2, int n_threads) {
   std::vector<float> nd(N);

@@ -36,6 +36,8 @@ void orc_normalize(float* desc, int n, int dim);
  *   dist(q,d) = max(0, fmaf(-2, dot(q,d), dot(q,q) + dot(d,d)))
  * ties on distance -> lower DB index.  idx1[i] = -1 when N == 0; d2 = +inf
  * when N < 2.  n_threads <= 0 -> all OpenMP threads. */
+/* dot(d,d) chain of every row: the norm term of the canonical distance. */
+void orc_row_norms(const float* desc, int n, int dim, float* out);
 void orc_match_2nn(const float* db, int N, const float* q, int Q, int dim,
                    int32_t* idx1, float* d1, float* d2, int n_threads);
 

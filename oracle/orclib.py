@@ -46,6 +46,7 @@ def lib():
             build_oracle()
         L = C.CDLL(path)
         L.orc_normalize.argtypes = [_f32p, C.c_int, C.c_int]
+        L.orc_row_norms.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
         L.orc_match_2nn.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _i32p, _f32p, _f32p, C.c_int]
         L.orc_match_accept.argtypes = [_i32p, _f32p, _f32p, C.c_int, C.c_float, _i32p, C.c_int, _i32p, _i32p]
         L.orc_match_accept.restype = C.c_int
@@ -79,6 +80,13 @@ def normalize(desc):
     d = _c(desc, np.float32).copy()
     lib().orc_normalize(d, d.shape[0], d.shape[1])
     return d
+
+
+def row_norms(desc):
+    d = _c(desc, np.float32)
+    out = np.empty(d.shape[0], np.float32)
+    lib().orc_row_norms(d.reshape(-1), d.shape[0], d.shape[1], out)
+    return out
 
 
 def match_2nn(db, q, n_threads=0):
