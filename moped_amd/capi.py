@@ -80,6 +80,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # When PyTorch-ROCm shares the process (bench.py, multi-GPU tests) its bundled
+    # HIP/HSA runtime must be the one in the process: two HSA runtimes cannot both
+    # own the GPU.  Importing torch first makes libmoped_hip.so bind to that copy
+    # (same SONAME libamdhip64.so.7); without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch absent: plain ROCm runtime
+        pass
     if not os.path.exists(LIB_PATH):
         raise MhError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(LIB_PATH)

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NORM_ROWS) void normalize_kernel(float* __restrict_
   if (NORMALIZE) {
     float s = 0.f;
     for (int x = 0; x < DIM; ++x) s = __fadd_rn(s, __fmul_rn(mine[x], mine[x]));
-    const float inv = (float)(1.0 / (double)__fsqrt_rn(s));
+    const float inv = (float)(1.0 / (double)sqrtf(s));
     for (int x = 0; x < DIM; ++x) mine[x] = __fmul_rn(mine[x], inv);
   }
   const float nn = dot_chain_lds(mine, mine);
