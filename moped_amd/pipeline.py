@@ -1,0 +1,144 @@
+"""Frame driver over the C ABI: device-resident MATCH -> CLUSTER -> POSE -> FILTER ->
+POSE2 -> FILTER2, one mh_ctx per frame in flight, optional model sharding over
+ranks with the two small exchanges of SURVEY.md 8(e).
+
+PyTorch is used for what the C ABI does not own: device buffers for the frame
+inputs, HIP streams, and torch.distributed (RCCL) for the all-gathers.  All
+computation happens inside libmoped_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+class ShardedDB:
+    """This rank's slice of the model database, models assigned in contiguous
+    blocks: rank r owns models [r*n/W, (r+1)*n/W)."""
+
+    def __init__(self, desc, xyz, model_of, n_models, rank=0, world=1):
+        model_of = np.asarray(model_of, np.int32)
+        lo_m = (rank * n_models) // world
+        hi_m = ((rank + 1) * n_models) // world
+        rows = np.nonzero((model_of >= lo_m) & (model_of < hi_m))[0]
+        # rows of a model are contiguous in the flattened DB (MATCH_ANN_CPU::Update order)
+        self.row_lo = int(rows[0]) if len(rows) else 0
+        self.row_hi = int(rows[-1]) + 1 if len(rows) else 0
+        self.desc = np.ascontiguousarray(desc[self.row_lo:self.row_hi], np.float32)
+        self.xyz = np.ascontiguousarray(xyz[self.row_lo:self.row_hi], np.float32)
+        self.model_of = np.ascontiguousarray(model_of[self.row_lo:self.row_hi])
+        self.n_models = n_models          # model ids stay global
+        self.rank, self.world = rank, world
+
+
+class FramePipeline:
+    """`depth` frames in flight on one GPU; each has its own mh_ctx + HIP stream so
+    the latency-bound CLUSTER/POSE/FILTER kernels of one frame overlap the MATCH
+    kernel of the next."""
+
+    def __init__(self, device: int, db: ShardedDB, depth: int = 1, max_queries: int = 4096,
+                 params: capi.mh_frame_params | None = None, K=None, cam=None, group=None):
+        from . import synth
+        self.dev = torch.device(f"cuda:{device}")
+        torch.cuda.set_device(self.dev)
+        self.db = db
+        self.params = params or capi.default_frame_params()
+        self.K = synth.K_DEFAULT if K is None else K
+        self.cam = synth.CAM_IDENTITY if cam is None else cam
+        self.group = group
+        self.world = db.world
+        self.ctxs, self.streams = [], []
+        normalized = None
+        for i in range(depth):
+            c = capi.Context(device)
+            if normalized is None:
+                # model descriptors are L2-normalised once, like Update() (MATCH_ANN_CPU.hpp:94)
+                normalized = c.normalize(db.desc) if db.desc.shape[0] else db.desc
+            s = torch.cuda.Stream(device=self.dev)
+            c.set_stream(s.cuda_stream)
+            c.db_upload(normalized, db.model_of, db.xyz, db.n_models, index_base=db.row_lo)
+            c.reserve(max_queries)
+            self.ctxs.append(c)
+            self.streams.append(s)
+        self.depth = depth
+        self._gather = [None] * depth
+        self._res_gather = [None] * depth
+
+    # ---- single frame in slot i ------------------------------------------------------
+    def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1):
+        """q_desc [Q,128] float32 (normalised in place), q_uv [Q,2]; both on this GPU.
+        Returns immediately; work is on the slot's stream."""
+        c, s = self.ctxs[slot], self.streams[slot]
+        Q = q_desc.shape[0]
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        if self.world == 1:
+            c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
+            return
+        import torch.distributed as dist
+        with torch.cuda.stream(s):
+            pi, p1, p2 = c.frame_enqueue_match_local(q_desc.data_ptr(), Q)
+            # exchange 1: per-query local (idx1, d1, d2) of every shard -> [W][Q]
+            buf = self._gather[slot]
+            if buf is None or buf.shape[2] != Q:
+                buf = torch.empty((3, self.world, Q), dtype=torch.int32, device=self.dev)
+                self._gather[slot] = buf
+            local = torch.empty((3, Q), dtype=torch.int32, device=self.dev)
+            for k, p in enumerate((pi, p1, p2)):
+                src = _wrap_int32(p, Q, self.dev)
+                local[k].copy_(src)
+            # one fused all-gather: [W][3][Q] then viewed per field
+            gathered = torch.empty((self.world, 3, Q), dtype=torch.int32, device=self.dev)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            buf.copy_(gathered.permute(1, 0, 2))
+            c.frame_enqueue_rest(q_uv.data_ptr(), Q, buf[0].data_ptr(), buf[1].data_ptr(),
+                                 buf[2].data_ptr(), self.world, self.K, self.cam, self.params, seed)
+
+    def fetch(self, slot: int):
+        """Objects of the frame in `slot` (model ids global), counts[4]."""
+        return self.ctxs[slot].frame_fetch()
+
+    def gather_objects(self, slot: int):
+        """Exchange 2: every rank's result block -> all ranks; returns the merged
+        object array (rank order = model order)."""
+        import torch.distributed as dist
+        c, s = self.ctxs[slot], self.streams[slot]
+        ptr, nbytes = c.frame_result_dev()
+        with torch.cuda.stream(s):
+            mine = _wrap_uint8(ptr, nbytes, self.dev)
+            out = torch.empty((self.world, nbytes), dtype=torch.uint8, device=self.dev)
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        s.synchronize()
+        host = out.cpu().numpy()
+        objs = []
+        for r in range(self.world):
+            n = int(host[r, :4].view(np.int32)[0])
+            blk = host[r, 16:16 + n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE)
+            objs.append(blk.copy())
+        return np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+
+class _DevMem:
+    """__cuda_array_interface__ view over memory owned by the HIP library."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def _wrap_int32(ptr, n, dev):
+    return torch.as_tensor(_DevMem(ptr, (n,), "<i4"), device=dev)
+
+
+def _wrap_uint8(ptr, n, dev):
+    return torch.as_tensor(_DevMem(ptr, (n,), "|u1"), device=dev)

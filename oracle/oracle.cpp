@@ -717,4 +717,136 @@ int orc_filter(const float* uv, const float* xyz, const int32_t* model_off, int 
   return kept;
 }
 
+
+// ---------------------------------------------------------------------------
+// Whole frame after the nearest-neighbour search: the loop of
+// MopedPimpl::processImages (src/moped.cpp:184-191) over
+//   MATCH tail (ratio + scatter) -> CLUSTER -> POSE -> FILTER -> POSE2 -> FILTER2
+// with the reference's constants (config.hpp:83-120), single image.
+// OpenMP over models (CLUSTER, :186) and over (model, cluster, replica) tasks
+// (POSE, :282) as the reference does; rand() is shared like there.
+// Returns the number of final objects; obj_model/obj_pose/obj_score (capacity
+// max_obj).  counts[4] = matches, clusters, objects after POSE, after FILTER.
+// ---------------------------------------------------------------------------
+int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, const float* d2, int Q,
+                   float ratio, const int32_t* model_of, const float* db_xyz, int n_models,
+                   const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
+                   int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
+                   int32_t* counts) {
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+  n_threads = 1;
+#endif
+  std::vector<int32_t> out_q(Q > 0 ? Q : 1), model_off(n_models + 1);
+  const int M = orc_match_accept(idx1, d1, d2, Q, ratio, model_of, n_models, &out_q[0], &model_off[0]);
+  std::vector<float> uv(2 * (size_t)std::max(M, 1)), xyz(3 * (size_t)std::max(M, 1));
+  for (int i = 0; i < M; i++) {
+    const int q = out_q[i];
+    uv[2 * i] = q_uv[2 * q];
+    uv[2 * i + 1] = q_uv[2 * q + 1];
+    const int r = idx1[q];
+    xyz[3 * i] = db_xyz[3 * (size_t)r];
+    xyz[3 * i + 1] = db_xyz[3 * (size_t)r + 1];
+    xyz[3 * i + 2] = db_xyz[3 * (size_t)r + 2];
+  }
+  // CLUSTER
+  std::vector<std::vector<std::vector<int> > > clusters(n_models);
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+  for (int m = 0; m < n_models; m++) {
+    const int b = model_off[m], n = model_off[m + 1] - b;
+    if (n == 0) continue;
+    std::vector<int32_t> members(n), off(n + 2);
+    const int k = orc_meanshift(&uv[2 * (size_t)b], n, 2, fp->ms_radius, fp->ms_merge, fp->ms_min_pts,
+                                fp->ms_max_iter, &members[0], &off[0], NULL);
+    for (int c = 0; c < k; c++)
+      clusters[m].push_back(std::vector<int>(members.begin() + off[c], members.begin() + off[c + 1]));
+  }
+  int ncl = 0;
+  for (int m = 0; m < n_models; m++) ncl += (int)clusters[m].size();
+  // POSE / POSE2 share this
+  struct Obj {
+    int model;
+    float pose[7];
+  };
+  std::vector<Obj> objects;
+  auto run_pose = [&](const orc_pose_params& pp) {
+    std::vector<std::pair<int, int> > tasks;
+    for (int m = 0; m < n_models; m++)
+      for (size_t c = 0; c < clusters[m].size(); c++)
+        for (int r = 0; r < pp.max_objects_per_cluster; r++) tasks.push_back(std::make_pair(m, (int)c));
+    std::vector<Obj> found(tasks.size());
+    std::vector<char> ok(tasks.size(), 0);
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1)
+    for (int t = 0; t < (int)tasks.size(); t++) {
+      const int m = tasks[t].first;
+      const std::vector<int>& cl = clusters[m][tasks[t].second];
+      std::vector<float> cuv(2 * cl.size()), cxyz(3 * cl.size());
+      for (size_t i = 0; i < cl.size(); i++) {
+        const int g = model_off[m] + cl[i];
+        cuv[2 * i] = uv[2 * g];
+        cuv[2 * i + 1] = uv[2 * g + 1];
+        cxyz[3 * i] = xyz[3 * g];
+        cxyz[3 * i + 1] = xyz[3 * g + 1];
+        cxyz[3 * i + 2] = xyz[3 * g + 2];
+      }
+      found[t].model = m;
+      ok[t] = (char)orc_ransac(&cuv[0], &cxyz[0], (int)cl.size(), K, cam, &pp, found[t].pose);
+    }
+    for (size_t t = 0; t < tasks.size(); t++)
+      if (ok[t]) objects.push_back(found[t]);  // task order (the 1-thread order of :294-303)
+  };
+  auto run_filter = [&](int min_points, float fdist, float min_score, std::vector<float>& score_out) {
+    const int n_obj = (int)objects.size();
+    std::vector<int32_t> om(std::max(n_obj, 1)), order(std::max(n_obj, 1)), members(std::max(M, 1)), off(n_obj + 2);
+    std::vector<float> op(7 * (size_t)std::max(n_obj, 1)), score(std::max(n_obj, 1));
+    std::vector<uint8_t> keep(std::max(n_obj, 1));
+    for (int o = 0; o < n_obj; o++) {
+      om[o] = objects[o].model;
+      memcpy(&op[7 * (size_t)o], objects[o].pose, 28);
+    }
+    const int kept = orc_filter(&uv[0], &xyz[0], &model_off[0], n_models, &om[0], &op[0], n_obj, K, cam,
+                                min_points, fdist, min_score, &score[0], &keep[0], &order[0], &members[0], &off[0]);
+    std::vector<Obj> nobj;
+    score_out.clear();
+    for (int m = 0; m < n_models; m++) clusters[m].clear();
+    // list order is preserved by the erase; clusters[m] receive kept objects of model m in list order
+    std::vector<int> kept_of(n_obj, -1);
+    for (int k = 0; k < kept; k++) kept_of[order[k]] = k;
+    for (int o = 0; o < n_obj; o++)
+      if (keep[o]) {
+        nobj.push_back(objects[o]);
+        score_out.push_back(score[o]);
+      }
+    for (int k = 0; k < kept; k++)
+      clusters[om[order[k]]].push_back(std::vector<int>(members.begin() + off[k], members.begin() + off[k + 1]));
+    objects.swap(nobj);
+    return kept;
+  };
+  run_pose(fp->pose1);
+  const int n_pose1 = (int)objects.size();
+  std::vector<float> scores;
+  int n_f1 = n_pose1;
+  if (fp->run_stage2) {
+    n_f1 = run_filter(fp->f1_min_points, fp->f1_feature_distance, fp->f1_min_score, scores);
+    run_pose(fp->pose2);
+    run_filter(fp->f2_min_points, fp->f2_feature_distance, fp->f2_min_score, scores);
+  } else {
+    scores.assign(objects.size(), 0.f);
+  }
+  if (counts) {
+    counts[0] = M;
+    counts[1] = ncl;
+    counts[2] = n_pose1;
+    counts[3] = n_f1;
+  }
+  const int n_out = std::min((int)objects.size(), max_obj);
+  for (int o = 0; o < n_out; o++) {
+    obj_model[o] = objects[o].model;
+    memcpy(obj_pose + 7 * (size_t)o, objects[o].pose, 28);
+    obj_score[o] = scores[o];
+  }
+  return (int)objects.size();
+}
+
 }  // extern "C"

@@ -120,6 +120,27 @@ int orc_filter(const float* uv, const float* xyz, const int32_t* model_off, int 
                float* score, uint8_t* keep, int32_t* out_order,
                int32_t* cl_members, int32_t* cl_off);
 
+typedef struct {
+  float ratio;                 /* 0.8 */
+  float ms_radius, ms_merge;   /* 200, 20 */
+  int ms_min_pts, ms_max_iter; /* 7, 100 */
+  orc_pose_params pose1;       /* (600, 200, 4, 5, 6, 10) */
+  int f1_min_points; float f1_feature_distance, f1_min_score; /* 5, 4096, 2 */
+  orc_pose_params pose2;       /* (100, 500, 4, 6, 8, 5) */
+  int f2_min_points; float f2_feature_distance, f2_min_score; /* 7, 4096, 3 */
+  int run_stage2;
+} orc_frame_params;
+
+/* Everything after the nearest-neighbour search of one frame: the loop of
+ * MopedPimpl::processImages (src/moped.cpp:184-191) over MATCH's ratio test +
+ * scatter, CLUSTER, POSE, FILTER, POSE2, FILTER2 with the reference's
+ * OpenMP structure.  Returns the number of final objects. */
+int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, const float* d2, int Q,
+                   float ratio, const int32_t* model_of, const float* db_xyz, int n_models,
+                   const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
+                   int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
+                   int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,15 @@ class PoseParams(C.Structure):
                 ("min_n_pts_object", C.c_int), ("error_threshold", C.c_float)]
 
 
+class FrameParams(C.Structure):
+    _fields_ = [("ratio", C.c_float), ("ms_radius", C.c_float), ("ms_merge", C.c_float),
+                ("ms_min_pts", C.c_int), ("ms_max_iter", C.c_int), ("pose1", PoseParams),
+                ("f1_min_points", C.c_int), ("f1_feature_distance", C.c_float), ("f1_min_score", C.c_float),
+                ("pose2", PoseParams),
+                ("f2_min_points", C.c_int), ("f2_feature_distance", C.c_float), ("f2_min_score", C.c_float),
+                ("run_stage2", C.c_int)]
+
+
 POSE1 = dict(max_ransac_tests=600, max_lm_tests=200, max_objects_per_cluster=4,
              n_pts_align=5, min_n_pts_object=6, error_threshold=10.0)   # config.hpp:110
 POSE2 = dict(max_ransac_tests=100, max_lm_tests=500, max_objects_per_cluster=4,
@@ -65,6 +74,10 @@ def lib():
         L.orc_filter.argtypes = [_f32p, _f32p, _i32p, C.c_int, _i32p, _f32p, C.c_int, _f32p, _f32p,
                                  C.c_int, C.c_float, C.c_float, _f32p, _u8p, _i32p, _i32p, _i32p]
         L.orc_filter.restype = C.c_int
+        L.orc_frame_rest.argtypes = [_f32p, _i32p, _f32p, _f32p, C.c_int, C.c_float, _i32p, _f32p, C.c_int,
+                                     _f32p, _f32p, C.POINTER(FrameParams), C.c_int, _i32p, _f32p, _f32p,
+                                     C.c_int, _i32p]
+        L.orc_frame_rest.restype = C.c_int
         L.srand = C.CDLL(None).srand
         _lib = L
     return _lib
@@ -196,6 +209,31 @@ def filter_projection(uv, xyz, model_off, obj_model, obj_pose, K, cam, min_point
                          score, keep, order, members, off)
     clusters = [members[off[i]:off[i + 1]].copy() for i in range(k)]
     return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters
+
+
+def default_frame_params(run_stage2=True):
+    """The shipped constants of moped2/libmoped/src/config.hpp:83-120."""
+    return FrameParams(0.8, 200.0, 20.0, 7, 100, PoseParams(**POSE1), 5, 4096.0, 2.0,
+                       PoseParams(**POSE2), 7, 4096.0, 3.0, int(run_stage2))
+
+
+def frame_rest(q_uv, idx1, d1, d2, model_of, db_xyz, n_models, K, cam, params=None, n_threads=1,
+               seed=None, max_obj=4096):
+    """CPU frame after the NN search -> (objects structured array, counts[4])."""
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    fp = params or default_frame_params()
+    om = np.zeros(max_obj, np.int32)
+    op = np.zeros(max_obj * 7, np.float32)
+    osc = np.zeros(max_obj, np.float32)
+    counts = np.zeros(4, np.int32)
+    q_uv = _c(q_uv, np.float32)
+    n = lib().orc_frame_rest(q_uv.reshape(-1), _c(idx1, np.int32), _c(d1, np.float32), _c(d2, np.float32),
+                             q_uv.shape[0], fp.ratio, _c(model_of, np.int32), _c(db_xyz, np.float32).reshape(-1),
+                             n_models, _c(K, np.float32), _c(cam, np.float32), C.byref(fp), n_threads,
+                             om, op, osc, max_obj, counts)
+    n = min(n, max_obj)
+    return om[:n].copy(), op[:7 * n].reshape(n, 7).copy(), osc[:n].copy(), counts
 
 
 # ---- the reference's own libraries (only where oracle/_ref was built) ----------
