@@ -145,7 +145,11 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
           ++stamp;
           for (int ps = 0; ps < npass; ++ps) {
             const int pj = ps * 64 + lane;
-            if (pj < pi && L.order2[pj] == 1) L.flag[L.merges[L.order[pj]]] = stamp;
+            if (pj < pi && L.order2[pj] == 1) {
+              const int cj = L.order[pj];
+              const int tj = L.merges[cj];
+              if (tj != cj) L.flag[tj] = stamp;  // a canopy is not its own predecessor
+            }
           }
           bool changed = false;
           for (int ps = 0; ps < npass; ++ps) {
