@@ -1,0 +1,67 @@
+// CLUSTER_MEAN_SHIFT_HIP -- drop-in for CLUSTER_MEAN_SHIFT_CPU
+// (src/cluster/CLUSTER_MEAN_SHIFT_CPU.hpp):
+//     pipeline.addAlg( "CLUSTER", new CLUSTER_MEAN_SHIFT_HIP( 200, 20, 7, 100 ) );
+// Same constructor arguments and the same result: per model, per image, the
+// clusters of match indices in the reference's emission and splice order (:80-158,
+// :182-199); sets oldClusters when the step is named "CLUSTER" (:198).
+#pragma once
+#include "hip_session.hpp"
+
+namespace MopedNS {
+
+class CLUSTER_MEAN_SHIFT_HIP : public MopedAlg {
+  float Radius;
+  float Merge;
+  int MinPts;
+  int MaxIterations;
+
+ public:
+  CLUSTER_MEAN_SHIFT_HIP(float Radius, float Merge, unsigned int MinPts, unsigned int MaxIterations)
+      : Radius(Radius), Merge(Merge), MinPts(MinPts), MaxIterations(MaxIterations) {
+    capable = HipSession::get() != 0;
+  }
+
+  void getConfig(map<string, string>& config) const {
+    hipGetConfig(config, _stepName, _alg, "CLUSTER_MEAN_SHIFT_HIP", "Radius", Radius);
+    hipGetConfig(config, _stepName, _alg, "CLUSTER_MEAN_SHIFT_HIP", "Merge", Merge);
+    hipGetConfig(config, _stepName, _alg, "CLUSTER_MEAN_SHIFT_HIP", "MinPts", MinPts);
+    hipGetConfig(config, _stepName, _alg, "CLUSTER_MEAN_SHIFT_HIP", "MaxIterations", MaxIterations);
+  }
+  void setConfig(map<string, string>&) {}
+
+  void process(FrameData& frameData) {
+    frameData.clusters.resize(models->size());
+    mh_ctx* ctx = HipSession::get();
+    for (int model = 0; model < (int)frameData.matches.size(); ++model) {
+      const vector<FrameData::Match>& mm = frameData.matches[model];
+      for (int img = 0; img < (int)frameData.images.size(); ++img) {
+        vector<float> pts;
+        vector<int> matchIdx;
+        for (int k = 0; k < (int)mm.size(); ++k)
+          if (mm[k].imageIdx == img) {
+            pts.push_back(mm[k].coord2D[0]);
+            pts.push_back(mm[k].coord2D[1]);
+            matchIdx.push_back(k);
+          }
+        const int n = (int)matchIdx.size();
+        if (n == 0) continue;
+        vector<int32_t> label(n), order(n);
+        int32_t ncl = 0;
+        if (mh_meanshift(ctx, &pts[0], n, 2, Radius, Merge, MinPts, MaxIterations, &label[0], &order[0],
+                         &ncl) != MH_OK) {
+          HipSession::warn("mh_meanshift");
+          continue;
+        }
+        int pos = 0;
+        for (int c = 0; c < ncl; ++c) {
+          frameData.clusters[model].resize(frameData.clusters[model].size() + 1);
+          FrameData::Cluster& cl = frameData.clusters[model].back();
+          while (pos < n && order[pos] >= 0 && label[order[pos]] == c) cl.push_back(matchIdx[order[pos++]]);
+        }
+      }
+    }
+    if (_stepName == "CLUSTER") frameData.oldClusters = frameData.clusters;
+  }
+};
+
+}  // namespace MopedNS

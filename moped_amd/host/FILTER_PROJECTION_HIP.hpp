@@ -1,0 +1,96 @@
+// FILTER_PROJECTION_HIP -- drop-in for FILTER_PROJECTION_CPU
+// (src/filter/FILTER_PROJECTION_CPU.hpp), same constructor arguments:
+//     pipeline.addAlg( "FILTER",  new FILTER_PROJECTION_HIP( 5, 4096., 2 ) );
+//     pipeline.addAlg( "FILTER2", new FILTER_PROJECTION_HIP( 7, 4096., 3 ) );
+// Scores every object, gives each keypoint to the best-scoring object, erases
+// objects with too few points / too low a score and rewrites frameData.clusters
+// (:80-162).  Single-image frames (every shipped moped2 driver); with more images
+// the step leaves the frame untouched.
+#pragma once
+#include "hip_session.hpp"
+
+namespace MopedNS {
+
+class FILTER_PROJECTION_HIP : public MopedAlg {
+  int MinPoints;
+  Float FeatureDistance;
+  Float MinScore;
+
+ public:
+  FILTER_PROJECTION_HIP(int MinPoints, Float FeatureDistance)
+      : MinPoints(MinPoints), FeatureDistance(FeatureDistance), MinScore(0) {
+    capable = HipSession::get() != 0;
+  }
+  FILTER_PROJECTION_HIP(int MinPoints, Float FeatureDistance, Float MinScore)
+      : MinPoints(MinPoints), FeatureDistance(FeatureDistance), MinScore(MinScore) {
+    capable = HipSession::get() != 0;
+  }
+
+  void getConfig(map<string, string>& config) const {
+    hipGetConfig(config, _stepName, _alg, "FILTER_PROJECTION_HIP", "MinPoints", MinPoints);
+    hipGetConfig(config, _stepName, _alg, "FILTER_PROJECTION_HIP", "FeatureDistance", FeatureDistance);
+    hipGetConfig(config, _stepName, _alg, "FILTER_PROJECTION_HIP", "MinScore", MinScore);
+  }
+  void setConfig(map<string, string>&) {}
+
+  void process(FrameData& frameData) {
+    vector<vector<FrameData::Match> >& matches = frameData.matches;
+    if (matches.size() < models->size()) return;  // the reference's sanity check (:85-87)
+    if (frameData.images.size() != 1) return;
+    const int nm = (int)models->size();
+    vector<mh_corr> corr;
+    vector<int32_t> off(nm + 1, 0);
+    for (int m = 0; m < nm; ++m) {
+      for (size_t k = 0; k < matches[m].size(); ++k) {
+        mh_corr c;
+        c.u = matches[m][k].coord2D[0]; c.v = matches[m][k].coord2D[1];
+        c.x = matches[m][k].coord3D[0]; c.y = matches[m][k].coord3D[1]; c.z = matches[m][k].coord3D[2];
+        corr.push_back(c);
+      }
+      off[m + 1] = (int32_t)corr.size();
+    }
+    // objects in (model, list) order -- the order the reference's double loop visits them (:94-96)
+    vector<list<SP_Object>::iterator> its;
+    vector<int32_t> objModel;
+    vector<float> objPose;
+    for (int m = 0; m < nm; ++m)
+      for (list<SP_Object>::iterator it = frameData.objects->begin(); it != frameData.objects->end(); ++it)
+        if ((*it)->model->name == (*models)[m]->name) {
+          its.push_back(it);
+          objModel.push_back(m);
+          for (int i = 0; i < 4; ++i) objPose.push_back((*it)->pose.rotation[i]);
+          for (int i = 0; i < 3; ++i) objPose.push_back((*it)->pose.translation[i]);
+        }
+    const int nobj = (int)its.size();
+    frameData.clusters.clear();
+    frameData.clusters.resize(nm);
+    if (nobj == 0) return;
+    const Image& im = *frameData.images[0];
+    mh_cam cam;
+    for (int i = 0; i < 4; ++i) cam.K[i] = im.intrinsicLinearCalibration[i];
+    for (int i = 0; i < 4; ++i) cam.cam[i] = im.cameraPose.rotation[i];
+    for (int i = 0; i < 3; ++i) cam.cam[4 + i] = im.cameraPose.translation[i];
+    vector<float> score(nobj);
+    vector<uint8_t> keep(nobj);
+    vector<int32_t> order(nobj), members(corr.size() + 1), cloff(nobj + 1);
+    int32_t kept = 0;
+    mh_corr dummy;
+    if (mh_filter(HipSession::get(), corr.empty() ? &dummy : &corr[0], &off[0], nm, &objModel[0], &objPose[0], nobj,
+                  &cam, MinPoints, FeatureDistance, MinScore, &score[0], &keep[0], &order[0], &members[0],
+                  &cloff[0], &kept) != MH_OK) {
+      HipSession::warn("mh_filter");
+      return;
+    }
+    for (int o = 0; o < nobj; ++o) (*its[o])->score = score[o];
+    for (int k = 0; k < kept; ++k) {
+      const int o = order[k];
+      FrameData::Cluster cl;
+      for (int j = cloff[k]; j < cloff[k + 1]; ++j) cl.push_back(members[j]);
+      frameData.clusters[objModel[o]].push_back(cl);
+    }
+    for (int o = 0; o < nobj; ++o)
+      if (!keep[o]) frameData.objects->erase(its[o]);
+  }
+};
+
+}  // namespace MopedNS

@@ -1,0 +1,154 @@
+// Clean-room declaration of the libmoped types the STEP plugins are written
+// against, for building OUTSIDE a libmoped tree (the GPU box has no reference).
+// Inside libmoped, include the real <moped.hpp> and <util.hpp> instead and do not
+// include this file: the plugin headers only use the members declared here, with
+// the reference's names and meaning (include/moped.hpp:84-290, src/util.hpp:68-201).
+// Written from the interface description in SURVEY.md 8(a) A15 -- no reference
+// code is copied; only what the four HIP steps touch is declared.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace MopedNS {
+
+using std::list;
+using std::map;
+using std::string;
+using std::vector;
+using std::shared_ptr;
+
+typedef float Float;
+
+template <int N>
+struct Pt {
+  Float p[N];
+  Float& operator[](int n) { return p[n]; }
+  const Float& operator[](int n) const { return p[n]; }
+  template <typename T> Pt<N>& init(T a, T b) { p[0] = a; p[1] = b; return *this; }
+  template <typename T> Pt<N>& init(T a, T b, T c) { p[0] = a; p[1] = b; p[2] = c; return *this; }
+  template <typename T> Pt<N>& init(T a, T b, T c, T d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; return *this; }
+};
+typedef Pt<4> Quat;
+
+struct Pose {
+  Quat rotation;      // (x, y, z, w)
+  Pt<3> translation;
+};
+
+struct Model {
+  struct IP {
+    Pt<3> coord3D;
+    vector<float> descriptor;
+  };
+  string name;
+  map<string, vector<IP> > IPs;
+  Pt<3> boundingBox[2];
+};
+typedef shared_ptr<Model> SP_Model;
+
+struct Image {
+  vector<unsigned char> data;
+  string name;
+  int width, height;
+  Pt<4> intrinsicLinearCalibration;     // fx, fy, cx, cy
+  Pt<4> intrinsicNonlinearCalibration;
+  Pose cameraPose;
+};
+typedef shared_ptr<Image> SP_Image;
+
+struct Object {
+  SP_Model model;
+  Pose pose;
+  Float score;
+};
+typedef shared_ptr<Object> SP_Object;
+
+template <typename T>
+inline string toString(const T& v) {
+  std::ostringstream o;
+  o << v;
+  return o.str();
+}
+
+struct FrameData {
+  struct DetectedFeature {
+    int imageIdx;
+    Pt<2> coord2D;
+    vector<float> descriptor;
+  };
+  struct Match {
+    int imageIdx;
+    Pt<2> coord2D;
+    Pt<3> coord3D;
+  };
+  typedef list<int> Cluster;
+  vector<SP_Image> images;
+  map<string, vector<DetectedFeature> > detectedFeatures;
+  vector<vector<Match> > matches;
+  vector<vector<Cluster> > clusters;
+  list<SP_Object>* objects;
+  int correctMatches, incorrectMatches;
+  vector<vector<Cluster> > oldClusters;
+  list<SP_Object> oldObjects;
+  map<string, Float> times;
+};
+
+class MopedAlg {
+ public:
+  vector<SP_Model>* models;
+  bool capable;
+  bool configUpdated;
+  string _stepName;
+  int _alg;
+  MopedAlg() : models(0), capable(true), configUpdated(true), _alg(0) {}
+  virtual ~MopedAlg() {}
+  bool isCapable() const { return capable; }
+  void setStepNameAndAlg(string& stepName, int alg) { _stepName = stepName; _alg = alg; }
+  virtual void modelsUpdated(vector<SP_Model>& m) { models = &m; configUpdated = true; }
+  virtual void getConfig(map<string, string>&) const {}
+  virtual void setConfig(map<string, string>&) {}
+  virtual void process(FrameData& frameData) = 0;
+};
+
+struct MopedStep : public vector<shared_ptr<MopedAlg> > {
+  MopedAlg* getAlg() {
+    for (size_t i = 0; i < size(); ++i)
+      if ((*this)[i]->isCapable()) return (*this)[i].get();
+    return 0;
+  }
+};
+
+struct MopedPipeline : public vector<MopedStep> {
+  map<string, int> fromStepNameToIndex;
+  void addAlg(string stepName, MopedAlg* alg) {
+    int step;
+    if (fromStepNameToIndex.find(stepName) == fromStepNameToIndex.end()) {
+      step = (int)fromStepNameToIndex.size();
+      fromStepNameToIndex[stepName] = step;
+    } else {
+      step = fromStepNameToIndex[stepName];
+    }
+    if (step >= (int)size()) resize(step + 1);
+    alg->setStepNameAndAlg(stepName, (int)(*this)[step].size());
+    (*this)[step].push_back(shared_ptr<MopedAlg>(alg));
+  }
+  list<MopedAlg*> getAlgs(bool onlyActive = false) {
+    list<MopedAlg*> out;
+    for (size_t s = 0; s < size(); ++s) {
+      if (!onlyActive) {
+        for (size_t a = 0; a < (*this)[s].size(); ++a) out.push_back((*this)[s][a].get());
+      } else if ((*this)[s].getAlg()) {
+        out.push_back((*this)[s].getAlg());
+      }
+    }
+    return out;
+  }
+};
+
+}  // namespace MopedNS

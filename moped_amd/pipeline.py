@@ -79,19 +79,12 @@ class FramePipeline:
         import torch.distributed as dist
         with torch.cuda.stream(s):
             pi, p1, p2 = c.frame_enqueue_match_local(q_desc.data_ptr(), Q)
-            # exchange 1: per-query local (idx1, d1, d2) of every shard -> [W][Q]
-            buf = self._gather[slot]
-            if buf is None or buf.shape[2] != Q:
-                buf = torch.empty((3, self.world, Q), dtype=torch.int32, device=self.dev)
-                self._gather[slot] = buf
+            # exchange 1: per-query local (idx1, d1, d2) of every shard -> [3][W][Q]
             local = torch.empty((3, Q), dtype=torch.int32, device=self.dev)
             for k, p in enumerate((pi, p1, p2)):
-                src = _wrap_int32(p, Q, self.dev)
-                local[k].copy_(src)
-            # one fused all-gather: [W][3][Q] then viewed per field
-            gathered = torch.empty((self.world, 3, Q), dtype=torch.int32, device=self.dev)
-            dist.all_gather_into_tensor(gathered, local, group=self.group)
-            buf.copy_(gathered.permute(1, 0, 2))
+                local[k].copy_(_wrap_int32(p, Q, self.dev))
+            buf = exchange_top2(local, self.world, self.group)
+            self._gather[slot] = buf   # keep alive until the stream has consumed it
             c.frame_enqueue_rest(q_uv.data_ptr(), Q, buf[0].data_ptr(), buf[1].data_ptr(),
                                  buf[2].data_ptr(), self.world, self.K, self.cam, self.params, seed)
 
@@ -107,8 +100,9 @@ class FramePipeline:
         ptr, nbytes = c.frame_result_dev()
         with torch.cuda.stream(s):
             mine = _wrap_uint8(ptr, nbytes, self.dev)
-            out = torch.empty((self.world, nbytes), dtype=torch.uint8, device=self.dev)
+            out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.dev)
             dist.all_gather_into_tensor(out, mine, group=self.group)
+            out = out.view(self.world, nbytes)
         s.synchronize()
         host = out.cpu().numpy()
         objs = []
@@ -126,6 +120,26 @@ class FramePipeline:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+
+
+def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """Exchange 1: one fused all-gather of every rank's per-query
+    local top-2.  local = [3][Q] int32 words (idx1, bits of d1, bits of d2);
+    returns [3][W][Q] so that each field is the [W][Q] array mh_match_merge_dev
+    expects.  Device-agnostic (RCCL on GPU, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    Q = local.shape[1]
+    gathered = torch.empty(world * 3 * Q, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous().view(-1), group=group)  # flat: gloo and RCCL agree
+    return gathered.view(world, 3, Q).permute(1, 0, 2).contiguous()
+
+
+def owner_of_model(model: int, n_models: int, world: int) -> int:
+    """Rank that owns `model` under the contiguous block partition of ShardedDB."""
+    for r in range(world):
+        if (r * n_models) // world <= model < ((r + 1) * n_models) // world:
+            return r
+    raise ValueError(model)
 
 
 class _DevMem:

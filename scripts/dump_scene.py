@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Write a scene file for moped_amd/host/moped_hip_test (format in its header)."""
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from moped_amd import synth  # noqa: E402
+
+
+def dump(path, db, frame, K=synth.K_DEFAULT, cam=synth.CAM_IDENTITY):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<ii", db.n_models, frame.desc.shape[0]))
+        f.write(np.asarray(K, "<f4").tobytes())
+        f.write(np.asarray(cam, "<f4").tobytes())
+        for m in range(db.n_models):
+            rows = np.nonzero(db.model_of == m)[0]
+            f.write(struct.pack("<i", len(rows)))
+            f.write(db.xyz[rows].astype("<f4").tobytes())
+            f.write(db.desc[rows].astype("<f4").tobytes())
+        f.write(frame.uv.astype("<f4").tobytes())
+        f.write(frame.desc.astype("<f4").tobytes())
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else "scene.bin"
+    n_models = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    db = synth.make_db(n_models, 5000)
+    dump(out, db, synth.make_frame(db, n_vis=2, seed=0))
+    print("wrote", out)

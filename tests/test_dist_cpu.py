@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: two gloo ranks shard the model DB, run the oracle matcher on
+their shard, do exchange 1 with the same helper the GPU pipeline uses, merge, and
+keep the matches of the models they own.  The union must equal the single-rank result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib
+    from moped_amd import synth
+    from moped_amd.pipeline import ShardedDB, exchange_top2, owner_of_model
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    base, _, _ = synth.load_sift_fixture()
+    db = synth.make_db(5, 300, seed=11)
+    dbn = orclib.normalize(db.desc)
+    qn = orclib.normalize(base[:500])
+    sh = ShardedDB(dbn, db.xyz, db.model_of, db.n_models, rank, world)
+    idx, d1, d2 = orclib.match_2nn(sh.desc, qn)
+    idx = np.where(idx >= 0, idx + sh.row_lo, -1).astype(np.int32)   # index_base, as mh_db_upload applies it
+    local = torch.from_numpy(np.stack([idx, d1.view(np.int32), d2.view(np.int32)]))
+    g = exchange_top2(local, world).numpy()
+    gi, g1, g2 = orclib.match_merge(g[0], g[1].view(np.float32), g[2].view(np.float32))
+    # every rank holds the same merged top-2; it keeps the matches of the models it owns
+    acc = (gi >= 0) & (g1 / g2 < np.float32(0.8))
+    mine = np.array([acc[q] and owner_of_model(int(db.model_of[gi[q]]), db.n_models, world) == rank
+                     for q in range(len(gi))])
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), gi=gi, g1=g1, g2=g2, mine=mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_model_sharded_match_equals_single_rank(tmp_path, world):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib
+    from moped_amd import synth
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    base, _, _ = synth.load_sift_fixture()
+    db = synth.make_db(5, 300, seed=11)
+    dbn = orclib.normalize(db.desc)
+    qn = orclib.normalize(base[:500])
+    oi, o1, o2 = orclib.match_2nn(dbn, qn)
+    acc = (oi >= 0) & (o1 / o2 < np.float32(0.8))
+    owned = np.zeros(len(oi), int)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.array_equal(z["gi"], oi) and np.array_equal(z["g1"], o1) and np.array_equal(z["g2"], o2)
+        owned += z["mine"].astype(int)
+    assert np.array_equal(owned, acc.astype(int))   # every accepted match kept by exactly one rank
