@@ -33,6 +33,14 @@ int ensure_pinned(mh_ctx* ctx, size_t bytes) {
 }
 
 int ensure_match_scratch(mh_ctx* ctx, int Q) {
+  const size_t need_pack = match_pack_floats(Q);
+  if (need_pack > ctx->match_pack_cap) {
+    if (ctx->match_pack) MH_HIP(ctx, hipFree(ctx->match_pack));
+    ctx->match_pack = nullptr;
+    ctx->match_pack_cap = 0;
+    MH_HIP(ctx, hipMalloc(&ctx->match_pack, need_pack * sizeof(float)));
+    ctx->match_pack_cap = need_pack;
+  }
   size_t need = match_scratch_elems(Q, ctx->N > 0 ? ctx->N : 1);
   if (need <= ctx->match_scratch_cap) return MH_OK;
   if (ctx->match_scratch) MH_HIP(ctx, hipFree(ctx->match_scratch));
@@ -101,7 +109,7 @@ void mh_destroy(mh_ctx* ctx) {
   mh_free_frame_state(ctx);
   void* ptrs[] = {ctx->db_desc, ctx->db_norm, ctx->db_xyz, ctx->db_model, ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
-                  ctx->scratch};
+                  ctx->scratch, ctx->match_pack};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (ctx->pinned) hipHostFree(ctx->pinned);
@@ -197,7 +205,7 @@ int mh_match_local_dev(mh_ctx* ctx, const float* qn_dev, const float* qnorm_dev,
   int rc = ensure_match_scratch(ctx, Q);
   if (rc) return rc;
   launch_match(qn_dev, qnorm_dev, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, idx1_dev, d1_dev, d2_dev, ctx->stream);
+               ctx->match_scratch, ctx->match_pack, idx1_dev, d1_dev, d2_dev, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;
 }
@@ -228,7 +236,7 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
                              hipMemcpyHostToDevice, ctx->stream));
   launch_row_norms(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
   launch_match(ctx->q_desc, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
   // the reference's acceptance test on squared distances (MATCH_ANN_CPU.hpp:165)
   int32_t* d_acc = (int32_t*)ctx->scratch;
   launch_accept(ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, ratio, d_acc, ctx->stream);

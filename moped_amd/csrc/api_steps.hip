@@ -489,7 +489,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   stamp(ctx, 0);
   launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
   launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
   stamp(ctx, 1);
   return frame_rest(ctx, q_uv_dev, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, cam, prm, seed);
 }
@@ -503,7 +503,7 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
   stamp(ctx, 0);
   launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
   launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   *idx1_dev = ctx->nn_idx;
   *d1_dev = ctx->nn_d1;

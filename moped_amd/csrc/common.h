@@ -27,9 +27,11 @@ void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s);
 // Scratch (in Top2 units) the match kernel needs for Q queries.
 size_t match_scratch_elems(int Q, int N);
 // Local top-2 of Q queries vs N rows.
+// Floats of packed-query scratch launch_match needs for Q queries.
+size_t match_pack_floats(int Q);
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, int32_t index_base, Top2* scratch, int32_t* idx1, float* d1, float* d2,
-                  hipStream_t s);
+                  int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                  float* d2, hipStream_t s);
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,
                         int32_t* idx1, float* d1, float* d2, hipStream_t s);
 

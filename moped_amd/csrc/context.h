@@ -32,6 +32,8 @@ struct mh_ctx {
   float* nn_d2 = nullptr;        // [max_q]
   mh::Top2* match_scratch = nullptr;
   size_t match_scratch_cap = 0;
+  float* match_pack = nullptr;   // queries re-laid out for scalar loads (match.hip)
+  size_t match_pack_cap = 0;
 
   // generic byte scratch for host-pointer entry points
   void* scratch = nullptr;

@@ -24,12 +24,10 @@ namespace mh {
 
 namespace {
 
-constexpr int TQ = 8;                  // queries per wavefront
+constexpr int TQ = 8;                  // queries per wavefront (pack_queries_kernel assumes 8)
 constexpr int NWAVES = 16;             // wavefronts per workgroup
 constexpr int QB = TQ * NWAVES;        // queries per workgroup (128)
 constexpr int TILE_ROWS = 128;         // database rows per LDS tile (2 per lane)
-constexpr int LDS_STRIDE = DIM + 4;    // floats per staged row: +16 B keeps ds_read_b128 conflict-free
-constexpr int TILE_FLOATS = TILE_ROWS * LDS_STRIDE;
 constexpr int MATCH_THREADS = NWAVES * 64;
 constexpr int TARGET_BLOCKS = 768;     // 3 workgroups per CU over the launch
 
@@ -105,38 +103,117 @@ __device__ __forceinline__ void merge(Best& a, float ob1, float ob2, int oi1) {
   a.i1 = take ? oi1 : a.i1;
 }
 
+// ---- query packing ----------------------------------------------------------------
+// P[g][k][8]: the 8 queries of group g interleaved per coordinate, zero padded, so a
+// wavefront fetches "coordinate k of its 8 queries" as 8 consecutive dwords and four
+// coordinates with two s_load_dwordx16.  Even-aligned SGPR pairs = query pairs.
+__global__ void pack_queries_kernel(const float* __restrict__ qn, const float* __restrict__ qnorm,
+                                    int Q, float* __restrict__ P, float* __restrict__ Pnorm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one element of P
+  const int G = (Q + TQ - 1) / TQ;
+  if (i >= G * DIM * TQ) return;
+  const int t = i & (TQ - 1), k = (i >> 3) & (DIM - 1), g = i >> 10;
+  const int q = g * TQ + t;
+  P[i] = (q < Q) ? qn[(size_t)q * DIM + k] : 0.f;
+  if (k == 0) Pnorm[g * TQ + t] = (q < Q) ? qnorm[q] : 0.f;
+}
+
 // ---- the match kernel -----------------------------------------------------------
 // grid.x = query groups of QB, grid.y = database splits.  Each block scans rows
 // [split*rows_per_split, +rows_per_split) and writes one Top2 per query.
+//
+// Inner loop, per wavefront and 2 coordinates ("chunk"): one s_load_dwordx16 brings
+// 2 coordinates x 8 queries into SGPRs, two ds_read_b64 bring 2 coordinates of the
+// lane's two rows into VGPRs, then 16 v_pk_fma_f32: each packs a QUERY PAIR (an
+// even-aligned SGPR pair) against one row coordinate broadcast to both halves by
+// op_sel -- no register moves on either pipe.  The loads of chunk c+1 are issued
+// (inline asm, so the compiler cannot sink them) before the FMAs of chunk c and
+// waited for with one lgkmcnt(0) after them: SMEM returns out of order, so a
+// counted wait is not available, but a full chunk of FMAs (x4 wavefronts per SIMD)
+// covers the latency.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int LDS_STRIDE = DIM + 4;    // floats per staged row: +16 B keeps ds_read_b128 conflict-free
+constexpr int TILE_FLOATS = TILE_ROWS * LDS_STRIDE;
+constexpr int NCHUNK = DIM / 2;        // two coordinates per pipeline stage
+
+// The accumulators ride through the issue/wait statements as in-out operands: that
+// pins the FMAs of chunk c between the issue of chunk c+1 and its wait (otherwise
+// the scheduler is free to hoist every load of the tile to the front and spill).
+#define ACC_TIE(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+template <int KC>
+__device__ __forceinline__ void chunk_issue(const float* qp, unsigned la, v16f& q, v2f& ra, v2f& rb,
+                                            v2f (&acc)[TQ]) {
+  asm volatile("s_load_dwordx16 %0, %11, %13\n\tds_read_b64 %1, %12 offset:%14\n\tds_read_b64 %2, %12 offset:%15"
+               : "=s"(q), "=v"(ra), "=v"(rb), ACC_TIE(acc)
+               : "s"(qp), "v"(la), "i"(KC * 64), "i"(KC * 8), "i"(KC * 8 + 64 * LDS_STRIDE * 4)
+               : "memory");
+}
+// One wait for everything in flight; the operands tie the loaded registers to the
+// wait so no consumer can be scheduled above it.
+__device__ __forceinline__ void chunk_wait(v16f& q, v2f& ra, v2f& rb, v2f (&acc)[TQ]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(ra), "+v"(rb), ACC_TIE(acc) : : "memory");
+}
+// q = coordinate k0: queries 0..7, then k1: queries 0..7.  ra / rb = row a / b at k0,k1.
+// acc[2*tp + row]: query pair tp x row.  Each chain sees k ascending.
+__device__ __forceinline__ void chunk_fma(const v16f& q, const v2f& ra, const v2f& rb, v2f (&acc)[TQ]) {
+#pragma unroll
+  for (int tp = 0; tp < TQ / 2; ++tp) {
+    const v2f q0 = (v2f){q[2 * tp], q[2 * tp + 1]}, q1 = (v2f){q[8 + 2 * tp], q[8 + 2 * tp + 1]};
+    acc[2 * tp] = __builtin_elementwise_fma(q0, (v2f){ra.x, ra.x}, acc[2 * tp]);
+    acc[2 * tp + 1] = __builtin_elementwise_fma(q0, (v2f){rb.x, rb.x}, acc[2 * tp + 1]);
+    acc[2 * tp] = __builtin_elementwise_fma(q1, (v2f){ra.y, ra.y}, acc[2 * tp]);
+    acc[2 * tp + 1] = __builtin_elementwise_fma(q1, (v2f){rb.y, rb.y}, acc[2 * tp + 1]);
+  }
+}
+template <int KC>
+__device__ __forceinline__ void chunk_pipe(const float* qp, unsigned la, v16f& q0, v2f& ra0, v2f& rb0,
+                                           v16f& q1, v2f& ra1, v2f& rb1, v2f (&acc)[TQ]) {
+  if constexpr (KC < NCHUNK) {
+    if constexpr (KC + 1 < NCHUNK) chunk_issue<KC + 1>(qp, la, q1, ra1, rb1, acc);
+    chunk_fma(q0, ra0, rb0, acc);
+    if constexpr (KC + 1 < NCHUNK) chunk_wait(q1, ra1, rb1, acc);
+    chunk_pipe<KC + 1>(qp, la, q1, ra1, rb1, q0, ra0, rb0, acc);
+  }
+}
+
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
-    const float* __restrict__ qn, const float* __restrict__ qnorm, int Q,
+    const float* __restrict__ P, const float* __restrict__ Pnorm, int Q,
     const float* __restrict__ db, const float* __restrict__ dnorm, int N,
     int tiles_per_split, int32_t index_base, Top2* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 tiles
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q0 = (blockIdx.x * NWAVES + wave) * TQ;  // wave-uniform
+  const int n_groups = (Q + TQ - 1) / TQ;
+  const int g_raw = (int)blockIdx.x * NWAVES + wave;                 // wave-uniform
+  const bool live = g_raw < n_groups;
+  const int g = live ? g_raw : n_groups - 1;                         // surplus waves redo the last group
+  const int q0 = g * TQ;
+  // the packed-query base must sit in SGPRs for s_load: make the uniformity explicit
+  const unsigned long long qp_bits = (unsigned long long)(P + (size_t)g * (DIM * TQ));
+  const unsigned qp_lo = __builtin_amdgcn_readfirstlane((unsigned)qp_bits);
+  const unsigned qp_hi = __builtin_amdgcn_readfirstlane((unsigned)(qp_bits >> 32));
+  const float* qp = (const float*)(((unsigned long long)qp_hi << 32) | qp_lo);
   const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int tile_end = min(tile_begin + tiles_per_split, n_tiles);
 
-  // wave-uniform query row pointers (clamped so out-of-range groups stay in bounds)
-  const float* qrow[TQ];
-  float qn2[TQ];
+  v2f nq[TQ / 2];  // dot(q,q) of the query pairs
 #pragma unroll
-  for (int t = 0; t < TQ; ++t) {
-    const int qi = min(q0 + t, Q - 1);
-    qrow[t] = qn + (size_t)qi * DIM;
-    qn2[t] = qnorm[qi];
-  }
+  for (int tp = 0; tp < TQ / 2; ++tp) nq[tp] = (v2f){Pnorm[q0 + 2 * tp], Pnorm[q0 + 2 * tp + 1]};
 
-  Best st[TQ];
+  // per-lane running top-2 per query, packed by query pair
+  v2f b1[TQ / 2], b2[TQ / 2];
+  int i1[TQ];
 #pragma unroll
-  for (int t = 0; t < TQ; ++t) {
-    st[t].b1 = __builtin_inff();
-    st[t].b2 = __builtin_inff();
-    st[t].i1 = -1;
+  for (int tp = 0; tp < TQ / 2; ++tp) {
+    b1[tp] = (v2f){__builtin_inff(), __builtin_inff()};
+    b2[tp] = b1[tp];
+    i1[2 * tp] = -1;
+    i1[2 * tp + 1] = -1;
   }
 
   // staging: 4096 float4 per tile over 1024 threads = 4 each, coalesced
@@ -166,6 +243,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   }
   __syncthreads();
 
+  const unsigned lds_base = (unsigned)(size_t)lds;  // LDS byte address of the dynamic region
   int buf = 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const bool more = tile + 1 < tile_end;
@@ -176,37 +254,36 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
     const float dn_a = (row_a < N) ? dnorm[row_a] : 0.f;
     const float dn_b = (row_b < N) ? dnorm[row_b] : 0.f;
 
-    const float* la = lds + buf * TILE_FLOATS + lane * LDS_STRIDE;
-    const float* lb = la + 64 * LDS_STRIDE;
-    float acc_a[TQ], acc_b[TQ];
+    const unsigned la = lds_base + (unsigned)((buf * TILE_FLOATS + lane * LDS_STRIDE) * 4);
+    v2f acc[TQ];
 #pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-      acc_a[t] = 0.f;
-      acc_b[t] = 0.f;
+    for (int t = 0; t < TQ; ++t) acc[t] = (v2f){0.f, 0.f};
+    {
+      v16f qs0, qs1;
+      v2f ra0, rb0, ra1, rb1;
+      chunk_issue<0>(qp, la, qs0, ra0, rb0, acc);
+      chunk_wait(qs0, ra0, rb0, acc);
+      chunk_pipe<0>(qp, la, qs0, ra0, rb0, qs1, ra1, rb1, acc);
     }
-#pragma unroll 2
-    for (int kc = 0; kc < DIM / 4; ++kc) {
-      const float4 a = *reinterpret_cast<const float4*>(la + kc * 4);
-      const float4 b = *reinterpret_cast<const float4*>(lb + kc * 4);
+    // distances + fold: row a first, then row b (ascending row index within the lane)
+    const bool va = row_a < N, vb = row_b < N;
 #pragma unroll
-      for (int t = 0; t < TQ; ++t) {
-        const float4 q = *reinterpret_cast<const float4*>(qrow[t] + kc * 4);  // scalar load
-        acc_a[t] = fmaf(q.x, a.x, acc_a[t]);
-        acc_b[t] = fmaf(q.x, b.x, acc_b[t]);
-        acc_a[t] = fmaf(q.y, a.y, acc_a[t]);
-        acc_b[t] = fmaf(q.y, b.y, acc_b[t]);
-        acc_a[t] = fmaf(q.z, a.z, acc_a[t]);
-        acc_b[t] = fmaf(q.z, b.z, acc_b[t]);
-        acc_a[t] = fmaf(q.w, a.w, acc_a[t]);
-        acc_b[t] = fmaf(q.w, b.w, acc_b[t]);
+    for (int tp = 0; tp < TQ / 2; ++tp) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float dnr = r ? dn_b : dn_a;
+        const int row = r ? row_b : row_a;
+        const bool valid = r ? vb : va;
+        const v2f nsum = nq[tp] + (v2f){dnr, dnr};
+        v2f d = __builtin_elementwise_fma((v2f){-2.f, -2.f}, acc[2 * tp + r], nsum);
+        d = __builtin_elementwise_max(d, (v2f){0.f, 0.f});
+        if (!valid) d = (v2f){__builtin_inff(), __builtin_inff()};  // rows past the end never win
+        const bool lt0 = d.x < b1[tp].x, lt1 = d.y < b1[tp].y;
+        b2[tp] = __builtin_elementwise_min(b2[tp], __builtin_elementwise_max(b1[tp], d));
+        b1[tp] = __builtin_elementwise_min(b1[tp], d);
+        i1[2 * tp] = lt0 ? row : i1[2 * tp];
+        i1[2 * tp + 1] = lt1 ? row : i1[2 * tp + 1];
       }
-    }
-#pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-      const float da = fmaxf(0.f, fmaf(-2.f, acc_a[t], qn2[t] + dn_a));
-      const float db2 = fmaxf(0.f, fmaf(-2.f, acc_b[t], qn2[t] + dn_b));
-      if (row_a < N) fold(st[t], da, row_a);
-      if (row_b < N) fold(st[t], db2, row_b);
     }
 
     if (more) stage_store(buf ^ 1);
@@ -217,16 +294,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   // wavefront min-reduce of the per-lane top-2, one query at a time
 #pragma unroll
   for (int t = 0; t < TQ; ++t) {
-    Best s = st[t];
+    Best s = {(t & 1) ? b1[t / 2].y : b1[t / 2].x, (t & 1) ? b2[t / 2].y : b2[t / 2].x, i1[t]};
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const float ob1 = __shfl_xor(s.b1, off);
       const float ob2 = __shfl_xor(s.b2, off);
       const int oi1 = __shfl_xor(s.i1, off);
-      merge(s, ob1, ob2, oi1);
+      if (oi1 >= 0) merge(s, ob1, ob2, oi1);
     }
     const int qi = q0 + t;
-    if (lane == 0 && qi < Q) {
+    if (live && lane == 0 && qi < Q) {
       Top2 o;
       o.d1 = s.b1;
       o.d2 = s.b2;
@@ -299,12 +376,20 @@ void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s) 
 
 size_t match_scratch_elems(int Q, int N) { return (size_t)splits_for(Q, N) * (size_t)(Q > 0 ? Q : 1); }
 
+size_t match_pack_floats(int Q) { return (size_t)((Q + TQ - 1) / TQ) * TQ * (DIM + 1); }
+
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, int32_t index_base, Top2* scratch, int32_t* idx1, float* d1, float* d2,
-                  hipStream_t s) {
+                  int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                  float* d2, hipStream_t s) {
   if (Q <= 0) return;
   const int S = (N > 0) ? splits_for(Q, N) : 0;
   if (S > 0) {
+    const int n_groups = (Q + TQ - 1) / TQ;
+    float* P = pack;
+    float* Pnorm = pack + (size_t)n_groups * TQ * DIM;
+    const int pack_elems = n_groups * TQ * DIM;
+    hipLaunchKernelGGL(pack_queries_kernel, dim3((pack_elems + 255) / 256), dim3(256), 0, s, qn, qnorm,
+                       Q, P, Pnorm);
     const int qgroups = (Q + QB - 1) / QB;
     const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
     const int tiles_per_split = (n_tiles + S - 1) / S;
@@ -315,8 +400,8 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       attr_set = true;
     }
-    hipLaunchKernelGGL(match_kernel, dim3(qgroups, S), dim3(MATCH_THREADS), lds_bytes, s, qn, qnorm,
-                       Q, db, dnorm, N, tiles_per_split, index_base, scratch);
+    hipLaunchKernelGGL(match_kernel, dim3(qgroups, S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
+                       db, dnorm, N, tiles_per_split, index_base, scratch);
   }
   hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, S, Q,
                      idx1, d1, d2);
