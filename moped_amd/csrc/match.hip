@@ -137,45 +137,53 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_STRIDE = DIM + 4;    // floats per staged row: +16 B keeps ds_read_b128 conflict-free
 constexpr int TILE_FLOATS = TILE_ROWS * LDS_STRIDE;
-constexpr int NCHUNK = DIM / 2;        // two coordinates per pipeline stage
+constexpr int NCHUNK = DIM / 4;        // four coordinates per pipeline stage
 
 // The accumulators ride through the issue/wait statements as in-out operands: that
 // pins the FMAs of chunk c between the issue of chunk c+1 and its wait (otherwise
 // the scheduler is free to hoist every load of the tile to the front and spill).
 #define ACC_TIE(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
 template <int KC>
-__device__ __forceinline__ void chunk_issue(const float* qp, unsigned la, v16f& q, v2f& ra, v2f& rb,
+__device__ __forceinline__ void chunk_issue(const float* qp, unsigned la, v16f& qa, v16f& qb, v4f& ra, v4f& rb,
                                             v2f (&acc)[TQ]) {
-  asm volatile("s_load_dwordx16 %0, %11, %13\n\tds_read_b64 %1, %12 offset:%14\n\tds_read_b64 %2, %12 offset:%15"
-               : "=s"(q), "=v"(ra), "=v"(rb), ACC_TIE(acc)
-               : "s"(qp), "v"(la), "i"(KC * 64), "i"(KC * 8), "i"(KC * 8 + 64 * LDS_STRIDE * 4)
+  asm volatile("s_load_dwordx16 %0, %12, %14\n\ts_load_dwordx16 %1, %12, %15\n\t"
+               "ds_read_b128 %2, %13 offset:%16\n\tds_read_b128 %3, %13 offset:%17"
+               : "=s"(qa), "=s"(qb), "=v"(ra), "=v"(rb), ACC_TIE(acc)
+               : "s"(qp), "v"(la), "i"(KC * 128), "i"(KC * 128 + 64), "i"(KC * 16),
+                 "i"(KC * 16 + 64 * LDS_STRIDE * 4)
                : "memory");
 }
 // One wait for everything in flight; the operands tie the loaded registers to the
 // wait so no consumer can be scheduled above it.
-__device__ __forceinline__ void chunk_wait(v16f& q, v2f& ra, v2f& rb, v2f (&acc)[TQ]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(ra), "+v"(rb), ACC_TIE(acc) : : "memory");
+__device__ __forceinline__ void chunk_wait(v16f& qa, v16f& qb, v4f& ra, v4f& rb, v2f (&acc)[TQ]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(qa), "+s"(qb), "+v"(ra), "+v"(rb), ACC_TIE(acc) : : "memory");
 }
-// q = coordinate k0: queries 0..7, then k1: queries 0..7.  ra / rb = row a / b at k0,k1.
+// qa = coordinate k0: queries 0..7, k1: 0..7 ; qb = k2, k3.  ra / rb = row a / b at k0..k3.
 // acc[2*tp + row]: query pair tp x row.  Each chain sees k ascending.
-__device__ __forceinline__ void chunk_fma(const v16f& q, const v2f& ra, const v2f& rb, v2f (&acc)[TQ]) {
+__device__ __forceinline__ void chunk_fma(const v16f& qa, const v16f& qb, const v4f& ra, const v4f& rb,
+                                          v2f (&acc)[TQ]) {
 #pragma unroll
   for (int tp = 0; tp < TQ / 2; ++tp) {
-    const v2f q0 = (v2f){q[2 * tp], q[2 * tp + 1]}, q1 = (v2f){q[8 + 2 * tp], q[8 + 2 * tp + 1]};
+    const v2f q0 = (v2f){qa[2 * tp], qa[2 * tp + 1]}, q1 = (v2f){qa[8 + 2 * tp], qa[8 + 2 * tp + 1]};
+    const v2f q2 = (v2f){qb[2 * tp], qb[2 * tp + 1]}, q3 = (v2f){qb[8 + 2 * tp], qb[8 + 2 * tp + 1]};
     acc[2 * tp] = __builtin_elementwise_fma(q0, (v2f){ra.x, ra.x}, acc[2 * tp]);
     acc[2 * tp + 1] = __builtin_elementwise_fma(q0, (v2f){rb.x, rb.x}, acc[2 * tp + 1]);
     acc[2 * tp] = __builtin_elementwise_fma(q1, (v2f){ra.y, ra.y}, acc[2 * tp]);
     acc[2 * tp + 1] = __builtin_elementwise_fma(q1, (v2f){rb.y, rb.y}, acc[2 * tp + 1]);
+    acc[2 * tp] = __builtin_elementwise_fma(q2, (v2f){ra.z, ra.z}, acc[2 * tp]);
+    acc[2 * tp + 1] = __builtin_elementwise_fma(q2, (v2f){rb.z, rb.z}, acc[2 * tp + 1]);
+    acc[2 * tp] = __builtin_elementwise_fma(q3, (v2f){ra.w, ra.w}, acc[2 * tp]);
+    acc[2 * tp + 1] = __builtin_elementwise_fma(q3, (v2f){rb.w, rb.w}, acc[2 * tp + 1]);
   }
 }
 template <int KC>
-__device__ __forceinline__ void chunk_pipe(const float* qp, unsigned la, v16f& q0, v2f& ra0, v2f& rb0,
-                                           v16f& q1, v2f& ra1, v2f& rb1, v2f (&acc)[TQ]) {
+__device__ __forceinline__ void chunk_pipe(const float* qp, unsigned la, v16f& qa0, v16f& qb0, v4f& ra0, v4f& rb0,
+                                           v16f& qa1, v16f& qb1, v4f& ra1, v4f& rb1, v2f (&acc)[TQ]) {
   if constexpr (KC < NCHUNK) {
-    if constexpr (KC + 1 < NCHUNK) chunk_issue<KC + 1>(qp, la, q1, ra1, rb1, acc);
-    chunk_fma(q0, ra0, rb0, acc);
-    if constexpr (KC + 1 < NCHUNK) chunk_wait(q1, ra1, rb1, acc);
-    chunk_pipe<KC + 1>(qp, la, q1, ra1, rb1, q0, ra0, rb0, acc);
+    if constexpr (KC + 1 < NCHUNK) chunk_issue<KC + 1>(qp, la, qa1, qb1, ra1, rb1, acc);
+    chunk_fma(qa0, qb0, ra0, rb0, acc);
+    if constexpr (KC + 1 < NCHUNK) chunk_wait(qa1, qb1, ra1, rb1, acc);
+    chunk_pipe<KC + 1>(qp, la, qa1, qb1, ra1, rb1, qa0, qb0, ra0, rb0, acc);
   }
 }
 
@@ -201,9 +209,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int tile_end = min(tile_begin + tiles_per_split, n_tiles);
 
-  v2f nq[TQ / 2];  // dot(q,q) of the query pairs
+  v2f nq[TQ / 2];  // dot(q,q) of the query pairs; parked in VGPRs (the SGPR file is for the query stream)
 #pragma unroll
-  for (int tp = 0; tp < TQ / 2; ++tp) nq[tp] = (v2f){Pnorm[q0 + 2 * tp], Pnorm[q0 + 2 * tp + 1]};
+  for (int tp = 0; tp < TQ / 2; ++tp) {
+    float x = Pnorm[q0 + 2 * tp], y = Pnorm[q0 + 2 * tp + 1];
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(nq[tp].x), "=v"(nq[tp].y) : "s"(x), "s"(y));
+  }
 
   // per-lane running top-2 per query, packed by query pair
   v2f b1[TQ / 2], b2[TQ / 2];
@@ -259,11 +270,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
 #pragma unroll
     for (int t = 0; t < TQ; ++t) acc[t] = (v2f){0.f, 0.f};
     {
-      v16f qs0, qs1;
-      v2f ra0, rb0, ra1, rb1;
-      chunk_issue<0>(qp, la, qs0, ra0, rb0, acc);
-      chunk_wait(qs0, ra0, rb0, acc);
-      chunk_pipe<0>(qp, la, qs0, ra0, rb0, qs1, ra1, rb1, acc);
+      v16f qa0, qb0, qa1, qb1;
+      v4f ra0, rb0, ra1, rb1;
+      chunk_issue<0>(qp, la, qa0, qb0, ra0, rb0, acc);
+      chunk_wait(qa0, qb0, ra0, rb0, acc);
+      chunk_pipe<0>(qp, la, qa0, qb0, ra0, rb0, qa1, qb1, ra1, rb1, acc);
     }
     // distances + fold: row a first, then row b (ascending row index within the lane)
     const bool va = row_a < N, vb = row_b < N;
