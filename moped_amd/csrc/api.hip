@@ -141,13 +141,16 @@ int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_ho
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if ((size_t)N > ctx->db_cap) {
+  // rows are padded to whole 128-row tiles for the match kernel: zero descriptors,
+  // +inf norm terms (a padding row can never enter a top-2)
+  const size_t Npad = ((size_t)N + 127) / 128 * 128;
+  if (Npad > ctx->db_cap) {
     int rc;
-    if ((rc = realloc_dev(ctx, ctx->db_desc, (size_t)N * DIM))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_norm, N))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_xyz, (size_t)N * 3))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_model, N))) return rc;
-    ctx->db_cap = N;
+    if ((rc = realloc_dev(ctx, ctx->db_desc, Npad * DIM))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_norm, Npad))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_xyz, Npad * 3))) return rc;
+    if ((rc = realloc_dev(ctx, ctx->db_model, Npad))) return rc;
+    ctx->db_cap = Npad;
   }
   ctx->N = N;
   ctx->n_models = n_models;
@@ -159,6 +162,10 @@ int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_ho
                                hipMemcpyHostToDevice, ctx->stream));
     MH_HIP(ctx, hipMemcpyAsync(ctx->db_model, model_of_host, (size_t)N * sizeof(int32_t),
                                hipMemcpyHostToDevice, ctx->stream));
+    if (Npad > (size_t)N) {
+      MH_HIP(ctx, hipMemsetAsync(ctx->db_desc + (size_t)N * DIM, 0, (Npad - N) * DIM * sizeof(float), ctx->stream));
+      MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->db_norm + N), 0x7F800000, Npad - N, ctx->stream));
+    }
     launch_row_norms(ctx->db_desc, ctx->db_norm, N, ctx->stream);
     MH_HIP(ctx, hipGetLastError());
   }

@@ -86,11 +86,11 @@ struct Best {
 
 // Fold candidate (v, idx) into a lane-private running top-2.  Rows reach a lane
 // in increasing index order, so strict '<' keeps the lower index on ties.
-__device__ __forceinline__ void fold(Best& s, float v, int idx) {
-  const bool lt = v < s.b1;
-  s.b2 = __builtin_amdgcn_fmed3f(s.b1, s.b2, v);  // median(b1 <= b2, v) = new second best
-  s.i1 = lt ? idx : s.i1;
-  s.b1 = fminf(s.b1, v);
+__device__ __forceinline__ void fold(float& b1, float& b2, int& i1, float v, int idx) {
+  const bool lt = v < b1;
+  b2 = __builtin_amdgcn_fmed3f(b1, b2, v);  // median(b1 <= b2, v) = new second best
+  i1 = lt ? idx : i1;
+  b1 = fminf(b1, v);
 }
 
 // Merge two disjoint top-2 sets; lower index wins a tie on the best distance.
@@ -160,20 +160,27 @@ __device__ __forceinline__ void chunk_wait(v16f& qa, v16f& qb, v4f& ra, v4f& rb,
 }
 // qa = coordinate k0: queries 0..7, k1: 0..7 ; qb = k2, k3.  ra / rb = row a / b at k0..k3.
 // acc[2*tp + row]: query pair tp x row.  Each chain sees k ascending.
+// v_pk_fma_f32 D = S0 * S1 + D with S0 = an aligned SGPR pair (two queries) and S1 =
+// one half of a VGPR pair broadcast to both lanes of the packed op:
+//   LO: op_sel_hi:[1,0,1]  -> S1.lo for both halves ; HI: op_sel:[0,1,0] -> S1.hi for both.
+#define PKFMA_LO(acc, q, r) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(q), "v"(r))
+#define PKFMA_HI(acc, q, r) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "s"(q), "v"(r))
 __device__ __forceinline__ void chunk_fma(const v16f& qa, const v16f& qb, const v4f& ra, const v4f& rb,
                                           v2f (&acc)[TQ]) {
+  const v2f a01 = (v2f){ra.x, ra.y}, a23 = (v2f){ra.z, ra.w};
+  const v2f b01 = (v2f){rb.x, rb.y}, b23 = (v2f){rb.z, rb.w};
 #pragma unroll
   for (int tp = 0; tp < TQ / 2; ++tp) {
     const v2f q0 = (v2f){qa[2 * tp], qa[2 * tp + 1]}, q1 = (v2f){qa[8 + 2 * tp], qa[8 + 2 * tp + 1]};
     const v2f q2 = (v2f){qb[2 * tp], qb[2 * tp + 1]}, q3 = (v2f){qb[8 + 2 * tp], qb[8 + 2 * tp + 1]};
-    acc[2 * tp] = __builtin_elementwise_fma(q0, (v2f){ra.x, ra.x}, acc[2 * tp]);
-    acc[2 * tp + 1] = __builtin_elementwise_fma(q0, (v2f){rb.x, rb.x}, acc[2 * tp + 1]);
-    acc[2 * tp] = __builtin_elementwise_fma(q1, (v2f){ra.y, ra.y}, acc[2 * tp]);
-    acc[2 * tp + 1] = __builtin_elementwise_fma(q1, (v2f){rb.y, rb.y}, acc[2 * tp + 1]);
-    acc[2 * tp] = __builtin_elementwise_fma(q2, (v2f){ra.z, ra.z}, acc[2 * tp]);
-    acc[2 * tp + 1] = __builtin_elementwise_fma(q2, (v2f){rb.z, rb.z}, acc[2 * tp + 1]);
-    acc[2 * tp] = __builtin_elementwise_fma(q3, (v2f){ra.w, ra.w}, acc[2 * tp]);
-    acc[2 * tp + 1] = __builtin_elementwise_fma(q3, (v2f){rb.w, rb.w}, acc[2 * tp + 1]);
+    PKFMA_LO(acc[2 * tp], q0, a01);
+    PKFMA_LO(acc[2 * tp + 1], q0, b01);
+    PKFMA_HI(acc[2 * tp], q1, a01);
+    PKFMA_HI(acc[2 * tp + 1], q1, b01);
+    PKFMA_LO(acc[2 * tp], q2, a23);
+    PKFMA_LO(acc[2 * tp + 1], q2, b23);
+    PKFMA_HI(acc[2 * tp], q3, a23);
+    PKFMA_HI(acc[2 * tp + 1], q3, b23);
   }
 }
 template <int KC>
@@ -216,41 +223,43 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
     asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(nq[tp].x), "=v"(nq[tp].y) : "s"(x), "s"(y));
   }
 
-  // per-lane running top-2 per query, packed by query pair
-  v2f b1[TQ / 2], b2[TQ / 2];
+  // per-lane running top-2 per query
+  float b1[TQ], b2[TQ];
   int i1[TQ];
 #pragma unroll
-  for (int tp = 0; tp < TQ / 2; ++tp) {
-    b1[tp] = (v2f){__builtin_inff(), __builtin_inff()};
-    b2[tp] = b1[tp];
-    i1[2 * tp] = -1;
-    i1[2 * tp + 1] = -1;
+  for (int t = 0; t < TQ; ++t) {
+    b1[t] = __builtin_inff();
+    b2[t] = __builtin_inff();
+    i1[t] = -1;
   }
 
-  // staging: 4096 float4 per tile over 1024 threads = 4 each, coalesced
-  float4 stage[4];
-  auto stage_load = [&](int tile) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * MATCH_THREADS;
-      const int r = c >> 5, c4 = c & 31;
-      const int row = tile * TILE_ROWS + r;
-      stage[i] = (row < N) ? *reinterpret_cast<const float4*>(db + (size_t)row * DIM + c4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * MATCH_THREADS;
-      const int r = c >> 5, c4 = c & 31;
-      *reinterpret_cast<float4*>(lds + buf * TILE_FLOATS + r * LDS_STRIDE + c4 * 4) = stage[i];
-    }
-  };
+  // Staging.  The DB is padded to whole tiles (zero rows, +inf norms), so there are
+  // no bounds checks; a tile is 64 KB contiguous, each thread copies 4 x 16 B at
+  // (wave-uniform tile base) + (constant per-thread offset).
+  float4 st0, st1, st2, st3;  // named registers (an array captured by a lambda ends up in scratch)
+  const unsigned st_off = (unsigned)tid * 16u;
+#define STAGE_LOAD(tile_)                                                                          \
+  do {                                                                                             \
+    const char* tb_ = reinterpret_cast<const char*>(db) + (size_t)(tile_) * (TILE_ROWS * DIM * 4); \
+    st0 = *reinterpret_cast<const float4*>(tb_ + st_off);                                          \
+    st1 = *reinterpret_cast<const float4*>(tb_ + st_off + 1 * (MATCH_THREADS * 16));               \
+    st2 = *reinterpret_cast<const float4*>(tb_ + st_off + 2 * (MATCH_THREADS * 16));               \
+    st3 = *reinterpret_cast<const float4*>(tb_ + st_off + 3 * (MATCH_THREADS * 16));               \
+  } while (0)
+  // thread c = tid + i*1024 holds chunk c4 = c & 31 of tile row r = c >> 5
+  float* const st_dst = lds + (tid >> 5) * LDS_STRIDE + (tid & 31) * 4;
+#define STAGE_STORE(buf_)                                                                  \
+  do {                                                                                     \
+    float* d_ = st_dst + (buf_) * TILE_FLOATS;                                             \
+    *reinterpret_cast<float4*>(d_) = st0;                                                  \
+    *reinterpret_cast<float4*>(d_ + 32 * LDS_STRIDE) = st1;                                \
+    *reinterpret_cast<float4*>(d_ + 64 * LDS_STRIDE) = st2;                                \
+    *reinterpret_cast<float4*>(d_ + 96 * LDS_STRIDE) = st3;                                \
+  } while (0)
 
   if (tile_begin < tile_end) {
-    stage_load(tile_begin);
-    stage_store(0);
+    STAGE_LOAD(tile_begin);
+    STAGE_STORE(0);
   }
   __syncthreads();
 
@@ -258,12 +267,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   int buf = 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const bool more = tile + 1 < tile_end;
-    if (more) stage_load(tile + 1);
+    if (more) STAGE_LOAD(tile + 1);
 
     const int row_a = tile * TILE_ROWS + lane;
     const int row_b = row_a + 64;
-    const float dn_a = (row_a < N) ? dnorm[row_a] : 0.f;
-    const float dn_b = (row_b < N) ? dnorm[row_b] : 0.f;
+    const float dn_a = dnorm[row_a];  // +inf on padding rows: they can never enter a top-2
+    const float dn_b = dnorm[row_b];
 
     const unsigned la = lds_base + (unsigned)((buf * TILE_FLOATS + lane * LDS_STRIDE) * 4);
     v2f acc[TQ];
@@ -277,27 +286,19 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
       chunk_pipe<0>(qp, la, qa0, qb0, ra0, rb0, qa1, qb1, ra1, rb1, acc);
     }
     // distances + fold: row a first, then row b (ascending row index within the lane)
-    const bool va = row_a < N, vb = row_b < N;
 #pragma unroll
     for (int tp = 0; tp < TQ / 2; ++tp) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const float dnr = r ? dn_b : dn_a;
         const int row = r ? row_b : row_a;
-        const bool valid = r ? vb : va;
-        const v2f nsum = nq[tp] + (v2f){dnr, dnr};
-        v2f d = __builtin_elementwise_fma((v2f){-2.f, -2.f}, acc[2 * tp + r], nsum);
-        d = __builtin_elementwise_max(d, (v2f){0.f, 0.f});
-        if (!valid) d = (v2f){__builtin_inff(), __builtin_inff()};  // rows past the end never win
-        const bool lt0 = d.x < b1[tp].x, lt1 = d.y < b1[tp].y;
-        b2[tp] = __builtin_elementwise_min(b2[tp], __builtin_elementwise_max(b1[tp], d));
-        b1[tp] = __builtin_elementwise_min(b1[tp], d);
-        i1[2 * tp] = lt0 ? row : i1[2 * tp];
-        i1[2 * tp + 1] = lt1 ? row : i1[2 * tp + 1];
+        const v2f d = __builtin_elementwise_fma((v2f){-2.f, -2.f}, acc[2 * tp + r], nq[tp] + (v2f){dnr, dnr});
+        fold(b1[2 * tp], b2[2 * tp], i1[2 * tp], fmaxf(d.x, 0.f), row);
+        fold(b1[2 * tp + 1], b2[2 * tp + 1], i1[2 * tp + 1], fmaxf(d.y, 0.f), row);
       }
     }
 
-    if (more) stage_store(buf ^ 1);
+    if (more) STAGE_STORE(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   // wavefront min-reduce of the per-lane top-2, one query at a time
 #pragma unroll
   for (int t = 0; t < TQ; ++t) {
-    Best s = {(t & 1) ? b1[t / 2].y : b1[t / 2].x, (t & 1) ? b2[t / 2].y : b2[t / 2].x, i1[t]};
+    Best s = {b1[t], b2[t], i1[t]};
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const float ob1 = __shfl_xor(s.b1, off);

@@ -1,5 +1,7 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'oracle')
+import os
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'oracle'))
 import orclib
 from moped_amd import capi, synth
 ctx = capi.Context(0)
