@@ -18,6 +18,8 @@
 // double-buffered 128-row LDS tile, which is what makes the database stream
 // through L2/HBM only Q/128 times.  Per-lane running top-2 per query, one
 // wavefront min-reduce at the end of the block's database split.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mh {
@@ -29,7 +31,7 @@ constexpr int NWAVES = 16;             // wavefronts per workgroup
 constexpr int QB = TQ * NWAVES;        // queries per workgroup (128)
 constexpr int TILE_ROWS = 128;         // database rows per LDS tile (2 per lane)
 constexpr int MATCH_THREADS = NWAVES * 64;
-constexpr int TARGET_BLOCKS = 768;     // 3 workgroups per CU over the launch
+constexpr int TARGET_BLOCKS_DEFAULT = 768;  // 3 workgroups per CU over the launch (MH_MATCH_BLOCKS overrides)
 
 __device__ __forceinline__ float dot_chain_lds(const float* a, const float* b) {
   float s = 0.f;
@@ -119,8 +121,8 @@ __global__ void pack_queries_kernel(const float* __restrict__ qn, const float* _
 }
 
 // ---- the match kernel -----------------------------------------------------------
-// grid.x = query groups of QB, grid.y = database splits.  Each block scans rows
-// [split*rows_per_split, +rows_per_split) and writes one Top2 per query.
+// 1-D grid of (query blocks of QB) x (database splits).  Each block scans the rows of
+// its split and writes one Top2 per query.
 //
 // Inner loop, per wavefront and 2 coordinates ("chunk"): one s_load_dwordx16 brings
 // 2 coordinates x 8 queries into SGPRs, two ds_read_b64 bring 2 coordinates of the
@@ -197,13 +199,31 @@ __device__ __forceinline__ void chunk_pipe(const float* qp, unsigned la, v16f& q
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
     const float* __restrict__ P, const float* __restrict__ Pnorm, int Q,
     const float* __restrict__ db, const float* __restrict__ dnorm, int N,
-    int tiles_per_split, int32_t index_base, Top2* __restrict__ partial) {
+    int tiles_per_split, int n_splits, int32_t index_base, Top2* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 tiles
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware block -> (query group block, split) map.  Workgroups are dealt to the
+  // 8 XCDs round-robin by linear id, and every XCD has its own L2: giving each XCD
+  // whole splits (all query blocks of a split share that split's DB rows) makes the
+  // DB leave HBM/MALL once instead of once per XCD.  Pure locality: any placement is
+  // correct.
+  const int nqb = gridDim.x / n_splits;                  // query blocks
+  int qblock, split;
+  {
+    const int L = blockIdx.x;
+    if ((n_splits & 7) == 0) {
+      const int x = L & 7, j = L >> 3;
+      split = x + 8 * (j / nqb);
+      qblock = j % nqb;
+    } else {
+      split = L / nqb;
+      qblock = L % nqb;
+    }
+  }
   const int n_groups = (Q + TQ - 1) / TQ;
-  const int g_raw = (int)blockIdx.x * NWAVES + wave;                 // wave-uniform
+  const int g_raw = qblock * NWAVES + wave;                          // wave-uniform
   const bool live = g_raw < n_groups;
   const int g = live ? g_raw : n_groups - 1;                         // surplus waves redo the last group
   const int q0 = g * TQ;
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
   const unsigned qp_hi = __builtin_amdgcn_readfirstlane((unsigned)(qp_bits >> 32));
   const float* qp = (const float*)(((unsigned long long)qp_hi << 32) | qp_lo);
   const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
-  const int tile_begin = blockIdx.y * tiles_per_split;
+  const int tile_begin = split * tiles_per_split;
   const int tile_end = min(tile_begin + tiles_per_split, n_tiles);
 
   v2f nq[TQ / 2];  // dot(q,q) of the query pairs; parked in VGPRs (the SGPR file is for the query stream)
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
       o.d2 = s.b2;
       o.i1 = (s.i1 >= 0) ? s.i1 + index_base : -1;
       o.pad = 0;
-      partial[(size_t)blockIdx.y * Q + qi] = o;
+      partial[(size_t)split * Q + qi] = o;
     }
   }
 }
@@ -365,7 +385,13 @@ __global__ void merge_shards_kernel(const int32_t* __restrict__ idx1_s,
 int splits_for(int Q, int N) {
   const int qgroups = (Q + QB - 1) / QB;
   const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
-  int S = (TARGET_BLOCKS + qgroups - 1) / qgroups;
+  static const int target = [] {
+    const char* e = getenv("MH_MATCH_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : TARGET_BLOCKS_DEFAULT;
+  }();
+  int S = (target + qgroups - 1) / qgroups;
+  if (S >= 8) S = (S + 7) / 8 * 8;  // whole splits per XCD (see match_kernel)
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
   return S;
@@ -412,8 +438,8 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       attr_set = true;
     }
-    hipLaunchKernelGGL(match_kernel, dim3(qgroups, S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
-                       db, dnorm, N, tiles_per_split, index_base, scratch);
+    hipLaunchKernelGGL(match_kernel, dim3(qgroups * S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
+                       db, dnorm, N, tiles_per_split, S, index_base, scratch);
   }
   hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, S, Q,
                      idx1, d1, d2);

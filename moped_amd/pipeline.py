@@ -67,12 +67,16 @@ class FramePipeline:
         self._res_gather = [None] * depth
 
     # ---- single frame in slot i ------------------------------------------------------
-    def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1):
+    def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
+                after: "torch.cuda.Stream | None" = None):
         """q_desc [Q,128] float32 (normalised in place), q_uv [Q,2]; both on this GPU.
-        Returns immediately; work is on the slot's stream."""
+        Returns immediately; work is on the slot's stream.  `after`: a stream whose
+        pending work produces the inputs (omit when they are already resident --
+        waiting on the legacy default stream serialises every frame behind it)."""
         c, s = self.ctxs[slot], self.streams[slot]
         Q = q_desc.shape[0]
-        s.wait_stream(torch.cuda.current_stream(self.dev))
+        if after is not None:
+            s.wait_stream(after)
         if self.world == 1:
             c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
             return
