@@ -104,9 +104,7 @@ class FramePipeline:
         ptr, nbytes = c.frame_result_dev()
         with torch.cuda.stream(s):
             mine = _wrap_uint8(ptr, nbytes, self.dev)
-            out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.dev)
-            dist.all_gather_into_tensor(out, mine, group=self.group)
-            out = out.view(self.world, nbytes)
+            out = _all_gather_flat(mine, self.world, self.group).view(self.world, nbytes)
         s.synchronize()
         host = out.cpu().numpy()
         objs = []
@@ -131,11 +129,24 @@ def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
     local top-2.  local = [3][Q] int32 words (idx1, bits of d1, bits of d2);
     returns [3][W][Q] so that each field is the [W][Q] array mh_match_merge_dev
     expects.  Device-agnostic (RCCL on GPU, gloo in the CPU tests)."""
-    import torch.distributed as dist
     Q = local.shape[1]
-    gathered = torch.empty(world * 3 * Q, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous().view(-1), group=group)  # flat: gloo and RCCL agree
+    gathered = _all_gather_flat(local.contiguous().view(-1), world, group)
     return gathered.view(world, 3, Q).permute(1, 0, 2).contiguous()
+
+
+def _all_gather_flat(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """all_gather_into_tensor on flat buffers.  RCCL takes device tensors directly;
+    the gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the N > 1
+    path) is fed through host memory."""
+    import torch.distributed as dist
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        host = mine.cpu()
+        out = torch.empty(world * host.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(mine.device)
+    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out
 
 
 def owner_of_model(model: int, n_models: int, world: int) -> int:

@@ -1,0 +1,82 @@
+"""Rehearsal of the N > 1 path on ONE GPU: two processes, each with its own model
+shard and mh_ctx on cuda:0, gloo for the two exchanges (RCCL cannot put two ranks on
+one device).  Everything except the collective's transport is the code bench.py runs
+with --gpus N: mh_frame_enqueue_match_local -> exchange 1 -> mh_frame_enqueue_rest ->
+exchange 2.  The merged result must equal the single-context frame."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.gpu
+
+N_MODELS, PPM, Q = 8, 1500, 1200
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from moped_amd import synth
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    db = synth.make_db(N_MODELS, PPM)
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world), depth=1, max_queries=Q)
+    dev = torch.device("cuda:0")
+    res = {}
+    for seed in (0, 1):
+        fr = synth.make_frame(db, n_vis=3, seed=seed, Q=Q, pts_per_obj=120)
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seed + 5)
+        objs = pipe.gather_objects(0)
+        local, counts = pipe.fetch(0)
+        res[f"objs{seed}"] = objs
+        res[f"local{seed}"] = local
+        res[f"counts{seed}"] = counts
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
+    pipe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equals_single_context(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib
+    from moped_amd import synth
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    world = 2
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    db = synth.make_db(N_MODELS, PPM)
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=Q)
+    dev = torch.device("cuda:0")
+    z = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for seed in (0, 1):
+        fr = synth.make_frame(db, n_vis=3, seed=seed, Q=Q, pts_per_obj=120)
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seed + 5)
+        single, counts = pipe.fetch(0)
+        merged = z[0][f"objs{seed}"]
+        assert np.array_equal(z[1][f"objs{seed}"]["model"], merged["model"])       # every rank sees the same list
+        # accepted matches: each kept by exactly one rank
+        assert z[0][f"counts{seed}"][0] + z[1][f"counts{seed}"][0] == counts[0]
+        assert z[0][f"counts{seed}"][1] + z[1][f"counts{seed}"][1] == counts[1]
+        assert sorted(merged["model"].tolist()) == sorted(single["model"].tolist())
+        assert set(single["model"].tolist()) == set(fr.visible.tolist())
+        # rank r only reports models it owns
+        for r in range(world):
+            lo, hi = (r * N_MODELS) // world, ((r + 1) * N_MODELS) // world
+            assert all(lo <= m < hi for m in z[r][f"local{seed}"]["model"])
+        for o in merged:
+            s = single[single["model"] == o["model"]][0]
+            rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+            rows = rows[db.model_of[fr.src_point[rows]] == o["model"]]
+            xyz, uv = db.xyz[fr.src_point[rows]], fr.uv[rows]
+            e_m = np.sqrt(((orclib.project(o["pose"], xyz, synth.K_DEFAULT, synth.CAM_IDENTITY) - uv) ** 2).sum(1)).mean()
+            e_s = np.sqrt(((orclib.project(s["pose"], xyz, synth.K_DEFAULT, synth.CAM_IDENTITY) - uv) ** 2).sum(1)).mean()
+            assert e_m < 1.0 and abs(e_m - e_s) < 0.5
+    pipe.close()
