@@ -19,6 +19,9 @@
  *   mh_meanshift        CLUSTER_MEAN_SHIFT_CPU::MeanShift src/cluster/CLUSTER_MEAN_SHIFT_CPU.hpp:80-158
  *   mh_pose_ransac      POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::RANSAC/process
  *                                                        src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:76-211,264-307
+ *   mh_pose_ransac_depth  POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU / ..._REPROJECTION_DEPTH_CPU
+ *                       moped3d/libmoped/src/pose/POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU.hpp:108-325,
+ *                       moped3d/libmoped/src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_DEPTH_CPU.hpp:106-216
  *   mh_project_test     testAllPoints / project()        …REPROJECTION_CPU.hpp:166-180, include/moped.hpp:330-354
  *   mh_filter           FILTER_PROJECTION_CPU::process   src/filter/FILTER_PROJECTION_CPU.hpp:80-162
  *   mh_frame_*          the per-frame loop over those steps, MopedPimpl::processImages
@@ -147,6 +150,28 @@ int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster
                    int n_clusters, const mh_cam* cam, const mh_pose_params* prm,
                    uint64_t seed, mh_pose_out* out_host, int32_t* n_out);
 
+/* moped3d (Kinect) variants: every correspondence also carries the camera-frame point
+ * read from the depth map and its Cauchy weight (Match.depthData.coord3D and
+ * getCauchyWeight(fillDistance), moped3d/libmoped/src/util.hpp:73-84,
+ * ...BACKPROJECTION_DEPTH_CPU.hpp:194-197). */
+typedef struct {
+  float wx, wy, wz; /* world3D: camera-frame xyz of the keypoint from the depth map */
+  float w;          /* cauchyWeight */
+} mh_depth;
+
+#define MH_DEPTH_NONE 0          /* moped2 residuals (u,v only) */
+#define MH_DEPTH_BACKPROJECTION 1 /* POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU (moped3d default) */
+#define MH_DEPTH_REPROJECTION 2   /* POSE_RANSAC_LM_DIFF_REPROJECTION_DEPTH_CPU */
+
+/* As mh_pose_ransac, with depth_host[i] beside corr_host[i]; kind = MH_DEPTH_*, alpha =
+ * the class's Alpha (0.5 in moped3d/libmoped/src/config.hpp:46,48).  Hypotheses and the
+ * inlier test are the 2-D ones (the reference's testAllPoints is unchanged); the refine
+ * minimises the depth-aware residuals of the chosen class. */
+int mh_pose_ransac_depth(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host,
+                         const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
+                         const mh_pose_params* prm, int kind, float alpha, uint64_t seed,
+                         mh_pose_out* out_host, int32_t* n_out);
+
 /* testAllPoints: inlier_host[i] = squared reprojection error < thr; err2_host
  * (optional) the squared error (FLT_MAX-based for z < 0.001 like project()). */
 int mh_project_test(mh_ctx* ctx, const float pose[7], const mh_corr* corr_host, int n,
@@ -194,6 +219,10 @@ typedef struct {
  * synchronisation.  Results stay on the device until mh_frame_fetch. */
 int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
                      const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* Per-query depth attributes for the next frames (device pointer, [Q] mh_depth, in query
+ * order; NULL switches back to the 2-D residuals).  POSE and POSE2 of the frame then use
+ * the MH_DEPTH_* residuals `kind` with `alpha`. */
+int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float alpha);
 /* The two halves around exchange 1 when the DB is sharded over ranks:
  *   mh_frame_enqueue_match_local : normalise + local top-2 -> ctx-owned
  *       device arrays (pointers returned for the all-gather)

@@ -61,13 +61,16 @@ class mh_times(C.Structure):
 
 CORR_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
 OBJECT_DTYPE = np.dtype([("model", "<i4"), ("pose", "<f4", (7,)), ("score", "<f4"), ("n_points", "<i4")])
+DEPTH_DTYPE = np.dtype([("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("w", "<f4")])
+DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
 
 # every symbol include/moped_hip.h declares
 EXPORTS = [
     "mh_create", "mh_destroy", "mh_last_error", "mh_set_stream", "mh_synchronize", "mh_reserve",
     "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
-    "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_pose_ransac", "mh_project_test",
+    "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_pose_ransac", "mh_pose_ransac_depth",
+    "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
 ]
@@ -110,6 +113,9 @@ def load():
     L.mh_meanshift.argtypes = [vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, C.POINTER(C.c_int32)]
     L.mh_pose_ransac.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_pose_params),
                                  C.c_uint64, vp, C.POINTER(C.c_int32)]
+    L.mh_pose_ransac_depth.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_pose_params), i32, f32,
+                                       C.c_uint64, vp, C.POINTER(C.c_int32)]
+    L.mh_frame_set_depth.argtypes = [vp, vp, i32, f32]
     L.mh_project_test.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, vp, vp, C.POINTER(C.c_int32)]
     L.mh_filter.argtypes = [vp, vp, vp, i32, vp, vp, i32, C.POINTER(mh_cam), i32, f32, f32,
                             vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
@@ -148,6 +154,16 @@ def default_frame_params() -> mh_frame_params:
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack_depth(world, wgt) -> np.ndarray:
+    n = len(world)
+    d = np.zeros(n, DEPTH_DTYPE)
+    if n:
+        world = np.asarray(world, np.float32)
+        d["wx"], d["wy"], d["wz"] = world[:, 0], world[:, 1], world[:, 2]
+        d["w"] = np.asarray(wgt, np.float32)
+    return d
 
 
 def pack_corr(uv, xyz) -> np.ndarray:
@@ -254,6 +270,24 @@ class Context:
         self._ck(self.L.mh_pose_ransac(self.h, _ptr(corr), _ptr(cluster_off), ncl, C.byref(c),
                                        C.byref(params), seed, _ptr(out), C.byref(n_out)), "mh_pose_ransac")
         return out[:n_out.value].copy()
+
+    def pose_ransac_depth(self, corr, depth, cluster_off, K, cam, params: mh_pose_params, kind, alpha=0.5, seed=1):
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        depth = np.ascontiguousarray(depth, DEPTH_DTYPE)
+        cluster_off = np.ascontiguousarray(cluster_off, np.int32)
+        ncl = len(cluster_off) - 1
+        R = max(params.max_objects_per_cluster, 1)
+        out = np.zeros(max(ncl * R, 1), POSE_OUT_DTYPE)
+        n_out = C.c_int32(0)
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_pose_ransac_depth(self.h, _ptr(corr), _ptr(depth), _ptr(cluster_off), ncl, C.byref(c),
+                                             C.byref(params), kind, alpha, seed, _ptr(out), C.byref(n_out)),
+                 "mh_pose_ransac_depth")
+        return out[:n_out.value].copy()
+
+    def frame_set_depth(self, q_depth_ptr, kind, alpha=0.5):
+        self._ck(self.L.mh_frame_set_depth(self.h, C.c_void_p(q_depth_ptr) if q_depth_ptr else None, kind, alpha),
+                 "mh_frame_set_depth")
 
     def project_test(self, pose7, corr, K, cam, thr):
         corr = np.ascontiguousarray(corr, CORR_DTYPE)

@@ -17,6 +17,7 @@ struct FrameState {
   // group
   int32_t *acc_q = nullptr, *acc_model = nullptr, *m_q = nullptr, *m_model = nullptr, *m_rep = nullptr;
   mh_corr* m_corr = nullptr;
+  mh_depth* m_depth = nullptr;     // per match, when the frame carries depth attributes
   int32_t* model_off = nullptr;
   // cluster
   int32_t *ms_members = nullptr, *ms_cl_start = nullptr, *ms_ncl = nullptr;
@@ -49,7 +50,8 @@ void free_fs(FrameState* fs) {
                   fs->ms_members, fs->ms_cl_start, fs->ms_ncl,   fs->cl_model,   fs->cl_begin,
                   fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
                   fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
-                  fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw};
+                  fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw,
+                  fs->m_depth};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete fs;
@@ -85,6 +87,7 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->m_model, max_m);
   rc |= dev_alloc(ctx, fs->m_rep, max_m);
   rc |= dev_alloc(ctx, fs->m_corr, max_m);
+  rc |= dev_alloc(ctx, fs->m_depth, max_m);
   rc |= dev_alloc(ctx, fs->model_off, (size_t)n_models + 1);
   rc |= dev_alloc(ctx, fs->ms_members, max_m);
   rc |= dev_alloc(ctx, fs->ms_cl_start, (size_t)max_m + n_models + 1);
@@ -188,7 +191,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, c
   // MATCH tail: ratio test + per-model lists
   launch_group(idx1, d1, d2, Q, prm->ratio, q_uv_dev, ctx->db_model, ctx->db_xyz, ctx->N,
                ctx->index_base, nm, fs->max_m, fs->acc_q, fs->acc_model, fs->m_q, fs->m_model,
-               fs->m_corr, fs->m_rep, fs->model_off, fs->counts, s);
+               fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth, fs->m_depth, fs->counts, s);
   stamp(ctx, 2);
   // CLUSTER
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
@@ -201,8 +204,9 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, c
   hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 1, &fs->counts->n_clusters);
   stamp(ctx, 3);
   // POSE
-  launch_pose(fs->m_corr, fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
-              fs->max_clusters, dc, prm->pose1, seed, fs->n_slots, fs->max_objects, fs->obj_model,
+  const float* depth4 = ctx->q_depth ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
+  launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
+              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, fs->n_slots, fs->max_objects, fs->obj_model,
               fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
   hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
                      prm->pose1.max_objects_per_cluster > 0 ? prm->pose1.max_objects_per_cluster : 1,
@@ -217,8 +221,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, c
     hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 3, fs->n_slots);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
-    launch_pose(fs->m_corr, fs->new_members, fs->cl_model, fs->cl_begin, fs->cl_count,
-                fs->n_clusters, fs->max_clusters, dc, prm->pose2, seed ^ 0x5DEECE66Dull, fs->n_slots,
+    launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
+                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2, seed ^ 0x5DEECE66Dull, fs->n_slots,
                 fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err,
                 fs->obj_cluster, fs->obj_valid, fs->counts, s);
     hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
@@ -329,9 +333,10 @@ int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radiu
   return MH_OK;
 }
 
-int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster_off,
-                   int n_clusters, const mh_cam* cam, const mh_pose_params* prm, uint64_t seed,
-                   mh_pose_out* out_host, int32_t* n_out) {
+static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host, int kind,
+                            float alpha, const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
+                            const mh_pose_params* prm, uint64_t seed, mh_pose_out* out_host,
+                            int32_t* n_out) {
   if (!ctx || n_clusters < 0 || !cam || !prm || !n_out || (n_clusters > 0 && (!corr_host || !cluster_off || !out_host))) {
     if (ctx) ctx->err = "mh_pose_ransac: bad argument";
     return MH_ERR_ARG;
@@ -353,6 +358,8 @@ int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster
     h_count[c] = cluster_off[c + 1] - cluster_off[c];
   }
   MH_HIP(ctx, hipMemcpyAsync(fs->m_corr, corr_host, (size_t)total * sizeof(mh_corr), hipMemcpyHostToDevice, s));
+  if (depth_host)
+    MH_HIP(ctx, hipMemcpyAsync(fs->m_depth, depth_host, (size_t)total * sizeof(mh_depth), hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->ms_members, h_members.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->cl_model, h_model.data(), (size_t)n_clusters * 4, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->cl_begin, h_begin.data(), (size_t)n_clusters * 4, hipMemcpyHostToDevice, s));
@@ -361,8 +368,8 @@ int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_clusters, n_clusters);
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
   const DevCam dc = make_devcam(*cam);
-  launch_pose(fs->m_corr, fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
-              n_clusters, dc, *prm, seed, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+  launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
+              fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
               fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
   MH_HIP(ctx, hipGetLastError());
   std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
@@ -383,6 +390,32 @@ int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster
     po.err = err[o];
   }
   *n_out = k;
+  return MH_OK;
+}
+
+int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster_off,
+                   int n_clusters, const mh_cam* cam, const mh_pose_params* prm, uint64_t seed,
+                   mh_pose_out* out_host, int32_t* n_out) {
+  return pose_ransac_impl(ctx, corr_host, nullptr, MH_DEPTH_NONE, 0.f, cluster_off, n_clusters, cam, prm, seed,
+                          out_host, n_out);
+}
+
+int mh_pose_ransac_depth(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host,
+                         const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
+                         const mh_pose_params* prm, int kind, float alpha, uint64_t seed,
+                         mh_pose_out* out_host, int32_t* n_out) {
+  if (kind != MH_DEPTH_BACKPROJECTION && kind != MH_DEPTH_REPROJECTION) return MH_ERR_ARG;
+  if (n_clusters > 0 && !depth_host) return MH_ERR_ARG;
+  return pose_ransac_impl(ctx, corr_host, depth_host, kind, alpha, cluster_off, n_clusters, cam, prm, seed,
+                          out_host, n_out);
+}
+
+int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float alpha) {
+  if (!ctx) return MH_ERR_ARG;
+  if (q_depth_dev && kind != MH_DEPTH_BACKPROJECTION && kind != MH_DEPTH_REPROJECTION) return MH_ERR_ARG;
+  ctx->q_depth = q_depth_dev;
+  ctx->depth_kind = q_depth_dev ? kind : MH_DEPTH_NONE;
+  ctx->depth_alpha = alpha;
   return MH_OK;
 }
 

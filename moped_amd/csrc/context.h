@@ -44,6 +44,11 @@ struct mh_ctx {
   // frame state (group / cluster / pose / filter); defined in frame.h
   struct FrameState* fs = nullptr;
 
+  // optional depth attributes of the current queries (moped3d residuals)
+  const mh_depth* q_depth = nullptr;
+  int depth_kind = 0;
+  float depth_alpha = 0.5f;
+
   bool timing = false;
   hipEvent_t ev[10] = {};
   bool ev_made = false;

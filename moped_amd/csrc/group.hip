@@ -33,7 +33,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     const float* __restrict__ db_xyz, int N, int32_t index_base, int n_models, int max_m,
     int32_t* __restrict__ acc_q, int32_t* __restrict__ acc_model, int32_t* __restrict__ m_q,
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
-    int32_t* __restrict__ model_off, FrameCounts* counts) {
+    int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
+    mh_depth* __restrict__ m_depth, FrameCounts* counts) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int base_s;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     c.y = db_xyz[3 * (size_t)li + 1];
     c.z = db_xyz[3 * (size_t)li + 2];
     m_corr[dst] = c;
+    if (q_depth) m_depth[dst] = q_depth[q];
   }
   __threadfence_block();
   __syncthreads();
@@ -178,10 +180,11 @@ void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, 
                   const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
-                  int32_t* model_off, FrameCounts* counts, hipStream_t s) {
+                  int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, FrameCounts* counts,
+                  hipStream_t s) {
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, idx1, d1, d2, Q, ratio, q_uv,
                      db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model, m_q,
-                     m_model, m_corr, m_rep, model_off, counts);
+                     m_model, m_corr, m_rep, model_off, q_depth, m_depth, counts);
 }
 
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {

@@ -270,68 +270,149 @@ __device__ void rot_to_quat(const float* r, float* q) {
 
 // ---- LM refine, one wavefront ----------------------------------------------------
 // 6-DoF local update (omega, dt): R <- exp(omega) R, t <- t + dt.
-// mode 0: residual (du, dv); mode 1: residual (du^2, dv^2) as lmFuncQuat.
+//
+// KIND selects the residual model (what the reference class minimises):
+//   0  POSE_RANSAC_LM_DIFF_REPROJECTION_CPU   (moped2 …REPROJECTION_CPU.hpp:100-138)
+//   1  POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU (moped3d …BACKPROJECTION_DEPTH_CPU.hpp:108-190)
+//   2  POSE_RANSAC_LM_DIFF_REPROJECTION_DEPTH_CPU   (moped3d …REPROJECTION_DEPTH_CPU.hpp:106-216)
+// phase 0 minimises the plain (un-squared) errors for fast convergence, phase 1 the
+// reference's squared errors so the result sits at the minimiser levmar converges to.
+// A point is pts[PS*i ..] = u,v, x,y,z [, wx,wy,wz, cauchyWeight].
+constexpr int MAX_ROWS = 4;
+template <int KIND> struct PointStride { static constexpr int value = (KIND == 0) ? 5 : 9; };
+
 struct Accum {
   float H[21];  // upper triangle of J^T J
   float g[6];   // J^T r
-  float cost;
 };
 
-__device__ __forceinline__ void residual_point(const float* R, const float* t, const DevCam& cam,
-                                               const float* p /*u,v,x,y,z*/, int mode, float* r2,
-                                               float J[2][6], bool want_j) {
+// J row for a residual whose gradient w.r.t. the camera-frame point is gc:
+// dc/dw = Rc^T, dw/d(dt) = I, dw/d(omega) = -[y]_x with y the rotated model point
+// ->  translation part = Rc gc (world frame), rotation part = y x (Rc gc).
+__device__ __forceinline__ void row_from_grad(const DevCam& cam, const float* y, const float* gc, float* J) {
+  float gw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gw[k] = gc[0] * cam.Rc[k * 3 + 0] + gc[1] * cam.Rc[k * 3 + 1] + gc[2] * cam.Rc[k * 3 + 2];
+  J[0] = y[1] * gw[2] - y[2] * gw[1];
+  J[1] = y[2] * gw[0] - y[0] * gw[2];
+  J[2] = y[0] * gw[1] - y[1] * gw[0];
+  J[3] = gw[0];
+  J[4] = gw[1];
+  J[5] = gw[2];
+}
+
+// Residual rows of one correspondence.  Returns the row count; r[], and J[][6] when want_j.
+template <int KIND>
+__device__ __forceinline__ int residual_rows(const float* R, const float* t, const DevCam& cam, const float* p,
+                                             float alpha, int phase, float* r, float (*J)[6], bool want_j) {
   const float X = p[2], Y = p[3], Z = p[4];
-  const float yx = R[0] * X + R[1] * Y + R[2] * Z;  // rotated model point
-  const float yy = R[3] * X + R[4] * Y + R[5] * Z;
-  const float yz = R[6] * X + R[7] * Y + R[8] * Z;
-  const float wx = yx + t[0] - cam.tc[0], wy = yy + t[1] - cam.tc[1], wz = yz + t[2] - cam.tc[2];
-  const float cx = wx * cam.Rc[0] + wy * cam.Rc[3] + wz * cam.Rc[6];
-  const float cy = wx * cam.Rc[1] + wy * cam.Rc[4] + wz * cam.Rc[7];
-  const float cz = wx * cam.Rc[2] + wy * cam.Rc[5] + wz * cam.Rc[8];
-  if (cz < 0.f || !(fabsf(cz) > 1e-9f)) {  // behind the camera: lmFuncQuat's penalty, no gradient
-    r2[0] = -cz + 10.f;
-    r2[1] = -cz + 10.f;
-    if (want_j)
-      for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 6; ++b) J[a][b] = 0.f;
-    return;
+  float y[3];  // rotated model point
+  y[0] = R[0] * X + R[1] * Y + R[2] * Z;
+  y[1] = R[3] * X + R[4] * Y + R[5] * Z;
+  y[2] = R[6] * X + R[7] * Y + R[8] * Z;
+  const float wx = y[0] + t[0] - cam.tc[0], wy = y[1] + t[1] - cam.tc[1], wz = y[2] + t[2] - cam.tc[2];
+  float c[3];  // camera-frame point
+  c[0] = wx * cam.Rc[0] + wy * cam.Rc[3] + wz * cam.Rc[6];
+  c[1] = wx * cam.Rc[1] + wy * cam.Rc[4] + wz * cam.Rc[7];
+  c[2] = wx * cam.Rc[2] + wy * cam.Rc[5] + wz * cam.Rc[8];
+  constexpr int NR = (KIND == 0) ? 2 : ((KIND == 1) ? 4 : 3);      // rows in phase 0
+  const int nrows = (phase == 0) ? NR : ((KIND == 2) ? 3 : 2);   // the reference's row count in phase 1
+  float w3 = 0.f, w2 = 1.f;
+  if (KIND != 0) {
+    w3 = (1.f - alpha) * p[8];
+    w2 = 1.f - w3;
   }
-  const float iz = 1.f / cz;
-  const float du = cx * iz * cam.K[0] + cam.K[2] - p[0];
-  const float dv = cy * iz * cam.K[1] + cam.K[3] - p[1];
-  if (want_j) {
-    // d(u,v)/d(c) rows
-    const float ju[3] = {cam.K[0] * iz, 0.f, -cam.K[0] * cx * iz * iz};
-    const float jv[3] = {0.f, cam.K[1] * iz, -cam.K[1] * cy * iz * iz};
-    // dc/dw = Rc^T : row i of Rc^T is column i of Rc
-    float gu[3], gv[3];  // gradients w.r.t. world point
-    for (int k = 0; k < 3; ++k) {
-      gu[k] = ju[0] * cam.Rc[k * 3 + 0] + ju[1] * cam.Rc[k * 3 + 1] + ju[2] * cam.Rc[k * 3 + 2];
-      gv[k] = jv[0] * cam.Rc[k * 3 + 0] + jv[1] * cam.Rc[k * 3 + 1] + jv[2] * cam.Rc[k * 3 + 2];
+  if (c[2] < 0.f || !(fabsf(c[2]) > 1e-9f)) {  // behind the camera: the reference's penalty, no gradient
+    const float pen = -c[2] + 10.f;
+    for (int a = 0; a < nrows; ++a) {
+      float wgt = 1.f;
+      if (KIND == 1) wgt = (a == nrows - 1) ? w3 : w2;
+      if (KIND == 2) wgt = (a == 2) ? w3 : w2;
+      r[a] = pen * ((phase == 0) ? sqrtf(wgt) : wgt);
+      if (want_j)
+        for (int k = 0; k < 6; ++k) J[a][k] = 0.f;
     }
-    // dw/domega = -[y]_x  ->  g . (omega x y) = omega . (y x g)
-    J[0][0] = yy * gu[2] - yz * gu[1];
-    J[0][1] = yz * gu[0] - yx * gu[2];
-    J[0][2] = yx * gu[1] - yy * gu[0];
-    J[1][0] = yy * gv[2] - yz * gv[1];
-    J[1][1] = yz * gv[0] - yx * gv[2];
-    J[1][2] = yx * gv[1] - yy * gv[0];
-    for (int k = 0; k < 3; ++k) {
-      J[0][3 + k] = gu[k];
-      J[1][3 + k] = gv[k];
-    }
+    return nrows;
   }
-  if (mode == 0) {
-    r2[0] = du;
-    r2[1] = dv;
-  } else {
-    r2[0] = du * du;
-    r2[1] = dv * dv;
-    if (want_j)
-      for (int b = 0; b < 6; ++b) {
-        J[0][b] *= 2.f * du;
-        J[1][b] *= 2.f * dv;
+  if (KIND == 0 || KIND == 2) {
+    const float iz = 1.f / c[2];
+    const float du = c[0] * iz * cam.K[0] + cam.K[2] - p[0];
+    const float dv = c[1] * iz * cam.K[1] + cam.K[3] - p[1];
+    const float gu[3] = {cam.K[0] * iz, 0.f, -cam.K[0] * c[0] * iz * iz};
+    const float gv[3] = {0.f, cam.K[1] * iz, -cam.K[1] * c[1] * iz * iz};
+    const float s0 = (phase == 0) ? sqrtf(w2) : w2;
+    float g[3];
+    if (phase == 0) {
+      r[0] = s0 * du;
+      r[1] = s0 * dv;
+    } else {
+      r[0] = s0 * du * du;
+      r[1] = s0 * dv * dv;
+    }
+    if (want_j) {
+      const float fu = (phase == 0) ? s0 : 2.f * s0 * du, fv = (phase == 0) ? s0 : 2.f * s0 * dv;
+      for (int k = 0; k < 3; ++k) g[k] = fu * gu[k];
+      row_from_grad(cam, y, g, J[0]);
+      for (int k = 0; k < 3; ++k) g[k] = fv * gv[k];
+      row_from_grad(cam, y, g, J[1]);
+    }
+    if (KIND == 2) {
+      // depthError = | p (p.W) - p | = |p| |p.W - 1|  (…REPROJECTION_DEPTH_CPU.hpp:176-186), x50, weight3D
+      const float* W = p + 5;
+      const float pw = c[0] * W[0] + c[1] * W[1] + c[2] * W[2] - 1.f;
+      const float n2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+      const float nn = sqrtf(n2);
+      if (phase == 0) {
+        const float s3 = sqrtf(50.f * w3);
+        r[2] = s3 * nn * pw;
+        if (want_j) {
+          for (int k = 0; k < 3; ++k) g[k] = s3 * (c[k] / nn * pw + nn * W[k]);
+          row_from_grad(cam, y, g, J[2]);
+        }
+      } else {
+        r[2] = 50.f * w3 * n2 * pw * pw;
+        if (want_j) {
+          for (int k = 0; k < 3; ++k) g[k] = 50.f * w3 * (2.f * c[k] * pw * pw + n2 * 2.f * pw * W[k]);
+          row_from_grad(cam, y, g, J[2]);
+        }
       }
+    }
+    return nrows;
+  }
+  // KIND == 1: back-projection onto the ray through the depth-map point W
+  {
+    const float* W = p + 5;
+    const float wn = sqrtf(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+    const float n[3] = {W[0] / wn, W[1] / wn, W[2] / wn};
+    const float sp = n[0] * c[0] + n[1] * c[1] + n[2] * c[2];
+    const float e[3] = {c[0] - n[0] * sp, c[1] - n[1] * sp, c[2] - n[2] * sp};  // p - pHat
+    const float ez = wn - sp;                                                     // along the ray
+    float g[3];
+    if (phase == 0) {
+      const float s2 = sqrtf(w2), s3 = sqrtf(w3);
+      for (int a = 0; a < 3; ++a) {
+        r[a] = s2 * e[a];
+        if (want_j) {
+          for (int k = 0; k < 3; ++k) g[k] = s2 * ((a == k ? 1.f : 0.f) - n[a] * n[k]);
+          row_from_grad(cam, y, g, J[a]);
+        }
+      }
+      r[3] = s3 * ez;
+      if (want_j) {
+        for (int k = 0; k < 3; ++k) g[k] = -s3 * n[k];
+        row_from_grad(cam, y, g, J[3]);
+      }
+    } else {
+      r[0] = w2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);  // weight2D * dxy^2
+      r[1] = w3 * ez * ez;                                    // weight3D * dz^2
+      if (want_j) {
+        for (int k = 0; k < 3; ++k) g[k] = 2.f * w2 * e[k];
+        row_from_grad(cam, y, g, J[0]);
+        for (int k = 0; k < 3; ++k) g[k] = -2.f * w3 * ez * n[k];
+        row_from_grad(cam, y, g, J[1]);
+      }
+    }
+    return nrows;
   }
 }
 
@@ -342,13 +423,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Sum of squared residuals over the inlier list at pose (R,t); all 64 lanes return it.
+template <int KIND>
 __device__ float lm_cost(const float* R, const float* t, const DevCam& cam, const float* pts,
-                         const int* list, int n, int mode, int lane) {
+                         const int* list, int n, float alpha, int phase, int lane) {
+  constexpr int PS = PointStride<KIND>::value;
   float c = 0.f;
   for (int i = lane; i < n; i += 64) {
-    float r2[2], J[2][6];
-    residual_point(R, t, cam, pts + 5 * list[i], mode, r2, J, false);
-    c += r2[0] * r2[0] + r2[1] * r2[1];
+    float r[MAX_ROWS];
+    const int nr = residual_rows<KIND>(R, t, cam, pts + PS * list[i], alpha, phase, r, nullptr, false);
+    for (int a = 0; a < nr; ++a) c += r[a] * r[a];
   }
   return wave_sum(c);
 }
@@ -416,21 +499,25 @@ __device__ bool solve6(const float* Hp, const float* g, float mu, float* x) {
 }
 
 // Runs on one full wavefront; pose in/out is wave-uniform.
+template <int KIND>
 __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* pts, const int* list,
-                           int n, int mode, int iters, int lane) {
-  float cost = lm_cost(R, t, cam, pts, list, n, mode, lane);
+                           int n, float alpha, int phase, int iters, int lane) {
+  constexpr int PS = PointStride<KIND>::value;
+  float cost = lm_cost<KIND>(R, t, cam, pts, list, n, alpha, phase, lane);
   float mu = -1.f, nu = 2.f;
   for (int it = 0; it < iters; ++it) {
     Accum acc;
     for (int i = 0; i < 21; ++i) acc.H[i] = 0.f;
     for (int i = 0; i < 6; ++i) acc.g[i] = 0.f;
     for (int i = lane; i < n; i += 64) {
-      float r2[2], J[2][6];
-      residual_point(R, t, cam, pts + 5 * list[i], mode, r2, J, true);
-      int k = 0;
-      for (int a = 0; a < 6; ++a) {
-        for (int b = a; b < 6; ++b) acc.H[k++] += J[0][a] * J[0][b] + J[1][a] * J[1][b];
-        acc.g[a] += J[0][a] * r2[0] + J[1][a] * r2[1];
+      float r[MAX_ROWS], J[MAX_ROWS][6];
+      const int nr = residual_rows<KIND>(R, t, cam, pts + PS * list[i], alpha, phase, r, J, true);
+      for (int row = 0; row < nr; ++row) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a) {
+          for (int b = a; b < 6; ++b) acc.H[k++] += J[row][a] * J[row][b];
+          acc.g[a] += J[row][a] * r[row];
+        }
       }
     }
     for (int i = 0; i < 21; ++i) acc.H[i] = wave_sum(acc.H[i]);
@@ -443,7 +530,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
     }
     float ginf = 0.f;
     for (int i = 0; i < 6; ++i) ginf = fmaxf(ginf, fabsf(acc.g[i]));
-    if (!(ginf > 1e-12f)) break;
+    if (!(ginf > 0.f)) break;
     bool accepted = false;
     for (int attempt = 0; attempt < 8 && !accepted; ++attempt) {
       float dx[6];
@@ -451,7 +538,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
         float Rn[9], tn[3];
         rotate_left(dx, R, Rn);
         for (int i = 0; i < 3; ++i) tn[i] = t[i] + dx[3 + i];
-        const float c2 = lm_cost(Rn, tn, cam, pts, list, n, mode, lane);
+        const float c2 = lm_cost<KIND>(Rn, tn, cam, pts, list, n, alpha, phase, lane);
         float dL = 0.f;
         for (int i = 0; i < 6; ++i) dL += dx[i] * (mu * dx[i] - acc.g[i]);
         const float dF = cost - c2;
@@ -475,8 +562,9 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
   return cost;
 }
 
+template <int KIND>
 struct PoseLds {
-  float pts[POSE_MAX_PTS * 5];      // u,v,x,y,z of the cluster
+  float pts[POSE_MAX_PTS * PointStride<KIND>::value];  // u,v,x,y,z[,wx,wy,wz,w] of the cluster
   int list[POSE_MAX_PTS];           // inlier list of the winner
   unsigned long long wave_best[POSE_THREADS / 64];
   float best_pose[12];
@@ -484,8 +572,10 @@ struct PoseLds {
   int n_inl;
 };
 
+template <int KIND>
 __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
-    const mh_corr* __restrict__ corr, const int32_t* __restrict__ members,
+    const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
+    const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
     const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
     mh_pose_params prm, uint64_t seed, const int32_t* __restrict__ obj_base_dev, int max_objects,
@@ -493,7 +583,8 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
     FrameCounts* counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  PoseLds& L = *reinterpret_cast<PoseLds*>(smem);
+  PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
+  constexpr int PS = PointStride<KIND>::value;
   const int R_ = prm.max_objects_per_cluster;
   const int cluster = blockIdx.x / R_;
   const int replica = blockIdx.x % R_;
@@ -512,13 +603,21 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     k = POSE_MAX_PTS;
   }
   for (int i = tid; i < k; i += POSE_THREADS) {
-    const mh_corr c = corr[members[begin + i]];
-    float* p = L.pts + 5 * i;
+    const int mi = members[begin + i];
+    const mh_corr c = corr[mi];
+    float* p = L.pts + PS * i;
     p[0] = c.u;
     p[1] = c.v;
     p[2] = c.x;
     p[3] = c.y;
     p[4] = c.z;
+    if (KIND != 0) {
+      const float4 d = depth[mi];
+      p[5] = d.x;
+      p[6] = d.y;
+      p[7] = d.z;
+      p[8] = d.w;
+    }
   }
   if (tid == 0) {
     L.n_distinct = 0;
@@ -531,7 +630,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     for (int i = tid; i < k; i += POSE_THREADS) {
       bool first = true;
       for (int j = 0; j < i; ++j)
-        if (L.pts[5 * j] == L.pts[5 * i] && L.pts[5 * j + 1] == L.pts[5 * i + 1]) {
+        if (L.pts[PS * j] == L.pts[PS * i] && L.pts[PS * j + 1] == L.pts[PS * i + 1]) {
           first = false;
           break;
         }
@@ -558,7 +657,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     // 4 correspondences with pairwise distinct image coordinates (:76-98)
     int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
     auto same_uv = [&](int a, int b) {
-      return L.pts[5 * a] == L.pts[5 * b] && L.pts[5 * a + 1] == L.pts[5 * b + 1];
+      return L.pts[PS * a] == L.pts[PS * b] && L.pts[PS * a + 1] == L.pts[PS * b + 1];
     };
     i0 = (int)(splitmix64(st) % (uint64_t)k);
     for (int tries = 0; tries < 16 && i1 < 0; ++tries) {
@@ -578,7 +677,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     if (i3 < 0) continue;
     double X[3][3], y[3][3];
     auto load = [&](int s, int pi) {
-      const float* p = L.pts + 5 * pi;
+      const float* p = L.pts + PS * pi;
       X[s][0] = p[2];
       X[s][1] = p[3];
       X[s][2] = p[4];
@@ -594,7 +693,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     Pose34 cand;
     float best4 = __builtin_inff();
     bool have = false;
-    const float* p4 = L.pts + 5 * i3;
+    const float* p4 = L.pts + PS * i3;
     p3p(X, y, [&](const double* Rc_, const double* tc_) {
       Pose34 w;
       to_world(cam, Rc_, tc_, w);
@@ -608,7 +707,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     if (!have) continue;
     int cnt = 0;
     for (int i = 0; i < k; ++i) {
-      const float* p = L.pts + 5 * i;
+      const float* p = L.pts + PS * i;
       cnt += reproj_err2(cand.r, cand.t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
     }
     const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)h);
@@ -646,7 +745,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     const int i = base + lane;
     bool in = false;
     if (i < k) {
-      const float* p = L.pts + 5 * i;
+      const float* p = L.pts + PS * i;
       in = reproj_err2(R, t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
     }
     const unsigned long long m = __ballot(in);
@@ -654,8 +753,8 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     n_inl += __popcll(m);
   }
   __builtin_amdgcn_wave_barrier();
-  lm_refine(R, t, cam, L.pts, L.list, n_inl, 0, prm.lm_iters_l2, lane);
-  const float err = lm_refine(R, t, cam, L.pts, L.list, n_inl, 1, prm.lm_iters_l4, lane);
+  lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 0, prm.lm_iters_l2, lane);
+  const float err = lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
   if (lane == 0) {
     float q[4];
     rot_to_quat(R, q);
@@ -693,26 +792,48 @@ __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_co
 
 }  // namespace
 
-void launch_pose(const mh_corr* corr, const int32_t* members, const int32_t* cl_model,
+template <int KIND>
+static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alpha, const int32_t* members,
+                             const int32_t* cl_model, const int32_t* cl_begin, const int32_t* cl_count,
+                             const int32_t* n_clusters_dev, int max_clusters, const DevCam& cam,
+                             const mh_pose_params& p, uint64_t seed, const int32_t* obj_base_dev,
+                             int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
+                             float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
+                             hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(pose_kernel<KIND>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds<KIND>));
+    once = true;
+  }
+  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(max_clusters * p.max_objects_per_cluster), dim3(POSE_THREADS),
+                     sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
+                     n_clusters_dev, cam, p, seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
+                     obj_err, obj_cluster, obj_valid, counts);
+}
+
+void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
+                 const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, hipStream_t s) {
   if (max_clusters <= 0) return;
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pose_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds));
-    once = true;
-  }
-  const int R_ = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
   mh_pose_params p = prm;
-  p.max_objects_per_cluster = R_;
-  hipLaunchKernelGGL(pose_kernel, dim3(max_clusters * R_), dim3(POSE_THREADS), sizeof(PoseLds), s,
-                     corr, members, cl_model, cl_begin, cl_count, n_clusters_dev, cam, p, seed,
-                     obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err, obj_cluster,
-                     obj_valid, counts);
+  p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
+  const float4* d4 = reinterpret_cast<const float4*>(depth4);
+  const int kind = depth4 ? depth_kind : 0;
+#define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, p, \
+                  seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err, obj_cluster,       \
+                  obj_valid, counts, s
+  if (kind == 1)
+    launch_pose_kind<1>(POSE_ARGS);
+  else if (kind == 2)
+    launch_pose_kind<2>(POSE_ARGS);
+  else
+    launch_pose_kind<0>(POSE_ARGS);
+#undef POSE_ARGS
 }
 
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,

@@ -21,7 +21,8 @@ void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, 
                   const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
-                  int32_t* model_off, FrameCounts* counts, hipStream_t s);
+                  int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, FrameCounts* counts,
+                  hipStream_t s);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);
@@ -48,7 +49,10 @@ DevCam make_devcam(const mh_cam& cam);
 
 // One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
 // n_clusters_dev: device count (grid is launched for max_clusters).
-void launch_pose(const mh_corr* corr, const int32_t* members, const int32_t* cl_model,
+// depth4 (optional): per-match (wx,wy,wz,cauchyWeight) aligned with corr; depth_kind
+// 1 = back-projection residuals, 2 = reprojection+depth residuals (moped3d), 0 = moped2.
+void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
+                 const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,

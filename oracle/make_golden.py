@@ -12,6 +12,8 @@ without the reference.
                     descriptors quantised x512 to uint8 (values are defined as u8/512)
   match_ann_*.npz   ANN 1.1.1 kd-tree 2-NN at eps=0 (exact) and eps=5 (shipped
                     default, config.hpp:83) for fixture queries vs seeded DBs
+  pose_depth_ref.npz  the two moped3d depth residual models (A14): residual tables and
+                    slevmar_dif end states
   pose_ref.npz      project() / lmFuncQuat residual tables and slevmar_dif end
                     states for seeded 5/6-point and inlier-set problems
 """
@@ -128,12 +130,47 @@ def make_pose_golden():
     print("pose_ref.npz:", len(cases), "cases")
 
 
+def make_pose_depth_golden():
+    """moped3d residual tables and slevmar_dif end states for both depth classes."""
+    from moped_amd import synth
+    rng = np.random.default_rng(77)
+    K = synth.K_DEFAULT
+    cam = synth.CAM_IDENTITY
+    out = {"K": K}
+    i = 0
+    for mode in (1, 2):
+        for n in (5, 6, 20, 60):
+            xyz = ((rng.random((n, 3)) - 0.5) * [0.1, 0.1, 0.2]).astype(np.float32)
+            pose = np.concatenate([synth.random_quat(rng), [rng.uniform(-.1, .1), rng.uniform(-.1, .1),
+                                                            rng.uniform(0.5, 1.0)]]).astype(np.float32)
+            uv = (orclib.ref_project(pose, xyz, K, cam) + rng.uniform(-0.5, 0.5, (n, 2))).astype(np.float32)
+            R = synth.quat_to_R(pose[:4])
+            world = xyz.astype(np.float64) @ R.T + pose[4:].astype(np.float64)
+            world *= 1 + rng.normal(0, 0.0035, (n, 1)) * world[:, 2:3]      # Kinect-like depth noise ~ z^2
+            world = world.astype(np.float32)
+            fill = rng.uniform(0, 0.08 if mode == 1 else 20.0, n)
+            wgt = orclib.cauchy_weight(fill, 0.1 if mode == 1 else 25.0)
+            start = (pose + rng.normal(0, 0.02, 7)).astype(np.float32)
+            err = orclib.ref_residuals_depth(mode, start, uv, xyz, world, wgt, K, cam, 0.5)
+            ret, p_end, info = orclib.ref_optimize_camera_depth(mode, start, uv, xyz, world, wgt, K, cam, 0.5, 100)
+            for k, v in dict(mode=mode, xyz=xyz, uv=uv, world=world, wgt=wgt, pose_true=pose, start=start,
+                             err_start=err, ret=ret, pose_end=p_end, info=info).items():
+                out[f"c{i}_{k}"] = np.asarray(v)
+            i += 1
+    # a point behind the camera exercises the penalty branch
+    out["n_cases"] = i
+    np.savez_compressed(os.path.join(GOLD, "pose_depth_ref.npz"), **out)
+    print("pose_depth_ref.npz:", i, "cases")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["sift", "match", "pose"]
+    what = sys.argv[1:] or ["sift", "match", "pose", "depth"]
     if "sift" in what:
         make_sift_fixture()
     if "match" in what:
         make_match_golden()
     if "pose" in what:
         make_pose_golden()
+    if "depth" in what:
+        make_pose_depth_golden()

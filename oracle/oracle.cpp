@@ -175,17 +175,92 @@ bool solve_dense(const float* A_in, const float* b_in, float* x, int m) {
   return true;
 }
 
+// moped3d residuals (A14).  world = camera-frame point from the depth map,
+// w = cauchyWeight; alpha = the 2-D/3-D trade-off.
+// mode 1: POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU::lmFuncQuat
+//         (moped3d/libmoped/src/pose/...BACKPROJECTION_DEPTH_CPU.hpp:108-190), 2 per point
+// mode 2: POSE_RANSAC_LM_DIFF_REPROJECTION_DEPTH_CPU::lmFuncQuat
+//         (moped3d/.../...REPROJECTION_DEPTH_CPU.hpp:106-216), 3 per point
+void residuals_depth(int mode, const float* p7, const float* uv, const float* xyz, const float* world,
+                     const float* wgt, int n, const Camera& c, float alpha, float* err) {
+  float q[4] = {p7[0], p7[1], p7[2], p7[3]};
+  quat_normalize(q);
+  Mat34 T;
+  tm_init(T, q, p7 + 4);
+  for (int i = 0; i < n; i++) {
+    float p[3];
+    tm_apply(T, xyz + 3 * i, p);
+    tm_apply_inv(c.TM, p, p);
+    const float* W = world + 3 * i;
+    const float w3 = (1 - alpha) * wgt[i];
+    if (mode == 1) {
+      float* e = err + 2 * i;
+      if (p[2] < 0) {
+        e[0] = -p[2] + 10;
+        e[1] = -p[2] + 10;
+      } else {
+        float norm = std::sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+        float nx = W[0] / norm, ny = W[1] / norm, nz = W[2] / norm;
+        float dot = nx * p[0] + ny * p[1] + nz * p[2];
+        float hx = nx * dot, hy = ny * dot, hz = nz * dot;   // projection of p on the ray
+        // Pt::euclDist = sqrt(sqEuclDist), differences taken as (other - this)
+        float d0 = hx - p[0], d1 = hy - p[1], d2 = hz - p[2];
+        float dxy = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        float g0 = hx - W[0], g1 = hy - W[1], g2 = hz - W[2];
+        float dz = std::sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+        e[0] = dxy * dxy;
+        e[1] = dz * dz;
+      }
+      const float w2 = 1 - w3;
+      e[0] *= w2;
+      e[1] *= w3;
+    } else {
+      float* e = err + 3 * i;
+      float u = p[0] / p[2] * c.K[0] + c.K[2];
+      float v = p[1] / p[2] * c.K[1] + c.K[3];
+      if (p[2] < 0) {
+        e[0] = -p[2] + 10;
+        e[1] = -p[2] + 10;
+        e[2] = -p[2] + 10;
+      } else {
+        float dx = u - uv[2 * i], dy = v - uv[2 * i + 1];
+        e[0] = dx * dx;
+        e[1] = dy * dy;
+      }
+      float vtp = p[0] * W[0] + p[1] * W[1] + p[2] * W[2];
+      float a0 = p[0] - p[0] * vtp, a1 = p[1] - p[1] * vtp, a2 = p[2] - p[2] * vtp;  // (p3D - projWorld)
+      float de = std::sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+      e[2] = de * de;
+      e[2] *= 50;
+      e[0] *= (1 - w3);
+      e[1] *= (1 - w3);
+      e[2] *= w3;
+    }
+  }
+}
+
 struct LmProblem {
   const float* uv;
   const float* xyz;
   int npts;
   const Camera* cam;
-  void eval(const float* p, float* hx) const { residuals(p, uv, xyz, npts, *cam, hx); }
+  // depth variants (mode 0 = the moped2 residual)
+  int mode;
+  const float* world;
+  const float* wgt;
+  float alpha;
+  int per_item() const { return mode == 0 ? 2 : (mode == 1 ? 2 : 3); }
+  void eval(const float* p, float* hx) const {
+    if (mode == 0)
+      residuals(p, uv, xyz, npts, *cam, hx);
+    else
+      residuals_depth(mode, p, uv, xyz, world, wgt, npts, *cam, alpha, hx);
+  }
 };
 
 // Returns iterations or -1.  Target vector is zero, so e = -hx.
 int lm_dif(const LmProblem& f, float* p, int itmax, float* info) {
-  const int m = 7, n = 2 * f.npts;
+  const int m = 7, n = f.per_item() * f.npts;
   if (n < m) return -1;
   const float tau = 1e-3f, eps1 = 1e-17f, eps2 = 1e-17f, eps3 = 1e-17f, delta = 1e-6f;
   const float eps2_sq = eps2 * eps2;
@@ -333,7 +408,7 @@ float optimize_camera(float* pose7, const float* uv, const float* xyz, int n, co
                       int itmax, int* iters) {
   float p[7];
   memcpy(p, pose7, sizeof p);
-  LmProblem f = {uv, xyz, n, &cam};
+  LmProblem f = {uv, xyz, n, &cam, 0, NULL, NULL, 0.f};
   float info[3];
   int ret = lm_dif(f, p, itmax, info);
   if (iters) *iters = ret;
@@ -590,7 +665,7 @@ int orc_optimize_camera(float pose7[7], const float* uv, const float* xyz, int n
   camera_init(c, K, cam);
   float p[7];
   memcpy(p, pose7, sizeof p);
-  LmProblem f = {uv, xyz, n, &c};
+  LmProblem f = {uv, xyz, n, &c, 0, NULL, NULL, 0.f};
   float linfo[3] = {0, 0, 0};
   int ret = lm_dif(f, p, itmax, linfo);
   if (info) memcpy(info, linfo, sizeof linfo);
@@ -649,6 +724,102 @@ int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const
           sxyz.push_back(xyz[3 * i + 2]);
         }
       optimize_camera(pose7, &suv[0], &sxyz[0], cnt, c, prm->max_lm_tests, NULL);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+// ---- moped3d depth variants (A14) -------------------------------------------------
+void orc_residuals_depth(int mode, const float pose7[7], const float* uv, const float* xyz,
+                         const float* world, const float* wgt, int n, const float K[4],
+                         const float cam[7], float alpha, float* err) {
+  Camera c;
+  camera_init(c, K, cam);
+  residuals_depth(mode, pose7, uv, xyz, world, wgt, n, c, alpha, err);
+}
+
+int orc_optimize_camera_depth(int mode, float pose7[7], const float* uv, const float* xyz,
+                              const float* world, const float* wgt, int n, const float K[4],
+                              const float cam[7], float alpha, int itmax, float* info) {
+  Camera c;
+  camera_init(c, K, cam);
+  float p[7];
+  memcpy(p, pose7, sizeof p);
+  LmProblem f = {uv, xyz, n, &c, mode, world, wgt, alpha};
+  float linfo[3] = {0, 0, 0};
+  int ret = lm_dif(f, p, itmax, linfo);
+  if (info) memcpy(info, linfo, sizeof linfo);
+  if (ret < 0) return ret;
+  quat_normalize(p);
+  memcpy(pose7, p, sizeof p);
+  return ret;
+}
+
+// RANSAC of the depth variants: same skeleton as orc_ransac; initPose starts the
+// translation at the centroid of the sample's world3D
+// (...BACKPROJECTION_DEPTH_CPU.hpp:265-283), the inlier test is unchanged.
+int orc_ransac_depth(int mode, const float* uv, const float* xyz, const float* world,
+                     const float* wgt, int k, const float K[4], const float cam[7], float alpha,
+                     const orc_pose_params* prm, float pose7[7]) {
+  Camera c;
+  camera_init(c, K, cam);
+  std::vector<uint8_t> inl(k);
+  std::vector<int> pick;
+  auto gather = [&](const std::vector<int>& idx, std::vector<float>& a, std::vector<float>& b,
+                    std::vector<float>& w3, std::vector<float>& ww) {
+    a.clear(); b.clear(); w3.clear(); ww.clear();
+    for (size_t j = 0; j < idx.size(); j++) {
+      const int i = idx[j];
+      a.push_back(uv[2 * i]); a.push_back(uv[2 * i + 1]);
+      for (int x = 0; x < 3; x++) { b.push_back(xyz[3 * i + x]); w3.push_back(world[3 * i + x]); }
+      ww.push_back(wgt[i]);
+    }
+  };
+  std::vector<float> suv, sxyz, sw3, sww;
+  for (int it = 0; it < prm->max_ransac_tests; it++) {
+    std::vector<std::pair<float, int> > keyed(k);
+    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)rand(), i);
+    std::sort(keyed.begin(), keyed.end());
+    std::map<std::pair<float, float>, int> used;
+    pick.clear();
+    size_t pos = 0;
+    while ((int)used.size() < prm->n_pts_align && pos < keyed.size()) {
+      int i = keyed[pos++].second;
+      std::pair<float, float> key(uv[2 * i], uv[2 * i + 1]);
+      if (!used[key]++) pick.push_back(i);
+    }
+    if ((int)used.size() != prm->n_pts_align) return 0;
+    for (int j = 0; j < 4; j++) pose7[j] = (float)((rand() & 255) / 256.);
+    float sum[3] = {0, 0, 0};
+    for (size_t j = 0; j < pick.size(); j++)
+      for (int x = 0; x < 3; x++) sum[x] += world[3 * pick[j] + x];
+    const int ns = (int)pick.size();
+    for (int x = 0; x < 3; x++) pose7[4 + x] = sum[x] / ns;
+    gather(pick, suv, sxyz, sw3, sww);
+    float p[7];
+    memcpy(p, pose7, sizeof p);
+    LmProblem f = {&suv[0], &sxyz[0], ns, &c, mode, &sw3[0], &sww[0], alpha};
+    float info[3];
+    int ret = lm_dif(f, p, prm->max_lm_tests, info);
+    if (ret >= 0) {
+      quat_normalize(p);
+      memcpy(pose7, p, sizeof p);
+    }
+    const int lm = (ret < 0) ? ret : (int)info[1];
+    if (lm == -1) continue;
+    int cnt = test_all_points(pose7, uv, xyz, k, c, prm->error_threshold, &inl[0]);
+    if (cnt > prm->min_n_pts_object) {
+      pick.clear();
+      for (int i = 0; i < k; i++)
+        if (inl[i]) pick.push_back(i);
+      gather(pick, suv, sxyz, sw3, sww);
+      memcpy(p, pose7, sizeof p);
+      LmProblem g = {&suv[0], &sxyz[0], cnt, &c, mode, &sw3[0], &sww[0], alpha};
+      if (lm_dif(g, p, prm->max_lm_tests, info) >= 0) {
+        quat_normalize(p);
+        memcpy(pose7, p, sizeof p);
+      }
       return 1;
     }
   }

@@ -107,6 +107,21 @@ typedef struct {
 int orc_ransac(const float* uv, const float* xyz, int k, const float K[4],
                const float cam[7], const orc_pose_params* prm, float pose7[7]);
 
+/* A14 moped3d depth variants.  mode 1 = POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU
+ * (moped3d/libmoped/src/pose/...BACKPROJECTION_DEPTH_CPU.hpp:108-190; 2 residuals per
+ * point), mode 2 = POSE_RANSAC_LM_DIFF_REPROJECTION_DEPTH_CPU (...:106-216; 3 per
+ * point).  world = camera-frame xyz from the depth map (Match.depthData.coord3D),
+ * wgt = cauchyWeight (getCauchyWeight of fillDistance), alpha = the class's Alpha. */
+void orc_residuals_depth(int mode, const float pose7[7], const float* uv, const float* xyz,
+                         const float* world, const float* wgt, int n, const float K[4],
+                         const float cam[7], float alpha, float* err);
+int orc_optimize_camera_depth(int mode, float pose7[7], const float* uv, const float* xyz,
+                              const float* world, const float* wgt, int n, const float K[4],
+                              const float cam[7], float alpha, int itmax, float* info);
+int orc_ransac_depth(int mode, const float* uv, const float* xyz, const float* world,
+                     const float* wgt, int k, const float K[4], const float cam[7], float alpha,
+                     const orc_pose_params* prm, float pose7[7]);
+
 /* N1  FILTER_PROJECTION_CPU::process (filter/FILTER_PROJECTION_CPU.hpp:80-162)
  * for one image.  Matches in (model, query) order with CSR model_off; objects
  * given as (model, pose) in list order.  Outputs: score per object, keep flag

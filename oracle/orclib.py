@@ -71,6 +71,13 @@ def lib():
         L.orc_optimize_camera.restype = C.c_int
         L.orc_ransac.argtypes = [_f32p, _f32p, C.c_int, _f32p, _f32p, C.POINTER(PoseParams), _f32p]
         L.orc_ransac.restype = C.c_int
+        L.orc_residuals_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_float, _f32p]
+        L.orc_optimize_camera_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p,
+                                                C.c_float, C.c_int, _f32p]
+        L.orc_optimize_camera_depth.restype = C.c_int
+        L.orc_ransac_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_float,
+                                       C.POINTER(PoseParams), _f32p]
+        L.orc_ransac_depth.restype = C.c_int
         L.orc_filter.argtypes = [_f32p, _f32p, _i32p, C.c_int, _i32p, _f32p, C.c_int, _f32p, _f32p,
                                  C.c_int, C.c_float, C.c_float, _f32p, _u8p, _i32p, _i32p, _i32p]
         L.orc_filter.restype = C.c_int
@@ -192,6 +199,49 @@ def ransac(uv, xyz, K, cam, params=POSE1, seed=None):
     return bool(ok), p
 
 
+# moped3d constants (moped3d/libmoped/src/config.hpp:46,48)
+POSE1_3D = dict(max_ransac_tests=192, max_lm_tests=100, max_objects_per_cluster=4,
+                n_pts_align=5, min_n_pts_object=6, error_threshold=8.0)
+POSE2_3D = dict(max_ransac_tests=64, max_lm_tests=250, max_objects_per_cluster=4,
+                n_pts_align=6, min_n_pts_object=8, error_threshold=5.0)
+
+
+def cauchy_weight(fill_distance, scale=0.1):
+    """getCauchyWeight (…BACKPROJECTION_DEPTH_CPU.hpp:194-197; scale 0.1 there, 25 in
+    …REPROJECTION_DEPTH_CPU.hpp:66)."""
+    f = np.asarray(fill_distance, np.float32) / np.float32(scale)
+    return (1.0 / (1 + f * f)).astype(np.float32)
+
+
+def residuals_depth(mode, pose7, uv, xyz, world, wgt, K, cam, alpha):
+    n = uv.shape[0]
+    err = np.empty((2 if mode == 1 else 3) * n, np.float32)
+    lib().orc_residuals_depth(mode, _c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
+                              _c(xyz, np.float32).reshape(-1), _c(world, np.float32).reshape(-1),
+                              _c(wgt, np.float32), n, _c(K, np.float32), _c(cam, np.float32), alpha, err)
+    return err
+
+
+def optimize_camera_depth(mode, pose7, uv, xyz, world, wgt, K, cam, alpha, itmax):
+    p = _c(pose7, np.float32).copy()
+    info = np.zeros(3, np.float32)
+    ret = lib().orc_optimize_camera_depth(mode, p, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                                          _c(world, np.float32).reshape(-1), _c(wgt, np.float32), uv.shape[0],
+                                          _c(K, np.float32), _c(cam, np.float32), alpha, itmax, info)
+    return ret, p, info
+
+
+def ransac_depth(mode, uv, xyz, world, wgt, K, cam, alpha, params=POSE1_3D, seed=None):
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    prm = PoseParams(**params)
+    p = np.zeros(7, np.float32)
+    ok = lib().orc_ransac_depth(mode, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                                _c(world, np.float32).reshape(-1), _c(wgt, np.float32), uv.shape[0],
+                                _c(K, np.float32), _c(cam, np.float32), alpha, C.byref(prm), p)
+    return bool(ok), p
+
+
 def filter_projection(uv, xyz, model_off, obj_model, obj_pose, K, cam, min_points,
                       feature_distance, min_score):
     n_models = len(model_off) - 1
@@ -258,6 +308,11 @@ def ref(fast=False):
         R.ref_residuals.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
         R.ref_optimize_camera.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p]
         R.ref_optimize_camera.restype = C.c_int
+        R.ref_residuals_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p,
+                                          C.c_float, _f32p]
+        R.ref_optimize_camera_depth.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p, _f32p,
+                                                C.c_float, C.c_int, _f32p]
+        R.ref_optimize_camera_depth.restype = C.c_int
         R.ref_sift.argtypes = [_u8p, C.c_int, C.c_int, _f32p, _f32p, C.c_int]
         R.ref_sift.restype = C.c_int
         _ref[key] = R
@@ -299,6 +354,24 @@ def ref_residuals(pose7, uv, xyz, K, cam):
     ref().ref_residuals(_c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
                         _c(xyz, np.float32).reshape(-1), n, _c(K, np.float32), _c(cam, np.float32), hx)
     return hx
+
+
+def ref_residuals_depth(mode, pose7, uv, xyz, world, wgt, K, cam, alpha):
+    n = uv.shape[0]
+    err = np.empty((2 if mode == 1 else 3) * n, np.float32)
+    ref().ref_residuals_depth(mode, _c(pose7, np.float32), _c(uv, np.float32).reshape(-1),
+                              _c(xyz, np.float32).reshape(-1), _c(world, np.float32).reshape(-1),
+                              _c(wgt, np.float32), n, _c(K, np.float32), _c(cam, np.float32), alpha, err)
+    return err
+
+
+def ref_optimize_camera_depth(mode, pose7, uv, xyz, world, wgt, K, cam, alpha, itmax):
+    p = _c(pose7, np.float32).copy()
+    info = np.zeros(10, np.float32)
+    ret = ref().ref_optimize_camera_depth(mode, p, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
+                                          _c(world, np.float32).reshape(-1), _c(wgt, np.float32), uv.shape[0],
+                                          _c(K, np.float32), _c(cam, np.float32), alpha, itmax, info)
+    return ret, p, info
 
 
 def ref_optimize_camera(pose7, uv, xyz, K, cam, itmax):

@@ -91,6 +91,83 @@ void residual_cb(float* p, float* hx, int /*m*/, int n, void* adata) {
   }
 }
 
+// moped3d's LmData (…BACKPROJECTION_DEPTH_CPU.hpp:72-80) and the two depth residual
+// callbacks, restated over the reference's Pt / TransformMatrix arithmetic
+// (mode 1: …BACKPROJECTION_DEPTH_CPU.hpp:108-190; mode 2: …REPROJECTION_DEPTH_CPU.hpp:106-216).
+struct CorrD {
+  Image* image;
+  Pt<2> coord2D;
+  Pt<3> coord3D;
+  Pt<3> world3D;
+  float cauchyWeight;
+};
+struct DepthProblem {
+  std::vector<CorrD> c;
+  int mode;
+  float alpha;
+};
+
+void residual_depth_cb(float* lmPose, float* errors, int /*m*/, int nErrors, void* adata) {
+  DepthProblem& P = *(DepthProblem*)adata;
+  Pose pose;
+  pose.rotation.init(lmPose);
+  pose.rotation.norm();
+  pose.translation.init(lmPose + 4);
+  TransformMatrix tm;
+  tm.init(pose);
+  const int per = P.mode == 1 ? 2 : 3;
+  for (int i = 0; i < nErrors / per; i++) {
+    CorrD& d = P.c[i];
+    Pt<3> p3D;
+    tm.transform(p3D, d.coord3D);
+    d.image->TM.inverseTransform(p3D, p3D);
+    Pt<4> K = d.image->intrinsicLinearCalibration;
+    float wi = d.cauchyWeight;
+    float weight3D = (1 - P.alpha) * wi;
+    if (P.mode == 1) {
+      if (p3D[2] < 0) {
+        errors[2 * i] = -p3D[2] + 10;
+        errors[2 * i + 1] = -p3D[2] + 10;
+      } else {
+        float vx = d.world3D[0], vy = d.world3D[1], vz = d.world3D[2];
+        float norm = sqrt(vx * vx + vy * vy + vz * vz);
+        float nx = vx / norm, ny = vy / norm, nz = vz / norm;
+        float dotProd = nx * p3D[0] + ny * p3D[1] + nz * p3D[2];
+        Pt<3> pHat;
+        pHat.init(nx * dotProd, ny * dotProd, nz * dotProd);
+        float dxy = p3D.euclDist(pHat);
+        float dz = d.world3D.euclDist(pHat);
+        errors[2 * i] = dxy * dxy;
+        errors[2 * i + 1] = dz * dz;
+      }
+      float weight2D = 1 - weight3D;
+      errors[2 * i] *= weight2D;
+      errors[2 * i + 1] *= weight3D;
+    } else {
+      float u = p3D[0] / p3D[2] * K[0] + K[2];
+      float v = p3D[1] / p3D[2] * K[1] + K[3];
+      if (p3D[2] < 0) {
+        errors[3 * i] = -p3D[2] + 10;
+        errors[3 * i + 1] = -p3D[2] + 10;
+        errors[3 * i + 2] = -p3D[2] + 10;
+      } else {
+        float dx = u - d.coord2D[0], dy = v - d.coord2D[1];
+        errors[3 * i] = dx * dx;
+        errors[3 * i + 1] = dy * dy;
+      }
+      float vecTP = p3D[0] * d.world3D[0] + p3D[1] * d.world3D[1] + p3D[2] * d.world3D[2];
+      Pt<3> projWorld;
+      projWorld.init(p3D[0] * vecTP, p3D[1] * vecTP, p3D[2] * vecTP);
+      float depthError = projWorld.euclDist(p3D);
+      errors[3 * i + 2] = depthError * depthError;
+      errors[3 * i + 2] *= 50;
+      errors[3 * i] *= (1 - weight3D);
+      errors[3 * i + 1] *= (1 - weight3D);
+      errors[3 * i + 2] *= weight3D;
+    }
+  }
+}
+
 void fill_image(Image& img, const float K[4], const float cam[7]) {
   img.width = 640;
   img.height = 480;
@@ -197,6 +274,53 @@ int ref_optimize_camera(float pose7[7], const float* uv, const float* xyz, int n
   float linfo[LM_INFO_SZ];
   int ret = slevmar_dif(residual_cb, pose7, &target[0], 7, 2 * n, itmax, NULL, linfo, NULL, NULL,
                         (void*)&c);
+  if (info) memcpy(info, linfo, sizeof linfo);
+  if (ret < 0) return ret;
+  Quat q;
+  q.init(pose7[0], pose7[1], pose7[2], pose7[3]);
+  q.norm();
+  for (int i = 0; i < 4; i++) pose7[i] = q[i];
+  return ret;
+}
+
+// ---- moped3d depth residuals ----------------------------------------------------
+static void fill_depth(DepthProblem& P, Image& img, int mode, float alpha, const float* uv, const float* xyz,
+                       const float* world, const float* wgt, int n) {
+  P.mode = mode;
+  P.alpha = alpha;
+  P.c.resize(n);
+  for (int i = 0; i < n; i++) {
+    P.c[i].image = &img;
+    P.c[i].coord2D.init(uv[2 * i], uv[2 * i + 1]);
+    P.c[i].coord3D.init(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    P.c[i].world3D.init(world[3 * i], world[3 * i + 1], world[3 * i + 2]);
+    P.c[i].cauchyWeight = wgt[i];
+  }
+}
+
+void ref_residuals_depth(int mode, const float pose7[7], const float* uv, const float* xyz,
+                         const float* world, const float* wgt, int n, const float K[4],
+                         const float cam[7], float alpha, float* err) {
+  Image img;
+  fill_image(img, K, cam);
+  DepthProblem P;
+  fill_depth(P, img, mode, alpha, uv, xyz, world, wgt, n);
+  float p[7];
+  memcpy(p, pose7, sizeof p);
+  residual_depth_cb(p, err, 7, (mode == 1 ? 2 : 3) * n, &P);
+}
+
+int ref_optimize_camera_depth(int mode, float pose7[7], const float* uv, const float* xyz,
+                              const float* world, const float* wgt, int n, const float K[4],
+                              const float cam[7], float alpha, int itmax, float* info) {
+  Image img;
+  fill_image(img, K, cam);
+  DepthProblem P;
+  fill_depth(P, img, mode, alpha, uv, xyz, world, wgt, n);
+  const int ne = (mode == 1 ? 2 : 3) * n;
+  std::vector<float> target(ne, 0.f);
+  float linfo[LM_INFO_SZ];
+  int ret = slevmar_dif(residual_depth_cb, pose7, &target[0], 7, ne, itmax, NULL, linfo, NULL, NULL, (void*)&P);
   if (info) memcpy(info, linfo, sizeof linfo);
   if (ret < 0) return ret;
   Quat q;

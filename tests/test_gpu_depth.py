@@ -1,0 +1,101 @@
+"""moped3d depth-constrained pose (A14, BASELINE config 5) on the GPU vs the oracle's
+restatement of POSE_RANSAC_LM_DIFF_{BACKPROJECTION,REPROJECTION}_DEPTH_CPU."""
+import numpy as np
+import pytest
+
+import orclib
+from moped_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
+
+
+def _scene(rng, n, outliers=0.25):
+    xyz = ((rng.random((n, 3)) - 0.5) * [0.1, 0.1, 0.2]).astype(np.float32)
+    pose = np.concatenate([synth.random_quat(rng), [rng.uniform(-.1, .1), rng.uniform(-.1, .1),
+                                                    rng.uniform(0.5, 1.0)]]).astype(np.float32)
+    uv = (orclib.project(pose, xyz, K, CAM0) + rng.uniform(-0.5, 0.5, (n, 2))).astype(np.float32)
+    R = synth.quat_to_R(pose[:4])
+    world = xyz.astype(np.float64) @ R.T + pose[4:].astype(np.float64)
+    world *= 1 + rng.normal(0, 0.0035, (n, 1)) * world[:, 2:3]
+    bad = rng.random(n) < outliers
+    uv[bad] = rng.uniform([0, 0], [640, 480], size=(int(bad.sum()), 2)).astype(np.float32)
+    # the depth map is read at the (wrong) pixel: a point on that pixel's ray at a random depth
+    z = rng.uniform(0.5, 1.0, int(bad.sum()))
+    world[bad] = np.stack([(uv[bad, 0] - K[2]) / K[0] * z, (uv[bad, 1] - K[3]) / K[1] * z, z], 1)
+    return pose, uv, xyz, world.astype(np.float32), bad
+
+
+def _mean_reproj(pose, uv, xyz):
+    return float(np.sqrt(((orclib.project(pose, xyz, K, CAM0) - uv) ** 2).sum(1)).mean())
+
+
+@pytest.mark.parametrize("kind,scale,fillmax", [(capi.DEPTH_BACKPROJECTION, 0.1, 0.08), (capi.DEPTH_REPROJECTION, 25.0, 20.0)])
+@pytest.mark.parametrize("seed", range(3))
+def test_depth_pose_matches_oracle(ctx, kind, scale, fillmax, seed):
+    rng = np.random.default_rng(500 + 10 * kind + seed)
+    clusters, off = [], [0]
+    for c in range(3):
+        n = int(rng.integers(15, 140))
+        pose, uv, xyz, world, bad = _scene(rng, n)
+        wgt = orclib.cauchy_weight(rng.uniform(0, fillmax, n), scale)
+        clusters.append((pose, uv, xyz, world, wgt, bad))
+        off.append(off[-1] + n)
+    uv_all = np.concatenate([c[1] for c in clusters])
+    xyz_all = np.concatenate([c[2] for c in clusters])
+    w_all = np.concatenate([c[3] for c in clusters])
+    g_all = np.concatenate([c[4] for c in clusters])
+    prm = capi.make_pose_params(1024, 4, 5, 6, 8.0, 10, 10)    # moped3d POSE: (192,100,4,5,6,8,0.5)
+    out = ctx.pose_ransac_depth(capi.pack_corr(uv_all, xyz_all), capi.pack_depth(w_all, g_all),
+                                np.array(off, np.int32), K, CAM0, prm, kind, 0.5, seed=seed + 1)
+    by = {}
+    for o in out:
+        by.setdefault(int(o["cluster"]), []).append(o)
+    for c, (pose, uv, xyz, world, wgt, bad) in enumerate(clusters):
+        ok, op = orclib.ransac_depth(kind, uv, xyz, world, wgt, K, CAM0, 0.5, orclib.POSE1_3D, seed=seed)
+        if not ok:
+            continue
+        _, oinl = orclib.test_all_points(op, uv, xyz, K, CAM0, 8.0)
+        assert c in by
+        e_or = _mean_reproj(op, uv[oinl], xyz[oinl])
+        for o in by[c]:
+            # within 1 px of the oracle pose on the oracle's inliers
+            assert _mean_reproj(o["pose"], uv[oinl], xyz[oinl]) <= e_or + 1.0
+            # and the depth-aware objective is at least as low as the oracle's at its own optimum (+10%)
+            good = ~bad
+            eg = orclib.residuals_depth(kind, o["pose"], uv[good], xyz[good], world[good], wgt[good], K, CAM0, 0.5)
+            eo = orclib.residuals_depth(kind, op, uv[good], xyz[good], world[good], wgt[good], K, CAM0, 0.5)
+            assert (eg.astype(np.float64) ** 2).sum() <= 4.0 * (eo.astype(np.float64) ** 2).sum() + 1e-12
+
+
+def test_depth_frame_path(ctx):
+    """mh_frame_set_depth: per-query depth attributes ride through MATCH/group into POSE."""
+    import torch
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    db = synth.make_db(6, 2000)
+    fr = synth.make_frame(db, n_vis=2, seed=4, Q=1500, pts_per_obj=120)
+    # depth of every query: planted features get their true camera-frame point, clutter a plane at 1 m
+    Q = fr.uv.shape[0]
+    world = np.stack([(fr.uv[:, 0] - K[2]) / K[0], (fr.uv[:, 1] - K[3]) / K[1], np.ones(Q)], 1).astype(np.float32)
+    for j, m in enumerate(fr.visible):
+        rows = np.nonzero((fr.src_point >= 0) & (db.model_of[np.maximum(fr.src_point, 0)] == m) & ~fr.is_outlier)[0]
+        R = synth.quat_to_R(fr.poses[j][:4])
+        world[rows] = (db.xyz[fr.src_point[rows]].astype(np.float64) @ R.T + fr.poses[j][4:]).astype(np.float32)
+    depth = capi.pack_depth(world, np.ones(Q, np.float32))
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=Q)
+    dev = torch.device("cuda:0")
+    tdepth = torch.from_numpy(depth.view(np.float32).reshape(Q, 4)).to(dev)
+    res = {}
+    for kind in (0, capi.DEPTH_BACKPROJECTION, capi.DEPTH_REPROJECTION):
+        pipe.ctxs[0].frame_set_depth(tdepth.data_ptr() if kind else 0, kind, 0.5)
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=9)
+        objs, counts = pipe.fetch(0)
+        res[kind] = objs
+        assert sorted(objs["model"].tolist()) == sorted(fr.visible.tolist())
+        for o in objs:
+            j = list(fr.visible).index(o["model"])
+            assert np.allclose(o["pose"][4:], fr.poses[j][4:], atol=4e-3)
+    pipe.ctxs[0].frame_set_depth(0, 0, 0.5)
+    pipe.close()
+    # the depth objective moves the pose (slightly) away from the pure 2-D optimum
+    assert not np.array_equal(res[0]["pose"], res[capi.DEPTH_BACKPROJECTION]["pose"])
