@@ -94,7 +94,13 @@ def test_depth_frame_path(ctx):
         assert sorted(objs["model"].tolist()) == sorted(fr.visible.tolist())
         for o in objs:
             j = list(fr.visible).index(o["model"])
-            assert np.allclose(o["pose"][4:], fr.poses[j][4:], atol=4e-3)
+            # the reprojection+depth class minimises |p| |p.W - 1| (…REPROJECTION_DEPTH_CPU.hpp:176-186),
+            # which is not zero at the true pose: it trades some depth for it, by design of the reference
+            tol = 4e-3 if kind != capi.DEPTH_REPROJECTION else 2e-2
+            assert np.allclose(o["pose"][4:], fr.poses[j][4:], atol=tol)
+            rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+            rows = rows[db.model_of[fr.src_point[rows]] == o["model"]]
+            assert _mean_reproj(o["pose"], fr.uv[rows], db.xyz[fr.src_point[rows]]) < 1.5
     pipe.ctxs[0].frame_set_depth(0, 0, 0.5)
     pipe.close()
     # the depth objective moves the pose (slightly) away from the pure 2-D optimum
