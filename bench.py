@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--frames-per-step", type=int, default=8)
     ap.add_argument("--depth", type=int, default=4, help="frames in flight per GPU")
     ap.add_argument("--n-vis", type=int, default=2)
+    ap.add_argument("--depth-kind", type=int, default=0,
+                    help="0 = moped2 residuals; 1/2 = moped3d back-projection / reprojection+depth (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -116,10 +118,25 @@ def main():
     n_frames = max(args.frames_per_step, 1)
     frames = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_frames)]
     shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
-    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q)
+    params = capi.default_frame_params()
+    if args.depth_kind:
+        # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
+        params.pose1.error_threshold = 8.0
+        params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
+        params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
+    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q, params=params)
     pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
     work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
+    depths = None
+    if args.depth_kind:
+        depths = []
+        for i, f in enumerate(frames):
+            wpts, fill = synth.frame_depth(db, f, seed=i)
+            f32 = np.float32
+            wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
+            d = capi.pack_depth(wpts, wgt)
+            depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
     counts_host = torch.zeros(n_frames, dtype=torch.int32).pin_memory()
 
     def run_step(step, record=False):
@@ -128,6 +145,8 @@ def main():
             s = pipe.streams[slot]
             with torch.cuda.stream(s):
                 work[slot].copy_(pristine[b], non_blocking=True)   # restore raw descriptors (normalise is in place)
+            if depths is not None:
+                pipe.ctxs[slot].frame_set_depth(depths[b].data_ptr(), args.depth_kind, 0.5)
             pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + b + 1)
             if record and world == 1:
                 ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
@@ -171,7 +190,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.models}-model DB ({db.n} descriptors), 640x480 frames, "
                                f"{Q} SIFT-like keypoints, {args.n_vis} planted objects, "
-                               f"1024 P3P hypotheses x 4 replicas per cluster, MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2",
+                               f"1024 P3P hypotheses x 4 replicas per cluster, MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2"
+                               + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}"),
                    "frames_per_step": n_frames, "frames_in_flight": args.depth,
                    "parallelism": f"model-shard x{world}" if world > 1 else "single GPU",
                    "objects_per_frame": det_per_frame},

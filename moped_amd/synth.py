@@ -158,3 +158,24 @@ def make_frame(db: ModelDB, n_vis: int = 2, seed: int = 0, Q: int = 3000,
                  np.ascontiguousarray(uv[perm], dtype=np.float32),
                  visible, np.asarray(poses, dtype=np.float32).reshape(-1, 7),
                  src[perm], bad[perm])
+
+
+def frame_depth(db: ModelDB, frame: Frame, seed: int = 0, K=K_DEFAULT, fill_max: float = 0.02):
+    """Per-query depth attributes for the moped3d (Kinect) configuration: the camera-frame
+    point the depth map holds at each keypoint (planted inliers: the true point with
+    sigma = 0.0035 z^2 depth noise along the ray; everything else: a point on the pixel's
+    ray at a random depth) and a fill distance in [0, fill_max] m (0 = measured pixel).
+    Returns (world [Q,3] float32, fill [Q] float32)."""
+    rng = np.random.default_rng([0xD3B7, seed])
+    Q = frame.uv.shape[0]
+    z = rng.uniform(0.5, 1.5, Q)
+    world = np.stack([(frame.uv[:, 0] - K[2]) / K[0] * z, (frame.uv[:, 1] - K[3]) / K[1] * z, z], 1)
+    for j, m in enumerate(frame.visible):
+        rows = np.nonzero((frame.src_point >= 0) & ~frame.is_outlier)[0]
+        rows = rows[db.model_of[frame.src_point[rows]] == m]
+        R = quat_to_R(frame.poses[j][:4])
+        p = db.xyz[frame.src_point[rows]].astype(np.float64) @ R.T + frame.poses[j][4:].astype(np.float64)
+        p *= 1 + rng.normal(0, 0.0035, (len(rows), 1)) * p[:, 2:3]
+        world[rows] = p
+    fill = rng.uniform(0, fill_max, Q) * (rng.random(Q) < 0.3)
+    return world.astype(np.float32), fill.astype(np.float32)
