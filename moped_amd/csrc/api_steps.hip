@@ -1,4 +1,5 @@
 // C ABI: CLUSTER / POSE / FILTER entry points and the device-resident frame.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,6 +34,13 @@ struct FrameState {
   unsigned char* result = nullptr;
   size_t result_bytes = 0;
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
+  uint64_t* seed_dev = nullptr;  // per-frame seed, read by the pose kernels (keeps the launch list constant)
+  // hipGraph replay of the launch list (one graph per half of the frame)
+  struct Graph {
+    hipGraphExec_t exec = nullptr;
+    std::vector<unsigned char> key;
+    int uses = 0;   // identical enqueues seen so far (the first one runs eagerly)
+  } g_full, g_local, g_rest;
 };
 
 namespace {
@@ -51,9 +59,11 @@ void free_fs(FrameState* fs) {
                   fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
                   fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
                   fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw,
-                  fs->m_depth};
+                  fs->m_depth,    fs->seed_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  for (FrameState::Graph* g : {&fs->g_full, &fs->g_local, &fs->g_rest})
+    if (g->exec) hipGraphExecDestroy(g->exec);
   delete fs;
 }
 
@@ -110,6 +120,7 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   fs->result_bytes = 16 + sizeof(mh_object) * (size_t)max_objects;
   rc |= dev_alloc(ctx, fs->result, fs->result_bytes);
   rc |= dev_alloc(ctx, fs->snap, 4);
+  rc |= dev_alloc(ctx, fs->seed_dev, 1);
   if (rc) return MH_ERR_HIP;
   MH_HIP(ctx, hipMemsetAsync(fs->obj_valid, 0, sizeof(int32_t) * max_objects, ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->obj_score, 0, sizeof(float) * max_objects, ctx->stream));
@@ -181,7 +192,7 @@ void stamp(mh_ctx* ctx, int i) {
 }
 
 int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, const float* d1,
-               const float* d2, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+               const float* d2, const mh_cam* cam, const mh_frame_params* prm) {
   FrameState* fs = ctx->fs;
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
@@ -206,7 +217,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, c
   // POSE
   const float* depth4 = ctx->q_depth ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
   launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
-              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, fs->n_slots, fs->max_objects, fs->obj_model,
+              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, 0ull, fs->seed_dev, fs->n_slots, fs->max_objects, fs->obj_model,
               fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
   hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
                      prm->pose1.max_objects_per_cluster > 0 ? prm->pose1.max_objects_per_cluster : 1,
@@ -222,7 +233,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, c
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
-                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2, seed ^ 0x5DEECE66Dull, fs->n_slots,
+                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2, 0x5DEECE66Dull, fs->seed_dev, fs->n_slots,
                 fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err,
                 fs->obj_cluster, fs->obj_valid, fs->counts, s);
     hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
@@ -369,7 +380,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
   const DevCam dc = make_devcam(*cam);
   launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
-              fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+              fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, nullptr, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
               fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
   MH_HIP(ctx, hipGetLastError());
   std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
@@ -509,6 +520,97 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   return MH_OK;
 }
 
+}  // extern "C" (helpers below need C++ linkage)
+
+// ---- hipGraph replay of a frame's launch list --------------------------------------
+// A frame is ~40 small launches with fixed grids and device-side counts, so the list
+// is identical from frame to frame as long as the pointers / sizes / constants are.
+// The first enqueue with a given key runs eagerly (it also does the one-time
+// hipFuncSetAttribute calls), the second is captured, later ones replay the graph.
+// The per-frame seed travels through device memory.
+// EXPERIMENTAL, off unless MH_GRAPH=1: on ROCm 7.2 replay cuts the host cost of a frame
+// from 95 to 23 us but does not change throughput (the GPU-side dependent-launch chain is
+// the limit, not the host), and after a few replays of the same executable graph the
+// frame counters come back corrupted (scripts/graph_debug.py) -- not shipped as default.
+namespace {
+
+bool graphs_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MH_GRAPH");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
+template <typename T>
+void key_add(std::vector<unsigned char>& k, const T& v) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(&v);
+  k.insert(k.end(), p, p + sizeof(T));
+}
+
+void set_seed(mh_ctx* ctx, uint64_t seed) {
+  // two 32-bit memsets: the value rides in the command, no host buffer to keep alive
+  hipMemsetD32Async((hipDeviceptr_t)ctx->fs->seed_dev, (int)(uint32_t)seed, 1, ctx->stream);
+  hipMemsetD32Async((hipDeviceptr_t)((char*)ctx->fs->seed_dev + 4), (int)(uint32_t)(seed >> 32), 1, ctx->stream);
+}
+
+// Runs `body` (a list of stream launches) eagerly, under capture, or as a replay.
+template <typename Body>
+int run_graphed(mh_ctx* ctx, FrameState::Graph& g, const std::vector<unsigned char>& key, Body&& body) {
+  if (!graphs_enabled() || ctx->timing) return body();
+  if (g.key != key) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+    g.key = key;
+    g.uses = 0;
+  }
+  if (g.exec) {
+    MH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
+    return MH_OK;
+  }
+  if (g.uses++ == 0) return body();  // first time: eager (one-time attribute calls happen here)
+  hipGraph_t graph = nullptr;
+  MH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (rc != MH_OK || e != hipSuccess || !graph) {
+    if (graph) hipGraphDestroy(graph);
+    ctx->err = "frame graph capture failed; running eagerly";
+    g.uses = -1000000;  // never try again for this key
+    return rc != MH_OK ? rc : body();
+  }
+  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    g.exec = nullptr;
+    g.uses = -1000000;
+    return body();
+  }
+  MH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
+  return MH_OK;
+}
+
+void key_common(mh_ctx* ctx, std::vector<unsigned char>& k, int Q, const mh_cam* cam, const mh_frame_params* prm) {
+  key_add(k, Q);
+  key_add(k, ctx->N);
+  key_add(k, ctx->n_models);
+  key_add(k, ctx->index_base);
+  key_add(k, ctx->db_desc);
+  key_add(k, ctx->q_depth);
+  key_add(k, ctx->depth_kind);
+  key_add(k, ctx->depth_alpha);
+  key_add(k, ctx->fs);
+  key_add(k, ctx->match_scratch);
+  key_add(k, ctx->match_pack);
+  key_add(k, ctx->stream);
+  if (cam) key_add(k, *cam);
+  if (prm) key_add(k, *prm);
+}
+
+}  // namespace
+
+extern "C" {
+
 int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
                      const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
   if (!ctx || Q <= 0 || !q_desc_dev || !q_uv_dev || !cam || !prm) return MH_ERR_ARG;
@@ -519,12 +621,19 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   }
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  stamp(ctx, 0);
-  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-  launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
-  stamp(ctx, 1);
-  return frame_rest(ctx, q_uv_dev, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, cam, prm, seed);
+  set_seed(ctx, seed);
+  std::vector<unsigned char> key;
+  key_common(ctx, key, Q, cam, prm);
+  key_add(key, q_desc_dev);
+  key_add(key, q_uv_dev);
+  return run_graphed(ctx, ctx->fs->g_full, key, [&]() -> int {
+    stamp(ctx, 0);
+    launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+    launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+                 ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+    stamp(ctx, 1);
+    return frame_rest(ctx, q_uv_dev, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, cam, prm);
+  });
 }
 
 int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t** idx1_dev,
@@ -533,15 +642,20 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
   MH_HIP(ctx, hipSetDevice(ctx->device));
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  stamp(ctx, 0);
-  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-  launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
-  MH_HIP(ctx, hipGetLastError());
   *idx1_dev = ctx->nn_idx;
   *d1_dev = ctx->nn_d1;
   *d2_dev = ctx->nn_d2;
-  return MH_OK;
+  std::vector<unsigned char> key;
+  key_common(ctx, key, Q, nullptr, nullptr);
+  key_add(key, q_desc_dev);
+  return run_graphed(ctx, ctx->fs->g_local, key, [&]() -> int {
+    stamp(ctx, 0);
+    launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+    launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+                 ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+    MH_HIP(ctx, hipGetLastError());
+    return MH_OK;
+  });
 }
 
 int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1_s_dev,
@@ -557,9 +671,20 @@ int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32
   int32_t* g_idx = (int32_t*)ctx->scratch;
   float* g_d1 = (float*)(g_idx + Q);
   float* g_d2 = g_d1 + Q;
-  launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, g_idx, g_d1, g_d2, ctx->stream);
-  stamp(ctx, 1);
-  return frame_rest(ctx, q_uv_dev, Q, g_idx, g_d1, g_d2, cam, prm, seed);
+  set_seed(ctx, seed);
+  std::vector<unsigned char> key;
+  key_common(ctx, key, Q, cam, prm);
+  key_add(key, q_uv_dev);
+  key_add(key, idx1_s_dev);
+  key_add(key, d1_s_dev);
+  key_add(key, d2_s_dev);
+  key_add(key, n_shards);
+  key_add(key, ctx->scratch);
+  return run_graphed(ctx, ctx->fs->g_rest, key, [&]() -> int {
+    launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, g_idx, g_d1, g_d2, ctx->stream);
+    stamp(ctx, 1);
+    return frame_rest(ctx, q_uv_dev, Q, g_idx, g_d1, g_d2, cam, prm);
+  });
 }
 
 int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_t* n_objects,

@@ -578,7 +578,8 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
     const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
-    mh_pose_params prm, uint64_t seed, const int32_t* __restrict__ obj_base_dev, int max_objects,
+    mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+    const int32_t* __restrict__ obj_base_dev, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
     float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
     FrameCounts* counts) {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
   for (int h = tid; h < H; h += POSE_THREADS) {
-    uint64_t st = seed ^ ((uint64_t)(cluster + 1) << 40) ^ ((uint64_t)(replica + 1) << 32) ^ (uint64_t)h;
+    uint64_t st = (seed ^ (seed_dev ? *seed_dev : 0ull)) ^ ((uint64_t)(cluster + 1) << 40) ^ ((uint64_t)(replica + 1) << 32) ^ (uint64_t)h;
     splitmix64(st);
     // 4 correspondences with pairwise distinct image coordinates (:76-98)
     int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
@@ -796,7 +797,8 @@ template <int KIND>
 static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alpha, const int32_t* members,
                              const int32_t* cl_model, const int32_t* cl_begin, const int32_t* cl_count,
                              const int32_t* n_clusters_dev, int max_clusters, const DevCam& cam,
-                             const mh_pose_params& p, uint64_t seed, const int32_t* obj_base_dev,
+                             const mh_pose_params& p, uint64_t seed, const uint64_t* seed_dev,
+                             const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
                              hipStream_t s) {
@@ -808,7 +810,7 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   }
   hipLaunchKernelGGL(pose_kernel<KIND>, dim3(max_clusters * p.max_objects_per_cluster), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
-                     n_clusters_dev, cam, p, seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
+                     n_clusters_dev, cam, p, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
                      obj_err, obj_cluster, obj_valid, counts);
 }
 
@@ -816,16 +818,17 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
-                 const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
-                 int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
-                 FrameCounts* counts, hipStream_t s) {
+                 const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
+                 float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
+                 int32_t* obj_valid, FrameCounts* counts, hipStream_t s) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
   const float4* d4 = reinterpret_cast<const float4*>(depth4);
   const int kind = depth4 ? depth_kind : 0;
 #define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, p, \
-                  seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err, obj_cluster,       \
+                  seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
+                  obj_cluster,                                                                             \
                   obj_valid, counts, s
   if (kind == 1)
     launch_pose_kind<1>(POSE_ARGS);

@@ -55,6 +55,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
+                 const uint64_t* seed_dev /* optional: XORed into seed, read on the device */,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, hipStream_t s);
