@@ -10,6 +10,13 @@ using namespace mh;
 
 namespace mh {
 
+int use_stream(mh_ctx* ctx) {
+  if (ctx->stream) return MH_OK;
+  if (!ctx->own_stream) MH_HIP(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->own_stream;
+  return MH_OK;
+}
+
 int ensure_scratch(mh_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_cap) return MH_OK;
   if (ctx->scratch) MH_HIP(ctx, hipFree(ctx->scratch));
@@ -91,11 +98,9 @@ int mh_create(int device, mh_ctx** out) {
   mh_ctx* ctx = new (std::nothrow) mh_ctx;
   if (!ctx) return MH_ERR_HIP;
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
-    delete ctx;
-    return MH_ERR_HIP;
-  }
-  ctx->stream = ctx->own_stream;
+  // The context's own stream is created on first use (mh_use_stream): a host that
+  // installs its own stream with mh_set_stream never takes a hardware queue for it.
+  ctx->stream = nullptr;
   *out = ctx;
   return MH_OK;
 }
@@ -105,7 +110,7 @@ void mh_free_frame_state(mh_ctx* ctx);  // api_steps.hip
 void mh_destroy(mh_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
   mh_free_frame_state(ctx);
   void* ptrs[] = {ctx->db_desc, ctx->db_norm, ctx->db_xyz, ctx->db_model, ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
@@ -115,7 +120,7 @@ void mh_destroy(mh_ctx* ctx) {
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ev_made)
     for (auto& e : ctx->ev) hipEventDestroy(e);
-  hipStreamDestroy(ctx->own_stream);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
@@ -123,8 +128,8 @@ const char* mh_last_error(const mh_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 
 int mh_set_stream(mh_ctx* ctx, void* hip_stream) {
   if (!ctx) return MH_ERR_ARG;
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-  return MH_OK;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : nullptr;
+  return hip_stream ? MH_OK : mh::use_stream(ctx);
 }
 
 int mh_synchronize(mh_ctx* ctx) {
@@ -140,6 +145,7 @@ int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_ho
     return MH_ERR_ARG;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // rows are padded to whole 128-row tiles for the match kernel: zero descriptors,
   // +inf norm terms (a padding row can never enter a top-2)
@@ -184,6 +190,7 @@ int mh_normalize(mh_ctx* ctx, float* desc_host, int n) {
   if (!ctx || n < 0 || (n > 0 && !desc_host)) return MH_ERR_ARG;
   if (n == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = ensure_frame_buffers(ctx, n);
   if (rc) return rc;
   const size_t bytes = (size_t)n * DIM * sizeof(float);
@@ -198,6 +205,7 @@ int mh_normalize(mh_ctx* ctx, float* desc_host, int n) {
 int mh_normalize_dev(mh_ctx* ctx, float* q_dev, float* qnorm_dev, int Q) {
   if (!ctx || Q < 0 || (Q > 0 && (!q_dev || !qnorm_dev))) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   launch_normalize(q_dev, qnorm_dev, Q, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;
@@ -209,6 +217,7 @@ int mh_match_local_dev(mh_ctx* ctx, const float* qn_dev, const float* qnorm_dev,
     return MH_ERR_ARG;
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = ensure_match_scratch(ctx, Q);
   if (rc) return rc;
   launch_match(qn_dev, qnorm_dev, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
@@ -223,6 +232,7 @@ int mh_match_merge_dev(mh_ctx* ctx, const int32_t* idx1_s_dev, const float* d1_s
   if (!ctx || Q < 0 || n_shards < 0) return MH_ERR_ARG;
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, idx1_dev, d1_dev, d2_dev,
                      ctx->stream);
   MH_HIP(ctx, hipGetLastError());
@@ -234,6 +244,7 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
   if (!ctx || Q < 0 || (Q > 0 && (!q_host || !nn_idx))) return MH_ERR_ARG;
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = ensure_frame_buffers(ctx, Q);
   if (rc) return rc;
   if ((rc = ensure_match_scratch(ctx, Q))) return rc;
@@ -267,6 +278,7 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
 int mh_enable_timing(mh_ctx* ctx, int on) {
   if (!ctx) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   if (on && !ctx->ev_made) {
     for (auto& e : ctx->ev) MH_HIP(ctx, hipEventCreate(&e));
     ctx->ev_made = true;

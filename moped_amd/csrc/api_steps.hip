@@ -277,6 +277,7 @@ void mh_free_frame_state(mh_ctx* ctx) {
 int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects) {
   if (!ctx || max_queries <= 0 || max_clusters <= 0 || max_objects <= 0) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = ensure_frame_buffers(ctx, max_queries);
   if (rc) return rc;
   return ensure_fs(ctx, ctx->max_q, max_clusters, max_objects, ctx->n_models);
@@ -314,6 +315,7 @@ int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radiu
     return MH_ERR_CAPACITY;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const size_t b_pts = (size_t)n * dim * sizeof(float);
   const size_t b_i = (size_t)(n + 2) * sizeof(int32_t);
   int rc = ensure_scratch(ctx, b_pts + 4 * b_i + 64);
@@ -355,6 +357,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   *n_out = 0;
   if (n_clusters == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const int R_ = prm->max_objects_per_cluster > 0 ? prm->max_objects_per_cluster : 1;
   const int total = cluster_off[n_clusters];
   const int n_obj = n_clusters * R_;
@@ -437,6 +440,7 @@ int mh_project_test(mh_ctx* ctx, const float pose[7], const mh_corr* corr_host, 
   if (n_inliers) *n_inliers = 0;
   if (n == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const size_t b_c = (size_t)n * sizeof(mh_corr);
   int rc = ensure_scratch(ctx, b_c + (size_t)n * 5 + 256);
   if (rc) return rc;
@@ -470,6 +474,7 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   if (cl_off) cl_off[0] = 0;
   if (n_obj == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const int M = model_off[n_models];
   int rc = ensure_fs(ctx, std::max(M, 1), std::max(n_obj, 1), std::max(n_obj, 1), n_models);
   if (rc) return rc;
@@ -615,6 +620,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
                      const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
   if (!ctx || Q <= 0 || !q_desc_dev || !q_uv_dev || !cam || !prm) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   if (ctx->n_models > 8192) {
     ctx->err = "more than 8192 models per context";
     return MH_ERR_CAPACITY;
@@ -640,6 +646,7 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
                                  float** d1_dev, float** d2_dev) {
   if (!ctx || Q <= 0 || !q_desc_dev || !idx1_dev || !d1_dev || !d2_dev) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   *idx1_dev = ctx->nn_idx;
@@ -664,6 +671,7 @@ int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32
   if (!ctx || Q <= 0 || !q_uv_dev || !idx1_s_dev || !d1_s_dev || !d2_s_dev || n_shards <= 0 || !cam || !prm)
     return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   // merged top-2 goes to scratch so the local arrays handed to the all-gather stay intact
@@ -691,6 +699,7 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
                    int32_t* counts) {
   if (!ctx || !n_objects || !ctx->fs) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   FrameState* fs = ctx->fs;
   int32_t head[4];
   MH_HIP(ctx, hipMemcpyAsync(head, fs->result, sizeof head, hipMemcpyDeviceToHost, ctx->stream));
@@ -722,6 +731,7 @@ int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes) {
 int mh_timing(mh_ctx* ctx, mh_times* out) {
   if (!ctx || !out || !ctx->timing || !ctx->ev_made) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   MH_HIP(ctx, hipEventSynchronize(ctx->ev[8]));
   float* dst[8] = {&out->match_ms, &out->group_ms, &out->cluster_ms, &out->pose1_ms,
                    &out->filter1_ms, &out->pose2_ms, &out->filter2_ms, nullptr};

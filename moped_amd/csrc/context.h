@@ -65,6 +65,7 @@ namespace mh {
     }                                                                             \
   } while (0)
 
+int use_stream(mh_ctx* ctx);  // make sure ctx->stream is valid (creates the own stream lazily)
 int ensure_frame_buffers(mh_ctx* ctx, int Q);
 int ensure_scratch(mh_ctx* ctx, size_t bytes);
 int ensure_pinned(mh_ctx* ctx, size_t bytes);

@@ -18,6 +18,7 @@ namespace mh {
 namespace {
 
 constexpr int FT = 256;
+constexpr int FILTER_GRID = 128;  // grid-stride over the object slots (their count lives on the device)
 
 __device__ __forceinline__ unsigned long long pack_best(float score, int obj) {
   return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)obj);
@@ -31,9 +32,10 @@ __global__ __launch_bounds__(FT) void filter_score_kernel(FilterBuffers fb, DevC
                                                           const int32_t* __restrict__ n_slots_dev) {
   __shared__ float err_s[FT];
   __shared__ float score_s;
-  const int o = blockIdx.x;
-  if (o >= *n_slots_dev || !fb.obj_valid[o]) return;
   const int tid = threadIdx.x;
+  for (int o = blockIdx.x; o < *n_slots_dev; o += gridDim.x) {
+  __syncthreads();
+  if (!fb.obj_valid[o]) continue;
   const int m = fb.obj_model[o];
   const int b = fb.model_off[m];
   const int n = fb.model_off[m + 1] - b;
@@ -63,21 +65,22 @@ __global__ __launch_bounds__(FT) void filter_score_kernel(FilterBuffers fb, DevC
   }
   __syncthreads();
   score = score_s;
-  if (!(score > 0.f)) return;
+  if (!(score > 0.f)) continue;
   const unsigned long long key = pack_best(score, o);
   for (int i = tid; i < n; i += FT) {
     const mh_corr c = fb.corr[b + i];
     if (reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v) < feature_distance)
       atomicMax(&fb.best[fb.m_rep[b + i]], key);
   }
+  }  // object loop
 }
 
 __global__ __launch_bounds__(FT) void filter_count_kernel(FilterBuffers fb,
                                                           const int32_t* __restrict__ n_slots_dev) {
   __shared__ int cnt_s;
-  const int o = blockIdx.x;
-  if (o >= *n_slots_dev) return;
   const int tid = threadIdx.x;
+  for (int o = blockIdx.x; o < *n_slots_dev; o += gridDim.x) {
+  __syncthreads();
   if (tid == 0) cnt_s = 0;
   __syncthreads();
   if (fb.obj_valid[o]) {
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(FT) void filter_count_kernel(FilterBuffers fb,
   }
   __syncthreads();
   if (tid == 0) fb.obj_clsize[o] = cnt_s;
+  }  // object loop
 }
 
 // Single thread: erase / compact the object list in place (ascending, so a move
@@ -129,9 +133,8 @@ __global__ void filter_compact_kernel(FilterBuffers fb, int min_points, float mi
 __global__ __launch_bounds__(64) void filter_fill_kernel(FilterBuffers fb,
                                                          const int32_t* __restrict__ n_slots_dev,
                                                          const int32_t* __restrict__ old_of) {
-  const int r = blockIdx.x;
-  if (r >= *n_slots_dev) return;
   const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < *n_slots_dev; r += gridDim.x) {
   const int o = old_of[r];
   const int m = fb.obj_model[r];
   const int b = fb.model_off[m];
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(64) void filter_fill_kernel(FilterBuffers fb,
     if (mine) fb.new_members[w + __popcll(bal & ((1ull << lane) - 1ull))] = b + i;
     w += __popcll(bal);
   }
+  }  // kept-object loop
 }
 
 }  // namespace
@@ -152,13 +156,14 @@ void launch_filter(const FilterBuffers& fb, const DevCam& cam, int min_points,
                    float feature_distance, float min_score, int32_t* n_slots_dev,
                    int32_t* n_clusters_dev, FrameCounts* counts, hipStream_t s) {
   hipMemsetAsync(fb.best, 0, (size_t)fb.max_m * sizeof(unsigned long long), s);
-  hipLaunchKernelGGL(filter_score_kernel, dim3(fb.max_objects), dim3(FT), 0, s, fb, cam,
+  const int grid = fb.max_objects < FILTER_GRID ? fb.max_objects : FILTER_GRID;
+  hipLaunchKernelGGL(filter_score_kernel, dim3(grid), dim3(FT), 0, s, fb, cam,
                      feature_distance, n_slots_dev);
-  hipLaunchKernelGGL(filter_count_kernel, dim3(fb.max_objects), dim3(FT), 0, s, fb, n_slots_dev);
+  hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(FT), 0, s, fb, n_slots_dev);
   int32_t* old_of = fb.obj_clsize + fb.max_objects;  // second half of the scratch array
   hipLaunchKernelGGL(filter_compact_kernel, dim3(1), dim3(64), 0, s, fb, min_points, min_score,
                      n_slots_dev, n_clusters_dev, old_of, counts);
-  hipLaunchKernelGGL(filter_fill_kernel, dim3(fb.max_objects), dim3(64), 0, s, fb, n_slots_dev,
+  hipLaunchKernelGGL(filter_fill_kernel, dim3(grid), dim3(64), 0, s, fb, n_slots_dev,
                      old_of);
 }
 

@@ -16,6 +16,8 @@
 // then on the reference's squared-pixel residuals (lmFuncQuat, :100-138) so the
 // refined pose sits at the minimiser optimizeCamera (:140-164) converges to.
 // Parity with the reference is therefore at final-pose level.
+#include <algorithm>
+
 #include "geom.h"
 
 namespace mh {
@@ -572,25 +574,22 @@ struct PoseLds {
   int n_inl;
 };
 
+// One (cluster, replica) task, executed by a whole workgroup.  Every early exit is
+// workgroup-uniform.
 template <int KIND>
-__global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
+__device__ void pose_task(
+    PoseLds<KIND>& L, const int cluster, const int replica,
     const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
     const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
-    const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
-    mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+    const int32_t* __restrict__ cl_count, const DevCam& cam,
+    const mh_pose_params& prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
     const int32_t* __restrict__ obj_base_dev, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
     float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
     FrameCounts* counts) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
   constexpr int PS = PointStride<KIND>::value;
   const int R_ = prm.max_objects_per_cluster;
-  const int cluster = blockIdx.x / R_;
-  const int replica = blockIdx.x % R_;
-  const int ncl = *n_clusters_dev;
-  if (cluster >= ncl) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = (obj_base_dev ? *obj_base_dev : 0) + cluster * R_ + replica;
   if (slot >= max_objects) {
@@ -773,6 +772,33 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
   }
 }
 
+// Grid-stride loop over the (cluster, replica) tasks: the cluster count lives on the
+// device, so the grid is a fixed small number of workgroups instead of one (mostly
+// idle) workgroup per reserved slot.
+constexpr int POSE_GRID = 96;
+template <int KIND>
+__global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
+    const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
+    const int32_t* __restrict__ members,
+    const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
+    const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
+    mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+    const int32_t* __restrict__ obj_base_dev, int max_objects,
+    int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
+    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
+    FrameCounts* counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
+  const int R_ = prm.max_objects_per_cluster;
+  const int n_tasks = *n_clusters_dev * R_;
+  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    pose_task<KIND>(L, task / R_, task % R_, corr, depth, alpha, members, cl_model, cl_begin, cl_count, cam,
+                    prm, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
+                    obj_cluster, obj_valid, counts);
+    __syncthreads();  // LDS is reused by the next task
+  }
+}
+
 __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_corr* __restrict__ corr,
                                     int n, DevCam cam, float thr, uint8_t* __restrict__ inlier,
                                     float* __restrict__ err2, int32_t* __restrict__ n_inliers) {
@@ -808,7 +834,7 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds<KIND>));
     once = true;
   }
-  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(max_clusters * p.max_objects_per_cluster), dim3(POSE_THREADS),
+  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::min(POSE_GRID, max_clusters * p.max_objects_per_cluster)), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, p, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
                      obj_err, obj_cluster, obj_valid, counts);

@@ -53,11 +53,11 @@ class FramePipeline:
         normalized = None
         for i in range(depth):
             c = capi.Context(device)
+            s = torch.cuda.Stream(device=self.dev)
+            c.set_stream(s.cuda_stream)   # before any work: the context then never creates a stream of its own
             if normalized is None:
                 # model descriptors are L2-normalised once, like Update() (MATCH_ANN_CPU.hpp:94)
                 normalized = c.normalize(db.desc) if db.desc.shape[0] else db.desc
-            s = torch.cuda.Stream(device=self.dev)
-            c.set_stream(s.cuda_stream)
             c.db_upload(normalized, db.model_of, db.xyz, db.n_models, index_base=db.row_lo)
             c.reserve(max_queries)
             self.ctxs.append(c)

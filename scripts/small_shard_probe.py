@@ -1,0 +1,31 @@
+"""What bounds frames/s on a small shard (the per-rank load at N=8)?"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from moped_amd import synth, capi
+from moped_amd.pipeline import FramePipeline, ShardedDB
+models = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+db = synth.make_db(models, 5000)
+frames = [synth.make_frame(db, n_vis=2, seed=s) for s in range(8)]
+dev = torch.device("cuda:0")
+def run(label, stage2=1, match_only=False, n=240):
+    prm = capi.default_frame_params(); prm.run_stage2 = stage2
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=depth, max_queries=3000, params=prm)
+    q = [torch.from_numpy(f.desc).to(dev) for f in frames]; uv = [torch.from_numpy(f.uv).to(dev) for f in frames]
+    qn = torch.empty(3000, device=dev); idx = torch.empty(3000, dtype=torch.int32, device=dev)
+    d1 = torch.empty(3000, device=dev); d2 = torch.empty(3000, device=dev)
+    def go(k):
+        for i in range(k):
+            s = i % depth
+            if match_only:
+                pipe.ctxs[s].match_local_dev(q[i % 8].data_ptr(), qn.data_ptr(), 3000, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+            else:
+                pipe.enqueue(s, q[i % 8], uv[i % 8], seed=i + 1)
+    go(16); pipe.synchronize()
+    t0 = time.perf_counter(); go(n); pipe.synchronize(); dt = time.perf_counter() - t0
+    print(f"{label:28s} {n/dt:8.1f} frames/s  ({1e3*dt/n:.3f} ms/frame)")
+    pipe.close()
+run("match stage only", match_only=True)
+run("through POSE (no stage 2)", stage2=0)
+run("full frame", stage2=1)
