@@ -76,6 +76,16 @@ inline string toString(const T& v) {
   return o.str();
 }
 
+#ifdef MOPED_AMD_WITH_DEPTH
+// moped3d only (moped3d/libmoped/src/util.hpp:73-84): what DEPTHMAP_PROP_CPU attaches to a match
+struct depthInformation {
+  bool depthValid;
+  Pt<3> coord3D;       // camera-frame xyz read from the depth map
+  Float depth;
+  Float fillDistance;  // distance to the pixel the depth was filled in from (-1: unknown)
+};
+#endif
+
 struct FrameData {
   struct DetectedFeature {
     int imageIdx;
@@ -86,6 +96,9 @@ struct FrameData {
     int imageIdx;
     Pt<2> coord2D;
     Pt<3> coord3D;
+#ifdef MOPED_AMD_WITH_DEPTH
+    depthInformation depthData;  // moped3d/libmoped/src/util.hpp:107
+#endif
   };
   typedef list<int> Cluster;
   vector<SP_Image> images;
