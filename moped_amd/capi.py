@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoped_hip.so")
+LIB_PATH = os.environ.get("MH_LIB_PATH") or os.path.join(_HERE, "libmoped_hip.so")  # override: A/B kernel builds
 
 MH_OK = 0
 

@@ -92,7 +92,7 @@ __device__ __forceinline__ void fold(float& b1, float& b2, int& i1, float v, int
   const bool lt = v < b1;
   b2 = __builtin_amdgcn_fmed3f(b1, b2, v);  // median(b1 <= b2, v) = new second best
   i1 = lt ? idx : i1;
-  b1 = fminf(b1, v);
+  b1 = lt ? v : b1;                         // select on the same compare (a min would re-canonicalise b1)
 }
 
 // Merge two disjoint top-2 sets; lower index wins a tie on the best distance.
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
     v2f acc[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) acc[t] = (v2f){0.f, 0.f};
-    {
+    if (live) {  // wavefronts beyond the last query group only help with staging (small-Q launches)
       v16f qa0, qb0, qa1, qb1;
       v4f ra0, rb0, ra1, rb1;
       chunk_issue<0>(qp, la, qa0, qb0, ra0, rb0, acc);
@@ -434,7 +434,7 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
     const size_t lds_bytes = 2 * TILE_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       attr_set = true;
     }
