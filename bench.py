@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--n-vis", type=int, default=2)
     ap.add_argument("--depth-kind", type=int, default=0,
                     help="0 = moped2 residuals; 1/2 = moped3d back-projection / reprojection+depth (config 5)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -110,8 +112,13 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or args.force_exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     Q = args.queries
     db = synth.make_db(args.models, 5000)
@@ -124,7 +131,8 @@ def main():
         params.pose1.error_threshold = 8.0
         params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
         params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
-    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q, params=params)
+    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q, params=params,
+                         force_exchange=args.force_exchange)
     pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
     work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
@@ -245,7 +253,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     pipe.close()
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

@@ -223,17 +223,17 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
  * order; NULL switches back to the 2-D residuals).  POSE and POSE2 of the frame then use
  * the MH_DEPTH_* residuals `kind` with `alpha`. */
 int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float alpha);
-/* The two halves around exchange 1 when the DB is sharded over ranks:
- *   mh_frame_enqueue_match_local : normalise + local top-2 -> ctx-owned
- *       device arrays (pointers returned for the all-gather)
- *   mh_frame_enqueue_rest        : merge gathered [S][Q] top-2, keep matches of
- *       models this context owns, then CLUSTER..FILTER2 as above. */
-int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q,
-                                 int32_t** idx1_dev, float** d1_dev, float** d2_dev);
-int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q,
-                          const int32_t* idx1_s_dev, const float* d1_s_dev,
-                          const float* d2_s_dev, int n_shards,
-                          const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* The two halves around exchange 1 when the DB is sharded over ranks.
+ *   mh_frame_enqueue_match_local : normalise + this shard's top-2 -> top2_dev, a
+ *       caller-owned device block of [3][Q] 32-bit words {idx1 (global row, int32),
+ *       bits of d1, bits of d2}: the send buffer of the all-gather
+ *   mh_frame_enqueue_rest        : gathered_dev = the all-gather's receive buffer,
+ *       [n_shards][3][Q] words in rank order; merges the shards' top-2, keeps the
+ *       matches of models this context owns, then CLUSTER..FILTER2 as above. */
+int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t* top2_dev);
+int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
+                          int n_shards, const mh_cam* cam, const mh_frame_params* prm,
+                          uint64_t seed);
 /* Synchronises the stream and copies the frame's objects out (capacity
  * max_objects); *n_objects = count.  counts (optional, 4 ints): accepted
  * matches, clusters, objects after POSE, objects after FILTER. */

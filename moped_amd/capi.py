@@ -122,8 +122,8 @@ def load():
     L.mh_frame_default_params.argtypes = [C.POINTER(mh_frame_params)]
     L.mh_frame_default_params.restype = None
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
-    L.mh_frame_enqueue_match_local.argtypes = [vp, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
-    L.mh_frame_enqueue_rest.argtypes = [vp, vp, i32, vp, vp, vp, i32, C.POINTER(mh_cam),
+    L.mh_frame_enqueue_match_local.argtypes = [vp, vp, i32, vp]
+    L.mh_frame_enqueue_rest.argtypes = [vp, vp, i32, vp, i32, C.POINTER(mh_cam),
                                         C.POINTER(mh_frame_params), C.c_uint64]
     L.mh_frame_fetch.argtypes = [vp, vp, i32, C.POINTER(C.c_int32), vp]
     L.mh_frame_result_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -330,18 +330,18 @@ class Context:
         self._ck(self.L.mh_frame_enqueue(self.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q,
                                          C.byref(c), C.byref(params), seed), "mh_frame_enqueue")
 
-    def frame_enqueue_match_local(self, q_desc_ptr, Q):
-        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._ck(self.L.mh_frame_enqueue_match_local(self.h, C.c_void_p(q_desc_ptr), Q, C.byref(a),
-                                                     C.byref(b), C.byref(c)), "mh_frame_enqueue_match_local")
-        return a.value, b.value, c.value
+    def frame_enqueue_match_local(self, q_desc_ptr, Q, top2_ptr):
+        """top2_ptr: device block of [3][Q] 32-bit words (idx1, d1 bits, d2 bits)."""
+        self._ck(self.L.mh_frame_enqueue_match_local(self.h, C.c_void_p(q_desc_ptr), Q, C.c_void_p(top2_ptr)),
+                 "mh_frame_enqueue_match_local")
 
-    def frame_enqueue_rest(self, q_uv_ptr, Q, idx_ptr, d1_ptr, d2_ptr, n_shards, K, cam,
-                           params: mh_frame_params, seed=1):
-        c = make_cam(K, cam)
-        self._ck(self.L.mh_frame_enqueue_rest(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(idx_ptr),
-                                              C.c_void_p(d1_ptr), C.c_void_p(d2_ptr), n_shards,
-                                              C.byref(c), C.byref(params), seed), "mh_frame_enqueue_rest")
+    def frame_enqueue_rest(self, q_uv_ptr, Q, gathered_ptr, n_shards, K, cam, params: mh_frame_params,
+                           seed=1, _cam_struct=None):
+        """gathered_ptr: device block of [n_shards][3][Q] words (rank order)."""
+        c = _cam_struct or make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_rest(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr),
+                                              n_shards, C.byref(c), C.byref(params), seed),
+                 "mh_frame_enqueue_rest")
 
     def frame_fetch(self, max_objects=4096):
         objs = np.zeros(max_objects, OBJECT_DTYPE)

@@ -233,7 +233,7 @@ int mh_match_merge_dev(mh_ctx* ctx, const int32_t* idx1_s_dev, const float* d1_s
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, idx1_dev, d1_dev, d2_dev,
+  launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, (size_t)Q, idx1_dev, d1_dev, d2_dev,
                      ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;

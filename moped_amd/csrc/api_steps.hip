@@ -34,7 +34,8 @@ struct FrameState {
   unsigned char* result = nullptr;
   size_t result_bytes = 0;
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
-  uint64_t* seed_dev = nullptr;  // per-frame seed, read by the pose kernels (keeps the launch list constant)
+  uint64_t* seed_dev = nullptr;  // per-frame seed in device memory: only when the launch list is replayed as a graph
+  unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
   // hipGraph replay of the launch list (one graph per half of the frame)
   struct Graph {
     hipGraphExec_t exec = nullptr;
@@ -59,7 +60,7 @@ void free_fs(FrameState* fs) {
                   fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
                   fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
                   fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw,
-                  fs->m_depth,    fs->seed_dev};
+                  fs->m_depth,    fs->seed_dev,    fs->tickets};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (FrameState::Graph* g : {&fs->g_full, &fs->g_local, &fs->g_rest})
@@ -121,7 +122,10 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->result, fs->result_bytes);
   rc |= dev_alloc(ctx, fs->snap, 4);
   rc |= dev_alloc(ctx, fs->seed_dev, 1);
+  rc |= dev_alloc(ctx, fs->tickets, 8);
   if (rc) return MH_ERR_HIP;
+  MH_HIP(ctx, hipMemsetAsync(fs->tickets, 0, 8 * sizeof(unsigned int), ctx->stream));
+  MH_HIP(ctx, hipMemsetAsync(fs->best, 0, sizeof(unsigned long long) * max_m, ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->obj_valid, 0, sizeof(int32_t) * max_objects, ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->obj_score, 0, sizeof(float) * max_objects, ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->obj_npts, 0, sizeof(int32_t) * max_objects, ctx->stream));
@@ -153,20 +157,10 @@ FilterBuffers make_fb(const mh_ctx* ctx, const FrameState* fs, int n_models) {
   return fb;
 }
 
-// n_slots += n_clusters * R after a POSE launch; optional snapshot of a counter.
-__global__ void advance_slots_kernel(int32_t* n_slots, const int32_t* n_clusters, int R, int max_objects) {
-  int v = *n_slots + *n_clusters * R;
-  *n_slots = v > max_objects ? max_objects : v;
-}
 __global__ void set_scalar_kernel(int32_t* p, int32_t v) { *p = v; }
-__global__ void snapshot_kernel(int32_t* dst, const int32_t* src) { *dst = *src; }
-__global__ void count_valid_kernel(int32_t* dst, const int32_t* valid, const int32_t* n_slots) {
-  int c = 0;
-  for (int i = 0; i < *n_slots; ++i) c += valid[i] != 0;
-  *dst = c;
-}
 
-// Pack the valid objects (list order) into the result block.
+// Result block of a frame that stops after POSE (run_stage2 = 0): the valid objects in
+// list order.  Frames with the FILTER stages get it from the last FILTER launch.
 __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots,
                                    const int32_t* obj_valid, const int32_t* obj_model,
                                    const float* obj_pose, const float* obj_score,
@@ -187,69 +181,68 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
   reinterpret_cast<int32_t*>(result)[0] = k;
 }
 
+bool graphs_enabled();
+void set_seed(mh_ctx* ctx, uint64_t seed);
+
 void stamp(mh_ctx* ctx, int i) {
   if (ctx->timing) hipEventRecord(ctx->ev[i], ctx->stream);
 }
 
-int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1, const float* d1,
-               const float* d2, const mh_cam* cam, const mh_frame_params* prm) {
+// CLUSTER .. FILTER2 of a device-resident frame in six launches.  gathered != nullptr:
+// exchange-1 blocks ([n_shards][3][Q]) to merge first.
+int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered, int n_shards,
+               const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
   FrameState* fs = ctx->fs;
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
   const int nm = ctx->n_models;
-  MH_HIP(ctx, hipMemsetAsync(fs->counts, 0, sizeof(FrameCounts), s));
-  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
-  // MATCH tail: ratio test + per-model lists
-  launch_group(idx1, d1, d2, Q, prm->ratio, q_uv_dev, ctx->db_model, ctx->db_xyz, ctx->N,
-               ctx->index_base, nm, fs->max_m, fs->acc_q, fs->acc_model, fs->m_q, fs->m_model,
-               fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth, fs->m_depth, fs->counts, s);
+  const uint64_t* seed_dev = nullptr;
+  if (graphs_enabled()) {   // replayed launch lists take the seed from device memory (set by the caller)
+    seed_dev = fs->seed_dev;
+    seed = 0;
+  }
+  // MATCH tail: (shard merge,) ratio test + per-model lists; resets the frame's counters
+  launch_group(gathered, n_shards, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, prm->ratio, q_uv_dev,
+               ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
+               fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
+               fs->m_depth, fs->counts, fs->n_slots, fs->best, s);
   stamp(ctx, 2);
-  // CLUSTER
+  // CLUSTER (+ flat cluster table, snap[0..1])
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
-                          fs->ms_ncl, fs->counts, s);
-  launch_cluster_table(fs->model_off, fs->ms_cl_start, fs->ms_ncl, nm, fs->max_clusters,
-                       fs->cl_model, fs->cl_begin, fs->cl_count, fs->counts, s);
-  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->n_clusters, &fs->counts->n_clusters);
-  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 0, &fs->counts->n_matches);
-  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 1, &fs->counts->n_clusters);
+                          fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
+                          fs->n_clusters, fs->snap, fs->counts, fs->tickets + 0, s);
   stamp(ctx, 3);
-  // POSE
+  // POSE (+ slot count, snap[2] = objects after POSE)
   const float* depth4 = ctx->q_depth ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
   launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
-              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, 0ull, fs->seed_dev, fs->n_slots, fs->max_objects, fs->obj_model,
-              fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
-  hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
-                     prm->pose1.max_objects_per_cluster > 0 ? prm->pose1.max_objects_per_cluster : 1,
-                     fs->max_objects);
-  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1), 0, s, fs->snap + 2, fs->obj_valid, fs->n_slots);
+              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
+              fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, fs->snap + 2}, s);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     FilterBuffers fb = make_fb(ctx, fs, nm);
-    // FILTER
+    // FILTER (snap[3] = objects kept)
     launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, s);
-    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, s, fs->snap + 3, fs->n_slots);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, fs->snap + 3, nullptr}, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
-                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2, 0x5DEECE66Dull, fs->seed_dev, fs->n_slots,
-                fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err,
-                fs->obj_cluster, fs->obj_valid, fs->counts, s);
-    hipLaunchKernelGGL(advance_slots_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, fs->n_clusters,
-                       prm->pose2.max_objects_per_cluster > 0 ? prm->pose2.max_objects_per_cluster : 1,
-                       fs->max_objects);
+                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
+                seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+                fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr}, s);
     stamp(ctx, 6);
-    // FILTER2
+    // FILTER2 (+ the frame's result block)
     launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, s);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, fs->result}, s);
     stamp(ctx, 7);
   } else {
     for (int i = 5; i <= 7; ++i) stamp(ctx, i);
+    hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, fs->result, fs->n_slots,
+                       fs->obj_valid, fs->obj_model, fs->obj_pose, fs->obj_score, fs->obj_npts,
+                       fs->max_objects);
   }
-  hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, fs->result, fs->n_slots,
-                     fs->obj_valid, fs->obj_model, fs->obj_pose, fs->obj_score, fs->obj_npts,
-                     fs->max_objects);
   stamp(ctx, 8);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;
@@ -384,7 +377,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   const DevCam dc = make_devcam(*cam);
   launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
               fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, nullptr, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
-              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, s);
+              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr}, s);
   MH_HIP(ctx, hipGetLastError());
   std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
   std::vector<float> pose((size_t)7 * n_obj), err(n_obj);
@@ -488,11 +481,12 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   MH_HIP(ctx, hipMemcpyAsync(fs->obj_pose, obj_pose, (size_t)n_obj * 28, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->obj_valid, ones.data(), (size_t)n_obj * 4, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemsetAsync(fs->counts, 0, sizeof(FrameCounts), s));
+  MH_HIP(ctx, hipMemsetAsync(fs->best, 0, sizeof(unsigned long long) * (size_t)std::max(M, 1), s));
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, n_obj);
   FilterBuffers fb = make_fb(ctx, fs, n_models);
   fb.max_objects = n_obj;  // grid size; arrays are at least this large
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
-                fs->n_clusters, fs->counts, s);
+                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr}, s);
   MH_HIP(ctx, hipGetLastError());
   int32_t kept = 0;
   MH_HIP(ctx, hipMemcpyAsync(&kept, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
@@ -528,7 +522,7 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
 }  // extern "C" (helpers below need C++ linkage)
 
 // ---- hipGraph replay of a frame's launch list --------------------------------------
-// A frame is ~40 small launches with fixed grids and device-side counts, so the list
+// A frame is a short list of launches with fixed grids and device-side counts, so the list
 // is identical from frame to frame as long as the pointers / sizes / constants are.
 // The first enqueue with a given key runs eagerly (it also does the one-time
 // hipFuncSetAttribute calls), the second is captured, later ones replay the graph.
@@ -627,7 +621,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   }
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  set_seed(ctx, seed);
+  if (graphs_enabled()) set_seed(ctx, seed);
   std::vector<unsigned char> key;
   key_common(ctx, key, Q, cam, prm);
   key_add(key, q_desc_dev);
@@ -638,60 +632,49 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
     launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
                  ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
     stamp(ctx, 1);
-    return frame_rest(ctx, q_uv_dev, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, cam, prm);
+    return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
   });
 }
 
-int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t** idx1_dev,
-                                 float** d1_dev, float** d2_dev) {
-  if (!ctx || Q <= 0 || !q_desc_dev || !idx1_dev || !d1_dev || !d2_dev) return MH_ERR_ARG;
+int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t* top2_dev) {
+  if (!ctx || Q <= 0 || !q_desc_dev || !top2_dev) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  *idx1_dev = ctx->nn_idx;
-  *d1_dev = ctx->nn_d1;
-  *d2_dev = ctx->nn_d2;
+  float* d1 = reinterpret_cast<float*>(top2_dev + Q);
   std::vector<unsigned char> key;
   key_common(ctx, key, Q, nullptr, nullptr);
   key_add(key, q_desc_dev);
+  key_add(key, top2_dev);
   return run_graphed(ctx, ctx->fs->g_local, key, [&]() -> int {
     stamp(ctx, 0);
     launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
     launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-                 ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+                 ctx->match_scratch, ctx->match_pack, top2_dev, d1, d1 + Q, ctx->stream);
     MH_HIP(ctx, hipGetLastError());
     return MH_OK;
   });
 }
 
-int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* idx1_s_dev,
-                          const float* d1_s_dev, const float* d2_s_dev, int n_shards,
-                          const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
-  if (!ctx || Q <= 0 || !q_uv_dev || !idx1_s_dev || !d1_s_dev || !d2_s_dev || n_shards <= 0 || !cam || !prm)
-    return MH_ERR_ARG;
+int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
+                          int n_shards, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || Q <= 0 || !q_uv_dev || !gathered_dev || n_shards <= 0 || !cam || !prm) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  // merged top-2 goes to scratch so the local arrays handed to the all-gather stay intact
-  if ((rc = ensure_scratch(ctx, (size_t)Q * 12 + 64))) return rc;
-  int32_t* g_idx = (int32_t*)ctx->scratch;
-  float* g_d1 = (float*)(g_idx + Q);
-  float* g_d2 = g_d1 + Q;
-  set_seed(ctx, seed);
+  if (graphs_enabled()) set_seed(ctx, seed);
   std::vector<unsigned char> key;
   key_common(ctx, key, Q, cam, prm);
   key_add(key, q_uv_dev);
-  key_add(key, idx1_s_dev);
-  key_add(key, d1_s_dev);
-  key_add(key, d2_s_dev);
+  key_add(key, gathered_dev);
   key_add(key, n_shards);
-  key_add(key, ctx->scratch);
   return run_graphed(ctx, ctx->fs->g_rest, key, [&]() -> int {
-    launch_match_merge(idx1_s_dev, d1_s_dev, d2_s_dev, n_shards, Q, g_idx, g_d1, g_d2, ctx->stream);
+    // shard k's block is [3][Q] words at gathered_dev + k*3*Q; the first launch merges them
+    // into the context's own top-2 arrays
     stamp(ctx, 1);
-    return frame_rest(ctx, q_uv_dev, Q, g_idx, g_d1, g_d2, cam, prm);
+    return frame_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
   });
 }
 

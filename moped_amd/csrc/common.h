@@ -32,8 +32,36 @@ size_t match_pack_floats(int Q);
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
                   int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
                   float* d2, hipStream_t s);
+// shard k's arrays start k * shard_stride elements after the given pointers
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,
-                        int32_t* idx1, float* d1, float* d2, hipStream_t s);
+                        size_t shard_stride, int32_t* idx1, float* d1, float* d2, hipStream_t s);
+
+// ---- launch fusion --------------------------------------------------------------
+// The GPU front end retires ~0.2 M dependent dispatches per second over all queues
+// (scripts/dispatch_rate.py), so a frame is kept to a handful of launches: the small
+// serial step that used to follow a grid-wide kernel in its own launch runs instead in
+// the LAST workgroup of that kernel to finish.
+// Returns true in exactly one workgroup of the launch -- the last one to call it; every
+// global write the other workgroups made before their call is visible to it afterwards.
+// All threads of every workgroup must call it exactly once.  The ticket (zero before
+// the first launch) re-arms itself.
+#ifdef __HIPCC__
+__device__ __forceinline__ bool last_workgroup(unsigned int* ticket) {
+  __shared__ int is_last_s;
+  __threadfence();   // release: this workgroup's results
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int n = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned int t = atomicAdd(ticket, 1u);
+    is_last_s = (t == n - 1u);
+    if (t == n - 1u) atomicExch(ticket, 0u);
+  }
+  __syncthreads();
+  const bool last = is_last_s != 0;
+  if (last) __threadfence();   // acquire: everybody else's results
+  return last;
+}
+#endif
 
 // ---- group ------------------------------------------------------------------
 struct FrameCounts {

@@ -11,6 +11,7 @@
 //  F3  one thread: erase objects with too few points or too low a score, keep list
 //      order, build the rewritten cluster table (:150-160)
 //  F4  per kept object: ordered member list
+// One launch: F1 in every workgroup, F2..F4 in the last workgroup to finish.
 #include "geom.h"
 
 namespace mh {
@@ -27,144 +28,157 @@ __device__ __forceinline__ int best_obj(unsigned long long k) {
   return k == 0ull ? -1 : (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
 }
 
-__global__ __launch_bounds__(FT) void filter_score_kernel(FilterBuffers fb, DevCam cam,
-                                                          float feature_distance,
-                                                          const int32_t* __restrict__ n_slots_dev) {
+// The whole step in one launch.  Every workgroup scores objects (F1, grid-stride); the
+// last one to finish does F2..F4 for all objects -- they are cheap sweeps over the few
+// hundred matches of each object's model -- re-arms the claim table for the next FILTER
+// of the frame and, if asked, packs the frame's result block.
+__global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam, float feature_distance,
+                                                    int min_points, float min_score,
+                                                    int32_t* n_slots_dev, int32_t* n_clusters_dev,
+                                                    FrameCounts* counts, FilterTail tail) {
   __shared__ float err_s[FT];
   __shared__ float score_s;
-  const int tid = threadIdx.x;
-  for (int o = blockIdx.x; o < *n_slots_dev; o += gridDim.x) {
-  __syncthreads();
-  if (!fb.obj_valid[o]) continue;
-  const int m = fb.obj_model[o];
-  const int b = fb.model_off[m];
-  const int n = fb.model_off[m + 1] - b;
-  TM T;
-  tm_from_pose(T, fb.obj_pose + 7 * (size_t)o, fb.obj_pose + 7 * (size_t)o + 4);
-  float score = 0.f;  // tid 0 only
-  for (int base = 0; base < n; base += FT) {
-    const int i = base + tid;
-    float e = __builtin_inff();
-    if (i < n) {
-      const mh_corr c = fb.corr[b + i];
-      e = reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v);
-    }
-    err_s[tid] = e;
+  __shared__ int cnt_s, kept_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_slots = *n_slots_dev;
+  // ---- F1 ----
+  for (int o = blockIdx.x; o < n_slots; o += gridDim.x) {
     __syncthreads();
-    if (tid == 0) {
-      const int cnt = min(FT, n - base);
-      for (int j = 0; j < cnt; ++j)
-        if (err_s[j] < feature_distance)
-          score = (float)((double)score + 1. / ((double)err_s[j] + 1.));  // score += 1./(err+1.)
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    score_s = score;
-    fb.obj_score[o] = score;
-  }
-  __syncthreads();
-  score = score_s;
-  if (!(score > 0.f)) continue;
-  const unsigned long long key = pack_best(score, o);
-  for (int i = tid; i < n; i += FT) {
-    const mh_corr c = fb.corr[b + i];
-    if (reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v) < feature_distance)
-      atomicMax(&fb.best[fb.m_rep[b + i]], key);
-  }
-  }  // object loop
-}
-
-__global__ __launch_bounds__(FT) void filter_count_kernel(FilterBuffers fb,
-                                                          const int32_t* __restrict__ n_slots_dev) {
-  __shared__ int cnt_s;
-  const int tid = threadIdx.x;
-  for (int o = blockIdx.x; o < *n_slots_dev; o += gridDim.x) {
-  __syncthreads();
-  if (tid == 0) cnt_s = 0;
-  __syncthreads();
-  if (fb.obj_valid[o]) {
+    if (!fb.obj_valid[o]) continue;
     const int m = fb.obj_model[o];
     const int b = fb.model_off[m];
     const int n = fb.model_off[m + 1] - b;
-    int mine = 0;
-    for (int i = tid; i < n; i += FT) mine += (best_obj(fb.best[fb.m_rep[b + i]]) == o);
-    if (mine) atomicAdd(&cnt_s, mine);
+    TM T;
+    tm_from_pose(T, fb.obj_pose + 7 * (size_t)o, fb.obj_pose + 7 * (size_t)o + 4);
+    float score = 0.f;  // tid 0 only
+    for (int base = 0; base < n; base += FT) {
+      const int i = base + tid;
+      float e = __builtin_inff();
+      if (i < n) {
+        const mh_corr c = fb.corr[b + i];
+        e = reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v);
+      }
+      err_s[tid] = e;
+      __syncthreads();
+      if (tid == 0) {
+        const int cnt = min(FT, n - base);
+        for (int j = 0; j < cnt; ++j)
+          if (err_s[j] < feature_distance)
+            score = (float)((double)score + 1. / ((double)err_s[j] + 1.));  // score += 1./(err+1.)
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      score_s = score;
+      fb.obj_score[o] = score;
+    }
+    __syncthreads();
+    score = score_s;
+    if (!(score > 0.f)) continue;
+    const unsigned long long key = pack_best(score, o);
+    for (int i = tid; i < n; i += FT) {
+      const mh_corr c = fb.corr[b + i];
+      if (reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v) < feature_distance)
+        atomicMax(&fb.best[fb.m_rep[b + i]], key);
+    }
+  }
+  if (!last_workgroup(tail.ticket)) return;
+
+  // ---- F2: keypoints each object owns ----
+  for (int o = 0; o < n_slots; ++o) {
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    if (fb.obj_valid[o]) {
+      const int m = fb.obj_model[o];
+      const int b = fb.model_off[m];
+      const int n = fb.model_off[m + 1] - b;
+      int mine = 0;
+      for (int i = tid; i < n; i += FT) mine += (best_obj(fb.best[fb.m_rep[b + i]]) == o);
+      if (mine) atomicAdd(&cnt_s, mine);
+    }
+    __syncthreads();
+    if (tid == 0) fb.obj_clsize[o] = cnt_s;
   }
   __syncthreads();
-  if (tid == 0) fb.obj_clsize[o] = cnt_s;
-  }  // object loop
-}
 
-// Single thread: erase / compact the object list in place (ascending, so a move
-// never overwrites an unread slot) and lay out the new cluster table.
-__global__ void filter_compact_kernel(FilterBuffers fb, int min_points, float min_score,
-                                      int32_t* n_slots_dev, int32_t* n_clusters_dev,
-                                      int32_t* old_of, FrameCounts* counts) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int n = *n_slots_dev;
-  int k = 0, w = 0;
-  for (int o = 0; o < n; ++o) {
-    fb.obj_score_raw[o] = fb.obj_valid[o] ? fb.obj_score[o] : 0.f;
-    if (!fb.obj_valid[o]) continue;
-    const int sz = fb.obj_clsize[o];
-    if (sz < min_points || fb.obj_score[o] < min_score) continue;
-    if (k >= fb.max_clusters) {
-      atomicOr(&counts->error, ERR_CLUSTER_CAP);
-      break;
+  // ---- F3: one thread erases / compacts the object list in place (ascending, so a move
+  // never overwrites an unread slot) and lays out the new cluster table ----
+  int32_t* old_of = fb.obj_clsize + fb.max_objects;  // second half of the scratch array
+  if (tid == 0) {
+    int k = 0, w = 0;
+    for (int o = 0; o < n_slots; ++o) {
+      fb.obj_score_raw[o] = fb.obj_valid[o] ? fb.obj_score[o] : 0.f;
+      if (!fb.obj_valid[o]) continue;
+      const int sz = fb.obj_clsize[o];
+      if (sz < min_points || fb.obj_score[o] < min_score) continue;
+      if (k >= fb.max_clusters) {
+        atomicOr(&counts->error, ERR_CLUSTER_CAP);
+        break;
+      }
+      old_of[k] = o;
+      fb.obj_model[k] = fb.obj_model[o];
+      for (int j = 0; j < 7; ++j) fb.obj_pose[7 * k + j] = fb.obj_pose[7 * o + j];
+      fb.obj_score[k] = fb.obj_score[o];
+      fb.obj_npts[k] = sz;
+      fb.obj_valid[k] = 1;
+      fb.cl_model[k] = fb.obj_model[k];
+      fb.cl_begin[k] = w;
+      fb.cl_count[k] = sz;
+      w += sz;
+      ++k;
     }
-    old_of[k] = o;
-    fb.obj_model[k] = fb.obj_model[o];
-    for (int j = 0; j < 7; ++j) fb.obj_pose[7 * k + j] = fb.obj_pose[7 * o + j];
-    fb.obj_score[k] = fb.obj_score[o];
-    fb.obj_npts[k] = sz;
-    fb.obj_valid[k] = 1;
-    fb.cl_model[k] = fb.obj_model[k];
-    fb.cl_begin[k] = w;
-    fb.cl_count[k] = sz;
-    w += sz;
-    ++k;
+    for (int o = k; o < n_slots; ++o) fb.obj_valid[o] = 0;
+    *n_slots_dev = k;
+    *n_clusters_dev = k;
+    if (tail.snap_kept) *tail.snap_kept = k;
+    kept_s = k;
   }
-  for (int o = k; o < n; ++o) fb.obj_valid[o] = 0;
-  *n_slots_dev = k;
-  *n_clusters_dev = k;
-}
+  __syncthreads();
+  const int kept = kept_s;
 
-__global__ __launch_bounds__(64) void filter_fill_kernel(FilterBuffers fb,
-                                                         const int32_t* __restrict__ n_slots_dev,
-                                                         const int32_t* __restrict__ old_of) {
-  const int lane = threadIdx.x;
-  for (int r = blockIdx.x; r < *n_slots_dev; r += gridDim.x) {
-  const int o = old_of[r];
-  const int m = fb.obj_model[r];
-  const int b = fb.model_off[m];
-  const int n = fb.model_off[m + 1] - b;
-  int w = fb.cl_begin[r];
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const bool mine = i < n && best_obj(fb.best[fb.m_rep[b + i]]) == o;
-    const unsigned long long bal = __ballot(mine);
-    if (mine) fb.new_members[w + __popcll(bal & ((1ull << lane) - 1ull))] = b + i;
-    w += __popcll(bal);
+  // ---- F4: ordered member list of each kept object, one wavefront per object ----
+  for (int r = wave; r < kept; r += FT / 64) {
+    const int o = old_of[r];
+    const int m = fb.obj_model[r];
+    const int b = fb.model_off[m];
+    const int n = fb.model_off[m + 1] - b;
+    int w = fb.cl_begin[r];
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool mine = i < n && best_obj(fb.best[fb.m_rep[b + i]]) == o;
+      const unsigned long long bal = __ballot(mine);
+      if (mine) fb.new_members[w + __popcll(bal & ((1ull << lane) - 1ull))] = b + i;
+      w += __popcll(bal);
+    }
   }
-  }  // kept-object loop
+  __syncthreads();
+  // the claim table goes back to "unclaimed" for the next FILTER of this frame
+  const int M = fb.model_off[fb.n_models];
+  for (int i = tid; i < M && i < fb.max_m; i += FT) fb.best[i] = 0ull;
+
+  // ---- result block {int32 n; int32 pad[3]; mh_object[n]} (list order) ----
+  if (tail.result && tid == 0) {
+    mh_object* out = reinterpret_cast<mh_object*>(tail.result + 16);
+    for (int r = 0; r < kept; ++r) {
+      mh_object ob;
+      ob.model = fb.obj_model[r];
+      for (int j = 0; j < 7; ++j) ob.pose[j] = fb.obj_pose[7 * r + j];
+      ob.score = fb.obj_score[r];
+      ob.n_points = fb.obj_npts[r];
+      out[r] = ob;
+    }
+    reinterpret_cast<int32_t*>(tail.result)[0] = kept;
+  }
 }
 
 }  // namespace
 
 void launch_filter(const FilterBuffers& fb, const DevCam& cam, int min_points,
                    float feature_distance, float min_score, int32_t* n_slots_dev,
-                   int32_t* n_clusters_dev, FrameCounts* counts, hipStream_t s) {
-  hipMemsetAsync(fb.best, 0, (size_t)fb.max_m * sizeof(unsigned long long), s);
-  const int grid = fb.max_objects < FILTER_GRID ? fb.max_objects : FILTER_GRID;
-  hipLaunchKernelGGL(filter_score_kernel, dim3(grid), dim3(FT), 0, s, fb, cam,
-                     feature_distance, n_slots_dev);
-  hipLaunchKernelGGL(filter_count_kernel, dim3(grid), dim3(FT), 0, s, fb, n_slots_dev);
-  int32_t* old_of = fb.obj_clsize + fb.max_objects;  // second half of the scratch array
-  hipLaunchKernelGGL(filter_compact_kernel, dim3(1), dim3(64), 0, s, fb, min_points, min_score,
-                     n_slots_dev, n_clusters_dev, old_of, counts);
-  hipLaunchKernelGGL(filter_fill_kernel, dim3(grid), dim3(64), 0, s, fb, n_slots_dev,
-                     old_of);
+                   int32_t* n_clusters_dev, FrameCounts* counts, const FilterTail& tail, hipStream_t s) {
+  const int grid = fb.max_objects < FILTER_GRID ? (fb.max_objects > 0 ? fb.max_objects : 1) : FILTER_GRID;
+  hipLaunchKernelGGL(filter_kernel, dim3(grid), dim3(FT), 0, s, fb, cam, feature_distance, min_points,
+                     min_score, n_slots_dev, n_clusters_dev, counts, tail);
 }
 
 }  // namespace mh

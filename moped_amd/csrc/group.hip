@@ -23,24 +23,59 @@ __global__ void accept_kernel(const int32_t* __restrict__ idx1, const float* __r
   if (q < Q) out_idx[q] = accepted(idx1[q], d1[q], d2[q], ratio) ? idx1[q] : -1;
 }
 
-// Single workgroup.  (a) ordered compaction of the accepted queries whose winning
+// Merge of the shards' top-2 (exchange 1 of a model-sharded DB): lower index wins a tie
+// on the best distance, second best = min over the other candidates.
+__device__ __forceinline__ void merge_top2(float& b1, float& b2, int32_t& i1, float ob1, float ob2,
+                                           int32_t oi1) {
+  const bool take = (ob1 < b1) || (ob1 == b1 && (unsigned)oi1 < (unsigned)i1);
+  const float lose1 = take ? b1 : ob1;
+  b2 = fminf(lose1, fminf(b2, ob2));
+  b1 = take ? ob1 : b1;
+  i1 = take ? oi1 : i1;
+}
+
+// Single workgroup, first launch of a frame after MATCH.  (0) reset the frame's
+// counters; with a sharded DB, merge the gathered [S][3][Q] top-2 blocks into
+// idx1/d1/d2; (a) ordered compaction of the accepted queries whose winning
 // row belongs to this shard, (b) per-model histogram + exclusive scan, (c) stable
 // placement by model, (d) m_rep: first match with the same image coordinate (the
-// key of FILTER's bestPoints map, FILTER_PROJECTION_CPU.hpp:89).
+// key of FILTER's bestPoints map, FILTER_PROJECTION_CPU.hpp:89); clears FILTER's
+// per-keypoint claim table for the matches of this frame.
 __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
-    const int32_t* __restrict__ idx1, const float* __restrict__ d1, const float* __restrict__ d2,
+    const int32_t* __restrict__ gathered, int n_shards, int32_t* idx1, float* d1, float* d2,
     int Q, float ratio, const float* __restrict__ q_uv, const int32_t* __restrict__ db_model,
     const float* __restrict__ db_xyz, int N, int32_t index_base, int n_models, int max_m,
     int32_t* __restrict__ acc_q, int32_t* __restrict__ acc_model, int32_t* __restrict__ m_q,
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
-    mh_depth* __restrict__ m_depth, FrameCounts* counts) {
+    mh_depth* __restrict__ m_depth, FrameCounts* counts, int32_t* __restrict__ n_slots,
+    unsigned long long* __restrict__ best) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int base_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int m = tid; m <= n_models; m += GROUP_THREADS) hist[m] = 0;
-  if (tid == 0) base_s = 0;
+  if (tid == 0) {
+    base_s = 0;
+    *counts = FrameCounts{};
+    if (n_slots) *n_slots = 0;
+  }
+  if (gathered) {
+    const float* gf = reinterpret_cast<const float*>(gathered);
+    for (int q = tid; q < Q; q += GROUP_THREADS) {
+      float b1 = __builtin_inff(), b2 = __builtin_inff();
+      int32_t i1 = -1;
+      for (int k = 0; k < n_shards; ++k) {
+        const size_t o = (size_t)k * 3 * Q + q;
+        const int32_t i = gathered[o];
+        if (i >= 0) merge_top2(b1, b2, i1, gf[o + Q], gf[o + 2 * (size_t)Q], i);
+      }
+      idx1[q] = i1;
+      d1[q] = b1;
+      d2[q] = b2;
+    }
+    __threadfence_block();
+  }
   __syncthreads();
 
   // (a) ordered compaction, 1024 queries per pass
@@ -125,6 +160,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
         break;
       }
     m_rep[i] = rep;
+    if (best) best[i] = 0ull;
   }
 }
 
@@ -142,31 +178,6 @@ __global__ void rep_kernel(const mh_corr* __restrict__ corr, int M, int32_t* __r
   rep_out[i] = rep;
 }
 
-// Per-model cluster lists -> flat table in (model, emission) order.
-__global__ void cluster_table_kernel(const int32_t* __restrict__ model_off,
-                                     const int32_t* __restrict__ cl_start,
-                                     const int32_t* __restrict__ ncl, int n_models, int max_clusters,
-                                     int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
-                                     int32_t* __restrict__ cl_count, FrameCounts* counts) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int k = 0;
-  for (int m = 0; m < n_models; ++m) {
-    const int b = model_off[m];
-    const int32_t* st = cl_start + b + m;
-    for (int c = 0; c < ncl[m]; ++c) {
-      if (k >= max_clusters) {
-        atomicOr(&counts->error, ERR_CLUSTER_CAP);
-        break;
-      }
-      cl_model[k] = m;
-      cl_begin[k] = b + st[c];
-      cl_count[k] = st[c + 1] - st[c];
-      ++k;
-    }
-  }
-  counts->n_clusters = k;
-}
-
 }  // namespace
 
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
@@ -176,27 +187,20 @@ void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q,
                      out_idx);
 }
 
-void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
-                  const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
+void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d1, float* d2, int Q,
+                  float ratio, const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, FrameCounts* counts,
-                  hipStream_t s) {
-  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, idx1, d1, d2, Q, ratio, q_uv,
-                     db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model, m_q,
-                     m_model, m_corr, m_rep, model_off, q_depth, m_depth, counts);
+                  int32_t* n_slots, unsigned long long* best, hipStream_t s) {
+  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
+                     Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
+                     m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, counts, n_slots, best);
 }
 
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {
   if (M <= 0) return;
   hipLaunchKernelGGL(rep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, corr, M, rep);
-}
-
-void launch_cluster_table(const int32_t* model_off, const int32_t* cl_start, const int32_t* ncl,
-                          int n_models, int max_clusters, int32_t* cl_model, int32_t* cl_begin,
-                          int32_t* cl_count, FrameCounts* counts, hipStream_t s) {
-  hipLaunchKernelGGL(cluster_table_kernel, dim3(1), dim3(64), 0, s, model_off, cl_start, ncl,
-                     n_models, max_clusters, cl_model, cl_begin, cl_count, counts);
 }
 
 }  // namespace mh

@@ -367,15 +367,15 @@ __global__ void combine_splits_kernel(const Top2* __restrict__ partial, int S, i
 __global__ void merge_shards_kernel(const int32_t* __restrict__ idx1_s,
                                     const float* __restrict__ d1_s,
                                     const float* __restrict__ d2_s, int S, int Q,
-                                    int32_t* __restrict__ idx1, float* __restrict__ d1,
-                                    float* __restrict__ d2) {
+                                    size_t shard_stride, int32_t* __restrict__ idx1,
+                                    float* __restrict__ d1, float* __restrict__ d2) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
   Best s = {__builtin_inff(), __builtin_inff(), -1};
   for (int k = 0; k < S; ++k) {
-    const int32_t i = idx1_s[(size_t)k * Q + q];
+    const int32_t i = idx1_s[k * shard_stride + q];
     if (i < 0) continue;
-    merge(s, d1_s[(size_t)k * Q + q], d2_s[(size_t)k * Q + q], i);
+    merge(s, d1_s[k * shard_stride + q], d2_s[k * shard_stride + q], i);
   }
   idx1[q] = s.i1;
   d1[q] = s.b1;
@@ -446,10 +446,10 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
 }
 
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,
-                        int32_t* idx1, float* d1, float* d2, hipStream_t s) {
+                        size_t shard_stride, int32_t* idx1, float* d1, float* d2, hipStream_t s) {
   if (Q <= 0) return;
   hipLaunchKernelGGL(merge_shards_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, idx1_s, d1_s, d2_s,
-                     S, Q, idx1, d1, d2);
+                     S, Q, shard_stride, idx1, d1, d2);
 }
 
 }  // namespace mh

@@ -257,29 +257,57 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
   }
 }
 
-// Frame form: one workgroup per model, points = uv of the model's matches.
+// Frame form: one workgroup per model, points = uv of the model's matches.  The last
+// workgroup to finish lays the per-model cluster lists out as the frame's flat cluster
+// table in (model, emission) order -- the order POSE walks `clusters[model]`
+// (POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:276-280) -- and publishes the counts.
 __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
-    const mh_corr* __restrict__ corr, const int32_t* __restrict__ model_off, float radius,
-    float merge, int min_pts, int max_iter, int32_t* __restrict__ members,
-    int32_t* __restrict__ cl_start, int32_t* __restrict__ ncl, FrameCounts* counts) {
+    const mh_corr* __restrict__ corr, const int32_t* __restrict__ model_off, int n_models, float radius,
+    float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start, int32_t* ncl,
+    int max_clusters, int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
+    int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out, int32_t* __restrict__ snap,
+    FrameCounts* counts, unsigned int* ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MsLds<2>& L = *reinterpret_cast<MsLds<2>*>(smem);
   const int m = blockIdx.x;
-  const int b = model_off[m];
-  int n = model_off[m + 1] - b;
+  const int b = m < n_models ? model_off[m] : 0;
+  int n = m < n_models ? model_off[m + 1] - b : 0;
   if (n <= 0) {
-    if (threadIdx.x == 0) ncl[m] = 0;
-    return;
+    if (threadIdx.x == 0 && m < n_models) ncl[m] = 0;
+  } else {
+    if (n > MS_CAP) {
+      if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
+      n = MS_CAP;
+    }
+    // cl_start needs n+1 slots inside a region of n: the final offset of the last
+    // cluster is implied by the region, so write starts only (see cluster table).
+    meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
+                      radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
+                      nullptr, nullptr);
   }
-  if (n > MS_CAP) {
-    if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
-    n = MS_CAP;
+  if (!last_workgroup(ticket) || threadIdx.x != 0) return;
+  int k = 0;
+  for (int mm = 0; mm < n_models; ++mm) {
+    const int bb = model_off[mm];
+    const int32_t* st = cl_start + bb + mm;
+    const int nc = ncl[mm];
+    for (int c = 0; c < nc; ++c) {
+      if (k >= max_clusters) {
+        atomicOr(&counts->error, ERR_CLUSTER_CAP);
+        break;
+      }
+      cl_model[k] = mm;
+      cl_begin[k] = bb + st[c];
+      cl_count[k] = st[c + 1] - st[c];
+      ++k;
+    }
   }
-  // cl_start needs n+1 slots inside a region of n: the final offset of the last
-  // cluster is implied by the region, so write starts only (see cluster table).
-  meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
-                    radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
-                    nullptr, nullptr);
+  counts->n_clusters = k;
+  *n_clusters_out = k;
+  if (snap) {
+    snap[0] = counts->n_matches;
+    snap[1] = k;
+  }
 }
 
 template <int ND>
@@ -303,16 +331,18 @@ void set_lds_attr(K kernel, size_t bytes) {
 
 void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
-                             int32_t* cl_start, int32_t* ncl, FrameCounts* counts, hipStream_t s) {
-  if (n_models <= 0) return;
+                             int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
+                             int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s) {
   static bool once = false;
   if (!once) {
     set_lds_attr(meanshift_models_kernel, sizeof(MsLds<2>));
     once = true;
   }
-  hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models), dim3(MS_THREADS), sizeof(MsLds<2>), s,
-                     corr, model_off, radius, merge, min_pts, max_iter, members, cl_start, ncl,
-                     counts);
+  // an empty database still gets one workgroup: it publishes "0 clusters"
+  hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
+                     corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
+                     max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket);
 }
 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,

@@ -584,14 +584,14 @@ __device__ void pose_task(
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
     const int32_t* __restrict__ cl_count, const DevCam& cam,
     const mh_pose_params& prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
-    const int32_t* __restrict__ obj_base_dev, int max_objects,
+    const int obj_base, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
-    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
+    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
     FrameCounts* counts) {
   constexpr int PS = PointStride<KIND>::value;
   const int R_ = prm.max_objects_per_cluster;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slot = (obj_base_dev ? *obj_base_dev : 0) + cluster * R_ + replica;
+  const int slot = obj_base + cluster * R_ + replica;
   if (slot >= max_objects) {
     if (tid == 0) atomicOr(&counts->error, ERR_OBJECT_CAP);
     return;
@@ -774,7 +774,8 @@ __device__ void pose_task(
 
 // Grid-stride loop over the (cluster, replica) tasks: the cluster count lives on the
 // device, so the grid is a fixed small number of workgroups instead of one (mostly
-// idle) workgroup per reserved slot.
+// idle) workgroup per reserved slot.  In a frame the last workgroup to finish advances
+// the object-slot count past this launch's slots and counts the valid objects.
 constexpr int POSE_GRID = 96;
 template <int KIND>
 __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
@@ -783,20 +784,40 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
     const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
     mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
-    const int32_t* __restrict__ obj_base_dev, int max_objects,
+    const int32_t* obj_base_dev, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
-    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* __restrict__ obj_valid,
-    FrameCounts* counts) {
+    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
+    FrameCounts* counts, PoseTail tail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
   const int R_ = prm.max_objects_per_cluster;
-  const int n_tasks = *n_clusters_dev * R_;
+  const int n_clusters = *n_clusters_dev;
+  const int n_tasks = n_clusters * R_;
+  const int obj_base = obj_base_dev ? *obj_base_dev : 0;
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     pose_task<KIND>(L, task / R_, task % R_, corr, depth, alpha, members, cl_model, cl_begin, cl_count, cam,
-                    prm, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
+                    prm, seed, seed_dev, obj_base, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
                     obj_cluster, obj_valid, counts);
     __syncthreads();  // LDS is reused by the next task
   }
+  if (!tail.ticket) return;
+  if (!last_workgroup(tail.ticket)) return;
+  int n_slots = obj_base + n_tasks;
+  if (n_slots > max_objects) n_slots = max_objects;
+  if (tail.snap_valid) {
+    int c = 0;
+    for (int i = threadIdx.x; i < n_slots; i += POSE_THREADS) c += obj_valid[i] != 0;
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ int wave_c[POSE_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) wave_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < POSE_THREADS / 64; ++w) tot += wave_c[w];
+      *tail.snap_valid = tot;
+    }
+  }
+  if (threadIdx.x == 0) *tail.n_slots = n_slots;
 }
 
 __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_corr* __restrict__ corr,
@@ -827,7 +848,7 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
-                             hipStream_t s) {
+                             const PoseTail& tail, hipStream_t s) {
   static bool once = false;
   if (!once) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(pose_kernel<KIND>),
@@ -837,7 +858,7 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::min(POSE_GRID, max_clusters * p.max_objects_per_cluster)), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, p, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
-                     obj_err, obj_cluster, obj_valid, counts);
+                     obj_err, obj_cluster, obj_valid, counts, tail);
 }
 
 void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
@@ -846,7 +867,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
                  const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
-                 int32_t* obj_valid, FrameCounts* counts, hipStream_t s) {
+                 int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
@@ -855,7 +876,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
 #define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, p, \
                   seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
-                  obj_valid, counts, s
+                  obj_valid, counts, tail, s
   if (kind == 1)
     launch_pose_kind<1>(POSE_ARGS);
   else if (kind == 2)

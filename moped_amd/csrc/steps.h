@@ -17,28 +17,31 @@ enum : int32_t {
 // ---- group -------------------------------------------------------------------
 // Ratio test + grouping by model in ascending query order (MATCH_ANN_CPU.hpp:165-176).
 // Rows outside [index_base, index_base+N) belong to another shard and are dropped.
-void launch_group(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
-                  const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
+// First launch of a frame's CLUSTER..FILTER2 part: also resets *counts and *n_slots, clears
+// best[0, n_matches) and -- when `gathered` ([n_shards][3][Q] words, exchange 1) is given --
+// first merges the shards' top-2 into idx1/d1/d2.
+void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d1, float* d2, int Q,
+                  float ratio, const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, FrameCounts* counts,
-                  hipStream_t s);
+                  int32_t* n_slots, unsigned long long* best, hipStream_t s);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);
 
 // ---- mean shift ----------------------------------------------------------------
+// CLUSTER of a frame: one workgroup per model; the last one to finish also writes the flat
+// cluster table in (model, emission) order, *n_clusters_out, counts->n_clusters and
+// snap[0..1] = (matches, clusters).  *ticket: zero-initialised device word (last_workgroup).
 void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
-                             int32_t* cl_start, int32_t* ncl, FrameCounts* counts, hipStream_t s);
+                             int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
+                             int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s);
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,
                              int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                              int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s);
-// Per-model cluster lists -> flat cluster table in (model, emission) order.
-void launch_cluster_table(const int32_t* model_off, const int32_t* cl_start, const int32_t* ncl,
-                          int n_models, int max_clusters, int32_t* cl_model, int32_t* cl_begin,
-                          int32_t* cl_count, FrameCounts* counts, hipStream_t s);
-
 // ---- pose ----------------------------------------------------------------------
 struct DevCam {
   float K[4];
@@ -46,6 +49,15 @@ struct DevCam {
   float tc[3];
 };
 DevCam make_devcam(const mh_cam& cam);
+
+// Work of the last workgroup of a POSE launch inside a frame (ticket == nullptr: none):
+// *n_slots = min(max_objects, *obj_base_dev + n_clusters * R); optionally the number of
+// valid objects in [0, *n_slots) -> *snap_valid.
+struct PoseTail {
+  unsigned int* ticket;
+  int32_t* n_slots;
+  int32_t* snap_valid;
+};
 
 // One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
 // n_clusters_dev: device count (grid is launched for max_clusters).
@@ -58,7 +70,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const uint64_t* seed_dev /* optional: XORed into seed, read on the device */,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
-                 FrameCounts* counts, hipStream_t s);
+                 FrameCounts* counts, const PoseTail& tail, hipStream_t s);
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
                          float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
                          hipStream_t s);
@@ -89,11 +101,17 @@ struct FilterBuffers {
   int32_t* cl_count;
   int max_clusters;
 };
+struct FilterTail {
+  unsigned int* ticket;     // zero-initialised device word (last_workgroup); required
+  int32_t* snap_kept;       // optional: number of kept objects
+  unsigned char* result;    // optional: packed result block {int32 n; int32 pad[3]; mh_object[]}
+};
 // n_slots_dev: number of object slots in use; after the call the kept objects are
 // compacted to slots [0, kept) in list order, *n_slots_dev = kept, and the cluster
-// table holds their rewritten clusters.
+// table holds their rewritten clusters.  fb.best[0, n_matches) must be zero on entry and
+// is zero again on exit.
 void launch_filter(const FilterBuffers& fb, const DevCam& cam, int min_points,
                    float feature_distance, float min_score, int32_t* n_slots_dev,
-                   int32_t* n_clusters_dev, FrameCounts* counts, hipStream_t s);
+                   int32_t* n_clusters_dev, FrameCounts* counts, const FilterTail& tail, hipStream_t s);
 
 }  // namespace mh

@@ -39,7 +39,8 @@ class FramePipeline:
     kernel of the next."""
 
     def __init__(self, device: int, db: ShardedDB, depth: int = 1, max_queries: int = 4096,
-                 params: capi.mh_frame_params | None = None, K=None, cam=None, group=None):
+                 params: capi.mh_frame_params | None = None, K=None, cam=None, group=None,
+                 force_exchange: bool = False):
         from . import synth
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -63,8 +64,10 @@ class FramePipeline:
             self.ctxs.append(c)
             self.streams.append(s)
         self.depth = depth
-        self._gather = [None] * depth
-        self._res_gather = [None] * depth
+        self.exchange = force_exchange or self.world > 1
+        self._local = [None] * depth    # [3][Q] send block of exchange 1, per slot
+        self._gather = [None] * depth   # [W][3][Q] receive block
+        self._cam = capi.make_cam(self.K, self.cam)
 
     # ---- single frame in slot i ------------------------------------------------------
     def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
@@ -77,20 +80,20 @@ class FramePipeline:
         Q = q_desc.shape[0]
         if after is not None:
             s.wait_stream(after)
-        if self.world == 1:
+        if not self.exchange:
             c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
             return
-        import torch.distributed as dist
+        if self._local[slot] is None or self._local[slot].numel() != 3 * Q:
+            s.synchronize()   # an earlier frame of this slot may still read the old blocks
+            self._local[slot] = torch.empty(3 * Q, dtype=torch.int32, device=self.dev)
+            self._gather[slot] = torch.empty(self.world * 3 * Q, dtype=torch.int32, device=self.dev)
+        local, gathered = self._local[slot], self._gather[slot]
         with torch.cuda.stream(s):
-            pi, p1, p2 = c.frame_enqueue_match_local(q_desc.data_ptr(), Q)
-            # exchange 1: per-query local (idx1, d1, d2) of every shard -> [3][W][Q]
-            local = torch.empty((3, Q), dtype=torch.int32, device=self.dev)
-            for k, p in enumerate((pi, p1, p2)):
-                local[k].copy_(_wrap_int32(p, Q, self.dev))
-            buf = exchange_top2(local, self.world, self.group)
-            self._gather[slot] = buf   # keep alive until the stream has consumed it
-            c.frame_enqueue_rest(q_uv.data_ptr(), Q, buf[0].data_ptr(), buf[1].data_ptr(),
-                                 buf[2].data_ptr(), self.world, self.K, self.cam, self.params, seed)
+            c.frame_enqueue_match_local(q_desc.data_ptr(), Q, local.data_ptr())
+            # exchange 1: every shard's per-query (idx1, d1, d2) -> [W][3][Q], one fused all-gather
+            _all_gather_into(gathered, local, self.group)
+            c.frame_enqueue_rest(q_uv.data_ptr(), Q, gathered.data_ptr(), self.world, self.K, self.cam,
+                                 self.params, seed, _cam_struct=self._cam)
 
     def fetch(self, slot: int):
         """Objects of the frame in `slot` (model ids global), counts[4]."""
@@ -127,25 +130,31 @@ class FramePipeline:
 def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
     """Exchange 1: one fused all-gather of every rank's per-query
     local top-2.  local = [3][Q] int32 words (idx1, bits of d1, bits of d2);
-    returns [3][W][Q] so that each field is the [W][Q] array mh_match_merge_dev
-    expects.  Device-agnostic (RCCL on GPU, gloo in the CPU tests)."""
-    Q = local.shape[1]
-    gathered = _all_gather_flat(local.contiguous().view(-1), world, group)
-    return gathered.view(world, 3, Q).permute(1, 0, 2).contiguous()
+    returns [W][3][Q], the block mh_frame_enqueue_rest takes.  Device-agnostic
+    (RCCL on GPU, gloo in the CPU tests)."""
+    Q = local.shape[-1] if local.dim() == 2 else local.numel() // 3
+    out = torch.empty(world * 3 * Q, dtype=local.dtype, device=local.device)
+    _all_gather_into(out, local.contiguous().view(-1), group)
+    return out.view(world, 3, Q)
 
 
-def _all_gather_flat(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
+def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
     """all_gather_into_tensor on flat buffers.  RCCL takes device tensors directly;
     the gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the N > 1
     path) is fed through host memory."""
     import torch.distributed as dist
     if mine.is_cuda and dist.get_backend(group) == "gloo":
         host = mine.cpu()
-        out = torch.empty(world * host.numel(), dtype=host.dtype)
-        dist.all_gather_into_tensor(out, host, group=group)
-        return out.to(mine.device)
-    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        tmp = torch.empty(out.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(tmp, host, group=group)
+        out.copy_(tmp)
+        return
     dist.all_gather_into_tensor(out, mine, group=group)
+
+
+def _all_gather_flat(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    _all_gather_into(out, mine, group)
     return out
 
 

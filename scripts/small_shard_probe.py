@@ -23,8 +23,8 @@ def run(label, stage2=1, match_only=False, n=240):
             else:
                 pipe.enqueue(s, q[i % 8], uv[i % 8], seed=i + 1)
     go(16); pipe.synchronize()
-    t0 = time.perf_counter(); go(n); pipe.synchronize(); dt = time.perf_counter() - t0
-    print(f"{label:28s} {n/dt:8.1f} frames/s  ({1e3*dt/n:.3f} ms/frame)")
+    t0 = time.perf_counter(); go(n); th = time.perf_counter() - t0; pipe.synchronize(); dt = time.perf_counter() - t0
+    print(f"{label:28s} {n/dt:8.1f} frames/s  ({1e3*dt/n:.3f} ms/frame; host enqueue {1e3*th/n:.3f} ms/frame)")
     pipe.close()
 run("match stage only", match_only=True)
 run("through POSE (no stage 2)", stage2=0)

@@ -31,8 +31,9 @@ def _worker(rank, world, port, out_dir):
     idx, d1, d2 = orclib.match_2nn(sh.desc, qn)
     idx = np.where(idx >= 0, idx + sh.row_lo, -1).astype(np.int32)   # index_base, as mh_db_upload applies it
     local = torch.from_numpy(np.stack([idx, d1.view(np.int32), d2.view(np.int32)]))
-    g = exchange_top2(local, world).numpy()
-    gi, g1, g2 = orclib.match_merge(g[0], g[1].view(np.float32), g[2].view(np.float32))
+    g = exchange_top2(local, world).numpy()          # [W][3][Q], the layout mh_frame_enqueue_rest takes
+    gi, g1, g2 = orclib.match_merge(np.ascontiguousarray(g[:, 0]), np.ascontiguousarray(g[:, 1]).view(np.float32),
+                                    np.ascontiguousarray(g[:, 2]).view(np.float32))
     # every rank holds the same merged top-2; it keeps the matches of the models it owns
     acc = (gi >= 0) & (g1 / g2 < np.float32(0.8))
     mine = np.array([acc[q] and owner_of_model(int(db.model_of[gi[q]]), db.n_models, world) == rank

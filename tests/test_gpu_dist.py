@@ -80,3 +80,54 @@ def test_two_ranks_one_gpu_equals_single_context(tmp_path):
             e_s = np.sqrt(((orclib.project(s["pose"], xyz, synth.K_DEFAULT, synth.CAM_IDENTITY) - uv) ** 2).sum(1)).mean()
             assert e_m < 1.0 and abs(e_m - e_s) < 0.5
     pipe.close()
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from moped_amd import synth
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    db = synth.make_db(N_MODELS, PPM)
+    dev = torch.device("cuda:0")
+    res = {}
+    for tag, force in (("direct", False), ("rccl", True)):
+        pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world), depth=2,
+                             max_queries=Q, force_exchange=force)
+        frames = [synth.make_frame(db, n_vis=3, seed=s, Q=Q, pts_per_obj=120) for s in range(4)]
+        qd = [torch.from_numpy(f.desc).to(dev) for f in frames]
+        uv = [torch.from_numpy(f.uv).to(dev) for f in frames]
+        # two rounds over both slots: the second reuses the slot's send/receive blocks
+        for i in range(4):
+            if i >= 2:
+                objs, counts = pipe.fetch(i % 2)
+                res[f"{tag}_objs{i - 2}"], res[f"{tag}_counts{i - 2}"] = objs, counts
+            pipe.enqueue(i % 2, qd[i], uv[i], seed=i + 5)
+        for i in (2, 3):
+            if force and i == 3:
+                res[f"{tag}_gathered"] = pipe.gather_objects(i % 2)
+            objs, counts = pipe.fetch(i % 2)
+            res[f"{tag}_objs{i}"], res[f"{tag}_counts{i}"] = objs, counts
+        pipe.close()
+    np.savez(os.path.join(out_dir, "rccl.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_exchange_path_world1_equals_direct(tmp_path):
+    """The N > 1 code path (match_local -> RCCL all-gather on the slot's stream -> rest,
+    exchange 2) with the real `nccl` backend and a single rank: same objects, bit for bit,
+    as the fused single-context frame."""
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_rccl_worker, args=(0 + 1, port, str(tmp_path)), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), "rccl.npz"))
+    for i in range(4):
+        assert np.array_equal(z[f"direct_counts{i}"], z[f"rccl_counts{i}"])
+        a, b = z[f"direct_objs{i}"], z[f"rccl_objs{i}"]
+        assert len(a) == len(b) and len(a) >= 3
+        assert np.array_equal(a["model"], b["model"])
+        assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["score"], b["score"])
+    g = z["rccl_gathered"]
+    assert np.array_equal(g["model"], z["rccl_objs3"]["model"]) and np.array_equal(g["pose"], z["rccl_objs3"]["pose"])
