@@ -35,6 +35,7 @@ struct FrameState {
   size_t result_bytes = 0;
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
   uint64_t* seed_dev = nullptr;  // per-frame seed in device memory: only when the launch list is replayed as a graph
+  int task_grid = 32;   // workgroups for the POSE/FILTER launches: follows the task count of the last fetched frame
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
   // hipGraph replay of the launch list (one graph per half of the frame)
   struct Graph {
@@ -196,6 +197,14 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
   const int nm = ctx->n_models;
+  // Every workgroup of the POSE / FILTER launches needs a free compute unit to start even if
+  // it has no task, and MATCH kernels of other frames keep all of them busy: launch about as
+  // many workgroups as the previous frame had tasks (MH_TASK_GRID pins the number).
+  static const int grid_env = [] {
+    const char* e = getenv("MH_TASK_GRID");
+    return e ? atoi(e) : 0;
+  }();
+  const int grid = grid_env > 0 ? grid_env : fs->task_grid;
   const uint64_t* seed_dev = nullptr;
   if (graphs_enabled()) {   // replayed launch lists take the seed from device memory (set by the caller)
     seed_dev = fs->seed_dev;
@@ -218,24 +227,24 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
               fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
-              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, fs->snap + 2}, s);
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, fs->snap + 2, grid}, s);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     FilterBuffers fb = make_fb(ctx, fs, nm);
     // FILTER (snap[3] = objects kept)
     launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, fs->snap + 3, nullptr}, s);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, fs->snap + 3, nullptr, grid}, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
                 fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr}, s);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, fs->result}, s);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, fs->result, grid}, s);
     stamp(ctx, 7);
   } else {
     for (int i = 5; i <= 7; ++i) stamp(ctx, i);
@@ -377,7 +386,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   const DevCam dc = make_devcam(*cam);
   launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
               fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, nullptr, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
-              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr}, s);
+              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0}, s);
   MH_HIP(ctx, hipGetLastError());
   std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
   std::vector<float> pose((size_t)7 * n_obj), err(n_obj);
@@ -486,7 +495,7 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   FilterBuffers fb = make_fb(ctx, fs, n_models);
   fb.max_objects = n_obj;  // grid size; arrays are at least this large
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
-                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr}, s);
+                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0}, s);
   MH_HIP(ctx, hipGetLastError());
   int32_t kept = 0;
   MH_HIP(ctx, hipMemcpyAsync(&kept, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
@@ -694,6 +703,9 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   const int n = head[0];
   *n_objects = n;
   if (counts) std::memcpy(counts, snap, sizeof snap);
+  // clusters x 4 replicas (POSE), kept objects x 4 (POSE2), + 50 % head room, in steps of 8
+  const int tasks = 4 * std::max(snap[1], snap[3]);
+  fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
   const int take = n < max_objects ? n : max_objects;
   if (take > 0 && objects_host)
     MH_HIP(ctx, hipMemcpy(objects_host, fs->result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));

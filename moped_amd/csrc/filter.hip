@@ -12,6 +12,8 @@
 //      order, build the rewritten cluster table (:150-160)
 //  F4  per kept object: ordered member list
 // One launch: F1 in every workgroup, F2..F4 in the last workgroup to finish.
+#include <cstdlib>
+
 #include "geom.h"
 
 namespace mh {
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
 void launch_filter(const FilterBuffers& fb, const DevCam& cam, int min_points,
                    float feature_distance, float min_score, int32_t* n_slots_dev,
                    int32_t* n_clusters_dev, FrameCounts* counts, const FilterTail& tail, hipStream_t s) {
-  const int grid = fb.max_objects < FILTER_GRID ? (fb.max_objects > 0 ? fb.max_objects : 1) : FILTER_GRID;
+  const int grid_cap = tail.grid > 0 ? (tail.grid < FILTER_GRID ? tail.grid : FILTER_GRID) : FILTER_GRID;
+  const int grid = fb.max_objects < grid_cap ? (fb.max_objects > 0 ? fb.max_objects : 1) : grid_cap;
   hipLaunchKernelGGL(filter_kernel, dim3(grid), dim3(FT), 0, s, fb, cam, feature_distance, min_points,
                      min_score, n_slots_dev, n_clusters_dev, counts, tail);
 }

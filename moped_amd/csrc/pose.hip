@@ -18,6 +18,8 @@
 // Parity with the reference is therefore at final-pose level.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "geom.h"
 
 namespace mh {
@@ -774,7 +776,9 @@ __device__ void pose_task(
 
 // Grid-stride loop over the (cluster, replica) tasks: the cluster count lives on the
 // device, so the grid is a fixed small number of workgroups instead of one (mostly
-// idle) workgroup per reserved slot.  In a frame the last workgroup to finish advances
+// idle) workgroup per reserved slot -- every workgroup of this kernel needs a compute unit
+// to itself to start, idle or not, so the grid follows the expected task count
+// (PoseTail::grid).  In a frame the last workgroup to finish advances
 // the object-slot count past this launch's slots and counts the valid objects.
 constexpr int POSE_GRID = 96;
 template <int KIND>
@@ -855,7 +859,8 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds<KIND>));
     once = true;
   }
-  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::min(POSE_GRID, max_clusters * p.max_objects_per_cluster)), dim3(POSE_THREADS),
+  const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
+  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster))), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, p, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
                      obj_err, obj_cluster, obj_valid, counts, tail);

@@ -57,6 +57,7 @@ struct PoseTail {
   unsigned int* ticket;
   int32_t* n_slots;
   int32_t* snap_valid;
+  int grid;   // workgroups to launch (0 = default cap); more tasks than that are looped over
 };
 
 // One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
@@ -105,6 +106,7 @@ struct FilterTail {
   unsigned int* ticket;     // zero-initialised device word (last_workgroup); required
   int32_t* snap_kept;       // optional: number of kept objects
   unsigned char* result;    // optional: packed result block {int32 n; int32 pad[3]; mh_object[]}
+  int grid;                 // workgroups to launch (0 = default cap)
 };
 // n_slots_dev: number of object slots in use; after the call the kept objects are
 // compacted to slots [0, kept) in list order, *n_slots_dev = kept, and the cluster
