@@ -113,6 +113,15 @@ int mh_normalize_dev(mh_ctx* ctx, float* q_dev, float* qnorm_dev, int Q);
 int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radius,
                  float merge, int min_pts, int max_iter, int32_t* label,
                  int32_t* order, int32_t* n_clusters);
+/* The same for n_problems independent point sets in one call -- the per-model loop of
+ * CLUSTER_MEAN_SHIFT_CPU::process (src/cluster/CLUSTER_MEAN_SHIFT_CPU.hpp:182-199): one
+ * upload, one launch (a workgroup per problem), one download.  pts_host = the problems'
+ * points concatenated, off[n_problems+1] = first point of each problem (off[0] = 0);
+ * label / order (optional) are laid out like pts and hold problem-local indices;
+ * n_clusters[n_problems]. */
+int mh_meanshift_batch(mh_ctx* ctx, const float* pts_host, const int32_t* off, int n_problems,
+                       int dim, float radius, float merge, int min_pts, int max_iter,
+                       int32_t* label, int32_t* order, int32_t* n_clusters);
 
 /* ---- POSE (A8-A13) ---------------------------------------------------------- */
 

@@ -69,7 +69,7 @@ POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inlier
 EXPORTS = [
     "mh_create", "mh_destroy", "mh_last_error", "mh_set_stream", "mh_synchronize", "mh_reserve",
     "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
-    "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_pose_ransac", "mh_pose_ransac_depth",
+    "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_meanshift_batch", "mh_pose_ransac", "mh_pose_ransac_depth",
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
@@ -111,6 +111,7 @@ def load():
     L.mh_match_merge_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.mh_normalize_dev.argtypes = [vp, vp, vp, i32]
     L.mh_meanshift.argtypes = [vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, C.POINTER(C.c_int32)]
+    L.mh_meanshift_batch.argtypes = [vp, vp, vp, i32, i32, f32, f32, i32, i32, vp, vp, vp]
     L.mh_pose_ransac.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_pose_params),
                                  C.c_uint64, vp, C.POINTER(C.c_int32)]
     L.mh_pose_ransac_depth.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_pose_params), i32, f32,
@@ -257,6 +258,37 @@ class Context:
             clusters.append(order[pos:pos + sz].copy())
             pos += sz
         return clusters, label
+
+    def meanshift_batch(self, problems, radius=200.0, merge=20.0, min_pts=7, max_iter=100):
+        """problems: list of [n_p, dim] point arrays (same dim) -> list of (clusters, label) like meanshift()."""
+        dim = 2
+        for p in problems:
+            if np.asarray(p).ndim == 2 and np.asarray(p).shape[0]:
+                dim = np.asarray(p).shape[1]
+        sizes = [int(np.asarray(p).shape[0]) for p in problems]
+        off = np.zeros(len(problems) + 1, np.int32)
+        off[1:] = np.cumsum(sizes)
+        total = int(off[-1])
+        pts = (np.concatenate([np.asarray(p, np.float32).reshape(-1, dim) for p in problems])
+               if total else np.zeros((0, dim), np.float32))
+        pts = np.ascontiguousarray(pts, np.float32)
+        label = np.full(max(total, 1), -1, np.int32)
+        order = np.full(max(total, 1), -1, np.int32)
+        ncl = np.zeros(max(len(problems), 1), np.int32)
+        self._ck(self.L.mh_meanshift_batch(self.h, _ptr(pts), _ptr(off), len(problems), dim, radius, merge,
+                                           min_pts, max_iter, _ptr(label), _ptr(order), _ptr(ncl)),
+                 "mh_meanshift_batch")
+        out = []
+        for i in range(len(problems)):
+            b, e = int(off[i]), int(off[i + 1])
+            lab, ordr = label[b:e], order[b:e]
+            clusters, pos = [], 0
+            for c in range(int(ncl[i])):
+                sz = int((lab == c).sum())
+                clusters.append(ordr[pos:pos + sz].copy())
+                pos += sz
+            out.append((clusters, lab.copy()))
+        return out
 
     # ---- POSE ----
     def pose_ransac(self, corr, cluster_off, K, cam, params: mh_pose_params, seed=1):

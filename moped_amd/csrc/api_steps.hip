@@ -348,6 +348,79 @@ int mh_meanshift(mh_ctx* ctx, const float* pts_host, int n, int dim, float radiu
   return MH_OK;
 }
 
+int mh_meanshift_batch(mh_ctx* ctx, const float* pts_host, const int32_t* off, int n_problems, int dim,
+                       float radius, float merge, int min_pts, int max_iter, int32_t* label,
+                       int32_t* order, int32_t* n_clusters) {
+  if (!ctx || n_problems < 0 || (dim != 2 && dim != 3) || (n_problems > 0 && (!off || !n_clusters))) {
+    if (ctx) ctx->err = "mh_meanshift_batch: bad argument";
+    return MH_ERR_ARG;
+  }
+  if (n_problems == 0) return MH_OK;
+  const int total = off[n_problems];
+  for (int p = 0; p < n_problems; ++p) {
+    n_clusters[p] = 0;
+    const int n = off[p + 1] - off[p];
+    if (n < 0 || off[0] != 0) {
+      ctx->err = "mh_meanshift_batch: offsets must start at 0 and not decrease";
+      return MH_ERR_ARG;
+    }
+    if (n > MS_CAP) {
+      ctx->err = "mh_meanshift_batch: more than 2048 points in one problem";
+      return MH_ERR_CAPACITY;
+    }
+  }
+  if (total == 0) return MH_OK;
+  if (!pts_host || !label) {
+    ctx->err = "mh_meanshift_batch: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  // device layout: pts | off | members | label | cl_start (total + n_problems + 1) | ncl
+  const size_t b_pts = ((size_t)total * dim * sizeof(float) + 15) & ~(size_t)15;
+  const size_t n_off = (size_t)n_problems + 1;
+  const size_t n_start = (size_t)total + n_problems + 1;
+  const size_t ints = n_off + 2 * (size_t)total + n_start + n_problems;
+  int rc = ensure_scratch(ctx, b_pts + ints * sizeof(int32_t) + 64);
+  if (rc) return rc;
+  if ((rc = ensure_pinned(ctx, (2 * (size_t)total + n_start + n_problems) * sizeof(int32_t)))) return rc;
+  unsigned char* base = (unsigned char*)ctx->scratch;
+  float* d_pts = (float*)base;
+  int32_t* d_off = (int32_t*)(base + b_pts);
+  int32_t* d_members = d_off + n_off;
+  int32_t* d_label = d_members + total;
+  int32_t* d_start = d_label + total;
+  int32_t* d_ncl = d_start + n_start;
+  hipStream_t s = ctx->stream;
+  MH_HIP(ctx, hipMemcpyAsync(d_pts, pts_host, (size_t)total * dim * sizeof(float), hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(d_off, off, n_off * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  launch_meanshift_batch(d_pts, d_off, n_problems, dim, radius, merge, min_pts, max_iter, d_members, d_start,
+                         d_ncl, d_label, s);
+  MH_HIP(ctx, hipGetLastError());
+  // members, label, cl_start, ncl are contiguous on the device: one copy back
+  int32_t* h = (int32_t*)ctx->pinned;
+  MH_HIP(ctx, hipMemcpyAsync(h, d_members, (2 * (size_t)total + n_start + n_problems) * sizeof(int32_t),
+                             hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  const int32_t* h_members = h;
+  const int32_t* h_label = h + total;
+  const int32_t* h_start = h_label + total;
+  const int32_t* h_ncl = h_start + n_start;
+  for (int p = 0; p < n_problems; ++p) {
+    const int b = off[p], n = off[p + 1] - b;
+    n_clusters[p] = n > 0 ? h_ncl[p] : 0;
+    for (int i = 0; i < n; ++i) label[b + i] = h_label[b + i];
+    if (order) {
+      for (int i = 0; i < n; ++i) order[b + i] = -1;
+      if (n > 0) {
+        const int kept = h_start[b + p + h_ncl[p]];
+        for (int i = 0; i < kept; ++i) order[b + i] = h_members[b + i];
+      }
+    }
+  }
+  return MH_OK;
+}
+
 static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host, int kind,
                             float alpha, const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
                             const mh_pose_params* prm, uint64_t seed, mh_pose_out* out_host,

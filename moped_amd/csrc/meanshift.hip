@@ -321,6 +321,26 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_single_kernel(
                      label, iters);
 }
 
+// Batch form: workgroup p clusters points [off[p], off[p+1]) of a concatenated array;
+// members / labels are problem-local indices, cl_start of problem p starts at off[p] + p.
+template <int ND>
+__global__ __launch_bounds__(MS_THREADS) void meanshift_batch_kernel(
+    const float* __restrict__ pts, const int32_t* __restrict__ off, float radius, float merge, int min_pts,
+    int max_iter, int32_t* __restrict__ members, int32_t* __restrict__ cl_start, int32_t* __restrict__ ncl,
+    int32_t* __restrict__ label) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MsLds<ND>& L = *reinterpret_cast<MsLds<ND>*>(smem);
+  const int p = blockIdx.x;
+  const int b = off[p];
+  const int n = off[p + 1] - b;
+  if (n <= 0 || n > MS_CAP) {   // the host checks the capacity before launching
+    if (threadIdx.x == 0) ncl[p] = 0;
+    return;
+  }
+  meanshift_body<ND>(L, pts + (size_t)b * ND, ND, n, radius, merge, min_pts, max_iter, members + b, 0,
+                     cl_start + b + p, ncl + p, label + b, nullptr);
+}
+
 template <typename K>
 void set_lds_attr(K kernel, size_t bytes) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -360,6 +380,24 @@ void launch_meanshift_single(const float* pts, int n, int dim, float radius, flo
   else
     hipLaunchKernelGGL(meanshift_single_kernel<2>, dim3(1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
                        pts, n, radius, merge, min_pts, max_iter, members, cl_start, ncl, label, iters);
+}
+
+void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems, int dim, float radius,
+                            float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
+                            int32_t* ncl, int32_t* label, hipStream_t s) {
+  if (n_problems <= 0) return;
+  static bool once = false;
+  if (!once) {
+    set_lds_attr(meanshift_batch_kernel<2>, sizeof(MsLds<2>));
+    set_lds_attr(meanshift_batch_kernel<3>, sizeof(MsLds<3>));
+    once = true;
+  }
+  if (dim == 3)
+    hipLaunchKernelGGL(meanshift_batch_kernel<3>, dim3(n_problems), dim3(MS_THREADS), sizeof(MsLds<3>), s,
+                       pts, off, radius, merge, min_pts, max_iter, members, cl_start, ncl, label);
+  else
+    hipLaunchKernelGGL(meanshift_batch_kernel<2>, dim3(n_problems), dim3(MS_THREADS), sizeof(MsLds<2>), s,
+                       pts, off, radius, merge, min_pts, max_iter, members, cl_start, ncl, label);
 }
 
 }  // namespace mh

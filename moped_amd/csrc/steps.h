@@ -42,6 +42,13 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,
                              int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                              int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s);
+// n_problems independent point sets in one launch: points of problem p are rows
+// [off[p], off[p+1]) of pts; members/label hold problem-local indices at the same rows,
+// cl_start of problem p lives at cl_start + off[p] + p (n_p + 1 entries), ncl[p] = clusters.
+void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems, int dim, float radius,
+                            float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
+                            int32_t* ncl, int32_t* label, hipStream_t s);
+
 // ---- pose ----------------------------------------------------------------------
 struct DevCam {
   float K[4];

@@ -32,31 +32,42 @@ class CLUSTER_MEAN_SHIFT_HIP : public MopedAlg {
   void process(FrameData& frameData) {
     frameData.clusters.resize(models->size());
     mh_ctx* ctx = HipSession::get();
+    // every (model, image) point set of the frame goes to the device in ONE call
+    vector<float> pts;
+    vector<int> matchIdx;
+    vector<int32_t> off(1, 0), owner;
     for (int model = 0; model < (int)frameData.matches.size(); ++model) {
       const vector<FrameData::Match>& mm = frameData.matches[model];
       for (int img = 0; img < (int)frameData.images.size(); ++img) {
-        vector<float> pts;
-        vector<int> matchIdx;
+        const size_t before = matchIdx.size();
         for (int k = 0; k < (int)mm.size(); ++k)
           if (mm[k].imageIdx == img) {
             pts.push_back(mm[k].coord2D[0]);
             pts.push_back(mm[k].coord2D[1]);
             matchIdx.push_back(k);
           }
-        const int n = (int)matchIdx.size();
-        if (n == 0) continue;
-        vector<int32_t> label(n), order(n);
-        int32_t ncl = 0;
-        if (mh_meanshift(ctx, &pts[0], n, 2, Radius, Merge, MinPts, MaxIterations, &label[0], &order[0],
-                         &ncl) != MH_OK) {
-          HipSession::warn("mh_meanshift");
-          continue;
-        }
-        int pos = 0;
-        for (int c = 0; c < ncl; ++c) {
-          frameData.clusters[model].resize(frameData.clusters[model].size() + 1);
-          FrameData::Cluster& cl = frameData.clusters[model].back();
-          while (pos < n && order[pos] >= 0 && label[order[pos]] == c) cl.push_back(matchIdx[order[pos++]]);
+        if (matchIdx.size() == before) continue;
+        off.push_back((int32_t)matchIdx.size());
+        owner.push_back(model);
+      }
+    }
+    const int n_problems = (int)owner.size();
+    if (n_problems > 0) {
+      const int total = off[n_problems];
+      vector<int32_t> label(total), order(total), ncl(n_problems);
+      if (mh_meanshift_batch(ctx, &pts[0], &off[0], n_problems, 2, Radius, Merge, MinPts, MaxIterations,
+                             &label[0], &order[0], &ncl[0]) != MH_OK) {
+        HipSession::warn("mh_meanshift_batch");
+      } else {
+        for (int p = 0; p < n_problems; ++p) {
+          const int b = off[p], n = off[p + 1] - b;
+          int pos = 0;
+          for (int c = 0; c < ncl[p]; ++c) {
+            frameData.clusters[owner[p]].resize(frameData.clusters[owner[p]].size() + 1);
+            FrameData::Cluster& cl = frameData.clusters[owner[p]].back();
+            while (pos < n && order[b + pos] >= 0 && label[b + order[b + pos]] == c)
+              cl.push_back(matchIdx[b + order[b + pos++]]);
+          }
         }
       }
     }

@@ -197,6 +197,25 @@ def test_meanshift_3d_and_iteration_cap(ctx):
         assert [list(a) for a in got] == [list(b) for b in want]
 
 
+def test_meanshift_batch_equals_per_problem_calls(ctx):
+    """mh_meanshift_batch (the per-model loop of CLUSTER_MEAN_SHIFT_CPU::process in one launch):
+    every problem, empty ones included, gets the oracle's clusters in the oracle's order."""
+    rng = np.random.default_rng(2024)
+    problems = [_ms_points(rng, kind, n) for kind, n in
+                (("blobs", 150), ("uniform", 0), ("chain", 90), ("uniform", 5), ("blobs", 400), ("grid", 49),
+                 ("uniform", 0))]
+    got = ctx.meanshift_batch(problems, 200.0, 20.0, 7, 100)
+    assert len(got) == len(problems)
+    for pts, (clusters, label) in zip(problems, got):
+        want = orclib.meanshift(pts, 200.0, 20.0, 7, 100)[0] if len(pts) else []
+        assert [list(a) for a in clusters] == [list(b) for b in want]
+        want_label = np.full(len(pts), -1, np.int32)
+        for c, members in enumerate(want):
+            want_label[members] = c
+        assert np.array_equal(label, want_label)
+    assert ctx.meanshift_batch([], 200.0, 20.0, 7, 100) == []
+
+
 # ---------------------------------------------------------------------------- A12
 def _planted(rng, n, cam=CAM0, noise=0.5, outliers=0.0):
     xyz = ((rng.random((n, 3)) - 0.5) * [0.1, 0.1, 0.2]).astype(np.float32)
