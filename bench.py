@@ -252,6 +252,11 @@ def main():
                     "which is the same number for the vector and the f32-input MFMA pipes; the kernel issues "
                     "v_pk_fma_f32 (VALU) -- no MFMA instruction is used",
             "ms_per_launch": round(t_ms, 4),
+            "measured": "HIP events around 20 back-to-back launches on one stream after the timed region "
+                        "(one kernel on the chip at a time); in the timed region `frames_in_flight` frames "
+                        "share the chip, so rocprof's per-kernel wall durations there are longer by the "
+                        "overlap -- profiles/*_depth1_kernel_stats.csv is the same command with --depth 1",
+            "whole_pipeline_tflops_per_gpu": round(flops * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
             "hbm": {"achieved": round(b_alg / (t_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(b_alg / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                     "algorithmic_bytes": int(b_alg)},

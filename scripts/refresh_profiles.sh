@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Regenerates the judged artifacts under gpurun_out/profiles_new (copy into profiles/ afterwards).
+# usage (GPU box): bash scripts/refresh_profiles.sh
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/profiles_new
+mkdir -p $out
+cd $root
+timeout -k 10 300 python bench.py > $out/r01_bench_20models.json 2>$out/bench20.err || exit 1
+timeout -k 10 400 python bench.py --models 200 --steps 6 --warmup 2 > $out/r01_bench_200models.json 2>$out/bench200.err || exit 1
+timeout -k 10 300 python bench.py --models 50 --depth-kind 1 > $out/r01_bench_50models_depth.json 2>$out/bench50.err || exit 1
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp20 -- python3 $root/bench.py --no-cpu-baseline > $out/r01_bench_20models_under_rocprof.json 2>/tmp/rp20.err || { tail /tmp/rp20.err; exit 1; }
+cp $(find /tmp/rp20 -name "*kernel_stats.csv" | head -1) $out/r01_bench_20models_kernel_stats.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp20d1 -- python3 $root/bench.py --depth 1 --no-cpu-baseline > $out/r01_bench_20models_depth1_under_rocprof.json 2>/tmp/rp20d1.err || { tail /tmp/rp20d1.err; exit 1; }
+cp $(find /tmp/rp20d1 -name "*kernel_stats.csv" | head -1) $out/r01_bench_20models_depth1_kernel_stats.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp200 -- python3 $root/bench.py --models 200 --depth 1 --steps 4 --warmup 1 --no-cpu-baseline > $out/r01_bench_200models_depth1_under_rocprof.json 2>/tmp/rp200.err || { tail /tmp/rp200.err; exit 1; }
+cp $(find /tmp/rp200 -name "*kernel_stats.csv" | head -1) $out/r01_bench_200models_depth1_kernel_stats.csv
+ls -la $out
