@@ -252,6 +252,38 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
  * for exchange 2 (gather of per-rank objects); *bytes = its size. */
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);
 
+/* ---- model files ------------------------------------------------ */
+
+/* Host-side set of models: parsed from `.moped.xml` files the way Moped::addModel(sXML&)
+ * reads them (src/moped.cpp:101-137 over include/sXML.hpp:53-118) or mapped from a packed
+ * `.mopeddb` container.  Rows are flattened in model order like
+ * MATCH_ANN_CPU::Update (src/match/MATCH_ANN_CPU.hpp:76-99).  Only points whose desc_type
+ * equals the set's (default "SIFT") are kept; a point whose descriptor does not have 128
+ * values is an error.  Adding a model whose name exists replaces it (moped.cpp:141-146). */
+typedef struct mh_model_set mh_model_set;
+int mh_models_create(mh_model_set** out, const char* desc_type /* NULL = "SIFT" */);
+void mh_models_destroy(mh_model_set* s);
+const char* mh_models_last_error(const mh_model_set* s);
+int mh_models_add_xml(mh_model_set* s, const char* path);
+int mh_models_add_xml_buffer(mh_model_set* s, const char* data, int64_t bytes);
+int mh_models_count(const mh_model_set* s);
+int64_t mh_models_rows(const mh_model_set* s);
+const char* mh_models_name(const mh_model_set* s, int i);
+/* rows [row_begin, row_begin + n_rows) of model i; bbox = min xyz, max xyz (moped.cpp:107-124) */
+int mh_models_range(const mh_model_set* s, int i, int64_t* row_begin, int64_t* n_rows, float bbox[6]);
+const float* mh_models_desc(const mh_model_set* s);   /* [rows][128], as parsed (not normalised) */
+const float* mh_models_xyz(const mh_model_set* s);    /* [rows][3] */
+/* Packed container: written once, then mapped read-only and uploaded as it lies. */
+int mh_models_save(const mh_model_set* s, const char* path);
+int mh_models_load(mh_model_set** out, const char* path);
+/* Update() for models [first_model, first_model + n_models) of the set (a rank's shard):
+ * uploads their rows, L2-normalises them on the device (A1) and sets index_base to the
+ * first row, so row and model ids stay global. */
+int mh_db_upload_models(mh_ctx* ctx, const mh_model_set* s, int first_model, int n_models);
+/* mh_db_upload with the normalisation done on the device (normalize != 0). */
+int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
+                     const float* xyz_host, int N, int n_models, int32_t index_base, int normalize);
+
 /* ---- timing --------------------------------------------------------------------- */
 
 typedef struct {

@@ -73,6 +73,10 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
+    "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
+    "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
+    "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
+    "mh_db_upload_raw",
 ]
 
 _lib = None
@@ -123,6 +127,27 @@ def load():
     L.mh_frame_default_params.argtypes = [C.POINTER(mh_frame_params)]
     L.mh_frame_default_params.restype = None
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_models_create.argtypes = [C.POINTER(vp), C.c_char_p]
+    L.mh_models_destroy.argtypes = [vp]
+    L.mh_models_destroy.restype = None
+    L.mh_models_last_error.argtypes = [vp]
+    L.mh_models_last_error.restype = C.c_char_p
+    L.mh_models_add_xml.argtypes = [vp, C.c_char_p]
+    L.mh_models_add_xml_buffer.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.mh_models_count.argtypes = [vp]
+    L.mh_models_rows.argtypes = [vp]
+    L.mh_models_rows.restype = C.c_int64
+    L.mh_models_name.argtypes = [vp, i32]
+    L.mh_models_name.restype = C.c_char_p
+    L.mh_models_range.argtypes = [vp, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
+    L.mh_models_desc.argtypes = [vp]
+    L.mh_models_desc.restype = vp
+    L.mh_models_xyz.argtypes = [vp]
+    L.mh_models_xyz.restype = vp
+    L.mh_models_save.argtypes = [vp, C.c_char_p]
+    L.mh_models_load.argtypes = [C.POINTER(vp), C.c_char_p]
+    L.mh_db_upload_models.argtypes = [vp, vp, i32, i32]
+    L.mh_db_upload_raw.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32]
     L.mh_frame_enqueue_match_local.argtypes = [vp, vp, i32, vp]
     L.mh_frame_enqueue_rest.argtypes = [vp, vp, i32, vp, i32, C.POINTER(mh_cam),
                                         C.POINTER(mh_frame_params), C.c_uint64]
@@ -400,3 +425,95 @@ class Context:
 
     def normalize_dev(self, q_ptr, qnorm_ptr, Q):
         self._ck(self.L.mh_normalize_dev(self.h, C.c_void_p(q_ptr), C.c_void_p(qnorm_ptr), Q), "mh_normalize_dev")
+
+
+class ModelSet:
+    """Host-side models (include/moped_hip.h "model files"): parsed `.moped.xml` files or a
+    mapped `.mopeddb` container.  Host code only -- usable without a GPU."""
+
+    def __init__(self, desc_type: str = "SIFT", _handle=None):
+        self.L = load()
+        if _handle is None:
+            h = C.c_void_p()
+            if self.L.mh_models_create(C.byref(h), desc_type.encode()) != 0:
+                raise MhError("mh_models_create")
+            _handle = h
+        self.h = _handle
+
+    @classmethod
+    def load(cls, path: str) -> "ModelSet":
+        L = load()
+        h = C.c_void_p()
+        if L.mh_models_load(C.byref(h), path.encode()) != 0:
+            raise MhError(f"mh_models_load: not a valid .mopeddb file: {path}")
+        return cls(_handle=h)
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MhError(f"{what}: {self.L.mh_models_last_error(self.h).decode('latin-1')}")
+
+    def add_xml(self, path: str):
+        self._ck(self.L.mh_models_add_xml(self.h, path.encode()), "mh_models_add_xml")
+
+    def add_xml_buffer(self, data: bytes):
+        self._ck(self.L.mh_models_add_xml_buffer(self.h, data, len(data)), "mh_models_add_xml_buffer")
+
+    def save(self, path: str):
+        self._ck(self.L.mh_models_save(self.h, path.encode()), "mh_models_save")
+
+    @property
+    def n_models(self) -> int:
+        return int(self.L.mh_models_count(self.h))
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.L.mh_models_rows(self.h))
+
+    def name(self, i: int) -> str:
+        return self.L.mh_models_name(self.h, i).decode("latin-1")
+
+    def model_range(self, i: int):
+        b, n = C.c_int64(0), C.c_int64(0)
+        bbox = np.zeros(6, np.float32)
+        self._ck(self.L.mh_models_range(self.h, i, C.byref(b), C.byref(n), _ptr(bbox)), "mh_models_range")
+        return int(b.value), int(n.value), bbox
+
+    def _view(self, ptr, cols):
+        n = self.n_rows
+        if n == 0 or not ptr:
+            return np.zeros((0, cols), np.float32)
+        buf = (C.c_float * (n * cols)).from_address(ptr)
+        return np.frombuffer(buf, np.float32).reshape(n, cols)
+
+    @property
+    def desc(self) -> np.ndarray:
+        """[rows,128] view (as parsed, not normalised); valid while the set lives and is not modified."""
+        return self._view(self.L.mh_models_desc(self.h), 128)
+
+    @property
+    def xyz(self) -> np.ndarray:
+        return self._view(self.L.mh_models_xyz(self.h), 3)
+
+    @property
+    def model_of(self) -> np.ndarray:
+        out = np.zeros(self.n_rows, np.int32)
+        for i in range(self.n_models):
+            b, n, _ = self.model_range(i)
+            out[b:b + n] = i
+        return out
+
+    def upload(self, ctx: "Context", first_model: int = 0, n_models: int | None = None):
+        """Update() for a block of models: rows normalised on the device, ids stay global."""
+        n_models = self.n_models - first_model if n_models is None else n_models
+        ctx._ck(self.L.mh_db_upload_models(ctx.h, self.h, first_model, n_models), "mh_db_upload_models")
+
+    def close(self):
+        if self.h:
+            self.L.mh_models_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -140,6 +140,11 @@ int mh_synchronize(mh_ctx* ctx) {
 
 int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
                  const float* xyz_host, int N, int n_models, int32_t index_base) {
+  return mh_db_upload_raw(ctx, desc_host, model_of_host, xyz_host, N, n_models, index_base, 0);
+}
+
+int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
+                     const float* xyz_host, int N, int n_models, int32_t index_base, int normalize) {
   if (!ctx || N < 0 || n_models < 0 || (N > 0 && (!desc_host || !model_of_host || !xyz_host))) {
     if (ctx) ctx->err = "mh_db_upload: bad argument";
     return MH_ERR_ARG;
@@ -172,7 +177,10 @@ int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_ho
       MH_HIP(ctx, hipMemsetAsync(ctx->db_desc + (size_t)N * DIM, 0, (Npad - N) * DIM * sizeof(float), ctx->stream));
       MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->db_norm + N), 0x7F800000, Npad - N, ctx->stream));
     }
-    launch_row_norms(ctx->db_desc, ctx->db_norm, N, ctx->stream);
+    if (normalize)
+      launch_normalize(ctx->db_desc, ctx->db_norm, N, ctx->stream);   // A1 on the device, like Update() (:94)
+    else
+      launch_row_norms(ctx->db_desc, ctx->db_norm, N, ctx->stream);
     MH_HIP(ctx, hipGetLastError());
   }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -179,3 +179,38 @@ def frame_depth(db: ModelDB, frame: Frame, seed: int = 0, K=K_DEFAULT, fill_max:
         world[rows] = p
     fill = rng.uniform(0, fill_max, Q) * (rng.random(Q) < 0.3)
     return world.astype(np.float32), fill.astype(np.float32)
+
+
+def write_model_xml(path, name: str, xyz: np.ndarray, desc: np.ndarray, full_export: bool = False,
+                    desc_type: str = "SIFT", seed: int = 0):
+    """A `.moped.xml` model file in the layout moped2/modeling/sfm_export_xml.m writes
+    (:62-131): `%.6f` decimals separated by blanks, one <Point> per model point, with
+    <Observation> children when full_export.  Returns the float32 arrays a loader must
+    produce (the decimals rounded to float32)."""
+    rng = np.random.default_rng([0xA11CE, seed])
+    n = xyz.shape[0]
+    out = [f'<Model name="{name}" version="Bundler v0.3">\n', "  <Openrave>\n", f"    <name>{name}</name>\n",
+           f"    <xml>{name}.kinbody.xml</xml>\n",
+           "    <transf>" + "".join("%.6f " % v for v in np.eye(3).reshape(-1).tolist() + [0, 0, 0]) + "</transf>\n",
+           "  </Openrave>\n", "  <Points>\n"]
+    for i in range(n):
+        out.append('    <Point p3d="%.6f %.6f %.6f" nviews="%d" avg_err="%.6f" color="%d %d %d" desc_type="%s" desc="'
+                   % (xyz[i, 0], xyz[i, 1], xyz[i, 2], 3 + i % 5, 0.25 + 0.01 * (i % 7), i % 256, (3 * i) % 256,
+                      (7 * i) % 256, desc_type))
+        out.append("".join("%.6f " % v for v in desc[i]))
+        out.append('">\n')
+        if full_export:
+            for j in range(2):
+                out.append('      <Observation camera_id="%d" desc_type="SIFT" loc="' % (j + 1))
+                out.append("".join("%.6f " % v for v in rng.uniform(0, 640, 4)))
+                out.append('" desc="')
+                out.append("".join("%.6f " % v for v in np.abs(desc[i] + rng.normal(0, 0.01, desc.shape[1]))))
+                out.append('"/>\n')
+        out.append("</Point>\n")
+    out.append("  </Points>\n")
+    out.append("</Model>\n")
+    text = "".join(out)
+    with open(path, "w") as f:
+        f.write(text)
+    r = lambda a: np.array([[np.float32("%.6f" % v) for v in row] for row in a], np.float32).reshape(a.shape)
+    return r(xyz), r(desc)

@@ -14,6 +14,8 @@ without the reference.
                     default, config.hpp:83) for fixture queries vs seeded DBs
   pose_depth_ref.npz  the two moped3d depth residual models (A14): residual tables and
                     slevmar_dif end states
+  models/*.moped.xml + model_xml_ref.npz   small model files and what the reference's
+                    sXML.hpp + stream operators read out of them (N3)
   pose_ref.npz      project() / lmFuncQuat residual tables and slevmar_dif end
                     states for seeded 5/6-point and inlier-set problems
 """
@@ -163,9 +165,55 @@ def make_pose_depth_golden():
     print("pose_depth_ref.npz:", i, "cases")
 
 
+def make_model_golden():
+    """Small `.moped.xml` fixtures (layout of moped2/modeling/sfm_export_xml.m) and what the
+    reference's own sXML.hpp + stream operators read out of them (oracle/_ref ref_model_xml)."""
+    from moped_amd import synth
+    d = os.path.join(GOLD, "models")
+    os.makedirs(d, exist_ok=True)
+    base, _, _ = synth.load_sift_fixture()
+    rng = np.random.default_rng(4242)
+    out = {}
+    names = []
+    for i, (nm, n, full) in enumerate((("tazo_box", 40, False), ("rice tuscan", 25, True), ("odwalla", 30, False))):
+        xyz = ((rng.random((n, 3)) - 0.5) * [0.1, 0.1, 0.2]).astype(np.float32)
+        desc = base[rng.integers(0, base.shape[0], n)]
+        path = os.path.join(d, f"{nm.replace(' ', '_')}.moped.xml")
+        synth.write_model_xml(path, nm, xyz, desc, full_export=full, seed=i)
+        names.append(os.path.basename(path))
+    # hand-made corner cases: comment before an element, escapes, attribute order, a point of
+    # another descriptor type, a short descriptor, '+' signs / exponents, a self-closed point,
+    # a second <Points> that replaces the first
+    quirks = os.path.join(d, "quirks.moped.xml")
+    d128 = " ".join("%.6f" % (0.001 * k) for k in range(128))
+    with open(quirks, "w") as f:
+        f.write('<Model version="x" name="quirk \\"quoted\\" model">\n'
+                '  <!-- a comment -->\n  <Openrave><name>q</name></Openrave>\n'
+                '  <Points>\n    <Point p3d="9 9 9" desc_type="SIFT" desc="' + d128 + '"/>\n  </Points>\n'
+                '  <Points>\n'
+                '    <Point desc="' + d128 + '" desc_type="SIFT" p3d="+1.5e-2 -2.5E-1 .125"/>\n'
+                '    <Point p3d="0.1 0.2 0.3" desc_type="SURF" desc="1 2 3"></Point>\n'
+                '    <!-- between points -->\n'
+                '    <Point p3d="-0.4 0.5" desc_type="SIFT" desc="' + d128 + '">\n'
+                '      <Observation camera_id="1" desc_type="SIFT" loc="1 2 3 4" desc="' + d128 + '"/>\n'
+                '    </Point>\n'
+                '    <Point p3d="0.7 0.8 0.9 1.0" desc_type="SIFT" desc="0.5 0.25 oops 0.125"/>\n'
+                '  </Points>\n</Model>\n')
+    names.append("quirks.moped.xml")
+    for nm in names:
+        r = orclib.ref_model_xml(os.path.join(d, nm))
+        assert r is not None, nm
+        key = nm.split(".")[0]
+        for k, v in r.items():
+            out[f"{key}_{k}"] = np.asarray(v)
+        print(f"{nm}: name={r['name']!r} points={len(r['xyz'])} bad_len={r['n_bad_len']}")
+    out["files"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "model_xml_ref.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["sift", "match", "pose", "depth"]
+    what = sys.argv[1:] or ["sift", "match", "pose", "depth", "models"]
     if "sift" in what:
         make_sift_fixture()
     if "match" in what:
@@ -174,3 +222,5 @@ if __name__ == "__main__":
         make_pose_golden()
     if "depth" in what:
         make_pose_depth_golden()
+    if "models" in what:
+        make_model_golden()

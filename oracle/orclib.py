@@ -380,3 +380,130 @@ def ref_optimize_camera(pose7, uv, xyz, K, cam, itmax):
     ret = ref().ref_optimize_camera(p, _c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1),
                                     uv.shape[0], _c(K, np.float32), _c(cam, np.float32), itmax, info)
     return ret, p, info
+
+
+# ---------------------------------------------------------------------------- N3: model files
+def parse_model_xml(path, desc_type="SIFT", dim=128):
+    """CPU restatement (test infrastructure, small files) of how the reference reads a
+    `.moped.xml` model: sXML's tokenizer (moped2/libmoped/include/sXML.hpp:53-118: element
+    name, name="value" properties with its backslash rule, nested children, `<!-- -->`
+    before an element) and Moped::addModel(sXML&) (src/moped.cpp:101-137: name = root
+    property, LAST child called Points, every child of it is a point, p3d -> 3 floats,
+    desc -> floats until the first bad token, filed by desc_type, bbox over all points).
+    -> dict(name, xyz [n,3], desc [n,dim], bbox [6], n_bad_len)."""
+    data = open(path, "rb").read().decode("latin-1")
+    pos = 0
+    n = len(data)
+
+    def token():                      # sXML::getToken (:55-61)
+        nonlocal pos
+        b = pos
+        while pos < n and not data[pos].isspace() and data[pos] not in ">=":
+            pos += 1
+        t = data[b:pos]
+        while pos < n and data[pos].isspace():
+            pos += 1
+        return t
+
+    def element():                    # sXML::process (:63-118) -> (name, props, children) or None at a close tag
+        nonlocal pos
+        while data[pos] != "<":
+            pos += 1
+        pos += 1
+        name = token()
+        while name == "!--":          # comment in front of an element (:73-83)
+            end = data.index("-->", pos)
+            pos = end + 2             # the reference leaves the stream ON the final '>' ...
+            while data[pos] != "<":   # ... and then looks for the next '<'
+                pos += 1
+            pos += 1
+            name = token()
+        if name == "" or name[0] == "/" or name[-1] == "/":
+            return (name, {}, [])
+        props = {}
+        while data[pos] != "/":       # properties (:85-103)
+            pname = token()
+            if pname == "" or data[pos] != "=":
+                break
+            while data[pos] != '"':
+                pos += 1
+            pos += 1
+            val = []
+            while data[pos] != '"':
+                if data[pos] == "\\":
+                    pos += 1
+                    if data[pos] == "n":
+                        val.append("\n")
+                        pos += 1
+                val.append(data[pos])
+                pos += 1
+            pos += 1
+            while data[pos].isspace():
+                pos += 1
+            props[pname] = "".join(val)
+        children = []
+        while data[pos] == ">":       # children (:105-113)
+            ch = element()
+            if ch[0][:1] == "/":
+                return (name, props, children)
+            if ch[0] != "":
+                children.append(ch)
+        while data[pos] != ">":
+            pos += 1
+        return (name, props, children)
+
+    def floats(text, cap=None):       # `while (jss >> f)`: blanks between, stop at the first bad token
+        out = []
+        for tok in text.split():
+            try:
+                if tok.lower().lstrip("+-")[:3] in ("nan", "inf"):
+                    break
+                out.append(np.float32(tok))
+            except ValueError:
+                break
+            if cap is not None and len(out) == cap:
+                break
+        return out
+
+    root = element()
+    name = root[1].get("name", "")
+    points = None
+    for ch in root[2]:
+        if ch[0] == "Points":
+            points = ch
+    lo = np.full(3, np.float32(10E10), np.float32)
+    hi = np.full(3, np.float32(-10E10), np.float32)
+    xyz, desc, bad = [], [], 0
+    for pt in (points[2] if points else []):
+        c = np.zeros(3, np.float32)
+        v = floats(pt[1].get("p3d", ""), 3)
+        c[:len(v)] = v
+        lo, hi = np.minimum(lo, c), np.maximum(hi, c)
+        if pt[1].get("desc_type", "") != desc_type:
+            continue
+        d = floats(pt[1].get("desc", ""))
+        bad += len(d) != dim
+        row = np.zeros(dim, np.float32)
+        row[:min(len(d), dim)] = d[:dim]
+        xyz.append(c)
+        desc.append(row)
+    return dict(name=name, xyz=np.array(xyz, np.float32).reshape(-1, 3), desc=np.array(desc, np.float32).reshape(-1, dim),
+                bbox=np.concatenate([lo, hi]).astype(np.float32), n_bad_len=bad)
+
+
+def ref_model_xml(path, desc_type="SIFT", dim=128, cap=1 << 16):
+    """The same through the reference's own sXML.hpp + stream operators (oracle/_ref)."""
+    R = ref()
+    R.ref_model_xml.restype = C.c_int
+    R.ref_model_xml.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                C.c_void_p, C.POINTER(C.c_int)]
+    xyz = np.zeros((cap, 3), np.float32)
+    desc = np.zeros((cap, dim), np.float32)
+    name = C.create_string_buffer(256)
+    bbox = np.zeros(6, np.float32)
+    bad = C.c_int(0)
+    k = R.ref_model_xml(path.encode(), desc_type.encode(), xyz.ctypes.data, desc.ctypes.data, cap, dim, name, 256,
+                        bbox.ctypes.data, C.byref(bad))
+    if k < 0:
+        return None
+    return dict(name=name.value.decode("latin-1"), xyz=xyz[:k].copy(), desc=desc[:k].copy(), bbox=bbox, n_bad_len=bad.value)

@@ -12,6 +12,8 @@
 //     libs.tgz -> levmar-2.4/lm_core.c:427-825)
 //   * include/moped.hpp: Pt<N>, Pose, TransformMatrix, project()
 //     (moped2/libmoped/include/moped.hpp:84-203,330-354)
+//   * include/sXML.hpp + the stream operators of moped.hpp -- model file parsing under
+//     Moped::addModel(sXML&) (moped2/libmoped/src/moped.cpp:101-137)
 //   * libsiftfast 1.1 GetKeypoints -- only to produce real SIFT descriptors
 //     for fixtures, called the way FEAT_SIFT_CPU does
 //     (moped2/libmoped/src/feat/FEAT_SIFT_CPU.hpp:78-112).
@@ -37,8 +39,11 @@
 #include <lm.h>
 #include <siftfast.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
+#include <string>
 #include <vector>
 
 using namespace MopedNS;
@@ -351,6 +356,58 @@ int ref_sift(const unsigned char* gray, int w, int h, float* xy, float* desc, in
   }
   FreeKeypoints(keypts);
   DestroyAllImages();
+  return n;
+}
+
+// ---- model files --------------------------------------------------------------
+// The reference's own XML tokenizer (include/sXML.hpp:53-118, pulled in by moped.hpp:52)
+// and number parsing (istream >> Pt<3>, moped.hpp:125; istream >> Float), walked the way
+// Moped::addModel(sXML&) walks them (src/moped.cpp:101-137).  addModel itself is a member
+// of MopedPimpl in moped.cpp, which includes config.hpp -> OpenCV (unbuildable here), so
+// the ~15-line walk below is OUR restatement of it; everything it calls is the reference's.
+// Writes the points filed under `desc_type`: xyz[cap][3], desc[cap][dim] (first `dim`
+// values of each descriptor), name, bbox = min xyz, max xyz.  Returns the number of such
+// points (may exceed cap), -1 if the file does not parse, -2 if there is no <Points>.
+int ref_model_xml(const char* path, const char* desc_type, float* xyz, float* desc, int cap, int dim,
+                  char* name, int name_cap, float* bbox6, int* n_bad_len) {
+  sXML sxml;
+  std::string fn(path);
+  if (!sxml.fromFile(fn)) return -1;
+  std::string nm = sxml["name"];
+  snprintf(name, name_cap, "%s", nm.c_str());
+  Pt<3> lo, hi;
+  lo.init(10E10, 10E10, 10E10);
+  hi.init(-10E10, -10E10, -10E10);
+  sXML* points = NULL;
+  for (size_t i = 0; i < sxml.children.size(); i++)
+    if (sxml.children[i].name == "Points") points = &sxml.children[i];
+  if (points == NULL) return -2;
+  int n = 0, bad = 0;
+  for (size_t i = 0; i < points->children.size(); i++) {
+    sXML& pt = points->children[i];
+    Pt<3> c;
+    c.init(0, 0, 0);
+    std::istringstream iss(pt["p3d"]);
+    iss >> c;
+    lo.min(c);
+    hi.max(c);
+    std::vector<float> d;
+    std::istringstream jss(pt["desc"]);
+    Float f;
+    while (jss >> f) d.push_back(f);
+    if (pt["desc_type"] != desc_type) continue;
+    if ((int)d.size() != dim) bad++;
+    if (n < cap) {
+      for (int k = 0; k < 3; k++) xyz[3 * n + k] = c[k];
+      for (int k = 0; k < dim; k++) desc[(size_t)n * dim + k] = k < (int)d.size() ? d[k] : 0.f;
+    }
+    n++;
+  }
+  for (int k = 0; k < 3; k++) {
+    bbox6[k] = lo[k];
+    bbox6[3 + k] = hi[k];
+  }
+  if (n_bad_len) *n_bad_len = bad;
   return n;
 }
 
