@@ -232,6 +232,16 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
  * order; NULL switches back to the 2-D residuals).  POSE and POSE2 of the frame then use
  * the MH_DEPTH_* residuals `kind` with `alpha`. */
 int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float alpha);
+/* The same from the depth map itself, as moped3d holds it (moped3d/moped3d.cpp:279-333):
+ * depth_xyzn_dev [height][width][4] floats (camera-frame x, y, z, norm or negative = invalid),
+ * fill_distance_dev [height][width] or NULL (DEPTH_FILL's ".distance" map; NULL = -1 everywhere).
+ * Each accepted match looks its pixel up on the device -- DEPTHMAP_PROP_CPU::process
+ * (moped3d/libmoped/src/depthprop/DEPTHMAP_PROP_CPU.hpp:101-134): truncated coordinates, no
+ * interpolation -- and gets weight getCauchyWeight(fillDistance) with `cauchy_scale` (0.1 in
+ * POSE_..._BACKPROJECTION_DEPTH_CPU.hpp:66, 25 in ..._REPROJECTION_DEPTH_CPU.hpp:66).
+ * NULL image switches depth off. */
+int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev,
+                             int width, int height, int kind, float alpha, float cauchy_scale);
 /* The two halves around exchange 1 when the DB is sharded over ranks.
  *   mh_frame_enqueue_match_local : normalise + this shard's top-2 -> top2_dev, a
  *       caller-owned device block of [3][Q] 32-bit words {idx1 (global row, int32),

@@ -71,7 +71,7 @@ EXPORTS = [
     "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
     "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_meanshift_batch", "mh_pose_ransac", "mh_pose_ransac_depth",
     "mh_frame_set_depth", "mh_project_test",
-    "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_enqueue_match_local",
+    "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
@@ -148,6 +148,7 @@ def load():
     L.mh_models_load.argtypes = [C.POINTER(vp), C.c_char_p]
     L.mh_db_upload_models.argtypes = [vp, vp, i32, i32]
     L.mh_db_upload_raw.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32]
+    L.mh_frame_set_depth_image.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32]
     L.mh_frame_enqueue_match_local.argtypes = [vp, vp, i32, vp]
     L.mh_frame_enqueue_rest.argtypes = [vp, vp, i32, vp, i32, C.POINTER(mh_cam),
                                         C.POINTER(mh_frame_params), C.c_uint64]
@@ -345,6 +346,11 @@ class Context:
     def frame_set_depth(self, q_depth_ptr, kind, alpha=0.5):
         self._ck(self.L.mh_frame_set_depth(self.h, C.c_void_p(q_depth_ptr) if q_depth_ptr else None, kind, alpha),
                  "mh_frame_set_depth")
+
+    def frame_set_depth_image(self, depth_ptr, fill_ptr, width, height, kind, alpha=0.5, cauchy_scale=0.1):
+        self._ck(self.L.mh_frame_set_depth_image(self.h, C.c_void_p(depth_ptr) if depth_ptr else None,
+                                                 C.c_void_p(fill_ptr) if fill_ptr else None, width, height, kind,
+                                                 alpha, cauchy_scale), "mh_frame_set_depth_image")
 
     def project_test(self, pose7, corr, K, cam, thr):
         corr = np.ascontiguousarray(corr, CORR_DTYPE)

@@ -214,7 +214,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   launch_group(gathered, n_shards, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
-               fs->m_depth, fs->counts, fs->n_slots, fs->best, s);
+               fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
@@ -223,7 +223,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                           fs->n_clusters, fs->snap, fs->counts, fs->tickets + 0, s);
   stamp(ctx, 3);
   // POSE (+ slot count, snap[2] = objects after POSE)
-  const float* depth4 = ctx->q_depth ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
+  const float* depth4 = (ctx->q_depth || ctx->depth_img.img) ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
   launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
               fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
@@ -503,7 +503,28 @@ int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float
   if (!ctx) return MH_ERR_ARG;
   if (q_depth_dev && kind != MH_DEPTH_BACKPROJECTION && kind != MH_DEPTH_REPROJECTION) return MH_ERR_ARG;
   ctx->q_depth = q_depth_dev;
+  ctx->depth_img = DepthImage{};
   ctx->depth_kind = q_depth_dev ? kind : MH_DEPTH_NONE;
+  ctx->depth_alpha = alpha;
+  return MH_OK;
+}
+
+int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev, int width,
+                             int height, int kind, float alpha, float cauchy_scale) {
+  if (!ctx) return MH_ERR_ARG;
+  if (depth_xyzn_dev && ((kind != MH_DEPTH_BACKPROJECTION && kind != MH_DEPTH_REPROJECTION) || width <= 0 ||
+                         height <= 0 || !(cauchy_scale > 0.f)))
+    return MH_ERR_ARG;
+  ctx->q_depth = nullptr;
+  ctx->depth_img = DepthImage{};
+  if (depth_xyzn_dev) {
+    ctx->depth_img.img = reinterpret_cast<const float4*>(depth_xyzn_dev);
+    ctx->depth_img.fill = fill_distance_dev;
+    ctx->depth_img.w = width;
+    ctx->depth_img.h = height;
+    ctx->depth_img.cauchy_scale = cauchy_scale;
+  }
+  ctx->depth_kind = depth_xyzn_dev ? kind : MH_DEPTH_NONE;
   ctx->depth_alpha = alpha;
   return MH_OK;
 }
@@ -678,6 +699,7 @@ void key_common(mh_ctx* ctx, std::vector<unsigned char>& k, int Q, const mh_cam*
   key_add(k, ctx->index_base);
   key_add(k, ctx->db_desc);
   key_add(k, ctx->q_depth);
+  key_add(k, ctx->depth_img);
   key_add(k, ctx->depth_kind);
   key_add(k, ctx->depth_alpha);
   key_add(k, ctx->fs);

@@ -63,6 +63,16 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* ticket) {
 }
 #endif
 
+// Depth map of the frame as moped3d holds it (moped3d/moped3d.cpp:279-333): 4 floats per pixel
+// (x, y, z in the camera frame, norm or negative = invalid) and, optionally, the per-pixel
+// fill distance (DEPTH_FILL's ".distance" map).  img == nullptr: none.
+struct DepthImage {
+  const float4* img = nullptr;
+  const float* fill = nullptr;
+  int w = 0, h = 0;
+  float cauchy_scale = 0.1f;
+};
+
 // ---- group ------------------------------------------------------------------
 struct FrameCounts {
   int32_t n_matches;

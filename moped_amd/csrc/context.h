@@ -48,6 +48,7 @@ struct mh_ctx {
   const mh_depth* q_depth = nullptr;
   int depth_kind = 0;
   float depth_alpha = 0.5f;
+  mh::DepthImage depth_img;      // or: the depth map itself, looked up per match on the device (DEPTHMAP_PROP)
 
   bool timing = false;
   hipEvent_t ev[10] = {};

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ acc_q, int32_t* __restrict__ acc_model, int32_t* __restrict__ m_q,
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
-    mh_depth* __restrict__ m_depth, FrameCounts* counts, int32_t* __restrict__ n_slots,
+    mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
     unsigned long long* __restrict__ best) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
@@ -145,7 +145,26 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     c.y = db_xyz[3 * (size_t)li + 1];
     c.z = db_xyz[3 * (size_t)li + 2];
     m_corr[dst] = c;
-    if (q_depth) m_depth[dst] = q_depth[q];
+    if (q_depth) {
+      m_depth[dst] = q_depth[q];
+    } else if (dimg.img) {
+      // DEPTHMAP_PROP_CPU::process (moped3d/libmoped/src/depthprop/DEPTHMAP_PROP_CPU.hpp:101-134):
+      // nearest pixel (truncation), no interpolation; fillDistance -1 without a distance map;
+      // weight = getCauchyWeight(fillDistance) (POSE_..._DEPTH_CPU.hpp:194-197,351).  Pixels
+      // outside the map (the reference reads out of bounds there) are clamped to the border.
+      int ix = (int)c.u, iy = (int)c.v;
+      ix = ix < 0 ? 0 : (ix >= dimg.w ? dimg.w - 1 : ix);
+      iy = iy < 0 ? 0 : (iy >= dimg.h ? dimg.h - 1 : iy);
+      const float4 px = dimg.img[(size_t)iy * dimg.w + ix];
+      const float fd = dimg.fill ? dimg.fill[(size_t)iy * dimg.w + ix] : -1.f;
+      const float factor = __fdiv_rn(fd, dimg.cauchy_scale);
+      mh_depth md;
+      md.wx = px.x;
+      md.wy = px.y;
+      md.wz = px.z;
+      md.w = (float)(1.0 / (double)__fadd_rn(1.f, __fmul_rn(factor, factor)));
+      m_depth[dst] = md;
+    }
   }
   __threadfence_block();
   __syncthreads();
@@ -191,11 +210,11 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   float ratio, const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
-                  int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, FrameCounts* counts,
-                  int32_t* n_slots, unsigned long long* best, hipStream_t s) {
+                  int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
+                  FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s) {
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
-                     m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, counts, n_slots, best);
+                     m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best);
 }
 
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {

@@ -214,3 +214,26 @@ def write_model_xml(path, name: str, xyz: np.ndarray, desc: np.ndarray, full_exp
         f.write(text)
     r = lambda a: np.array([[np.float32("%.6f" % v) for v in row] for row in a], np.float32).reshape(a.shape)
     return r(xyz), r(desc)
+
+
+def depth_image(db: ModelDB, frame: Frame, seed: int = 0, K=K_DEFAULT, fill_max: float = 0.02):
+    """The moped3d depth map of a frame (moped3d/moped3d.cpp:279-333): [480,640,4] float32 =
+    camera-frame (x, y, z, norm) per pixel -- a background surface at 1.5 m, the planted
+    objects' points at the pixels their keypoints truncate to (sigma = 0.0035 z^2 depth noise
+    along the ray), 5 % invalid pixels (norm = -1) -- and the per-pixel fill distance
+    [480,640] (0 on measured pixels, up to fill_max on 30 % "filled" ones)."""
+    rng = np.random.default_rng([0xD1A6, seed])
+    v, u = np.mgrid[0:IMG_H, 0:IMG_W].astype(np.float64)
+    z = 1.5 + 0.05 * np.sin(u / 40.0) * np.cos(v / 55.0)
+    img = np.stack([(u + 0.5 - K[2]) / K[0] * z, (v + 0.5 - K[3]) / K[1] * z, z, np.zeros_like(z)], -1)
+    world, _ = frame_depth(db, frame, seed=seed, K=K, fill_max=fill_max)
+    rows = np.nonzero((frame.src_point >= 0) & ~frame.is_outlier)[0]
+    ix = np.clip(frame.uv[rows, 0].astype(np.int32), 0, IMG_W - 1)
+    iy = np.clip(frame.uv[rows, 1].astype(np.int32), 0, IMG_H - 1)
+    img[iy, ix, :3] = world[rows]
+    img[..., 3] = np.sqrt((img[..., :3] ** 2).sum(-1))
+    invalid = rng.random((IMG_H, IMG_W)) < 0.05
+    invalid[iy, ix] = False
+    img[invalid, 3] = -1.0
+    fill = rng.uniform(0, fill_max, (IMG_H, IMG_W)) * (rng.random((IMG_H, IMG_W)) < 0.3)
+    return np.ascontiguousarray(img, np.float32), np.ascontiguousarray(fill, np.float32)

@@ -210,7 +210,21 @@ def cauchy_weight(fill_distance, scale=0.1):
     """getCauchyWeight (…BACKPROJECTION_DEPTH_CPU.hpp:194-197; scale 0.1 there, 25 in
     …REPROJECTION_DEPTH_CPU.hpp:66)."""
     f = np.asarray(fill_distance, np.float32) / np.float32(scale)
-    return (1.0 / (1 + f * f)).astype(np.float32)
+    # `return 1.0 / (1 + factor*factor)`: float sum, double division, rounded to Float on return
+    return (1.0 / (np.float32(1) + f * f).astype(np.float64)).astype(np.float32)
+
+
+def depthmap_prop(depth_img, fill_img, uv, scale=0.1):
+    """DEPTHMAP_PROP_CPU::process (moped3d/libmoped/src/depthprop/DEPTHMAP_PROP_CPU.hpp:101-134):
+    per keypoint the pixel (int)u, (int)v of the 4-float depth map -> world3D = its x,y,z;
+    fillDistance from the distance map or -1; -> (world [n,3], cauchy weight [n]).  Pixels
+    outside the map are clamped (the reference indexes out of bounds there)."""
+    h, w = depth_img.shape[:2]
+    ix = np.clip(uv[:, 0].astype(np.int32), 0, w - 1)
+    iy = np.clip(uv[:, 1].astype(np.int32), 0, h - 1)
+    world = depth_img[iy, ix, :3].astype(np.float32)
+    fd = fill_img[iy, ix].astype(np.float32) if fill_img is not None else np.full(len(uv), -1, np.float32)
+    return world, cauchy_weight(fd, scale)
 
 
 def residuals_depth(mode, pose7, uv, xyz, world, wgt, K, cam, alpha):

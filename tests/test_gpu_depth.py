@@ -105,3 +105,44 @@ def test_depth_frame_path(ctx):
     pipe.close()
     # the depth objective moves the pose (slightly) away from the pure 2-D optimum
     assert not np.array_equal(res[0]["pose"], res[capi.DEPTH_BACKPROJECTION]["pose"])
+
+
+@pytest.mark.parametrize("kind,scale", [(1, 0.1), (2, 25.0)])
+@pytest.mark.parametrize("with_fill", [True, False])
+def test_frame_from_depth_image_equals_host_side_depthmap_prop(kind, scale, with_fill):
+    """N4 piece: the frame takes the moped3d depth map itself and looks each accepted match up on
+    the device (DEPTHMAP_PROP_CPU.hpp:101-134 + getCauchyWeight); the result is bit-identical to
+    doing that lookup with the oracle on the host and handing per-query attributes over."""
+    import torch
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    db = synth.make_db(5, 1500, seed=3)
+    fr = synth.make_frame(db, n_vis=2, seed=11, Q=1400, pts_per_obj=140)
+    img, fill = synth.depth_image(db, fr, seed=11)
+    if not with_fill:
+        fill = None
+    dev = torch.device("cuda:0")
+    prm = capi.default_frame_params()
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=1400, params=prm)
+    c = pipe.ctxs[0]
+    d_img = torch.from_numpy(img).to(dev)
+    d_fill = torch.from_numpy(fill).to(dev) if fill is not None else None
+    uv = torch.from_numpy(fr.uv).to(dev)
+    c.frame_set_depth_image(d_img.data_ptr(), d_fill.data_ptr() if d_fill is not None else 0, 640, 480, kind, 0.5, scale)
+    pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), uv, seed=9)
+    got, got_counts = pipe.fetch(0)
+    world, wgt = orclib.depthmap_prop(img, fill, fr.uv, scale)
+    qd = torch.from_numpy(capi.pack_depth(world, wgt).view(np.float32).reshape(-1, 4)).to(dev)
+    c.frame_set_depth(qd.data_ptr(), kind, 0.5)
+    pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), uv, seed=9)
+    want, want_counts = pipe.fetch(0)
+    assert np.array_equal(got_counts, want_counts) and len(got) == len(want) >= 2
+    assert np.array_equal(got["model"], want["model"])
+    assert np.array_equal(got["pose"], want["pose"]) and np.array_equal(got["score"], want["score"])
+    assert set(got["model"].tolist()) == set(fr.visible.tolist())
+    if kind == 1 and with_fill:
+        # and the objects are the planted ones (depth residuals see consistent 3-D points)
+        for o in got:
+            j = list(fr.visible).index(o["model"])
+            assert np.linalg.norm(o["pose"][4:] - fr.poses[j][4:]) < 0.01
+    c.frame_set_depth_image(0, 0, 0, 0, 0)      # depth off again
+    pipe.close()
