@@ -14,6 +14,8 @@ without the reference.
                     default, config.hpp:83) for fixture queries vs seeded DBs
   pose_depth_ref.npz  the two moped3d depth residual models (A14): residual tables and
                     slevmar_dif end states
+  sift_ref_frames.npz   two bundled frames (gray) + the reference libsiftfast's keypoints for
+                    them, full precision (N2; `OMP_NUM_THREADS=1 make_golden.py siftref`)
   models/*.moped.xml + model_xml_ref.npz   small model files and what the reference's
                     sXML.hpp + stream operators read out of them (N3)
   pose_ref.npz      project() / lmFuncQuat residual tables and slevmar_dif end
@@ -165,6 +167,31 @@ def make_pose_depth_golden():
     print("pose_depth_ref.npz:", i, "cases")
 
 
+def make_sift_ref_golden():
+    """Two of the bundled frames (gray, uint8) and the reference's own libsiftfast output for them
+    (oracle/_ref ref_sift2, ONE OpenMP thread: with more the list order depends on timing)."""
+    assert os.environ.get("OMP_NUM_THREADS") == "1", "run with OMP_NUM_THREADS=1"
+    from PIL import Image
+    bag = open(BAG, "rb").read()
+    out = {}
+    pos, f = 0, 0
+    while True:
+        pos = bag.find(b"\xff\xd8\xff", pos)
+        if pos < 0:
+            break
+        if f in (0, 3):
+            img = Image.open(io.BytesIO(bag[pos:]))
+            img.load()
+            g = np.ascontiguousarray(np.array(img.convert("L")), dtype=np.uint8)
+            xy, so, d = orclib.ref_sift(g)
+            out[f"gray{f}"], out[f"xy{f}"], out[f"scale_ori{f}"], out[f"desc{f}"] = g, xy, so, d
+            print(f"frame {f}: {len(xy)} keypoints")
+        pos += 3
+        f += 1
+    out["frames"] = np.array([0, 3])
+    np.savez_compressed(os.path.join(GOLD, "sift_ref_frames.npz"), **out)
+
+
 def make_model_golden():
     """Small `.moped.xml` fixtures (layout of moped2/modeling/sfm_export_xml.m) and what the
     reference's own sXML.hpp + stream operators read out of them (oracle/_ref ref_model_xml)."""
@@ -224,3 +251,5 @@ if __name__ == "__main__":
         make_pose_depth_golden()
     if "models" in what:
         make_model_golden()
+    if "siftref" in what:
+        make_sift_ref_golden()

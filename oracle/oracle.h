@@ -156,6 +156,16 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
                    int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
                    int32_t* counts);
 
+/* N2  SIFT extraction as FEAT_SIFT_CPU runs it (feat/FEAT_SIFT_CPU.hpp:78-112 over libsiftfast
+ * 1.1, plain-C arithmetic; see sift_oracle.cpp).  gray = h x w bytes; keypoints in the
+ * reference's list order: xy[i] = (col, row), scale_ori[i] = (scale, orientation) (optional),
+ * desc[i][128].  Returns the keypoint count (only `cap` are written). */
+int orc_sift(const uint8_t* gray, int w, int h, int double_size, float* xy, float* scale_ori,
+             float* desc, int cap);
+/* One pyramid image of that run: kind 0 = Gaussian i, 1 = DoG i of `octave`. */
+int orc_sift_image(const uint8_t* gray, int w, int h, int double_size, int octave, int kind, int i,
+                   float* out, int* rows, int* cols);
+
 #ifdef __cplusplus
 }
 #endif

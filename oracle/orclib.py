@@ -521,3 +521,50 @@ def ref_model_xml(path, desc_type="SIFT", dim=128, cap=1 << 16):
     if k < 0:
         return None
     return dict(name=name.value.decode("latin-1"), xyz=xyz[:k].copy(), desc=desc[:k].copy(), bbox=bbox, n_bad_len=bad.value)
+
+
+# ---------------------------------------------------------------------------- N2: SIFT
+def sift(gray, double_size=True, cap=16384):
+    """orc_sift -> (xy [n,2] = (col,row), scale_ori [n,2], desc [n,128]) in the reference's list order."""
+    g = _c(gray, np.uint8)
+    h, w = g.shape
+    L = lib()
+    L.orc_sift.restype = C.c_int
+    L.orc_sift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    xy = np.zeros((cap, 2), np.float32)
+    so = np.zeros((cap, 2), np.float32)
+    d = np.zeros((cap, 128), np.float32)
+    n = L.orc_sift(g.ctypes.data, w, h, int(double_size), xy.ctypes.data, so.ctypes.data, d.ctypes.data, cap)
+    n = min(n, cap)
+    return xy[:n].copy(), so[:n].copy(), d[:n].copy()
+
+
+def sift_image(gray, octave, kind, i, double_size=True):
+    """One pyramid image of the oracle run (kind 0 Gaussian, 1 DoG)."""
+    g = _c(gray, np.uint8)
+    h, w = g.shape
+    L = lib()
+    L.orc_sift_image.restype = C.c_int
+    L.orc_sift_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    r, c = C.c_int(0), C.c_int(0)
+    n = L.orc_sift_image(g.ctypes.data, w, h, int(double_size), octave, kind, i, None, C.byref(r), C.byref(c))
+    if n == 0:
+        return None
+    out = np.zeros((r.value, c.value), np.float32)
+    L.orc_sift_image(g.ctypes.data, w, h, int(double_size), octave, kind, i, out.ctypes.data, C.byref(r), C.byref(c))
+    return out
+
+
+def ref_sift(gray, cap=16384):
+    """The reference's own libsiftfast build (oracle/_ref), called like FEAT_SIFT_CPU does."""
+    g = _c(gray, np.uint8)
+    h, w = g.shape
+    R = ref()
+    R.ref_sift2.restype = C.c_int
+    R.ref_sift2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    xy = np.zeros((cap, 2), np.float32)
+    so = np.zeros((cap, 2), np.float32)
+    d = np.zeros((cap, 128), np.float32)
+    n = min(R.ref_sift2(g.ctypes.data, w, h, xy.ctypes.data, so.ctypes.data, d.ctypes.data, cap), cap)
+    return xy[:n].copy(), so[:n].copy(), d[:n].copy()

@@ -340,7 +340,12 @@ int ref_optimize_camera_depth(int mode, float pose7[7], const float* uv, const f
 // gray: h x w bytes.  Keypoints in list order as FEAT_SIFT_CPU emits them:
 // xy = (col,row), 128 floats each.  Returns the keypoint count (may exceed
 // max_kp; only max_kp are written).
+int ref_sift2(const unsigned char* gray, int w, int h, float* xy, float* scale_ori, float* desc, int max_kp);
 int ref_sift(const unsigned char* gray, int w, int h, float* xy, float* desc, int max_kp) {
+  return ref_sift2(gray, w, h, xy, NULL, desc, max_kp);
+}
+// the same, also returning (scale, orientation) of every keypoint
+int ref_sift2(const unsigned char* gray, int w, int h, float* xy, float* scale_ori, float* desc, int max_kp) {
   DoubleImSize = 1;  // ScaleOrigin "-1" (config.hpp:69, FEAT_SIFT_CPU.hpp:72-73)
   SFImage image = CreateImage(h, w);
   for (int y = 0; y < h; y++)
@@ -352,6 +357,10 @@ int ref_sift(const unsigned char* gray, int w, int h, float* xy, float* desc, in
     if (n >= max_kp) continue;
     xy[2 * n] = k->col;
     xy[2 * n + 1] = k->row;
+    if (scale_ori) {
+      scale_ori[2 * n] = k->scale;
+      scale_ori[2 * n + 1] = k->ori;
+    }
     memcpy(desc + (size_t)n * 128, k->descrip, 128 * sizeof(float));
   }
   FreeKeypoints(keypts);
