@@ -262,6 +262,22 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
  * for exchange 2 (gather of per-rank objects); *bytes = its size. */
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);
 
+/* ---- FEAT: SIFT extraction ---------------------------------------- */
+
+/* FEAT_SIFT_CPU::process for one image (src/feat/FEAT_SIFT_CPU.hpp:78-112 over libsiftfast 1.1's
+ * GetKeypoints, libs.tgz -> libsiftfast-1.1-src/libsiftfast.cpp:301-361): gray = height x width
+ * bytes; double_size = the ScaleOrigin "-1" setting (config.hpp:69).  Keypoints come out in the
+ * reference's (single-thread) list order: xy = coord2D = (col, row), scale_ori (optional) =
+ * (scale, orientation), desc = 128 floats, unit length.  `cap` = capacity of the outputs; more
+ * keypoints than that -> MH_ERR_CAPACITY (the first `cap` are still written). */
+int mh_sift_extract(mh_ctx* ctx, const uint8_t* gray_host, int width, int height, int double_size,
+                    float* xy_host, float* scale_ori_host, float* desc_host, int cap,
+                    int32_t* n_keypoints);
+/* The same with everything on the device and no host synchronisation: desc_dev [cap][128] and
+ * xy_dev [cap][2] can be handed to mh_frame_enqueue once *n_dev (device int32) has been read. */
+int mh_sift_extract_dev(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
+                        float* desc_dev, float* xy_dev, float* scale_ori_dev, int cap, int32_t* n_dev);
+
 /* ---- model files ------------------------------------------------ */
 
 /* Host-side set of models: parsed from `.moped.xml` files the way Moped::addModel(sXML&)

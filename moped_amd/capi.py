@@ -73,6 +73,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
+    "mh_sift_extract", "mh_sift_extract_dev",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
@@ -127,6 +128,8 @@ def load():
     L.mh_frame_default_params.argtypes = [C.POINTER(mh_frame_params)]
     L.mh_frame_default_params.restype = None
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_sift_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_models_create.argtypes = [C.POINTER(vp), C.c_char_p]
     L.mh_models_destroy.argtypes = [vp]
     L.mh_models_destroy.restype = None
@@ -351,6 +354,24 @@ class Context:
         self._ck(self.L.mh_frame_set_depth_image(self.h, C.c_void_p(depth_ptr) if depth_ptr else None,
                                                  C.c_void_p(fill_ptr) if fill_ptr else None, width, height, kind,
                                                  alpha, cauchy_scale), "mh_frame_set_depth_image")
+
+    # ---- FEAT ----
+    def sift(self, gray, double_size=True, cap=16384):
+        """-> (xy [n,2] = (col,row), scale_ori [n,2], desc [n,128]) in the reference's list order."""
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        xy = np.zeros((cap, 2), np.float32)
+        so = np.zeros((cap, 2), np.float32)
+        d = np.zeros((cap, 128), np.float32)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_sift_extract(self.h, _ptr(g), w, h, int(double_size), _ptr(xy), _ptr(so), _ptr(d), cap,
+                                        C.byref(n)), "mh_sift_extract")
+        return xy[:n.value].copy(), so[:n.value].copy(), d[:n.value].copy()
+
+    def sift_dev(self, gray_ptr, w, h, double_size, desc_ptr, xy_ptr, scale_ori_ptr, cap, n_ptr):
+        self._ck(self.L.mh_sift_extract_dev(self.h, C.c_void_p(gray_ptr), w, h, int(double_size), C.c_void_p(desc_ptr),
+                                            C.c_void_p(xy_ptr), C.c_void_p(scale_ori_ptr) if scale_ori_ptr else None,
+                                            cap, C.c_void_p(n_ptr)), "mh_sift_extract_dev")
 
     def project_test(self, pose7, corr, K, cam, thr):
         corr = np.ascontiguousarray(corr, CORR_DTYPE)

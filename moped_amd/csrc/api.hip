@@ -106,12 +106,14 @@ int mh_create(int device, mh_ctx** out) {
 }
 
 void mh_free_frame_state(mh_ctx* ctx);  // api_steps.hip
+void mh_free_sift_state(mh_ctx* ctx);   // api_sift.hip
 
 void mh_destroy(mh_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   mh_free_frame_state(ctx);
+  mh_free_sift_state(ctx);
   void* ptrs[] = {ctx->db_desc, ctx->db_norm, ctx->db_xyz, ctx->db_model, ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
                   ctx->scratch, ctx->match_pack};

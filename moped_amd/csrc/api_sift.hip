@@ -1,0 +1,142 @@
+// C ABI: SIFT extraction (FEAT_SIFT_CPU's job).
+#include <algorithm>
+#include <vector>
+
+#include "context.h"
+#include "sift.h"
+
+using namespace mh;
+
+struct SiftState {
+  int width = 0, height = 0, double_size = -1, cap = 0;
+  SiftPlan plan;
+  SiftBuffers B = {};
+  uint8_t* gray = nullptr;       // staging for host-pointer calls
+  float *desc = nullptr, *xy = nullptr, *scale_ori = nullptr;
+  int32_t* n_dev = nullptr;
+};
+
+namespace {
+
+void free_sift(SiftState* st) {
+  if (!st) return;
+  void* ptrs[] = {st->B.pyramid, st->B.tmp, st->B.owner, st->B.cand,     st->B.keys, st->B.desc_tmp,
+                  st->B.geo_tmp, st->B.counters, st->gray, st->desc, st->xy,     st->scale_ori, st->n_dev};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete st;
+}
+
+template <typename T>
+int alloc(mh_ctx* ctx, T*& p, size_t n) {
+  MH_HIP(ctx, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+  return MH_OK;
+}
+
+int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
+  SiftState* st = ctx->sift;
+  if (st && st->width == width && st->height == height && st->double_size == double_size && st->cap >= cap)
+    return MH_OK;
+  if (st) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cap = std::max(cap, st->cap);
+    free_sift(st);
+    ctx->sift = nullptr;
+  }
+  st = new SiftState;
+  ctx->sift = st;
+  st->width = width;
+  st->height = height;
+  st->double_size = double_size;
+  st->cap = cap;
+  if (sift_plan(width, height, double_size, &st->plan) == 0) {
+    ctx->err = "mh_sift: image too small (both sides must exceed 12 pixels after scaling)";
+    return MH_ERR_ARG;
+  }
+  size_t owner = 0;
+  for (int o = 0; o < st->plan.n_octaves; ++o) owner += (size_t)st->plan.rows[o] * st->plan.cols[o];
+  int rc = 0;
+  rc |= alloc(ctx, st->B.pyramid, st->plan.floats);
+  rc |= alloc(ctx, st->B.tmp, (size_t)st->plan.rows0 * st->plan.cols0);
+  rc |= alloc(ctx, st->B.owner, owner);
+  st->B.owner_elems = owner;
+  st->B.cand_cap = 4 * cap;
+  st->B.key_cap = cap;
+  rc |= alloc(ctx, st->B.cand, (size_t)st->B.cand_cap);
+  rc |= alloc(ctx, st->B.keys, (size_t)cap);
+  rc |= alloc(ctx, st->B.desc_tmp, (size_t)cap * 128);
+  rc |= alloc(ctx, st->B.geo_tmp, (size_t)cap * 4);
+  rc |= alloc(ctx, st->B.counters, 4);
+  rc |= alloc(ctx, st->gray, (size_t)width * height);
+  rc |= alloc(ctx, st->desc, (size_t)cap * 128);
+  rc |= alloc(ctx, st->xy, (size_t)cap * 2);
+  rc |= alloc(ctx, st->scale_ori, (size_t)cap * 2);
+  rc |= alloc(ctx, st->n_dev, 1);
+  return rc ? MH_ERR_HIP : MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mh_free_sift_state(mh_ctx* ctx) {
+  free_sift(ctx->sift);
+  ctx->sift = nullptr;
+}
+
+int mh_sift_extract_dev(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
+                        float* desc_dev, float* xy_dev, float* scale_ori_dev, int cap, int32_t* n_dev) {
+  if (!ctx || !gray_dev || width <= 0 || height <= 0 || !desc_dev || !xy_dev || cap <= 0 || !n_dev) {
+    if (ctx) ctx->err = "mh_sift_extract_dev: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = ensure_sift(ctx, width, height, double_size ? 1 : 0, cap);
+  if (rc) return rc;
+  SiftState* st = ctx->sift;
+  launch_sift(gray_dev, width, height, double_size ? 1 : 0, st->plan, st->B, cap, desc_dev, xy_dev, scale_ori_dev,
+              n_dev, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
+}
+
+int mh_sift_extract(mh_ctx* ctx, const uint8_t* gray_host, int width, int height, int double_size, float* xy_host,
+                    float* scale_ori_host, float* desc_host, int cap, int32_t* n_keypoints) {
+  if (!ctx || !gray_host || width <= 0 || height <= 0 || !xy_host || !desc_host || cap <= 0 || !n_keypoints) {
+    if (ctx) ctx->err = "mh_sift_extract: bad argument";
+    return MH_ERR_ARG;
+  }
+  *n_keypoints = 0;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = ensure_sift(ctx, width, height, double_size ? 1 : 0, cap);
+  if (rc) return rc;
+  SiftState* st = ctx->sift;
+  hipStream_t s = ctx->stream;
+  MH_HIP(ctx, hipMemcpyAsync(st->gray, gray_host, (size_t)width * height, hipMemcpyHostToDevice, s));
+  launch_sift(st->gray, width, height, double_size ? 1 : 0, st->plan, st->B, st->cap, st->desc, st->xy, st->scale_ori,
+              st->n_dev, s);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t head[4] = {0, 0, 0, 0};
+  int32_t n = 0;
+  MH_HIP(ctx, hipMemcpyAsync(&n, st->n_dev, sizeof n, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(head, st->B.counters, sizeof head, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  const int take = std::min(n, cap);
+  if (take > 0) {
+    MH_HIP(ctx, hipMemcpyAsync(desc_host, st->desc, (size_t)take * 128 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MH_HIP(ctx, hipMemcpyAsync(xy_host, st->xy, (size_t)take * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (scale_ori_host)
+      MH_HIP(ctx, hipMemcpyAsync(scale_ori_host, st->scale_ori, (size_t)take * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    MH_HIP(ctx, hipStreamSynchronize(s));
+  }
+  *n_keypoints = take;
+  if (head[2]) {
+    ctx->err = "mh_sift_extract: more keypoints than the capacity given (" + std::to_string(head[1]) + " found)";
+    return MH_ERR_CAPACITY;
+  }
+  return MH_OK;
+}
+
+}  // extern "C"

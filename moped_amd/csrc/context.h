@@ -43,6 +43,7 @@ struct mh_ctx {
 
   // frame state (group / cluster / pose / filter); defined in frame.h
   struct FrameState* fs = nullptr;
+  struct SiftState* sift = nullptr;   // pyramid + keypoint buffers of the SIFT extractor (api_sift.hip)
 
   // optional depth attributes of the current queries (moped3d residuals)
   const mh_depth* q_depth = nullptr;

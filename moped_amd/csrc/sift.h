@@ -1,0 +1,70 @@
+// SIFT extraction (sift.hip): pyramid layout and launch entry.
+#pragma once
+#include "common.h"
+
+namespace mh {
+
+constexpr int SIFT_MAX_OCTAVES = 8;
+constexpr int SIFT_IMAGES_PER_OCTAVE = 17;  // 6 Gaussian + 5 DoG + 3 gradient + 3 orientation
+
+struct SiftOctave {
+  int rows, cols;
+  float fscale;             // octave pixel -> original image pixel (0.5 for the doubled image, :318)
+  float* gaus[6];
+  float* dog[5];
+  float* grad[3];           // of gaus[1..3]
+  float* ori[3];
+  unsigned int* owner;      // per pixel: generation key of the extremum that owns it (0xFFFFFFFF = free)
+};
+
+struct SiftPyramid {
+  int n_octaves;
+  SiftOctave oct[SIFT_MAX_OCTAVES];
+};
+
+struct SiftCandidate {      // a refined extremum (InterpKeyPoint's result)
+  int octave, index;
+  unsigned int key;         // (index-1) * rows*cols + scan position of the pixel it started from
+  int r, c;                 // final pixel
+  float x0, x1, x2;         // offsets in scale, row, column
+};
+
+struct SiftKey {            // one (extremum, orientation peak)
+  int octave, index;
+  unsigned long long order; // generation order: octave, scale index, scan position, histogram bin
+  float fsize, frow, fcol, ori;
+};
+
+struct SiftPlan {
+  int n_octaves;
+  int rows0, cols0;
+  int rows[SIFT_MAX_OCTAVES], cols[SIFT_MAX_OCTAVES];
+  float fscale[SIFT_MAX_OCTAVES];
+  size_t floats;            // pyramid size
+};
+
+struct SiftBuffers {
+  float* pyramid;           // plan.floats
+  float* tmp;               // rows0 * cols0 (row-blurred image)
+  unsigned int* owner;      // sum of rows*cols over the octaves
+  size_t owner_elems;
+  SiftCandidate* cand;
+  int cand_cap;
+  SiftKey* keys;
+  int key_cap;
+  float* desc_tmp;          // [key_cap][128] in generation order
+  float* geo_tmp;           // [key_cap][4]
+  int32_t* counters;        // [4]: candidates, keys, overflow flag, -
+};
+
+// Octave sizes of GetKeypoints' loop (:344-348).  Returns the number of octaves.
+int sift_plan(int width, int height, int double_size, SiftPlan* plan);
+
+// Everything on stream s.  desc_out [out_cap][128], xy_out [out_cap][2] = (col,row),
+// scale_ori_out (optional) [out_cap][2], *n_out = number of keypoints written, all on the device,
+// in the reference's list order.
+void launch_sift(const uint8_t* gray, int width, int height, int double_size, const SiftPlan& plan,
+                 const SiftBuffers& B, int out_cap, float* desc_out, float* xy_out, float* scale_ori_out,
+                 int32_t* n_out, hipStream_t s);
+
+}  // namespace mh

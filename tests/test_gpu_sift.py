@@ -1,0 +1,78 @@
+"""N2 on the GPU: the HIP SIFT extractor against the oracle (itself bit-identical to the
+reference's libsiftfast build, tests/test_sift_cpu.py).  The kernels do the oracle's operations
+in the oracle's order; what differs is the device's expf / atan2f / sinf / cosf / powf (a few
+ulp), which can flip a keypoint that sits on a threshold.  Tolerances are stated per test."""
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+from moped_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sift_ref_frames.npz"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _agreement(got, want):
+    """Pairs keypoints by (x, y, scale, orientation); returns (#paired, index pairs)."""
+    from scipy.spatial import cKDTree
+    gx, gs, gd = got
+    wx, ws, wd = want
+    t = cKDTree(np.concatenate([wx, ws], 1))
+    dist, j = t.query(np.concatenate([gx, gs], 1))
+    ok = dist < 1e-2
+    return ok, j
+
+
+@pytest.mark.parametrize("f", [int(x) for x in GOLD["frames"]])
+def test_hip_sift_matches_the_reference_keypoints(ctx, f):
+    gray = GOLD[f"gray{f}"]
+    want = (GOLD[f"xy{f}"], GOLD[f"scale_ori{f}"], GOLD[f"desc{f}"])        # the reference's own output
+    got = ctx.sift(gray)
+    n_ref = len(want[0])
+    assert abs(len(got[0]) - n_ref) <= max(2, n_ref // 200)                  # count within 0.5 %
+    ok, j = _agreement(got, want)
+    assert ok.sum() >= 0.995 * n_ref                                         # >= 99.5 % of the keypoints found
+    assert len(set(j[ok].tolist())) == ok.sum()                              # one to one
+    gx, gs, gd = got
+    wx, ws, wd = want
+    assert np.abs(gx[ok] - wx[j[ok]]).max() < 1e-3                           # position: 0.001 px
+    assert np.abs(gs[ok, 0] / ws[j[ok], 0] - 1).max() < 1e-4                 # scale: 1e-4 relative
+    assert np.abs(gs[ok, 1] - ws[j[ok], 1]).max() < 1e-3                     # orientation: 1e-3 rad
+    dd = np.abs(gd[ok] - wd[j[ok]]).max(1)
+    assert np.quantile(dd, 0.99) < 1e-4 and dd.max() < 5e-3                  # descriptors
+    # list order: the paired keypoints come in the same order as the reference's list
+    assert np.array_equal(j[ok], np.sort(j[ok]))
+
+
+def test_hip_sift_other_sizes_and_no_doubling(ctx):
+    rng = np.random.default_rng(3)
+    base = GOLD["gray0"]
+    for gray, dbl in ((base[40:300, 100:420], True), (base[::2, ::2].copy(), True), (base, False),
+                      ((rng.random((97, 131)) * 255).astype(np.uint8), True)):
+        gray = np.ascontiguousarray(gray)
+        want = orclib.sift(gray, double_size=dbl)
+        got = ctx.sift(gray, double_size=dbl)
+        n = len(want[0])
+        assert abs(len(got[0]) - n) <= max(2, n // 100)
+        ok, j = _agreement(got, want)
+        assert ok.sum() >= 0.99 * n
+        assert np.abs(got[2][ok] - want[2][j[ok]]).max() < 5e-3
+
+
+def test_hip_sift_flat_image_and_capacity(ctx):
+    flat = np.full((64, 80), 128, np.uint8)
+    assert len(ctx.sift(flat)[0]) == 0
+    with pytest.raises(capi.MhError, match="capacity"):
+        ctx.sift(GOLD["gray0"], cap=100)
+    tiny = np.zeros((6, 6), np.uint8)
+    with pytest.raises(capi.MhError):
+        ctx.sift(tiny)
