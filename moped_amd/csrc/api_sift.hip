@@ -132,7 +132,7 @@ int mh_sift_extract(mh_ctx* ctx, const uint8_t* gray_host, int width, int height
     MH_HIP(ctx, hipStreamSynchronize(s));
   }
   *n_keypoints = take;
-  if (head[2]) {
+  if (head[2] || n > cap) {
     ctx->err = "mh_sift_extract: more keypoints than the capacity given (" + std::to_string(head[1]) + " found)";
     return MH_ERR_CAPACITY;
   }
