@@ -278,6 +278,18 @@ int mh_sift_extract(mh_ctx* ctx, const uint8_t* gray_host, int width, int height
 int mh_sift_extract_dev(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
                         float* desc_dev, float* xy_dev, float* scale_ori_dev, int cap, int32_t* n_dev);
 
+/* FEAT + the whole frame, image in, objects out, nothing through the host: SIFT of the device image
+ * (as mh_sift_extract_dev) straight into the frame's query buffers, then mh_frame_enqueue's launch
+ * list.  The keypoint count stays on the device: every launch is sized for `max_keypoints` and the
+ * kernels read the count (query blocks beyond it leave at once); more keypoints than that -> the
+ * first max_keypoints in list order are used.  Results: mh_frame_fetch; mh_frame_keypoints = the
+ * keypoint count of the frame last fetched; mh_frame_features_dev = the device buffers
+ * (descriptors already L2-normalised like MATCH_ANN_CPU.hpp:157 leaves them). */
+int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
+                           int max_keypoints, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+int mh_frame_features_dev(mh_ctx* ctx, float** desc_dev, float** uv_dev, int32_t** n_dev);
+int mh_frame_keypoints(mh_ctx* ctx, int32_t* n_keypoints);
+
 /* ---- model files ------------------------------------------------ */
 
 /* Host-side set of models: parsed from `.moped.xml` files the way Moped::addModel(sXML&)

@@ -73,7 +73,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
-    "mh_sift_extract", "mh_sift_extract_dev",
+    "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
@@ -130,6 +130,10 @@ def load():
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
     L.mh_sift_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
+                                         C.c_uint64]
+    L.mh_frame_features_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mh_frame_keypoints.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mh_models_create.argtypes = [C.POINTER(vp), C.c_char_p]
     L.mh_models_destroy.argtypes = [vp]
     L.mh_models_destroy.restype = None
@@ -413,6 +417,23 @@ class Context:
         c = make_cam(K, cam)
         self._ck(self.L.mh_frame_enqueue(self.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q,
                                          C.byref(c), C.byref(params), seed), "mh_frame_enqueue")
+
+    def frame_enqueue_image(self, gray_ptr, w, h, double_size, max_keypoints, K, cam, params: mh_frame_params,
+                            seed=1, _cam_struct=None):
+        """FEAT -> FILTER2 of a device-resident 8-bit image; nothing goes through the host."""
+        c = _cam_struct or make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_image(self.h, C.c_void_p(gray_ptr), w, h, int(double_size), max_keypoints,
+                                               C.byref(c), C.byref(params), seed), "mh_frame_enqueue_image")
+
+    def frame_features_dev(self):
+        d, u, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self.L.mh_frame_features_dev(self.h, C.byref(d), C.byref(u), C.byref(n)), "mh_frame_features_dev")
+        return d.value, u.value, n.value
+
+    def frame_keypoints(self):
+        n = C.c_int32(0)
+        self._ck(self.L.mh_frame_keypoints(self.h, C.byref(n)), "mh_frame_keypoints")
+        return n.value
 
     def frame_enqueue_match_local(self, q_desc_ptr, Q, top2_ptr):
         """top2_ptr: device block of [3][Q] 32-bit words (idx1, d1 bits, d2 bits)."""

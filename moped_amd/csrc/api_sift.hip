@@ -35,6 +35,9 @@ int alloc(mh_ctx* ctx, T*& p, size_t n) {
 
 int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
   SiftState* st = ctx->sift;
+  // internal keypoint room is never below 8192, so that a small output capacity still selects
+  // the FIRST keypoints of the reference's list (which are the last ones generated)
+  cap = std::max(cap, 8192);
   if (st && st->width == width && st->height == height && st->double_size == double_size && st->cap >= cap)
     return MH_OK;
   if (st) {
@@ -76,6 +79,24 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
 }
 
 }  // namespace
+
+namespace mh {
+
+// SIFT of a device image into caller-chosen device buffers, on the context's stream;
+// *n_dev_out = the context's device word holding the keypoint count afterwards.
+int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
+              float* desc_dev, float* xy_dev, int32_t** n_dev_out) {
+  int rc = ensure_sift(ctx, width, height, double_size ? 1 : 0, cap);
+  if (rc) return rc;
+  SiftState* st = ctx->sift;
+  launch_sift(gray_dev, width, height, double_size ? 1 : 0, st->plan, st->B, cap, desc_dev, xy_dev, nullptr,
+              st->n_dev, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
+  *n_dev_out = st->n_dev;
+  return MH_OK;
+}
+
+}  // namespace mh
 
 extern "C" {
 

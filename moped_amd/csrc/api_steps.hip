@@ -725,6 +725,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   }
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
+  ctx->feat_count_dev = nullptr;
   if (graphs_enabled()) set_seed(ctx, seed);
   std::vector<unsigned char> key;
   key_common(ctx, key, Q, cam, prm);
@@ -740,6 +741,45 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   });
 }
 
+int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
+                           int max_keypoints, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || !gray_dev || width <= 0 || height <= 0 || max_keypoints <= 0 || !cam || !prm) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  if (ctx->n_models > 8192) {
+    ctx->err = "more than 8192 models per context";
+    return MH_ERR_CAPACITY;
+  }
+  const int Q = max_keypoints;
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  // FEAT: keypoints straight into the frame's query buffers; their number stays on the device
+  int32_t* n_dev = nullptr;
+  if ((rc = sift_into(ctx, gray_dev, width, height, double_size, Q, ctx->q_desc, ctx->q_uv, &n_dev))) return rc;
+  ctx->feat_count_dev = n_dev;
+  stamp(ctx, 0);
+  launch_normalize(ctx->q_desc, ctx->q_norm, Q, ctx->stream, n_dev);
+  launch_match(ctx->q_desc, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
+               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream, n_dev,
+               ctx->feat_expected);
+  stamp(ctx, 1);
+  return frame_rest(ctx, ctx->q_uv, Q, nullptr, 0, cam, prm, seed);
+}
+
+int mh_frame_features_dev(mh_ctx* ctx, float** desc_dev, float** uv_dev, int32_t** n_dev) {
+  if (!ctx || !ctx->feat_count_dev) return MH_ERR_ARG;
+  if (desc_dev) *desc_dev = ctx->q_desc;
+  if (uv_dev) *uv_dev = ctx->q_uv;
+  if (n_dev) *n_dev = ctx->feat_count_dev;
+  return MH_OK;
+}
+
+int mh_frame_keypoints(mh_ctx* ctx, int32_t* n_keypoints) {
+  if (!ctx || !n_keypoints || ctx->feat_last < 0) return MH_ERR_ARG;
+  *n_keypoints = ctx->feat_last;
+  return MH_OK;
+}
+
 int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t* top2_dev) {
   if (!ctx || Q <= 0 || !q_desc_dev || !top2_dev) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
@@ -747,6 +787,7 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   float* d1 = reinterpret_cast<float*>(top2_dev + Q);
+  ctx->feat_count_dev = nullptr;
   std::vector<unsigned char> key;
   key_common(ctx, key, Q, nullptr, nullptr);
   key_add(key, q_desc_dev);
@@ -794,7 +835,11 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   FrameCounts fc;
   MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(&fc, fs->counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t n_feat = -1;
+  if (ctx->feat_count_dev)
+    MH_HIP(ctx, hipMemcpyAsync(&n_feat, ctx->feat_count_dev, sizeof n_feat, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_feat >= 0) ctx->feat_expected = ctx->feat_last = n_feat;
   const int n = head[0];
   *n_objects = n;
   if (counts) std::memcpy(counts, snap, sizeof snap);

@@ -21,7 +21,8 @@ struct Top2 {
 };
 
 // A1: normalise rows in place + norm term of the normalised rows.
-void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s);
+// n_dev (optional): device-side row count, rows [min(n, *n_dev), n) are left alone.
+void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s, const int32_t* n_dev = nullptr);
 // dot(d,d) chain for every DB row.
 void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s);
 // Scratch (in Top2 units) the match kernel needs for Q queries.
@@ -31,7 +32,9 @@ size_t match_scratch_elems(int Q, int N);
 size_t match_pack_floats(int Q);
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
                   int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
-                  float* d2, hipStream_t s);
+                  float* d2, hipStream_t s, const int32_t* q_count = nullptr, int q_expected = 0);
+// q_count (optional): device-side query count; queries [min(Q, *q_count), Q) get "no neighbour"
+// (idx -1) without being searched.  q_expected: host estimate of it (sizes the DB splits).
 // shard k's arrays start k * shard_stride elements after the given pointers
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,
                         size_t shard_stride, int32_t* idx1, float* d1, float* d2, hipStream_t s);

@@ -44,6 +44,9 @@ struct mh_ctx {
   // frame state (group / cluster / pose / filter); defined in frame.h
   struct FrameState* fs = nullptr;
   struct SiftState* sift = nullptr;   // pyramid + keypoint buffers of the SIFT extractor (api_sift.hip)
+  int32_t* feat_count_dev = nullptr;  // frame enqueued from an image: device word with its keypoint count
+  int feat_expected = 0;              // keypoints of the last fetched image frame (sizes the next MATCH launch)
+  int feat_last = -1;
 
   // optional depth attributes of the current queries (moped3d residuals)
   const mh_depth* q_depth = nullptr;
@@ -72,5 +75,7 @@ int ensure_frame_buffers(mh_ctx* ctx, int Q);
 int ensure_scratch(mh_ctx* ctx, size_t bytes);
 int ensure_pinned(mh_ctx* ctx, size_t bytes);
 int ensure_match_scratch(mh_ctx* ctx, int Q);
+int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
+              float* desc_dev, float* xy_dev, int32_t** n_dev_out);
 
 }  // namespace mh

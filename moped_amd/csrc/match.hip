@@ -19,6 +19,7 @@
 // through L2/HBM only Q/128 times.  Per-lane running top-2 per query, one
 // wavefront min-reduce at the end of the block's database split.
 #include <cstdlib>
+#include <algorithm>
 
 #include "common.h"
 
@@ -48,11 +49,14 @@ constexpr int NORM_STRIDE = DIM + 1;
 
 template <bool NORMALIZE>
 __global__ __launch_bounds__(NORM_ROWS) void normalize_kernel(float* __restrict__ desc,
-                                                             float* __restrict__ norm_out, int n) {
+                                                             float* __restrict__ norm_out, int n,
+                                                             const int32_t* __restrict__ n_dev) {
   __shared__ float tile[NORM_ROWS * NORM_STRIDE];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * NORM_ROWS;
+  if (n_dev) n = min(n, *n_dev);   // row count known only on the device (features extracted there)
   const int rows = min(NORM_ROWS, n - (int)row0);
+  if (rows <= 0) return;
   const float* src = desc + row0 * DIM;
   for (int i = 0; i < DIM; ++i) {
     int e = i * NORM_ROWS + t;  // element of the block's [rows x 128] slab
@@ -110,10 +114,12 @@ __device__ __forceinline__ void merge(Best& a, float ob1, float ob2, int oi1) {
 // wavefront fetches "coordinate k of its 8 queries" as 8 consecutive dwords and four
 // coordinates with two s_load_dwordx16.  Even-aligned SGPR pairs = query pairs.
 __global__ void pack_queries_kernel(const float* __restrict__ qn, const float* __restrict__ qnorm,
-                                    int Q, float* __restrict__ P, float* __restrict__ Pnorm) {
+                                    int Q, const int32_t* __restrict__ q_count, float* __restrict__ P,
+                                    float* __restrict__ Pnorm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one element of P
   const int G = (Q + TQ - 1) / TQ;
   if (i >= G * DIM * TQ) return;
+  if (q_count) Q = min(Q, *q_count);
   const int t = i & (TQ - 1), k = (i >> 3) & (DIM - 1), g = i >> 10;
   const int q = g * TQ + t;
   P[i] = (q < Q) ? qn[(size_t)q * DIM + k] : 0.f;
@@ -199,7 +205,8 @@ __device__ __forceinline__ void chunk_pipe(const float* qp, unsigned la, v16f& q
 __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
     const float* __restrict__ P, const float* __restrict__ Pnorm, int Q,
     const float* __restrict__ db, const float* __restrict__ dnorm, int N,
-    int tiles_per_split, int n_splits, int32_t index_base, Top2* __restrict__ partial) {
+    int tiles_per_split, int n_splits, int32_t index_base, Top2* __restrict__ partial,
+    const int32_t* __restrict__ q_count) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 tiles
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -222,7 +229,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
       qblock = L % nqb;
     }
   }
-  const int n_groups = (Q + TQ - 1) / TQ;
+  // Q = capacity (stride of `partial`); with q_count the live queries are [0, min(Q, *q_count))
+  // and the query blocks beyond them leave at once
+  const int Qe = q_count ? min(Q, *q_count) : Q;
+  const int n_groups = (Qe + TQ - 1) / TQ;
+  if (qblock * NWAVES >= n_groups) return;                           // uniform over the workgroup
   const int g_raw = qblock * NWAVES + wave;                          // wave-uniform
   const bool live = g_raw < n_groups;
   const int g = live ? g_raw : n_groups - 1;                         // surplus waves redo the last group
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
       if (oi1 >= 0) merge(s, ob1, ob2, oi1);
     }
     const int qi = q0 + t;
-    if (live && lane == 0 && qi < Q) {
+    if (live && lane == 0 && qi < Qe) {
       Top2 o;
       o.d1 = s.b1;
       o.d2 = s.b2;
@@ -348,11 +359,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
 
 // Combine the splits of one shard: one thread per query.
 __global__ void combine_splits_kernel(const Top2* __restrict__ partial, int S, int Q,
-                                      int32_t* __restrict__ idx1, float* __restrict__ d1,
-                                      float* __restrict__ d2) {
+                                      const int32_t* __restrict__ q_count, int32_t* __restrict__ idx1,
+                                      float* __restrict__ d1, float* __restrict__ d2) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
   Best s = {__builtin_inff(), __builtin_inff(), -1};
+  if (q_count && q >= *q_count) S = 0;   // no such query in this frame: "no neighbour"
   for (int k = 0; k < S; ++k) {
     const Top2 p = partial[(size_t)k * Q + q];
     if (p.i1 < 0) continue;
@@ -399,35 +411,45 @@ int splits_for(int Q, int N) {
 
 }  // namespace
 
-void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s) {
+void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s, const int32_t* n_dev) {
   if (n <= 0) return;
   const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
-  hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks), dim3(NORM_ROWS), 0, s, desc, norm_out, n);
+  hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks), dim3(NORM_ROWS), 0, s, desc, norm_out, n, n_dev);
 }
 
 void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s) {
   if (n <= 0) return;
   const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
   hipLaunchKernelGGL(normalize_kernel<false>, dim3(blocks), dim3(NORM_ROWS), 0, s,
-                     const_cast<float*>(desc), norm_out, n);
+                     const_cast<float*>(desc), norm_out, n, (const int32_t*)nullptr);
 }
 
-size_t match_scratch_elems(int Q, int N) { return (size_t)splits_for(Q, N) * (size_t)(Q > 0 ? Q : 1); }
+// (the split count can follow a smaller expected query count: size for the largest)
+static int expected_queries(int Q, int q_expected) {
+  const int lo = std::max(QB, Q / 8);   // bounds the split count (and the scratch) at 8x the full-Q one
+  if (q_expected <= 0 || q_expected > Q) return Q;
+  return std::min(Q, std::max(q_expected, lo));
+}
+size_t match_scratch_elems(int Q, int N) {
+  return (size_t)splits_for(expected_queries(Q, 1), N) * (size_t)(Q > 0 ? Q : 1);
+}
 
 size_t match_pack_floats(int Q) { return (size_t)((Q + TQ - 1) / TQ) * TQ * (DIM + 1); }
 
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
                   int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
-                  float* d2, hipStream_t s) {
+                  float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
   if (Q <= 0) return;
-  const int S = (N > 0) ? splits_for(Q, N) : 0;
+  // the split count follows the number of queries expected (device-side counts: the caller's
+  // estimate), the grid covers the capacity
+  const int S = (N > 0) ? splits_for(expected_queries(Q, q_expected), N) : 0;
   if (S > 0) {
     const int n_groups = (Q + TQ - 1) / TQ;
     float* P = pack;
     float* Pnorm = pack + (size_t)n_groups * TQ * DIM;
     const int pack_elems = n_groups * TQ * DIM;
     hipLaunchKernelGGL(pack_queries_kernel, dim3((pack_elems + 255) / 256), dim3(256), 0, s, qn, qnorm,
-                       Q, P, Pnorm);
+                       Q, q_count, P, Pnorm);
     const int qgroups = (Q + QB - 1) / QB;
     const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
     const int tiles_per_split = (n_tiles + S - 1) / S;
@@ -439,10 +461,10 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
       attr_set = true;
     }
     hipLaunchKernelGGL(match_kernel, dim3(qgroups * S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
-                       db, dnorm, N, tiles_per_split, S, index_base, scratch);
+                       db, dnorm, N, tiles_per_split, S, index_base, scratch, q_count);
   }
   hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, S, Q,
-                     idx1, d1, d2);
+                     q_count, idx1, d1, d2);
 }
 
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,

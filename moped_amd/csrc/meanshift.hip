@@ -10,14 +10,16 @@
 //
 //  (1) one thread per canopy, inner loop over the others in list order
 //      (:102-120), no fused multiply-add;
-//  (2) one wavefront walks the list; for canopy i all earlier canopies are
-//      tested in parallel (64 per pass).  Every write of step i stores the
-//      value i, so the only order dependence inside a step is whether an
-//      earlier canopy j' (whose pointer is j) has already redirected j before
-//      j reads its own pointer.  That predicate ("ov") is resolved exactly by a
-//      short relaxation over the pointer chains inside the step (:122-132);
-//  (3) one lane folds the marked canopies in list order (:134-148) -- the
-//      weighted-mean updates of a target are sequential by definition.
+//  (2) the closeness tests (canopy i against every earlier canopy) are independent:
+//      all wavefronts compute them as bit rows, 64 canopies at a time.  One wavefront
+//      then walks the list over those bits.  Every write of step i stores the value
+//      i, so the only order dependence inside a step is whether an earlier canopy j'
+//      (whose pointer is j) has already redirected j before j reads its own pointer.
+//      That predicate ("ov") only matters when j's old target is not itself written in
+//      the step; in that case it is resolved exactly by a short relaxation over the
+//      pointer chains inside the step (:122-132);
+//  (3) the folds (:134-148) -- sequential weighted-mean updates per target -- run one
+//      thread per target, in rounds over the depth of the merge forest.
 //
 // One workgroup per point set (per model); all state in LDS; <= MS_CAP points.
 #include "steps.h"
@@ -26,24 +28,200 @@ namespace mh {
 
 namespace {
 
-constexpr int MS_THREADS = 256;
+#ifdef MS_PROF   // phase timing build (make EXTRA=-DMS_PROF): cycles of thread 0 per phase, summed over calls
+__device__ unsigned long long g_ms_prof[8];
+#define MS_T(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); g_ms_prof[k] += now_ - t_prof; t_prof = now_; } } while (0)
+#else
+#define MS_T(k) do { } while (0)
+#endif
 
+constexpr int MS_THREADS = 1024;   // one workgroup per point set owns a CU (LDS): use its 16 wavefronts
+constexpr int MS_WAVES = MS_THREADS / 64;
+constexpr int MS_ROWS = 64;            // outer canopies per block of the merge-marking phase
+constexpr int MS_WORDS = MS_CAP / 64;  // 64-bit words of one row of the closeness matrix
+
+// All per-canopy state is kept by LIST POSITION (canopiesRemaining order) and compacted in
+// place when canopies are erased, so the inner loops read consecutive, wave-uniform addresses.
 template <int ND>
 struct MsLds {
-  float c[ND][MS_CAP];    // canopy centre
+  float C[ND][MS_CAP];    // canopy centre
   float a[ND][MS_CAP];    // touchPtsAggregate
-  int size[MS_CAP];       // boundPointsSize
-  int merges[MS_CAP];     // canopy this one merges into (self = none)
-  int order[MS_CAP];      // canopiesRemaining, list order
-  int order2[MS_CAP];     // compaction target
-  int head[MS_CAP];       // boundPoints as a linked list over point ids
+  int S[MS_CAP];          // boundPointsSize
+  int ID[MS_CAP];         // canopy id (= its first point): index of head/tail
+  int mp[MS_CAP];         // merges: position this one merges into (self = none)
+  int head[MS_CAP];       // boundPoints as a linked list over point ids, by canopy id
   int tail[MS_CAP];
-  int next[MS_CAP];
-  int flag[MS_CAP];       // per-step stamps for the ov relaxation
+  int next[MS_CAP];       // by point
+  int flag[MS_CAP];       // per-step stamps
+  int st[MS_CAP];         // ov relaxation state of the members of the current step (0 outside it)
+  int pending[MS_CAP];    // fold phase: 1 = target with sources not folded yet, 2 = folded this round
+  int tlist[MS_CAP];      // fold phase: the targets
+  unsigned long long rowbits[MS_ROWS][MS_WORDS];  // closeness of the block's outer canopies to the earlier ones
+  unsigned long long tbw[MS_WORDS];   // positions that have been merge targets in this iteration (earlier blocks)
+  unsigned long long neblock[2];      // rows of the current block that have members (by block parity)
+  unsigned long long slowblock[2];    // rows of the current block that need the list walk
   int nrem;
   int merged_any;
-  int stamp;
+  int again;
+  int ntargets;
 };
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// One wavefront folds every source of target position t into it, in list order (:136-143):
+// centre = (centre * size + c.centre * c.size) / (size + c.size), splice c's points after t's.
+// The sources' data are fetched 64 at a time; the running centre is wave-uniform arithmetic
+// in the reference's operation order; the splices of one batch are independent of each other.
+template <int ND>
+__device__ __forceinline__ void fold_target(MsLds<ND>& L, int t, int lane) {
+  float tC[ND];
+#pragma unroll
+  for (int x = 0; x < ND; ++x) tC[x] = L.C[x][t];
+  int tsz = L.S[t];  // == boundPoints.size() of the target
+  const int idt = L.ID[t];
+  int carry_tail = L.tail[idt];
+  const int npass = (t + 63) >> 6;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int pj = ps * 64 + lane;
+    const bool src = pj < t && L.mp[pj] == t;
+    const unsigned long long mask = __ballot(src);
+    if (mask == 0ull) continue;
+    float sC[ND];
+    int ssz = 0, sh = -1, stl = -1;
+#pragma unroll
+    for (int x = 0; x < ND; ++x) sC[x] = 0.f;
+    if (src) {
+#pragma unroll
+      for (int x = 0; x < ND; ++x) sC[x] = L.C[x][pj];
+      ssz = L.S[pj];
+      const int id = L.ID[pj];
+      sh = L.head[id];
+      stl = L.tail[id];
+    }
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int prev_lane = below ? 63 - __builtin_clzll(below) : 0;
+    const int prev_tail_l = __shfl(stl, prev_lane);
+    if (src) L.next[below ? prev_tail_l : carry_tail] = sh;
+    carry_tail = __builtin_amdgcn_readlane(stl, __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask)));
+    for (unsigned long long m = mask; m; m &= m - 1ull) {
+      const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+      const int csz = __builtin_amdgcn_readlane(ssz, l);
+      const int nsz = tsz + csz;
+#pragma unroll
+      for (int x = 0; x < ND; ++x) {
+        const float cv = readlane_f(sC[x], l);
+        const float v = __fadd_rn(__fmul_rn(tC[x], (float)tsz), __fmul_rn(cv, (float)csz));
+        tC[x] = __fdiv_rn(v, (float)nsz);
+      }
+      tsz = nsz;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int x = 0; x < ND; ++x) L.C[x][t] = tC[x];
+    L.S[t] = tsz;
+    L.tail[idt] = carry_tail;
+  }
+}
+
+// (2b) for point sets of up to 64*NP canopies: the list walk of one block with the pointers of
+// the whole list in registers (lane l holds positions l, l+64, ...).  Only rows with members
+// are visited.  Per row: the row's closeness words arrive as wave-uniform loads, the only
+// dependent LDS access of the common step is the "is my pointer's target a member" bit test.
+// Rows with outward members use LDS stamps for the cross-lane parts (flag: targets of
+// members; st: positions written indirectly).
+template <int ND, int NP>
+__device__ __forceinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane,
+                                                int& stamp) {
+  int mpr[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int pos = u * 64 + lane;
+    mpr[u] = pos < nrem ? L.mp[pos] : pos;
+  }
+  for (unsigned long long rows = ne; rows; rows &= rows - 1ull) {
+    const int r = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rows));
+    const int i = i0 + r;
+    // loads are unconditional (clamped indices) so that each batch is one LDS round trip
+    unsigned long long W[NP], TW[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) W[u] = L.rowbits[r][u];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) TW[u] = L.rowbits[r][(mpr[u] >> 6) & (MS_WORDS - 1)];
+    bool mem[NP], out[NP];
+    bool any_out_l = false;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int pos = u * 64 + lane;
+      const int t = mpr[u];
+      mem[u] = pos < i && ((W[u] >> lane) & 1ull);           // words past the row's end are stale: pos < i masks them
+      out[u] = mem[u] && t != pos && !((TW[u] >> (t & 63)) & 1ull);
+      any_out_l |= out[u];
+    }
+    if (__ballot(any_out_l) != 0ull) {
+      // is an outward member the target of another member?
+      ++stamp;
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (mem[u] && mpr[u] != u * 64 + lane) L.flag[mpr[u]] = stamp;
+      int fl[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) fl[u] = L.flag[u * 64 + lane];
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) hit |= out[u] && fl[u] == stamp;
+      int stv[NP];   // 1 = member & not ov, 2 = member & ov
+#pragma unroll
+      for (int u = 0; u < NP; ++u) stv[u] = mem[u] ? 1 : 0;
+      if (__ballot(hit) != 0ull) {
+        // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), m[j'] == j (j' != j)
+        for (int round = 0; round < MS_CAP; ++round) {
+          ++stamp;
+#pragma unroll
+          for (int u = 0; u < NP; ++u)
+            if (stv[u] == 1 && mpr[u] != u * 64 + lane) L.flag[mpr[u]] = stamp;  // a canopy is not its own predecessor
+#pragma unroll
+          for (int u = 0; u < NP; ++u) fl[u] = L.flag[u * 64 + lane];
+          bool ch = false;
+#pragma unroll
+          for (int u = 0; u < NP; ++u)
+            if (stv[u] != 0) {
+              const int s1 = (fl[u] == stamp) ? 2 : 1;
+              ch |= s1 != stv[u];
+              stv[u] = s1;
+            }
+          if (__ballot(ch) == 0ull) break;
+        }
+      }
+      // indirect writes of step i: the old targets of the outward members that were not pre-empted
+      ++stamp;
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (out[u] && stv[u] != 2) L.st[mpr[u]] = stamp;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) fl[u] = L.st[u * 64 + lane];
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (u * 64 + lane < nrem && fl[u] == stamp) mpr[u] = i;
+    }
+    // direct writes: every member points at i
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (mem[u]) mpr[u] = i;
+  }
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int pos = u * 64 + lane;
+    if (pos < nrem) L.mp[pos] = mpr[u];
+  }
+}
 
 template <int ND>
 __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int pts_stride, int n,
@@ -53,208 +231,473 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
                                int32_t* __restrict__ label_out, int32_t* __restrict__ iters_out) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float sq_radius = __fmul_rn(radius, radius);
   const float sq_merge = __fmul_rn(merge, merge);
+#ifdef MS_PROF
+  unsigned long long t_prof = clock64();
+#endif
 
   for (int i = tid; i < n; i += MS_THREADS) {
 #pragma unroll
-    for (int x = 0; x < ND; ++x) L.c[x][i] = pts[(size_t)i * pts_stride + x];
-    L.size[i] = 1;
-    L.merges[i] = i;
-    L.order[i] = i;
+    for (int x = 0; x < ND; ++x) L.C[x][i] = pts[(size_t)i * pts_stride + x];
+    L.S[i] = 1;
+    L.ID[i] = i;
     L.head[i] = i;
     L.tail[i] = i;
     L.next[i] = -1;
     L.flag[i] = 0;
+    L.st[i] = 0;
   }
-  if (tid == 0) {
-    L.nrem = n;
-    L.stamp = 0;
-  }
+  if (tid == 0) L.nrem = n;
   __syncthreads();
 
+  int stamp = 0;  // used by wavefront 0 only
   int it = 0;
   for (; it < max_iter; ++it) {
     const int nrem = L.nrem;
-    // ---- (1) weighted mean of the canopies within Radius --------------------
-    for (int p = tid; p < nrem; p += MS_THREADS) {
-      const int c = L.order[p];
+    MS_T(0);
+    if (tid < MS_WORDS) L.tbw[tid] = 0ull;
+    if (tid < 2) {
+      L.neblock[tid] = 0ull;
+      L.slowblock[tid] = 0ull;
+    }
+    // ---- (1) weighted mean of the canopies within Radius (:102-120) ------------------
+    // One thread per canopy, the others in list order.  Every thread walks the same list, so
+    // a wavefront fetches 64 canopies at a time (one per lane) and broadcasts them one after
+    // the other through scalar registers.
+    for (int pb = wave * 64; pb < nrem; pb += MS_THREADS) {   // wave-uniform trip count
+      const int p = pb + lane;
+      const bool live = p < nrem;
       float cc[ND], agg[ND];
-      const float fsz = (float)L.size[c];
+      const int sz = live ? L.S[p] : 1;
+      const float fsz = (float)sz;
 #pragma unroll
       for (int x = 0; x < ND; ++x) {
-        cc[x] = L.c[x][c];
+        cc[x] = live ? L.C[x][p] : 0.f;
         agg[x] = __fmul_rn(cc[x], fsz);
       }
-      int touch = L.size[c];
-      for (int p2 = 0; p2 < nrem; ++p2) {
-        const int o = L.order[p2];
-        if (o == c) continue;
-        float dist = 0.f;
+      int touch = sz;
+      for (int p0 = 0; p0 < nrem; p0 += 64) {
+        const int q = p0 + lane;
+        float oc[ND], ow[ND];
+        int os = 0;
 #pragma unroll
-        for (int x = 0; x < ND; ++x) {
-          const float d = __fsub_rn(L.c[x][o], cc[x]);
-          dist = __fadd_rn(dist, __fmul_rn(d, d));
+        for (int x = 0; x < ND; ++x) oc[x] = ow[x] = 0.f;
+        if (q < nrem) {
+          os = L.S[q];
+#pragma unroll
+          for (int x = 0; x < ND; ++x) {
+            oc[x] = L.C[x][q];
+            ow[x] = __fmul_rn(oc[x], (float)os);   // center * boundPointsSize
+          }
         }
-        if (dist < sq_radius) {
-          const int os = L.size[o];
-          touch += os;
+        const int cnt = min(64, nrem - p0);
+        for (int l = 0; l < cnt; ++l) {
+          float bc[ND], bw[ND];
 #pragma unroll
-          for (int x = 0; x < ND; ++x) agg[x] = __fadd_rn(agg[x], __fmul_rn(L.c[x][o], (float)os));
+          for (int x = 0; x < ND; ++x) {
+            bc[x] = readlane_f(oc[x], l);
+            bw[x] = readlane_f(ow[x], l);
+          }
+          const int bs = __builtin_amdgcn_readlane(os, l);
+          float dist = 0.f;
+#pragma unroll
+          for (int x = 0; x < ND; ++x) {
+            const float d = __fsub_rn(bc[x], cc[x]);
+            dist = __fadd_rn(dist, __fmul_rn(d, d));
+          }
+          if (dist < sq_radius && p0 + l != p) {
+            touch += bs;
+#pragma unroll
+            for (int x = 0; x < ND; ++x) agg[x] = __fadd_rn(agg[x], bw[x]);
+          }
         }
       }
+      if (live) {
 #pragma unroll
-      for (int x = 0; x < ND; ++x) L.a[x][c] = __fdiv_rn(agg[x], (float)touch);
+        for (int x = 0; x < ND; ++x) L.a[x][p] = __fdiv_rn(agg[x], (float)touch);
+        L.mp[p] = p;
+      }
     }
     __syncthreads();
+    MS_T(1);
 
-    // ---- (2) merge marking, one wavefront, list order --------------------------
-    if (wave == 0) {
-      int stamp = L.stamp;
-      for (int pi = 1; pi < nrem; ++pi) {
-        const int ci = L.order[pi];
+    // ---- (2) merge marking (:122-132), in blocks of MS_ROWS outer canopies ------------
+    // The reference walks the list: for canopy i, every EARLIER canopy j whose mean is within
+    // Merge does `m[m[j]] = i; m[j] = i` in list order.  Every store of step i writes the value
+    // i, so step i is: all members of S_i = {j < i close to i} get i, and the old target t_j of
+    // member j gets i unless an earlier member j' whose pointer was j had already redirected j
+    // ("ov": j then reads i, and m[i] = i is a no-op).  ov only matters for "outward" members
+    // (t_j neither j nor a member: members get i anyway).
+    //  (2a) all wavefronts: closeness bits of the block's rows against the earlier positions;
+    //  (2b) wavefront 0 walks the block's rows.  `tb` = every position that has been a merge
+    //       target in this iteration (pointers only ever hold such positions): when all of
+    //       them are members of S_i no member can be outward and the step is just "members
+    //       get i"; otherwise the outward members are looked at, and only if one of them is
+    //       another member's target is the relaxation needed.
+    //       A block none of whose rows fails that test needs no walk at all: position j simply
+    //       ends up pointing at the last row of the block it is close to.
+    constexpr int RPW = MS_ROWS / MS_WAVES;   // rows per wavefront
+    for (int i0 = 0; i0 < nrem; i0 += MS_ROWS) {
+      const int ps0 = i0 >> 6;                // the block's rows are the positions of word ps0
+      const int par = ps0 & 1;                // the flag words alternate: they are reset a block later
+      unsigned long long mine[RPW];
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        mine[u] = 0ull;
+        const int r = wave * RPW + u;
+        const int i = i0 + r;
+        if (i >= nrem || i == 0) continue;
         float ai[ND];
 #pragma unroll
-        for (int x = 0; x < ND; ++x) ai[x] = L.a[x][ci];
-        // S_i membership of the earlier canopies, 64 per pass; remember which
-        // passes had any member so the later sweeps can skip the rest
-        const int npass = (pi + 63) >> 6;
-        bool any_close = false;
+        for (int x = 0; x < ND; ++x) ai[x] = L.a[x][i];
+        const int npass = (i + 63) >> 6;
         for (int ps = 0; ps < npass; ++ps) {
           const int pj = ps * 64 + lane;
           bool close = false;
-          if (pj < pi) {
-            const int cj = L.order[pj];
+          if (pj < i) {
             float dist = 0.f;
 #pragma unroll
             for (int x = 0; x < ND; ++x) {
-              const float d = __fsub_rn(L.a[x][cj], ai[x]);  // sqEuclDist(other) : other - this
+              const float d = __fsub_rn(L.a[x][pj], ai[x]);  // sqEuclDist(other) : other - this
               dist = __fadd_rn(dist, __fmul_rn(d, d));
             }
             close = dist < sq_merge;
-            // S_i marker: flag = 2*stamp_base+... kept in a register-free way: order2 as scratch
-            L.order2[pj] = close ? 1 : 0;
           }
-          any_close |= (__ballot(close) != 0ull);
+          const unsigned long long b = __ballot(close);
+          if (lane == ps) mine[u] = b;
         }
-        if (!any_close) continue;
-        // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), merges[j'] == j.
-        // ov state lives in order2 (1 = member & not ov, 2 = member & ov).
-        for (int round = 0; round < MS_CAP; ++round) {
-          ++stamp;
-          for (int ps = 0; ps < npass; ++ps) {
-            const int pj = ps * 64 + lane;
-            if (pj < pi && L.order2[pj] == 1) {
-              const int cj = L.order[pj];
-              const int tj = L.merges[cj];
-              if (tj != cj) L.flag[tj] = stamp;  // a canopy is not its own predecessor
-            }
-          }
-          bool changed = false;
-          for (int ps = 0; ps < npass; ++ps) {
-            const int pj = ps * 64 + lane;
-            bool ch = false;
-            if (pj < pi) {
-              const int st = L.order2[pj];
-              if (st != 0) {
-                const int nst = (L.flag[L.order[pj]] == stamp) ? 2 : 1;
-                ch = nst != st;
-                L.order2[pj] = nst;
-              }
-            }
-            changed |= (__ballot(ch) != 0ull);
-          }
-          if (!changed) break;
-        }
-        // writes of step i: every store is the value ci
-        for (int ps = 0; ps < npass; ++ps) {
-          const int pj = ps * 64 + lane;
-          if (pj < pi && L.order2[pj] == 1) L.merges[L.merges[L.order[pj]]] = ci;
-        }
-        for (int ps = 0; ps < npass; ++ps) {
-          const int pj = ps * 64 + lane;
-          if (pj < pi && L.order2[pj] != 0) L.merges[L.order[pj]] = ci;
-        }
+        if (lane < npass) L.rowbits[r][lane] = mine[u];
+        if (__ballot(mine[u] != 0ull) != 0ull && lane == 0) atomicOr(&L.neblock[par], 1ull << r);
       }
-      if (lane == 0) L.stamp = stamp;
-    }
-    __syncthreads();
-
-    // ---- (3) fold marked canopies into their targets, list order ----------------
-    if (tid == 0) {
-      int merged = 0;
-      for (int p = 0; p < nrem; ++p) {
-        const int c = L.order[p];
-        const int t = L.merges[c];
-        if (t == c) continue;
-        const int csz = L.size[c];
-        const int tsz = L.size[t];  // == boundPoints.size() of the target
-        const int nsz = tsz + csz;
+      __syncthreads();
+      {
+        const unsigned long long ne = L.neblock[par];
+        const unsigned long long tprev = lane < MS_WORDS ? L.tbw[lane] : 0ull;
 #pragma unroll
-        for (int x = 0; x < ND; ++x) {
-          const float v = __fadd_rn(__fmul_rn(L.c[x][t], (float)tsz), __fmul_rn(L.c[x][c], (float)csz));
-          L.c[x][t] = __fdiv_rn(v, (float)nsz);
+        for (int u = 0; u < RPW; ++u) {
+          const int r = wave * RPW + u;
+          if (!((ne >> r) & 1ull)) continue;
+          unsigned long long tbv = tprev;
+          if (lane == ps0) tbv |= ne & ((1ull << r) - 1ull);
+          if (__ballot((tbv & ~mine[u]) != 0ull) != 0ull && lane == 0) atomicOr(&L.slowblock[par], 1ull << r);
         }
-        L.next[L.tail[t]] = L.head[c];  // splice c's points after t's
-        L.tail[t] = L.tail[c];
-        L.size[t] = nsz;
-        merged = 1;
       }
-      L.merged_any = merged;
+      __syncthreads();
+      MS_T(2);
+      const unsigned long long ne = L.neblock[par];
+      if (L.slowblock[par] == 0ull) {
+        // no walk: position j points at the last row of the block that holds it
+        const int jend = min(nrem, i0 + MS_ROWS);
+        for (int j = tid; j < jend; j += MS_THREADS) {
+          unsigned long long m = ne;
+          if (j >= i0) m &= ~((2ull << (j - i0)) - 1ull);   // rows after j only
+          while (m) {
+            const int r = 63 - __builtin_clzll(m);
+            if ((L.rowbits[r][j >> 6] >> (j & 63)) & 1ull) {
+              L.mp[j] = i0 + r;
+              break;
+            }
+            m &= ~(1ull << r);
+          }
+        }
+      } else if (n <= 64 * 8) {
+        if (wave == 0) {
+          if (n <= 64 * 2) walk_block_regs<ND, 2>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 4) walk_block_regs<ND, 4>(L, i0, nrem, ne, lane, stamp);
+          else walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
+        }
+      } else if (wave == 0) {
+        unsigned long long tb = lane < MS_WORDS ? L.tbw[lane] : 0ull;   // lane ps: target bits of positions [64 ps, 64 ps + 64)
+        for (int r = (i0 == 0 ? 1 : 0); r < MS_ROWS; ++r) {
+          const int i = i0 + r;
+          if (i >= nrem) break;
+          const int npass = (i + 63) >> 6;
+          const unsigned long long w = lane < npass ? L.rowbits[r][lane] : 0ull;
+          const unsigned long long active = __ballot(w != 0ull);   // passes that hold members
+          if (active == 0ull) continue;
+          if (__ballot((tb & ~w) != 0ull) != 0ull) {
+            // outward members: pointer neither self nor a member of S_i
+            unsigned long long outw = 0ull;   // lane ps: outward bits of pass ps
+            bool any_out = false;
+            for (unsigned long long m = active; m; m &= m - 1ull) {
+              const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+              const bool mem = (readlane64(w, ps) >> lane) & 1ull;
+              const int pj = ps * 64 + lane;
+              bool out = false;
+              if (mem) {
+                const int t = L.mp[pj];
+                if (t != pj) out = !((L.rowbits[r][t >> 6] >> (t & 63)) & 1ull);
+              }
+              const unsigned long long ob = __ballot(out);
+              if (lane == ps) outw = ob;
+              any_out |= ob != 0ull;
+            }
+            if (any_out) {
+              // is an outward member the target of another member?
+              ++stamp;
+              for (unsigned long long m = active; m; m &= m - 1ull) {
+                const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                const bool mem = (readlane64(w, ps) >> lane) & 1ull;
+                const int pj = ps * 64 + lane;
+                if (mem) {
+                  const int t = L.mp[pj];
+                  if (t != pj) L.flag[t] = stamp;
+                }
+              }
+              bool need = false;
+              for (unsigned long long m = active; m; m &= m - 1ull) {
+                const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                const bool out = (readlane64(outw, ps) >> lane) & 1ull;
+                const int pj = ps * 64 + lane;
+                const bool hit = out && L.flag[pj] == stamp;
+                need |= __ballot(hit) != 0ull;
+              }
+              if (need) {
+                // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), m[j'] == j (j' != j).
+                // st: 1 = member & not ov, 2 = member & ov.
+                for (unsigned long long m = active; m; m &= m - 1ull) {
+                  const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                  if ((readlane64(w, ps) >> lane) & 1ull) L.st[ps * 64 + lane] = 1;
+                }
+                for (int round = 0; round < MS_CAP; ++round) {
+                  ++stamp;
+                  for (unsigned long long m = active; m; m &= m - 1ull) {
+                    const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                    const int pj = ps * 64 + lane;
+                    if (((readlane64(w, ps) >> lane) & 1ull) && L.st[pj] == 1) {
+                      const int t = L.mp[pj];
+                      if (t != pj) L.flag[t] = stamp;  // a canopy is not its own predecessor
+                    }
+                  }
+                  bool changed = false;
+                  for (unsigned long long m = active; m; m &= m - 1ull) {
+                    const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                    const int pj = ps * 64 + lane;
+                    bool ch = false;
+                    if ((readlane64(w, ps) >> lane) & 1ull) {
+                      const int s0 = L.st[pj];
+                      const int s1 = (L.flag[pj] == stamp) ? 2 : 1;
+                      ch = s1 != s0;
+                      L.st[pj] = s1;
+                    }
+                    changed |= __ballot(ch) != 0ull;
+                  }
+                  if (!changed) break;
+                }
+              }
+              // indirect writes of step i: the old targets of the outward members that were not pre-empted
+              for (unsigned long long m = active; m; m &= m - 1ull) {
+                const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                const bool out = (readlane64(outw, ps) >> lane) & 1ull;
+                const int pj = ps * 64 + lane;
+                if (out && !(need && L.st[pj] == 2)) L.mp[L.mp[pj]] = i;
+              }
+              if (need)
+                for (unsigned long long m = active; m; m &= m - 1ull) {
+                  const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                  if ((readlane64(w, ps) >> lane) & 1ull) L.st[ps * 64 + lane] = 0;
+                }
+            }
+          }
+          // direct writes: every member points at i
+          for (unsigned long long m = active; m; m &= m - 1ull) {
+            const int ps = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+            if ((readlane64(w, ps) >> lane) & 1ull) L.mp[ps * 64 + lane] = i;
+          }
+          if (lane == (i >> 6)) tb |= 1ull << (i & 63);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        L.tbw[ps0] |= ne;
+        L.neblock[par] = 0ull;
+        L.slowblock[par] = 0ull;
+      }
+      MS_T(3);
+    }
+
+    // ---- (3) fold marked canopies into their targets (:134-148) ------------------------
+    // The reference folds in list order.  A target always sits later in the list than its
+    // sources, so what matters is (a) a canopy is complete (has absorbed its own sources)
+    // before it is folded, (b) the sources of one target are folded in list order.  Targets
+    // whose sources are all complete are independent: one wavefront per target, in rounds
+    // over the depth of the merge forest; very deep forests finish in list order.
+    for (int p = tid; p < nrem; p += MS_THREADS) L.pending[p] = 0;
+    if (tid == 0) {
+      L.merged_any = 0;
+      L.ntargets = 0;
     }
     __syncthreads();
-    const bool merged_any = L.merged_any != 0;
-    if (!merged_any) {
+    for (int p = tid; p < nrem; p += MS_THREADS) {
+      const int t = L.mp[p];
+      if (t != p) {
+        if (atomicExch(&L.pending[t], 1) == 0) L.tlist[atomicAdd(&L.ntargets, 1)] = t;
+        L.merged_any = 1;
+      }
+    }
+    __syncthreads();
+    if (L.merged_any == 0) {
       ++it;
       break;
     }
-    // compact canopiesRemaining (erase merged), keep order; reset pointers
+    const int nt = L.ntargets;
+    for (int round = 0;; ++round) {
+      if (tid == 0) L.again = 0;
+      __syncthreads();
+      if (round >= 8) {
+        if (wave == 0)
+          for (int t = 1; t < nrem; ++t)
+            if (L.pending[t] == 1) {
+              fold_target<ND>(L, t, lane);
+              if (lane == 0) L.pending[t] = 0;
+            }
+        __syncthreads();
+        break;
+      }
+      for (int k = wave; k < nt; k += MS_WAVES) {
+        const int t = L.tlist[k];
+        if (L.pending[t] != 1) continue;
+        bool blocked = false;   // a source that still waits for its own sources
+        const int npass = (t + 63) >> 6;
+        for (int ps = 0; ps < npass; ++ps) {
+          const int pj = ps * 64 + lane;
+          const bool b = pj < t && L.mp[pj] == t && L.pending[pj] != 0;
+          blocked |= __ballot(b) != 0ull;
+        }
+        if (blocked) {
+          if (lane == 0) L.again = 1;
+          continue;
+        }
+        fold_target<ND>(L, t, lane);
+        if (lane == 0) L.pending[t] = 2;   // complete; visible as such from the next round on
+      }
+      __syncthreads();
+      for (int t = tid; t < nrem; t += MS_THREADS)
+        if (L.pending[t] == 2) L.pending[t] = 0;
+      const bool again = L.again != 0;
+      __syncthreads();
+      if (!again) break;
+    }
+    MS_T(4);
+    // erase the merged canopies (:145): in-place stable compaction of the position arrays
     if (wave == 0) {
       int base = 0;
       for (int ps = 0; ps * 64 < nrem; ++ps) {
         const int p = ps * 64 + lane;
-        int c = -1;
         bool keep = false;
+        float cv[ND];
+        int sv = 0, iv = 0;
+#pragma unroll
+        for (int x = 0; x < ND; ++x) cv[x] = 0.f;
         if (p < nrem) {
-          c = L.order[p];
-          keep = L.merges[c] == c;
+          keep = L.mp[p] == p;
+#pragma unroll
+          for (int x = 0; x < ND; ++x) cv[x] = L.C[x][p];
+          sv = L.S[p];
+          iv = L.ID[p];
         }
         const unsigned long long m = __ballot(keep);
-        if (keep) L.order2[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+        if (keep) {
+          const int dst = base + __popcll(m & ((1ull << lane) - 1ull));   // dst <= p
+#pragma unroll
+          for (int x = 0; x < ND; ++x) L.C[x][dst] = cv[x];
+          L.S[dst] = sv;
+          L.ID[dst] = iv;
+        }
         base += __popcll(m);
       }
       if (lane == 0) L.nrem = base;
     }
     __syncthreads();
-    const int nn = L.nrem;
-    for (int p = tid; p < nn; p += MS_THREADS) L.order[p] = L.order2[p];
-    __syncthreads();
+    MS_T(5);
   }
   if (tid == 0 && iters_out) *iters_out = it;
 
   // ---- emit clusters of size >= MinPts in list order (:151-157) -----------------
+  // cluster numbers and offsets by one wavefront; every point's place in its cluster's list
+  // by pointer jumping over the linked lists (distance to the list's tail), all threads.
   __syncthreads();
-  if (label_out)
-    for (int i = tid; i < n; i += MS_THREADS) label_out[i] = -1;
-  __syncthreads();
-  if (tid == 0) {
-    const int nrem = L.nrem;
+  const int nrem = L.nrem;
+  int* const clno = L.mp;        // by position: cluster number or -1
+  int* const clbase = L.st;      // by position: first output slot of the cluster
+  int* const nx = L.pending;     // by point
+  int* const dist = L.flag;      // by point: hops to the tail
+  int* const last = L.tlist;     // by point: node reached so far
+  int* const owner = reinterpret_cast<int*>(&L.rowbits[0][0]);  // by (tail) point: position of its canopy
+  if (wave == 0) {
     int ncl = 0, w = 0;
-    for (int p = 0; p < nrem; ++p) {
-      const int c = L.order[p];
-      if (L.size[c] < min_pts) continue;
-      if (cl_start_out) cl_start_out[ncl] = w;
-      for (int pt = L.head[c]; pt >= 0; pt = L.next[pt]) {
-        if (members_out) members_out[w] = member_base + pt;
-        if (label_out) label_out[pt] = ncl;
-        ++w;
+    for (int ps = 0; ps * 64 < nrem; ++ps) {
+      const int p = ps * 64 + lane;
+      const int sz = p < nrem ? L.S[p] : 0;
+      const bool ok = p < nrem && sz >= min_pts;
+      const unsigned long long m = __ballot(ok);
+      int incl = ok ? sz : 0;   // inclusive prefix sum of the kept sizes over the lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
       }
-      ++ncl;
+      const int k = ncl + __popcll(m & ((1ull << lane) - 1ull));
+      const int start = w + incl - (ok ? sz : 0);
+      if (p < nrem) {
+        clno[p] = ok ? k : -1;
+        clbase[p] = start;
+        owner[L.tail[L.ID[p]]] = p;
+      }
+      if (ok && cl_start_out) cl_start_out[k] = start;
+      ncl += __popcll(m);
+      w += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (cl_start_out) cl_start_out[ncl] = w;
-    *ncl_out = ncl;
+    if (lane == 0) {
+      if (cl_start_out) cl_start_out[ncl] = w;
+      *ncl_out = ncl;
+    }
   }
+  for (int pt = tid; pt < n; pt += MS_THREADS) {
+    const int nn = L.next[pt];
+    nx[pt] = nn;
+    dist[pt] = nn >= 0 ? 1 : 0;
+    last[pt] = pt;
+  }
+  __syncthreads();
+  for (int span = 1; span < n; span <<= 1) {
+    int nn[(MS_CAP + MS_THREADS - 1) / MS_THREADS], dd[(MS_CAP + MS_THREADS - 1) / MS_THREADS],
+        ll[(MS_CAP + MS_THREADS - 1) / MS_THREADS];
+#pragma unroll
+    for (int u = 0; u < (MS_CAP + MS_THREADS - 1) / MS_THREADS; ++u) {
+      const int pt = tid + u * MS_THREADS;
+      nn[u] = -1;
+      if (pt < n) {
+        const int q = nx[pt];
+        if (q >= 0) {
+          nn[u] = q;
+          dd[u] = dist[q];
+          ll[u] = last[q];
+          nn[u] = nx[q] >= 0 ? nx[q] : -2;   // -2: jumped onto the tail
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (MS_CAP + MS_THREADS - 1) / MS_THREADS; ++u) {
+      const int pt = tid + u * MS_THREADS;
+      if (pt < n && nn[u] != -1) {
+        dist[pt] += dd[u];
+        last[pt] = ll[u];
+        nx[pt] = nn[u] == -2 ? -1 : nn[u];
+      }
+    }
+    __syncthreads();
+  }
+  for (int pt = tid; pt < n; pt += MS_THREADS) {
+    const int p = owner[last[pt]];
+    const int k = clno[p];
+    if (k >= 0 && members_out) members_out[clbase[p] + L.S[p] - 1 - dist[pt]] = member_base + pt;
+    if (label_out) label_out[pt] = k;
+  }
+  MS_T(6);
 }
 
 // Frame form: one workgroup per model, points = uv of the model's matches.  The last
@@ -348,6 +791,17 @@ void set_lds_attr(K kernel, size_t bytes) {
 }
 
 }  // namespace
+
+#ifdef MS_PROF
+extern "C" int mh_debug_ms_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ms_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ms_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,

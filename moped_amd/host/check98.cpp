@@ -3,6 +3,7 @@
 #include <tr1/memory>
 namespace std { using tr1::shared_ptr; }
 #include "moped_types.hpp"
+#include "FEAT_SIFT_HIP.hpp"
 #include "MATCH_BRUTE_HIP.hpp"
 #include "CLUSTER_MEAN_SHIFT_HIP.hpp"
 #include "POSE_RANSAC_P3P_HIP.hpp"

@@ -4,6 +4,7 @@
 // scene file (models + one frame of detected features) and prints the objects.
 //
 //   moped_hip_test scene.bin [repeats]
+//   moped_hip_test --sift image.pgm      (FEAT step only: binary P5 image -> keypoints)
 //
 // Scene file (little endian, written by scripts/dump_scene.py):
 //   int32 n_models, Q ; float K[4] ; float cam[7]
@@ -15,6 +16,7 @@
 
 #include "moped_types.hpp"
 
+#include "FEAT_SIFT_HIP.hpp"
 #include "MATCH_BRUTE_HIP.hpp"
 #include "CLUSTER_MEAN_SHIFT_HIP.hpp"
 #include "POSE_RANSAC_P3P_HIP.hpp"
@@ -35,7 +37,40 @@ static void createPipeline(MopedPipeline& pipeline) {
 template <typename T>
 static bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
 
+// FEAT slot alone (src/config.hpp:69): one 8-bit gray image through FEAT_SIFT_HIP::process.
+static int run_sift(const char* path) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { std::perror(path); return 2; }
+  int w = 0, h = 0, maxv = 0;
+  if (std::fscanf(f, "P5 %d %d %d", &w, &h, &maxv) != 3 || maxv != 255 || w <= 0 || h <= 0) return 2;
+  std::fgetc(f);
+  SP_Image image(new Image);
+  image->width = w;
+  image->height = h;
+  image->data.resize((size_t)w * h);
+  if (!rd(f, &image->data[0], image->data.size())) return 2;
+  std::fclose(f);
+  MopedPipeline pipeline;
+  pipeline.addAlg("SIFT", new FEAT_SIFT_HIP("-1"));
+  list<MopedAlg*> algs = pipeline.getAlgs(true);
+  if (algs.empty() || !algs.front()->isCapable()) return 3;
+  list<SP_Object> objects;
+  FrameData frameData;
+  frameData.objects = &objects;
+  frameData.images.push_back(image);
+  algs.front()->process(frameData);
+  const vector<FrameData::DetectedFeature>& feats = frameData.detectedFeatures["SIFT"];
+  std::printf("KEYPOINTS %zu\n", feats.size());
+  for (size_t i = 0; i < feats.size(); ++i) {
+    double sum = 0;
+    for (int k = 0; k < 128; ++k) sum += feats[i].descriptor[k] * (k + 1);
+    std::printf("KP %d %.6f %.6f %.6f\n", feats[i].imageIdx, feats[i].coord2D[0], feats[i].coord2D[1], sum);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "--sift") return run_sift(argv[2]);
   if (argc < 2) {
     std::fprintf(stderr, "usage: %s scene.bin [repeats]\n", argv[0]);
     return 2;

@@ -51,3 +51,28 @@ def test_step_plugins_through_pipeline(tmp_path):
         e_o = np.sqrt(((orclib.project(op[j], xyz, K, CAM0) - uv) ** 2).sum(1)).mean()
         assert e_g <= e_o + 1.0
         assert abs(score - osc[j]) <= 0.05 * osc[j]
+
+
+@pytest.mark.gpu
+def test_feat_sift_plugin_through_pipeline(tmp_path):
+    """FEAT_SIFT_HIP in the "SIFT" slot (config.hpp:69): the features it appends to
+    detectedFeatures are the C ABI's, in the same order."""
+    from moped_amd import capi
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "sift_ref_frames.npz"))
+    gray = gold["gray0"]
+    pgm = tmp_path / "frame.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (gray.shape[1], gray.shape[0]))
+        f.write(gray.tobytes())
+    out = subprocess.check_output([os.path.join(HOST, "moped_hip_test"), "--sift", str(pgm)], text=True)
+    rows = [l.split() for l in out.splitlines()]
+    n = int(rows[0][1])
+    kp = np.array([[float(x) for x in r[2:5]] for r in rows[1:]], np.float64)
+    assert rows[0][0] == "KEYPOINTS" and n == len(kp) and all(r[1] == "0" for r in rows[1:])
+    c = capi.Context(0)
+    xy, so, desc = c.sift(gray)
+    c.close()
+    assert n == len(xy) and abs(n - len(gold["xy0"])) <= 2
+    assert np.abs(kp[:, :2] - xy).max() < 1e-5
+    assert np.abs(kp[:, 2] - (desc.astype(np.float64) * np.arange(1, 129)).sum(1)).max() < 1e-3
