@@ -420,10 +420,23 @@ __device__ __forceinline__ int residual_rows(const float* R, const float* t, con
   }
 }
 
+// Wave-wide sum, the same value in every lane: four DPP steps inside the rows of 16 lanes
+// (quad swaps, half-row mirror, row mirror), then the four row totals through scalar
+// registers -- no LDS round trips (a __shfl_xor butterfly is six dependent ds_bpermutes).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Sum of squared residuals over the inlier list at pose (R,t); all 64 lanes return it.
@@ -476,28 +489,30 @@ __device__ bool solve6(const float* Hp, const float* g, float mu, float* x) {
       ++k;
     }
   for (int i = 0; i < 6; ++i) A[i][i] += mu;
-  float Lm[6][6];
+  // L with the reciprocals of its diagonal kept beside it: one v_rsq per pivot, no divisions
+  float Lm[6][6], inv[6];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j <= i; ++j) {
       float s = A[i][j];
       for (int m = 0; m < j; ++m) s -= Lm[i][m] * Lm[j][m];
       if (i == j) {
         if (!(s > 0.f)) return false;
-        Lm[i][i] = sqrtf(s);
+        inv[i] = __frsqrt_rn(s);
+        Lm[i][i] = s * inv[i];
       } else {
-        Lm[i][j] = s / Lm[j][j];
+        Lm[i][j] = s * inv[j];
       }
     }
   float y[6];
   for (int i = 0; i < 6; ++i) {
     float s = -g[i];
     for (int m = 0; m < i; ++m) s -= Lm[i][m] * y[m];
-    y[i] = s / Lm[i][i];
+    y[i] = s * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     float s = y[i];
     for (int m = i + 1; m < 6; ++m) s -= Lm[m][i] * x[m];
-    x[i] = s / Lm[i][i];
+    x[i] = s * inv[i];
   }
   return true;
 }
@@ -535,7 +550,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
     float ginf = 0.f;
     for (int i = 0; i < 6; ++i) ginf = fmaxf(ginf, fabsf(acc.g[i]));
     if (!(ginf > 0.f)) break;
-    bool accepted = false;
+    bool accepted = false, converged = false;
     for (int attempt = 0; attempt < 8 && !accepted; ++attempt) {
       float dx[6];
       if (solve6(acc.H, acc.g, mu, dx)) {
@@ -549,6 +564,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
         if (dF > 0.f && dL > 0.f) {
           for (int i = 0; i < 9; ++i) R[i] = Rn[i];
           for (int i = 0; i < 3; ++i) t[i] = tn[i];
+          converged = dF <= 1e-6f * cost;   // nothing left at fp32 resolution: the next steps would only be rejected
           cost = c2;
           float tt = 2.f * dF / dL - 1.f;
           tt = 1.f - tt * tt * tt;
@@ -561,10 +577,17 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
       mu *= nu;
       nu *= 2.f;
     }
-    if (!accepted) break;
+    if (!accepted || converged) break;
   }
   return cost;
 }
+
+#ifdef POSE_PROF   // phase timing build (make EXTRA=-DPOSE_PROF): cycles of thread 0 per phase, summed over tasks
+__device__ unsigned long long g_pose_prof[8];
+#define PP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_pose_prof[k], now_ - t_prof); t_prof = now_; } } while (0)
+#else
+#define PP_T(k) do { } while (0)
+#endif
 
 template <int KIND>
 struct PoseLds {
@@ -598,6 +621,10 @@ __device__ void pose_task(
     if (tid == 0) atomicOr(&counts->error, ERR_OBJECT_CAP);
     return;
   }
+#ifdef POSE_PROF
+  unsigned long long t_prof = clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_pose_prof[7], 1ull);
+#endif
   int k = cl_count[cluster];
   const int begin = cl_begin[cluster];
   if (k > POSE_MAX_PTS) {
@@ -626,18 +653,24 @@ __device__ void pose_task(
     L.n_inl = 0;
   }
   __syncthreads();
-  // randSample needs n_pts_align correspondences with distinct image coordinates (:76-98)
+  // randSample needs n_pts_align correspondences with distinct image coordinates (:76-98):
+  // point i is a duplicate if an earlier point has its coordinates; the comparisons of one
+  // point are split over POSE_THREADS / k threads (L.list serves as the duplicate flags)
   {
-    int mine = 0;
-    for (int i = tid; i < k; i += POSE_THREADS) {
-      bool first = true;
-      for (int j = 0; j < i; ++j)
-        if (L.pts[PS * j] == L.pts[PS * i] && L.pts[PS * j + 1] == L.pts[PS * i + 1]) {
-          first = false;
-          break;
-        }
-      mine += first;
+    for (int i = tid; i < k; i += POSE_THREADS) L.list[i] = 0;
+    __syncthreads();
+    int per = POSE_THREADS / (k > 0 ? k : 1);
+    per = per < 1 ? 1 : (per > 32 ? 32 : per);
+    for (int w = tid; w < k * per; w += POSE_THREADS) {
+      const int i = w / per, part = w - i * per;
+      const float ui = L.pts[PS * i], vi = L.pts[PS * i + 1];
+      bool dup = false;
+      for (int j = part; j < i; j += per) dup |= (L.pts[PS * j] == ui) & (L.pts[PS * j + 1] == vi);
+      if (dup) L.list[i] = 1;
     }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < k; i += POSE_THREADS) mine += L.list[i] == 0;
     if (mine) atomicAdd(&L.n_distinct, mine);
   }
   __syncthreads();
@@ -648,12 +681,13 @@ __device__ void pose_task(
     obj_model[slot] = cl_model[cluster];
   }
   if (!enough) return;
+  PP_T(0);
 
   // ---- hypotheses: one per lane ------------------------------------------------------
   const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : POSE_THREADS;
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
-  for (int h = tid; h < H; h += POSE_THREADS) {
+  auto hypothesis = [&](const int h) {
     uint64_t st = (seed ^ (seed_dev ? *seed_dev : 0ull)) ^ ((uint64_t)(cluster + 1) << 40) ^ ((uint64_t)(replica + 1) << 32) ^ (uint64_t)h;
     splitmix64(st);
     // 4 correspondences with pairwise distinct image coordinates (:76-98)
@@ -666,17 +700,17 @@ __device__ void pose_task(
       const int c = (int)(splitmix64(st) % (uint64_t)k);
       if (!same_uv(c, i0)) i1 = c;
     }
-    if (i1 < 0) continue;
+    if (i1 < 0) return;
     for (int tries = 0; tries < 16 && i2 < 0; ++tries) {
       const int c = (int)(splitmix64(st) % (uint64_t)k);
       if (!same_uv(c, i0) && !same_uv(c, i1)) i2 = c;
     }
-    if (i2 < 0) continue;
+    if (i2 < 0) return;
     for (int tries = 0; tries < 16 && i3 < 0; ++tries) {
       const int c = (int)(splitmix64(st) % (uint64_t)k);
       if (!same_uv(c, i0) && !same_uv(c, i1) && !same_uv(c, i2)) i3 = c;
     }
-    if (i3 < 0) continue;
+    if (i3 < 0) return;
     double X[3][3], y[3][3];
     auto load = [&](int s, int pi) {
       const float* p = L.pts + PS * pi;
@@ -706,7 +740,7 @@ __device__ void pose_task(
         have = true;
       }
     });
-    if (!have) continue;
+    if (!have) return;
     int cnt = 0;
     for (int i = 0; i < k; ++i) {
       const float* p = L.pts + PS * i;
@@ -717,18 +751,40 @@ __device__ void pose_task(
       best_key = key;
       best_pose = cand;
     }
-  }
-  // ---- workgroup arg-max ---------------------------------------------------------------
-  unsigned long long wkey = best_key;
+  
+  };
+  // Two stages: the first 256 hypotheses run on four wavefronts (one per SIMD); the other
+  // n_hypotheses - 256 only if, with the inlier ratio w the best of them reached, another
+  // all-inlier sample is still likely to exist: (1 - w^4)^256 >= 1e-3 (the usual adaptive
+  // RANSAC bound; 4 = the P3P sample plus the point that picks its root).
+  auto wg_argmax = [&]() -> unsigned long long {
+    unsigned long long wkey = best_key;
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(wkey, off);
-    wkey = o > wkey ? o : wkey;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(wkey, off);
+      wkey = o > wkey ? o : wkey;
+    }
+    if (lane == 0) L.wave_best[wave] = wkey;
+    __syncthreads();
+    unsigned long long g = 0ull;
+    for (int w = 0; w < POSE_THREADS / 64; ++w) g = L.wave_best[w] > g ? L.wave_best[w] : g;
+    return g;
+  };
+  const int HA = H < 256 ? H : 256;
+  for (int h = tid; h < HA; h += POSE_THREADS) hypothesis(h);
+  PP_T(1);
+  unsigned long long gkey = wg_argmax();
+  if (H > HA) {
+    const int cnt_a = (int)(gkey >> 32);
+    const float w = (float)cnt_a / (float)k;
+    const float w4 = w * w * w * w;
+    const bool settled = cnt_a > prm.min_n_pts_object && powf(1.f - w4, (float)HA) < 1e-3f;
+    if (!settled) {
+      for (int h = HA + tid; h < H; h += POSE_THREADS) hypothesis(h);
+      __syncthreads();   // everybody has read wave_best of the first stage
+      gkey = wg_argmax();
+    }
   }
-  if (lane == 0) L.wave_best[wave] = wkey;
-  __syncthreads();
-  unsigned long long gkey = 0ull;
-  for (int w = 0; w < POSE_THREADS / 64; ++w) gkey = L.wave_best[w] > gkey ? L.wave_best[w] : gkey;
   const int best_cnt = (int)(gkey >> 32);
   if (best_cnt <= prm.min_n_pts_object) return;  // needs MORE than MinNPtsObject inliers (:204)
   if (best_key == gkey) {                        // unique: the key embeds the hypothesis id
@@ -737,6 +793,7 @@ __device__ void pose_task(
   }
   __syncthreads();
 
+  PP_T(2);
   // ---- refine on the winner's inliers, wavefront 0 ----------------------------------------
   if (wave != 0) return;
   float R[9], t[3];
@@ -755,8 +812,11 @@ __device__ void pose_task(
     n_inl += __popcll(m);
   }
   __builtin_amdgcn_wave_barrier();
+  PP_T(3);
   lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 0, prm.lm_iters_l2, lane);
+  PP_T(4);
   const float err = lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
+  PP_T(5);
   if (lane == 0) {
     float q[4];
     rot_to_quat(R, q);
@@ -843,6 +903,17 @@ __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_co
 }
 
 }  // namespace
+
+#ifdef POSE_PROF
+extern "C" int mh_debug_pose_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pose_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 template <int KIND>
 static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alpha, const int32_t* members,
