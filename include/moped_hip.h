@@ -242,6 +242,30 @@ int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float
  * NULL image switches depth off. */
 int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev,
                              int width, int height, int kind, float alpha, float cauchy_scale);
+/* moped3d's rules on which features and matches reach CLUSTER, applied on the device inside the
+ * frame (they need the depth map: mh_frame_set_depth_image):
+ *  - DEPTHFILTER_CPU (moped3d/libmoped/src/depthfilter/DEPTHFILTER_CPU.hpp:117-254), ToFilter = 1
+ *    on the detected features (`feature_density`, config.hpp: 0.05) and ToFilter = 2 on every
+ *    model's matches (`match_density`, 0.01): density per square metre of scene surface over
+ *    PatchSize x PatchSize pixel patches, dilated 3x3, must exceed Density.  K = the depth map's
+ *    intrinsicLinearCalibration.  A negative density switches that filter off.
+ *  - MATCH_ADAPTIVE_FLANN_CPU's ratio (.../match/MATCH_ADAPTIVE_FLANN_CPU.hpp:193-215,361-376,
+ *    457-467): ratio_table[m] = (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh) of model m as
+ *    its Update() derives them (:144-177; the host plugin MATCH_ADAPTIVE_BRUTE_HIP does);
+ *    features deeper than maximum_depth never match; NULL = mh_frame_params.ratio for all.
+ * Coordinates outside the depth map are clamped to it (the reference reads out of bounds).
+ * rules == NULL switches all of it off. */
+typedef struct mh_depth_rules {
+  int32_t patch_size;
+  float feature_density;
+  float match_density;
+  const float* ratio_table; /* host, [n_models][4]; copied by the call */
+  int32_t n_models;
+  float maximum_depth;      /* 4.0  (MATCH_ADAPTIVE_FLANN_CPU.hpp:107) */
+  float default_depth;      /* 1.0  (:108) */
+  float cauchy_scale;       /* 0.1  (:109) */
+} mh_depth_rules;
+int mh_frame_set_depth_rules(mh_ctx* ctx, const mh_depth_rules* rules, const float K[4]);
 /* The two halves around exchange 1 when the DB is sharded over ranks.
  *   mh_frame_enqueue_match_local : normalise + this shard's top-2 -> top2_dev, a
  *       caller-owned device block of [3][Q] 32-bit words {idx1 (global row, int32),
@@ -258,6 +282,10 @@ int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32
  * matches, clusters, objects after POSE, objects after FILTER. */
 int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
                    int32_t* n_objects, int32_t* counts);
+/* The frame's accepted matches after MATCH (+ the depth rules): query index and model of each,
+ * sorted by (model, query) = the reference's `matches[model]` lists one after the other
+ * (MATCH_ANN_CPU.hpp:165-176).  Synchronises the stream; *n_matches = their number. */
+int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches);
 /* Device address of the frame's packed result block {int32 n; mh_object[cap]}
  * for exchange 2 (gather of per-rank objects); *bytes = its size. */
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);

@@ -66,6 +66,12 @@ DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
 
 # every symbol include/moped_hip.h declares
+class mh_depth_rules(C.Structure):
+    _fields_ = [("patch_size", C.c_int32), ("feature_density", C.c_float), ("match_density", C.c_float),
+                ("ratio_table", C.c_void_p), ("n_models", C.c_int32), ("maximum_depth", C.c_float),
+                ("default_depth", C.c_float), ("cauchy_scale", C.c_float)]
+
+
 EXPORTS = [
     "mh_create", "mh_destroy", "mh_last_error", "mh_set_stream", "mh_synchronize", "mh_reserve",
     "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
@@ -73,6 +79,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
+    "mh_frame_set_depth_rules", "mh_frame_fetch_matches",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
@@ -132,6 +139,8 @@ def load():
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
+    L.mh_frame_set_depth_rules.argtypes = [vp, C.POINTER(mh_depth_rules), vp]
+    L.mh_frame_fetch_matches.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_features_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.mh_frame_keypoints.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mh_models_create.argtypes = [C.POINTER(vp), C.c_char_p]
@@ -424,6 +433,28 @@ class Context:
         c = _cam_struct or make_cam(K, cam)
         self._ck(self.L.mh_frame_enqueue_image(self.h, C.c_void_p(gray_ptr), w, h, int(double_size), max_keypoints,
                                                C.byref(c), C.byref(params), seed), "mh_frame_enqueue_image")
+
+    def frame_set_depth_rules(self, K=None, patch_size=64, feature_density=-1.0, match_density=-1.0, ratio_table=None,
+                              maximum_depth=4.0, default_depth=1.0, cauchy_scale=0.1, off=False):
+        """moped3d's DEPTHFILTER / DEPTHFILTER2 / adaptive ratio inside the frame (needs frame_set_depth_image)."""
+        if off:
+            self._ck(self.L.mh_frame_set_depth_rules(self.h, None, None), "mh_frame_set_depth_rules")
+            return
+        r = mh_depth_rules(patch_size, feature_density, match_density, None, 0, maximum_depth, default_depth, cauchy_scale)
+        tab = None
+        if ratio_table is not None:
+            tab = np.ascontiguousarray(ratio_table, np.float32)
+            r.ratio_table = tab.ctypes.data
+            r.n_models = tab.shape[0]
+        k = np.ascontiguousarray(K if K is not None else [0, 0, 0, 0], np.float32)
+        self._ck(self.L.mh_frame_set_depth_rules(self.h, C.byref(r), _ptr(k)), "mh_frame_set_depth_rules")
+
+    def frame_fetch_matches(self, cap=1 << 16):
+        q = np.zeros(cap, np.int32)
+        m = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_frame_fetch_matches(self.h, _ptr(q), _ptr(m), cap, C.byref(n)), "mh_frame_fetch_matches")
+        return q[:min(n.value, cap)].copy(), m[:min(n.value, cap)].copy()
 
     def frame_features_dev(self):
         d, u, n = C.c_void_p(), C.c_void_p(), C.c_void_p()

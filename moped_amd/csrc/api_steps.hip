@@ -185,6 +185,38 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
 bool graphs_enabled();
 void set_seed(mh_ctx* ctx, uint64_t seed);
 
+// Device buffers of the depth rules: patch map, per-(model, patch) counts (kept zero), keep flags.
+int ensure_rule_buffers(mh_ctx* ctx, int patches, int Q) {
+  mh_ctx::DepthRuleState& rs = ctx->rules;
+  if (patches > 4096) {
+    ctx->err = "depth rules: more than 4096 patches (raise PatchSize)";
+    return MH_ERR_CAPACITY;
+  }
+  if (patches > rs.patches_cap) {
+    if (rs.inv_size) MH_HIP(ctx, hipFree(rs.inv_size));
+    rs.inv_size = nullptr;
+    MH_HIP(ctx, hipMalloc(&rs.inv_size, sizeof(double) * patches));
+    rs.patches_cap = patches;
+  }
+  const size_t need = (size_t)std::max(ctx->n_models, 1) * patches;
+  if (need > rs.cnt_cap) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rs.cnt) MH_HIP(ctx, hipFree(rs.cnt));
+    rs.cnt = nullptr;
+    MH_HIP(ctx, hipMalloc(&rs.cnt, sizeof(int32_t) * need));
+    MH_HIP(ctx, hipMemsetAsync(rs.cnt, 0, sizeof(int32_t) * need, ctx->stream));
+    rs.cnt_cap = need;
+  }
+  if (Q > rs.keep_cap) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rs.keep1) MH_HIP(ctx, hipFree(rs.keep1));
+    rs.keep1 = nullptr;
+    MH_HIP(ctx, hipMalloc(&rs.keep1, (size_t)Q));
+    rs.keep_cap = Q;
+  }
+  return MH_OK;
+}
+
 void stamp(mh_ctx* ctx, int i) {
   if (ctx->timing) hipEventRecord(ctx->ev[i], ctx->stream);
 }
@@ -210,11 +242,38 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     seed_dev = fs->seed_dev;
     seed = 0;
   }
+  // moped3d depth rules: patch maps of this frame's depth image, DEPTHFILTER on the features
+  DepthRules rules;
+  if (ctx->rules.on && ctx->depth_img.img) {
+    mh_ctx::DepthRuleState& rs = ctx->rules;
+    const int pw = (ctx->depth_img.w + rs.patch - 1) / rs.patch, ph = (ctx->depth_img.h + rs.patch - 1) / rs.patch;
+    int rc = ensure_rule_buffers(ctx, pw * ph, Q);
+    if (rc) return rc;
+    const bool filters = rs.feature_filter >= 0.f || rs.match_filter >= 0.f;
+    if (filters) launch_depth_patches(ctx->depth_img, rs.K, rs.patch, rs.inv_size, s);
+    if (rs.feature_filter >= 0.f) {
+      launch_feature_density(q_uv_dev, Q, ctx->feat_count_dev, rs.patch, pw, ph, rs.inv_size, rs.feature_filter,
+                             rs.keep1, s);
+      rules.keep1 = rs.keep1;
+    }
+    if (rs.match_filter >= 0.f) {
+      rules.inv_size = rs.inv_size;
+      rules.cnt = rs.cnt;
+      rules.filter2 = rs.match_filter;
+    }
+    rules.patch = rs.patch;
+    rules.pw = pw;
+    rules.ph = ph;
+    if (rs.ratio_table && rs.table_models >= nm) rules.ratio_table = reinterpret_cast<const float4*>(rs.ratio_table);
+    rules.max_depth = rs.max_depth;
+    rules.default_depth = rs.default_depth;
+    rules.cauchy_scale = rs.cauchy_scale;
+  }
   // MATCH tail: (shard merge,) ratio test + per-model lists; resets the frame's counters
   launch_group(gathered, n_shards, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
-               fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s);
+               fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
@@ -526,6 +585,50 @@ int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const flo
   }
   ctx->depth_kind = depth_xyzn_dev ? kind : MH_DEPTH_NONE;
   ctx->depth_alpha = alpha;
+  return MH_OK;
+}
+
+int mh_frame_set_depth_rules(mh_ctx* ctx, const mh_depth_rules* r, const float K[4]) {
+  if (!ctx) return MH_ERR_ARG;
+  mh_ctx::DepthRuleState& rs = ctx->rules;
+  if (!r) {
+    rs.on = false;
+    return MH_OK;
+  }
+  const bool filters = r->feature_density >= 0.f || r->match_density >= 0.f;
+  if ((filters && (r->patch_size <= 0 || !K)) || (r->ratio_table && (r->n_models <= 0 || !(r->cauchy_scale > 0.f)))) {
+    ctx->err = "mh_frame_set_depth_rules: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  rs.patch = r->patch_size > 0 ? r->patch_size : 64;
+  // `Float filter = Density*100*100` (DEPTHFILTER_CPU.hpp:132)
+  rs.feature_filter = r->feature_density >= 0.f ? r->feature_density * 100 * 100 : -1.f;
+  rs.match_filter = r->match_density >= 0.f ? r->match_density * 100 * 100 : -1.f;
+  for (int i = 0; i < 4; ++i) rs.K[i] = K ? K[i] : 0.f;
+  rs.max_depth = r->maximum_depth;
+  rs.default_depth = r->default_depth;
+  rs.cauchy_scale = r->cauchy_scale;
+  if (r->ratio_table) {
+    if (r->n_models > rs.table_models) {
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (rs.ratio_table) MH_HIP(ctx, hipFree(rs.ratio_table));
+      rs.ratio_table = nullptr;
+      rs.table_models = 0;
+      MH_HIP(ctx, hipMalloc(&rs.ratio_table, sizeof(float) * 4 * r->n_models));
+    }
+    MH_HIP(ctx, hipMemcpyAsync(rs.ratio_table, r->ratio_table, sizeof(float) * 4 * r->n_models, hipMemcpyHostToDevice,
+                               ctx->stream));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host table may go away after the call
+    rs.table_models = r->n_models;
+  } else if (rs.ratio_table) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MH_HIP(ctx, hipFree(rs.ratio_table));
+    rs.ratio_table = nullptr;
+    rs.table_models = 0;
+  }
+  rs.on = true;
   return MH_OK;
 }
 
@@ -853,6 +956,23 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
     ctx->err = "frame: capacity exceeded (flags " + std::to_string(fc.error) + ")";
     return MH_ERR_CAPACITY;
   }
+  return MH_OK;
+}
+
+int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches) {
+  if (!ctx || !ctx->fs || !n_matches || cap < 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  FrameState* fs = ctx->fs;
+  int32_t snap[4] = {0, 0, 0, 0};
+  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_matches = snap[0];
+  const int take = std::min(snap[0], cap);
+  if (take > 0 && query_host)
+    MH_HIP(ctx, hipMemcpy(query_host, fs->m_q, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
+  if (take > 0 && model_host)
+    MH_HIP(ctx, hipMemcpy(model_host, fs->m_model, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
   return MH_OK;
 }
 

@@ -54,6 +54,23 @@ struct mh_ctx {
   float depth_alpha = 0.5f;
   mh::DepthImage depth_img;      // or: the depth map itself, looked up per match on the device (DEPTHMAP_PROP)
 
+  // moped3d depth rules (mh_frame_set_depth_rules): DEPTHFILTER / DEPTHFILTER2 / adaptive ratio
+  struct DepthRuleState {
+    bool on = false;
+    int patch = 64;
+    float feature_filter = -1.f, match_filter = -1.f;   // Density * 100 * 100; < 0 = off
+    float K[4] = {0, 0, 0, 0};
+    float max_depth = 4.f, default_depth = 1.f, cauchy_scale = 0.1f;
+    float* ratio_table = nullptr;   // device [n_models][4] or nullptr
+    int table_models = 0;
+    double* inv_size = nullptr;     // device [patches]
+    int patches_cap = 0;
+    int32_t* cnt = nullptr;         // device [n_models][patches], zero between frames
+    size_t cnt_cap = 0;
+    uint8_t* keep1 = nullptr;       // device [max_q]
+    int keep_cap = 0;
+  } rules;
+
   bool timing = false;
   hipEvent_t ev[10] = {};
   bool ev_made = false;

@@ -16,6 +16,30 @@ __device__ __forceinline__ bool accepted(int32_t idx, float d1, float d2, float 
   return idx >= 0 && (__fdiv_rn(d1, d2) < ratio);
 }
 
+// MATCH_ADAPTIVE_FLANN_CPU::getRatio (moped3d/libmoped/src/match/MATCH_ADAPTIVE_FLANN_CPU.hpp:193-215);
+// cp = (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh) of the model.
+__device__ __forceinline__ float ratio_at(float depth, const float4 cp, float max_depth) {
+  if (depth > max_depth) return 0.f;
+  if (depth < cp.x) {
+    const float progress = __fdiv_rn(depth, cp.x);
+    return __fadd_rn(cp.z, __fmul_rn(progress, __fsub_rn(cp.w, cp.z)));
+  } else if (depth < cp.y) {
+    return cp.w;
+  } else if (depth < __fmul_rn(cp.y, 2.f)) {
+    const float progress = __fdiv_rn(__fsub_rn(__fmul_rn(cp.y, 2.f), depth), cp.y);
+    return __fmul_rn(progress, cp.w);
+  }
+  return 0.f;
+}
+// getAdjustedRatio (:361-376): Cauchy weight of the pixel's fill distance blends the ratio at the
+// measured depth with the ratio at DefaultDepth (double where the reference's literals make it so).
+__device__ __forceinline__ float adjusted_ratio(float depth, float fill, const float4 cp, const DepthRules& R) {
+  const float wt = __fdiv_rn(fill, R.cauchy_scale);
+  const float weight = (float)(1.0 / (1.0 + (double)__fmul_rn(wt, wt)));
+  const float put = ratio_at(depth, cp, R.max_depth), def = ratio_at(R.default_depth, cp, R.max_depth);
+  return (float)((double)__fmul_rn(weight, put) + (1.0 - (double)weight) * (double)def);
+}
+
 __global__ void accept_kernel(const int32_t* __restrict__ idx1, const float* __restrict__ d1,
                               const float* __restrict__ d2, int Q, float ratio,
                               int32_t* __restrict__ out_idx) {
@@ -49,7 +73,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
-    unsigned long long* __restrict__ best) {
+    unsigned long long* __restrict__ best, DepthRules rules) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int base_s;
@@ -86,9 +110,21 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     if (q < Q) {
       const int32_t gi = idx1[q];
       const int32_t li = gi - index_base;
-      if (accepted(gi, d1[q], d2[q], ratio) && li >= 0 && li < N) {
-        ok = true;
+      if (gi >= 0 && li >= 0 && li < N && !(rules.keep1 && !rules.keep1[q])) {
         model = db_model[li];
+        float rq = ratio;
+        bool reachable = true;
+        if (rules.ratio_table) {
+          // the feature's pixel (:447-450; clamped to the map, the reference clamps to [0, width])
+          int x = (int)q_uv[2 * q], y = (int)q_uv[2 * q + 1];
+          x = x < 0 ? 0 : (x >= dimg.w ? dimg.w - 1 : x);
+          y = y < 0 ? 0 : (y >= dimg.h ? dimg.h - 1 : y);
+          const float depth = dimg.img[(size_t)y * dimg.w + x].z;
+          reachable = !(depth > rules.max_depth);   // "Don't even bother searching" (:457-460)
+          const float fill = dimg.fill ? dimg.fill[(size_t)y * dimg.w + x] : 0.f;
+          rq = adjusted_ratio(depth, fill, rules.ratio_table[model], rules);
+        }
+        ok = reachable && accepted(gi, d1[q], d2[q], rq);
       }
     }
     const unsigned long long bal = __ballot(ok);
@@ -112,6 +148,64 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   }
   int M = base_s;
   if (M > max_m) M = max_m;
+
+  // (a') DEPTHFILTER with ToFilter = 2 (moped3d DEPTHFILTER_CPU.hpp:212-249): per model, the
+  // density of its matches over the image patches, dilated, must exceed Density where the
+  // match sits.  Counts per (model, patch) in global scratch (zero before and after).
+  if (rules.inv_size) {
+    const int P = rules.pw * rules.ph;
+    for (int i = tid; i < M; i += GROUP_THREADS) {
+      const int q = acc_q[i];
+      atomicAdd(&rules.cnt[(size_t)acc_model[i] * P + patch_of(q_uv[2 * q], q_uv[2 * q + 1], rules.patch, rules.pw, rules.ph)], 1);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < M; i += GROUP_THREADS) {
+      const int q = acc_q[i];
+      const int32_t* cm = rules.cnt + (size_t)acc_model[i] * P;
+      const int p = patch_of(q_uv[2 * q], q_uv[2 * q + 1], rules.patch, rules.pw, rules.ph);
+      const float v = dilated_by([&](int pp) { return density_replay(cm[pp], rules.inv_size[pp]); }, p, rules.pw, rules.ph);
+      m_rep[i] = v > rules.filter2;   // scratch until (d)
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < M; i += GROUP_THREADS) {
+      const int q = acc_q[i];
+      rules.cnt[(size_t)acc_model[i] * P + patch_of(q_uv[2 * q], q_uv[2 * q + 1], rules.patch, rules.pw, rules.ph)] = 0;
+    }
+    // ordered compaction of the accepted list, in place (destinations never pass the sources)
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += GROUP_THREADS) {
+      const int i = i0 + tid;
+      bool keep = false;
+      int q = 0, model = 0;
+      if (i < M) {
+        q = acc_q[i];
+        model = acc_model[i];
+        keep = m_rep[i] != 0;
+        if (!keep) atomicSub(&hist[model], 1);
+      }
+      const unsigned long long bal = __ballot(keep);
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int before = base_s;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (keep) {
+        acc_q[pos] = q;
+        acc_model[pos] = model;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < GROUP_THREADS / 64; ++w) tot += wave_cnt[w];
+        base_s += tot;
+      }
+      __syncthreads();
+    }
+    M = base_s;
+  }
 
   // (b) exclusive scan of the histogram (single thread: n_models is small)
   if (tid == 0) {
@@ -211,10 +305,11 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
-                  FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s) {
+                  FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
+                  const DepthRules& rules) {
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
-                     m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best);
+                     m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules);
 }
 
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {

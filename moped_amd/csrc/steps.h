@@ -14,6 +14,61 @@ enum : int32_t {
   ERR_POSE_CAP = 8,      // a cluster had more than POSE_MAX_PTS points (truncated)
 };
 
+// ---- moped3d depth rules (depth.hip; applied inside group_kernel) --------------------
+struct DepthRules {
+  // MATCH_ADAPTIVE_FLANN_CPU's ratio: per model (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh)
+  const float4* ratio_table = nullptr;   // nullptr = fixed ratio
+  float max_depth = 4.f, default_depth = 1.f, cauchy_scale = 0.1f;
+  // DEPTHFILTER (features): per query keep flag, nullptr = none
+  const uint8_t* keep1 = nullptr;
+  // DEPTHFILTER2 (matches of each model): nullptr inv_size = none
+  const double* inv_size = nullptr;      // per patch 1.0 / sizeMap
+  int32_t* cnt = nullptr;                // [n_models][pw*ph], zero between frames
+  int patch = 64, pw = 0, ph = 0;
+  float filter2 = 0.f;
+};
+#ifdef __HIPCC__
+// patch of an image coordinate (:187: ((int) location) / PatchSize), clamped to the patch grid
+// (the reference indexes out of bounds for coordinates outside the depth map)
+__device__ __forceinline__ int patch_of(float u, float v, int patch, int pw, int ph) {
+  int px = ((int)u) / patch, py = ((int)v) / patch;
+  px = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+  py = py < 0 ? 0 : (py >= ph ? ph - 1 : py);
+  return py * pw + px;
+}
+// dilate (:76-113): the maximum over the patch and its existing 8 neighbours, of the values before dilation
+template <typename F>
+__device__ __forceinline__ float dilated_by(F&& value_at, int p, int pw, int ph) {
+  const int px = p % pw, py = p / pw;
+  float best = value_at(p);
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yp = py + dy;
+    if (yp < 0 || yp >= ph) continue;
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xp = px + dx;
+      if (xp < 0 || xp >= pw) continue;
+      const float v = value_at(yp * pw + xp);
+      if (v > best) best = v;
+    }
+  }
+  return best;
+}
+__device__ __forceinline__ float dilated(const float* val, int p, int pw, int ph) {
+  return dilated_by([&](int i) { return val[i]; }, p, pw, ph);
+}
+// countMap[p] after n features: n times `countMap[p] += 1.0 / sizeMap[p]` on a Float (:189)
+__device__ __forceinline__ float density_replay(int n, double inv) {
+  float c = 0.f;
+  for (int k = 0; k < n; ++k) c = (float)((double)c + inv);
+  return c;
+}
+#endif
+// Patch maps of the frame's depth image: inv_size[pw*ph] (pw = ceil(w / patch), ...).
+void launch_depth_patches(const DepthImage& dimg, const float K[4], int patch, double* inv_size, hipStream_t s);
+// DEPTHFILTER on the detected features: keep[q] for q < min(Q, *q_count).
+void launch_feature_density(const float* q_uv, int Q, const int32_t* q_count, int patch, int pw, int ph,
+                            const double* inv_size, float filter, uint8_t* keep, hipStream_t s);
+
 // ---- group -------------------------------------------------------------------
 // Ratio test + grouping by model in ascending query order (MATCH_ANN_CPU.hpp:165-176).
 // Rows outside [index_base, index_base+N) belong to another shard and are dropped.
@@ -25,7 +80,8 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
-                  FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s);
+                  FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
+                  const DepthRules& rules = DepthRules());
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);

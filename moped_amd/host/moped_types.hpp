@@ -52,7 +52,28 @@ struct Model {
 };
 typedef shared_ptr<Model> SP_Model;
 
+#ifdef MOPED_AMD_WITH_DEPTH
+// moped3d only (moped3d/libmoped/include/moped.hpp:230): what an Image holds
+enum Image_Type { IMAGE_TYPE_GRAY_IMAGE, IMAGE_TYPE_RGB_IMAGE, IMAGE_TYPE_DEPTH_MAP, IMAGE_TYPE_PROB_MAP };
+#endif
+
 struct Image {
+#ifdef MOPED_AMD_WITH_DEPTH
+  Image_Type imageType;
+  Image() : imageType(IMAGE_TYPE_GRAY_IMAGE) {}
+  // depth map: 4 floats per pixel (x, y, z, norm), getDepth = z; probability / distance map: 1 float
+  // per pixel (moped3d/libmoped/include/moped.hpp:261-284)
+  Float getDepth(int x, int y) const {
+    Float v;
+    std::memcpy(&v, &data[((size_t)y * width + x) * 4 * sizeof(Float) + 2 * sizeof(Float)], sizeof v);
+    return v;
+  }
+  Float getProb(int x, int y) const {
+    Float v;
+    std::memcpy(&v, &data[((size_t)y * width + x) * sizeof(Float)], sizeof v);
+    return v;
+  }
+#endif
   vector<unsigned char> data;
   string name;
   int width, height;

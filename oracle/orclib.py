@@ -568,3 +568,184 @@ def ref_sift(gray, cap=16384):
     d = np.zeros((cap, 128), np.float32)
     n = min(R.ref_sift2(g.ctypes.data, w, h, xy.ctypes.data, so.ctypes.data, d.ctypes.data, cap), cap)
     return xy[:n].copy(), so[:n].copy(), d[:n].copy()
+
+
+# ---- moped3d depth rules: DEPTHFILTER_CPU and MATCH_ADAPTIVE_FLANN_CPU's ratio ----
+# Restated from the source text in numpy with the reference's float / double mix (Float = float,
+# unsuffixed literals = double).  moped3d's step classes need OpenCV headers -> no reference build.
+
+_f = np.float32
+
+
+def _patch_of(uv, patch, pw, ph):
+    """((int) location) / PatchSize (DEPTHFILTER_CPU.hpp:187), clamped to the patch grid."""
+    px = np.clip(uv[:, 0].astype(np.int32) // patch, 0, pw - 1)
+    py = np.clip(uv[:, 1].astype(np.int32) // patch, 0, ph - 1)
+    return py * pw + px
+
+
+def depth_patch_inv_size(depth_img, K, patch):
+    """Per patch 1.0 / sizeMap (double): minDepthMap (DEPTHFILTER_CPU.hpp:146-166, std::min: NaN never
+    wins), getArea at that depth (:50-61, with `y1 = min(.., width)` as written, :170)."""
+    h, w = depth_img.shape[:2]
+    pw, ph = -(-w // patch), -(-h // patch)
+    K = np.asarray(K, _f)
+    z = depth_img[:, :, 2].astype(_f)
+    inv = np.empty(pw * ph, np.float64)
+
+    def pt(u, v, d):
+        return np.array([(_f(u) - K[2]) / K[0] * d, (_f(v) - K[3]) / K[1] * d, d], _f)
+
+    def dist(a, b):
+        r = _f(0)
+        for x in range(3):
+            d = _f(b[x] - a[x])
+            r = _f(r + _f(d * d))
+        return np.sqrt(r, dtype=_f)
+
+    with np.errstate(all="ignore"):
+        for py in range(ph):
+            for px in range(pw):
+                x0, y0, x1 = px * patch, py * patch, min((px + 1) * patch, w)
+                blk = z[y0:min(y0 + patch, h), x0:x1].ravel()
+                blk = blk[~np.isnan(blk)]
+                m = _f(1e10)
+                if len(blk) and blk.min() < m:
+                    m = blk.min()
+                y1 = min((py + 1) * patch, w)
+                c0, c1, c2 = pt(x0, y0, m), pt(x0, y1, m), pt(x1, y0, m)
+                area = _f(dist(c0, c2) * dist(c0, c1))
+                inv[py * pw + px] = np.float64(1.0) / np.float64(area)
+    return inv, pw, ph
+
+
+def _density_replay(n, inv):
+    c = _f(0)
+    for _ in range(int(n)):
+        c = _f(np.float64(c) + inv)      # countMap[..] += 1.0 / sizeMap[..] on a Float (:189)
+    return c
+
+
+def depthfilter_keep(depth_img, K, patch, density, uv, group_off=None):
+    """DEPTHFILTER_CPU::process (:181-249): keep[i] for points uv, filtered per group (ToFilter = 1:
+    one group = all features; ToFilter = 2: one group per model's matches)."""
+    inv, pw, ph = depth_patch_inv_size(depth_img, K, patch)
+    filt = _f(_f(_f(density) * _f(100)) * _f(100))            # Float filter = Density*100*100 (:132)
+    n = len(uv)
+    if group_off is None:
+        group_off = [0, n]
+    keep = np.zeros(n, bool)
+    with np.errstate(all="ignore"):
+        for g in range(len(group_off) - 1):
+            a, b = int(group_off[g]), int(group_off[g + 1])
+            if b <= a:
+                continue
+            p = _patch_of(uv[a:b], patch, pw, ph)
+            cnt = np.bincount(p, minlength=pw * ph)
+            val = np.array([_density_replay(cnt[i], inv[i]) for i in range(pw * ph)], _f).reshape(ph, pw)
+            dil = val.copy()                                  # dilate (:76-113): 3x3 max of the copy
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    ys, yd = slice(max(dy, 0), ph + min(dy, 0)), slice(max(-dy, 0), ph + min(-dy, 0))
+                    xs, xd = slice(max(dx, 0), pw + min(dx, 0)), slice(max(-dx, 0), pw + min(-dx, 0))
+                    src = val[ys, xs]
+                    upd = src > dil[yd, xd]
+                    dil[yd, xd] = np.where(upd, src, dil[yd, xd])
+            keep[a:b] = dil.ravel()[p] > filt
+    return keep
+
+
+def _ratio_at(depth, cp, max_depth):
+    """MATCH_ADAPTIVE_FLANN_CPU::getRatio (moped3d/.../MATCH_ADAPTIVE_FLANN_CPU.hpp:193-215)."""
+    depth = _f(depth)
+    max_rd, min_rd, lo, hi = (_f(x) for x in cp)
+    if depth > _f(max_depth):
+        return _f(0)
+    if depth < max_rd:
+        progress = _f(depth / max_rd)
+        return _f(lo + _f(progress * _f(hi - lo)))
+    if depth < min_rd:
+        return hi
+    if depth < _f(min_rd * _f(2)):
+        progress = _f(_f(_f(min_rd * _f(2)) - depth) / min_rd)
+        return _f(progress * hi)
+    return _f(0)
+
+
+def adaptive_ratio(depth_img, fill_img, uv, model_of_nn, table, max_depth=4.0, default_depth=1.0, cauchy_scale=0.1):
+    """getAdjustedRatio (:361-376) for every query given the model of its nearest neighbour ->
+    (ratio float32 [n], reachable bool [n]: depth <= MaximumDepth, :457-460)."""
+    h, w = depth_img.shape[:2]
+    n = len(uv)
+    ratio = np.zeros(n, _f)
+    reach = np.zeros(n, bool)
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            x = min(max(int(uv[i, 0]), 0), w - 1)
+            y = min(max(int(uv[i, 1]), 0), h - 1)
+            depth = _f(depth_img[y, x, 2])
+            reach[i] = not (depth > _f(max_depth))
+            m = int(model_of_nn[i])
+            if m < 0:
+                continue
+            fill = _f(fill_img[y, x]) if fill_img is not None else _f(0)
+            wt = _f(fill / _f(cauchy_scale))
+            weight = _f(np.float64(1.0) / (np.float64(1.0) + np.float64(_f(wt * wt))))
+            put, dft = _ratio_at(depth, table[m], max_depth), _ratio_at(default_depth, table[m], max_depth)
+            ratio[i] = _f(np.float64(_f(weight * put)) + (np.float64(1.0) - np.float64(weight)) * np.float64(dft))
+    return ratio, reach
+
+
+def adaptive_control_points(bbox_min, bbox_max, K, n_features, min_ratio=(0.6, 0.75), max_ratio=(0.65, 0.8),
+                            dimension_peak=150.0, dimension_fade=50.0):
+    """MATCH_ADAPTIVE_FLANN_CPU::Update's per-model control points (:100-177 with
+    solveProjectionDepth :318-357, getAverageProjectedLength :262-312, getProjectedArea :238-256):
+    -> (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh).  Defaults = moped3d config.hpp:43."""
+    K = [float(_f(k)) for k in K]
+    rng = [float(_f(bbox_max[i]) - _f(bbox_min[i])) for i in range(3)]
+
+    def projected_area(pts):
+        us = [_f(_f(_f(K[0]) * p[0] + _f(K[2]) * p[2]) / p[2]) for p in pts]
+        vs = [_f(_f(_f(K[1]) * p[1] + _f(K[3]) * p[2]) / p[2]) for p in pts]
+        return _f(_f(max(us) - min(us)) * _f(max(vs) - min(vs)))
+
+    def avg_len(depth):
+        xr, yr, zr = (_f(r) for r in rng)
+        mnx, mxx, mny, mxy, mnz, mxz = _f(-xr / 2), _f(xr / 2), _f(-yr / 2), _f(yr / 2), _f(-zr / 2), _f(zr / 2)
+        zc, yc, xc = _f((mxx - mnx) * (mxy - mny)), _f((mxx - mnx) * (mxz - mnz)), _f((mxy - mny) * (mxz - mnz))
+        d = _f(depth)
+        if zc >= xc and zc >= yc:
+            s = [(mnx, mny, d), (mnx, mxy, d), (mxx, mxy, d), (mxx, mny, d)]
+        elif yc >= xc and yc >= zc:
+            s = [(mnx, mnz, d), (mnx, mxz, d), (mxx, mxz, d), (mxx, mnz, d)]
+        else:
+            s = [(mny, mnz, d), (mny, mxz, d), (mxy, mxz, d), (mxy, mnz, d)]
+        return np.sqrt(projected_area(s), dtype=_f)
+
+    def solve(target, iters=100, tol=0.01):
+        left, right, it = _f(0), _f(2), 0
+        target = _f(target)
+        while it < iters:
+            it += 1
+            if avg_len(right) > target:
+                right = _f(right * 2)
+            else:
+                break
+        max_err = _f(target * _f(tol))
+        while it < iters:                      # the reference keeps counting with the same `iter`
+            it += 1
+            mid = _f(_f(left + right) / 2)
+            length = avg_len(mid)
+            if abs(_f(length - target)) < max_err:
+                return mid
+            if length > target:
+                left = mid
+            else:
+                right = mid
+        return _f(_f(left + right) / 2)
+
+    d_peak, d_fade = solve(dimension_peak), solve(dimension_fade)
+    adj = _f(1.0 / (1.0 + np.exp(-1.0 * float(_f((_f(1750) - _f(n_features)) / _f(250))))))   # canonicalSigmoid
+    lo = _f(_f(min_ratio[0]) + adj * _f(_f(min_ratio[1]) - _f(min_ratio[0])))
+    hi = _f(_f(max_ratio[0]) + adj * _f(_f(max_ratio[1]) - _f(max_ratio[0])))
+    return np.array([d_peak, d_fade, lo, hi], _f)
