@@ -277,6 +277,16 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
 int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
                           int n_shards, const mh_cam* cam, const mh_frame_params* prm,
                           uint64_t seed);
+/* The same with the shards' blocks `shard_stride_words` (>= 3 Q) 32-bit words apart in the
+ * gathered buffer: whatever rides behind each [3][Q] block (e.g. the previous frame's result
+ * block, so that exchange 2 needs no collective of its own) is ignored here. */
+int mh_frame_enqueue_rest_strided(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
+                                  int n_shards, int shard_stride_words, const mh_cam* cam,
+                                  const mh_frame_params* prm, uint64_t seed);
+/* Enqueues a device copy of the head of the context's result block {int32 n; int32 pad[3];
+ * mh_object[max_objects]} -- the result of the last frame enqueued on this context, n = 0
+ * before the first -- to dst_dev (16 + 40 max_objects bytes). */
+int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects);
 /* Synchronises the stream and copies the frame's objects out (capacity
  * max_objects); *n_objects = count.  counts (optional, 4 ints): accepted
  * matches, clusters, objects after POSE, objects after FILTER. */

@@ -79,7 +79,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
-    "mh_frame_set_depth_rules", "mh_frame_fetch_matches",
+    "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
@@ -140,6 +140,9 @@ def load():
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
     L.mh_frame_set_depth_rules.argtypes = [vp, C.POINTER(mh_depth_rules), vp]
+    L.mh_frame_enqueue_rest_strided.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(mh_cam),
+                                                C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_result_copy_dev.argtypes = [vp, vp, i32]
     L.mh_frame_fetch_matches.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_features_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.mh_frame_keypoints.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -478,6 +481,16 @@ class Context:
         self._ck(self.L.mh_frame_enqueue_rest(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr),
                                               n_shards, C.byref(c), C.byref(params), seed),
                  "mh_frame_enqueue_rest")
+
+    def frame_enqueue_rest_strided(self, q_uv_ptr, Q, gathered_ptr, n_shards, stride_words, K, cam,
+                                   params: mh_frame_params, seed=1, _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_rest_strided(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
+                                                      stride_words, C.byref(c), C.byref(params), seed),
+                 "mh_frame_enqueue_rest_strided")
+
+    def frame_result_copy_dev(self, dst_ptr, max_objects):
+        self._ck(self.L.mh_frame_result_copy_dev(self.h, C.c_void_p(dst_ptr), max_objects), "mh_frame_result_copy_dev")
 
     def frame_fetch(self, max_objects=4096):
         objs = np.zeros(max_objects, OBJECT_DTYPE)

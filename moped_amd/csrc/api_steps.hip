@@ -121,6 +121,7 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->new_members, max_m);
   fs->result_bytes = 16 + sizeof(mh_object) * (size_t)max_objects;
   rc |= dev_alloc(ctx, fs->result, fs->result_bytes);
+  if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes, ctx->stream));   // "0 objects" before the first frame
   rc |= dev_alloc(ctx, fs->snap, 4);
   rc |= dev_alloc(ctx, fs->seed_dev, 1);
   rc |= dev_alloc(ctx, fs->tickets, 8);
@@ -273,7 +274,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   launch_group(gathered, n_shards, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
-               fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules);
+               fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
+               gathered ? ctx->exchange_stride : 0);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
@@ -956,6 +958,28 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
     ctx->err = "frame: capacity exceeded (flags " + std::to_string(fc.error) + ")";
     return MH_ERR_CAPACITY;
   }
+  return MH_OK;
+}
+
+int mh_frame_enqueue_rest_strided(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
+                                  int n_shards, int shard_stride_words, const mh_cam* cam,
+                                  const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || shard_stride_words < 3 * Q) return MH_ERR_ARG;
+  ctx->exchange_stride = shard_stride_words;
+  const int rc = mh_frame_enqueue_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
+  ctx->exchange_stride = 0;
+  return rc;
+}
+
+int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects) {
+  if (!ctx || !dst_dev || max_objects < 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1);
+  if (rc) return rc;
+  FrameState* fs = ctx->fs;
+  const size_t bytes = std::min(fs->result_bytes, 16 + sizeof(mh_object) * (size_t)max_objects);
+  MH_HIP(ctx, hipMemcpyAsync(dst_dev, fs->result, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return MH_OK;
 }
 

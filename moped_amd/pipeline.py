@@ -65,9 +65,16 @@ class FramePipeline:
             self.streams.append(s)
         self.depth = depth
         self.exchange = force_exchange or self.world > 1
-        self._local = [None] * depth    # [3][Q] send block of exchange 1, per slot
-        self._gather = [None] * depth   # [W][3][Q] receive block
+        self._local = [None] * depth    # send block per slot: [3][Q] words of exchange 1 + the result block riding along
+        self._gather = [None] * depth   # receive block: W of those
+        self._ex_q = [0] * depth
         self._cam = capi.make_cam(self.K, self.cam)
+
+    # Exchange 2 rides on exchange 1: behind its [3][Q] top-2 words every rank sends the result block
+    # of the PREVIOUS frame of the same slot (complete by then: same stream), so one all-gather per
+    # frame carries both exchanges of SURVEY 8(e).  EX2_OBJECTS objects per rank and frame.
+    EX2_OBJECTS = 62
+    EX2_WORDS = (16 + EX2_OBJECTS * capi.OBJECT_DTYPE.itemsize) // 4
 
     # ---- single frame in slot i ------------------------------------------------------
     def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
@@ -83,17 +90,34 @@ class FramePipeline:
         if not self.exchange:
             c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
             return
-        if self._local[slot] is None or self._local[slot].numel() != 3 * Q:
+        stride = 3 * Q + self.EX2_WORDS
+        if self._local[slot] is None or self._ex_q[slot] != Q:
             s.synchronize()   # an earlier frame of this slot may still read the old blocks
-            self._local[slot] = torch.empty(3 * Q, dtype=torch.int32, device=self.dev)
-            self._gather[slot] = torch.empty(self.world * 3 * Q, dtype=torch.int32, device=self.dev)
+            self._local[slot] = torch.zeros(stride, dtype=torch.int32, device=self.dev)
+            self._gather[slot] = torch.zeros(self.world * stride, dtype=torch.int32, device=self.dev)
+            self._ex_q[slot] = Q
         local, gathered = self._local[slot], self._gather[slot]
         with torch.cuda.stream(s):
+            c.frame_result_copy_dev(local.data_ptr() + 12 * Q, self.EX2_OBJECTS)   # exchange 2 of the slot's last frame
             c.frame_enqueue_match_local(q_desc.data_ptr(), Q, local.data_ptr())
-            # exchange 1: every shard's per-query (idx1, d1, d2) -> [W][3][Q], one fused all-gather
+            # exchange 1 (+2): every shard's per-query (idx1, d1, d2) -> [W][3][Q] (+ result blocks), one all-gather
             _all_gather_into(gathered, local, self.group)
-            c.frame_enqueue_rest(q_uv.data_ptr(), Q, gathered.data_ptr(), self.world, self.K, self.cam,
-                                 self.params, seed, _cam_struct=self._cam)
+            c.frame_enqueue_rest_strided(q_uv.data_ptr(), Q, gathered.data_ptr(), self.world, stride, self.K,
+                                         self.cam, self.params, seed, _cam_struct=self._cam)
+
+    def previous_objects(self, slot: int):
+        """Objects of the frame enqueued in `slot` BEFORE the current one, from all ranks, as they
+        arrived with the current frame's exchange (no collective of its own).  Synchronises the slot."""
+        self.streams[slot].synchronize()
+        Q = self._ex_q[slot]
+        stride = 3 * Q + self.EX2_WORDS
+        host = self._gather[slot].view(self.world, stride)[:, 3 * Q:].contiguous().cpu().numpy()
+        objs = []
+        for r in range(self.world):
+            n = min(int(host[r, 0]), self.EX2_OBJECTS)
+            blk = host[r, 4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE)
+            objs.append(blk.copy())
+        return np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE)
 
     def fetch(self, slot: int):
         """Objects of the frame in `slot` (model ids global), counts[4]."""

@@ -33,6 +33,8 @@ def _worker(rank, world, port, out_dir):
     for seed in (0, 1):
         fr = synth.make_frame(db, n_vis=3, seed=seed, Q=Q, pts_per_obj=120)
         pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seed + 5)
+        if seed == 1:
+            res["prev0"] = pipe.previous_objects(0)    # frame 0's objects, carried by frame 1's exchange
         objs = pipe.gather_objects(0)
         local, counts = pipe.fetch(0)
         res[f"objs{seed}"] = objs
@@ -56,6 +58,9 @@ def test_two_ranks_one_gpu_equals_single_context(tmp_path):
     pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=Q)
     dev = torch.device("cuda:0")
     z = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for r in range(world):   # exchange 2 riding on the next frame's exchange 1 == the explicit gather
+        assert np.array_equal(z[r]["prev0"]["model"], z[r]["objs0"]["model"])
+        assert np.array_equal(z[r]["prev0"]["pose"], z[r]["objs0"]["pose"])
     for seed in (0, 1):
         fr = synth.make_frame(db, n_vis=3, seed=seed, Q=Q, pts_per_obj=120)
         pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seed + 5)
@@ -105,6 +110,8 @@ def _rccl_worker(rank, world, port, out_dir):
                 objs, counts = pipe.fetch(i % 2)
                 res[f"{tag}_objs{i - 2}"], res[f"{tag}_counts{i - 2}"] = objs, counts
             pipe.enqueue(i % 2, qd[i], uv[i], seed=i + 5)
+            if force and i >= 2:   # exchange 2 rode along: the slot's previous frame, from all ranks
+                res[f"{tag}_prev{i - 2}"] = pipe.previous_objects(i % 2)
         for i in (2, 3):
             if force and i == 3:
                 res[f"{tag}_gathered"] = pipe.gather_objects(i % 2)
@@ -129,5 +136,8 @@ def test_rccl_exchange_path_world1_equals_direct(tmp_path):
         assert len(a) == len(b) and len(a) >= 3
         assert np.array_equal(a["model"], b["model"])
         assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["score"], b["score"])
+    for i in range(2):   # the objects that rode on the next frame's exchange are the frame's own
+        p = z[f"rccl_prev{i}"]
+        assert np.array_equal(p["model"], z[f"rccl_objs{i}"]["model"]) and np.array_equal(p["pose"], z[f"rccl_objs{i}"]["pose"])
     g = z["rccl_gathered"]
     assert np.array_equal(g["model"], z["rccl_objs3"]["model"]) and np.array_equal(g["pose"], z["rccl_objs3"]["pose"])
