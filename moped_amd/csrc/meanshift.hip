@@ -181,8 +181,12 @@ __device__ __forceinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, 
 #pragma unroll
       for (int u = 0; u < NP; ++u) stv[u] = mem[u] ? 1 : 0;
       if (__ballot(hit) != 0ull) {
-        // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), m[j'] == j (j' != j)
-        for (int round = 0; round < MS_CAP; ++round) {
+        // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), m[j'] == j (j' != j).  The sweep above
+        // (every member flags its pointer) was its first round.
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+          if (mem[u] && fl[u] == stamp) stv[u] = 2;
+        for (int round = 1; round < MS_CAP; ++round) {
           ++stamp;
 #pragma unroll
           for (int u = 0; u < NP; ++u)
@@ -406,6 +410,7 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
         if (wave == 0) {
           if (n <= 64 * 2) walk_block_regs<ND, 2>(L, i0, nrem, ne, lane, stamp);
           else if (n <= 64 * 4) walk_block_regs<ND, 4>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 6) walk_block_regs<ND, 6>(L, i0, nrem, ne, lane, stamp);
           else walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
         }
       } else if (wave == 0) {
