@@ -266,6 +266,30 @@ typedef struct mh_depth_rules {
   float cauchy_scale;       /* 0.1  (:109) */
 } mh_depth_rules;
 int mh_frame_set_depth_rules(mh_ctx* ctx, const mh_depth_rules* rules, const float K[4]);
+/* moped3d's default clusterer instead of mean shift: CLUSTER_LINKAGE_CPU
+ * (moped3d/libmoped/src/cluster/CLUSTER_LINKAGE_CPU.hpp:573-704) as config.hpp:45 constructs it --
+ * per model a similarity matrix over its matches (Gaussian kernels on image / camera-frame
+ * distances with sigma = average nearest-neighbour distance, depth-discontinuity kernel along the
+ * image line between two matches, model/world distance-consistency kernel, fill-distance weighted
+ * sum) and average-linkage agglomeration down to `cutoff`.  Needs the depth map
+ * (mh_frame_set_depth_image); at most 1024 matches per model.  LinkageType 1 (average) only. */
+typedef struct mh_linkage_params {
+  float cutoff;         /* 0.1 */
+  int32_t min_pts;      /* 7: clusters need MORE than this many members (:535) */
+  int32_t use3d_filter; /* 2: multiply (1: add, 0: skip) the distance-consistency kernel */
+  float sigma2d;        /* -1: average nearest-neighbour distance */
+  float sigma3d;        /* -1 */
+} mh_linkage_params;
+/* CLUSTER of the following frames: linkage with *prm, or mean shift again when prm == NULL. */
+int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm);
+/* The step on its own, n_problems point sets (one per model) in one call: corr_host / depth_host
+ * = the matches (image point + model point / camera-frame point from the depth map), problem p =
+ * rows [off[p], off[p+1]).  label[i] = cluster of row i within its problem or -1; order (optional)
+ * = rows of each problem's clusters in the reference's member order, problem-local, -1 padded;
+ * n_clusters[p].  Uses the depth map set by mh_frame_set_depth_image. */
+int mh_cluster_linkage(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host, const int32_t* off,
+                       int n_problems, const mh_linkage_params* prm, int32_t* label, int32_t* order,
+                       int32_t* n_clusters);
 /* The two halves around exchange 1 when the DB is sharded over ranks.
  *   mh_frame_enqueue_match_local : normalise + this shard's top-2 -> top2_dev, a
  *       caller-owned device block of [3][Q] 32-bit words {idx1 (global row, int32),

@@ -66,6 +66,16 @@ DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
 
 # every symbol include/moped_hip.h declares
+class mh_linkage_params(C.Structure):
+    _fields_ = [("cutoff", C.c_float), ("min_pts", C.c_int32), ("use3d_filter", C.c_int32), ("sigma2d", C.c_float),
+                ("sigma3d", C.c_float)]
+
+
+def default_linkage_params():
+    """CLUSTER_LINKAGE_CPU( 0.1, 7, 2, 1, 0.0, 1, -1, -1 ) (moped3d/libmoped/src/config.hpp:45)."""
+    return mh_linkage_params(0.1, 7, 2, -1.0, -1.0)
+
+
 class mh_depth_rules(C.Structure):
     _fields_ = [("patch_size", C.c_int32), ("feature_density", C.c_float), ("match_density", C.c_float),
                 ("ratio_table", C.c_void_p), ("n_models", C.c_int32), ("maximum_depth", C.c_float),
@@ -79,6 +89,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
+    "mh_frame_set_cluster_linkage", "mh_cluster_linkage",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
@@ -139,6 +150,8 @@ def load():
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
+    L.mh_frame_set_cluster_linkage.argtypes = [vp, C.POINTER(mh_linkage_params)]
+    L.mh_cluster_linkage.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_linkage_params), vp, vp, vp]
     L.mh_frame_set_depth_rules.argtypes = [vp, C.POINTER(mh_depth_rules), vp]
     L.mh_frame_enqueue_rest_strided.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(mh_cam),
                                                 C.POINTER(mh_frame_params), C.c_uint64]
@@ -436,6 +449,42 @@ class Context:
         c = _cam_struct or make_cam(K, cam)
         self._ck(self.L.mh_frame_enqueue_image(self.h, C.c_void_p(gray_ptr), w, h, int(double_size), max_keypoints,
                                                C.byref(c), C.byref(params), seed), "mh_frame_enqueue_image")
+
+    def frame_set_cluster_linkage(self, params: "mh_linkage_params | None"):
+        """CLUSTER of the next frames: moped3d's linkage clusterer (None: mean shift again)."""
+        self._ck(self.L.mh_frame_set_cluster_linkage(self.h, C.byref(params) if params is not None else None),
+                 "mh_frame_set_cluster_linkage")
+
+    def cluster_linkage(self, problems, params=None):
+        """problems: list of (uv [n,2], model_xyz [n,3], world_xyz [n,3]) -> list of (clusters, label);
+        the depth map must have been set with frame_set_depth_image."""
+        prm = params or default_linkage_params()
+        sizes = [len(p[0]) for p in problems]
+        off = np.zeros(len(problems) + 1, np.int32)
+        off[1:] = np.cumsum(sizes)
+        total = int(off[-1])
+        if total:
+            corr = np.concatenate([pack_corr(np.asarray(p[0], np.float32), np.asarray(p[1], np.float32)) for p in problems if len(p[0])])
+            dep = np.concatenate([pack_depth(np.asarray(p[2], np.float32), np.ones(len(p[2]), np.float32)) for p in problems if len(p[0])])
+        else:
+            corr, dep = np.zeros(0, CORR_DTYPE), pack_depth(np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+        corr, dep = np.ascontiguousarray(corr), np.ascontiguousarray(dep)
+        label = np.full(max(total, 1), -1, np.int32)
+        order = np.full(max(total, 1), -1, np.int32)
+        ncl = np.zeros(max(len(problems), 1), np.int32)
+        self._ck(self.L.mh_cluster_linkage(self.h, _ptr(corr), _ptr(dep), _ptr(off), len(problems), C.byref(prm),
+                                           _ptr(label), _ptr(order), _ptr(ncl)), "mh_cluster_linkage")
+        out = []
+        for i in range(len(problems)):
+            b, e = int(off[i]), int(off[i + 1])
+            lab, ordr = label[b:e], order[b:e]
+            clusters, pos = [], 0
+            for c in range(int(ncl[i])):
+                sz = int((lab == c).sum())
+                clusters.append(ordr[pos:pos + sz].copy())
+                pos += sz
+            out.append((clusters, lab.copy()))
+        return out
 
     def frame_set_depth_rules(self, K=None, patch_size=64, feature_density=-1.0, match_density=-1.0, ratio_table=None,
                               maximum_depth=4.0, default_depth=1.0, cauchy_scale=0.1, off=False):

@@ -186,6 +186,17 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
 bool graphs_enabled();
 void set_seed(mh_ctx* ctx, uint64_t seed);
 
+int ensure_linkage_scratch(mh_ctx* ctx, size_t floats) {
+  if (floats <= ctx->lk_scratch_floats) return MH_OK;
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->lk_scratch) MH_HIP(ctx, hipFree(ctx->lk_scratch));
+  ctx->lk_scratch = nullptr;
+  ctx->lk_scratch_floats = 0;
+  MH_HIP(ctx, hipMalloc(&ctx->lk_scratch, floats * sizeof(float)));
+  ctx->lk_scratch_floats = floats;
+  return MH_OK;
+}
+
 // Device buffers of the depth rules: patch map, per-(model, patch) counts (kept zero), keep flags.
 int ensure_rule_buffers(mh_ctx* ctx, int patches, int Q) {
   mh_ctx::DepthRuleState& rs = ctx->rules;
@@ -278,6 +289,17 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                gathered ? ctx->exchange_stride : 0);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
+  const bool have_depth = ctx->q_depth || ctx->depth_img.img;
+  if (ctx->linkage_on && have_depth && ctx->depth_img.img) {
+    // moped3d: linkage over similarity matrices; 3 n^2 floats of scratch per model, n <= LK_CAP
+    const size_t need = 3 * (size_t)std::min(fs->max_m, LK_CAP) * (size_t)fs->max_m;
+    int rc = ensure_linkage_scratch(ctx, need);
+    if (rc) return rc;
+    launch_linkage_models(fs->m_corr, reinterpret_cast<const float*>(fs->m_depth), fs->model_off, nm, ctx->depth_img,
+                          ctx->linkage, ctx->lk_scratch, ctx->lk_scratch_floats, fs->ms_members, fs->ms_cl_start,
+                          fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
+                          fs->snap, fs->counts, fs->tickets + 0, s);
+  } else
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
@@ -587,6 +609,106 @@ int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const flo
   }
   ctx->depth_kind = depth_xyzn_dev ? kind : MH_DEPTH_NONE;
   ctx->depth_alpha = alpha;
+  return MH_OK;
+}
+
+int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {
+  if (!ctx) return MH_ERR_ARG;
+  ctx->linkage_on = prm != nullptr;
+  if (prm) {
+    ctx->linkage.cutoff = prm->cutoff;
+    ctx->linkage.min_pts = prm->min_pts;
+    ctx->linkage.use3d_filter = prm->use3d_filter;
+    ctx->linkage.sigma2d = prm->sigma2d;
+    ctx->linkage.sigma3d = prm->sigma3d;
+  }
+  return MH_OK;
+}
+
+int mh_cluster_linkage(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host, const int32_t* off,
+                       int n_problems, const mh_linkage_params* prm, int32_t* label, int32_t* order,
+                       int32_t* n_clusters) {
+  if (!ctx || n_problems < 0 || !prm || (n_problems > 0 && (!off || !n_clusters))) {
+    if (ctx) ctx->err = "mh_cluster_linkage: bad argument";
+    return MH_ERR_ARG;
+  }
+  if (n_problems == 0) return MH_OK;
+  if (!ctx->depth_img.img) {
+    ctx->err = "mh_cluster_linkage: no depth map (mh_frame_set_depth_image)";
+    return MH_ERR_ARG;
+  }
+  const int total = off[n_problems];
+  size_t need = 0;
+  for (int p = 0; p < n_problems; ++p) {
+    n_clusters[p] = 0;
+    const int n = off[p + 1] - off[p];
+    if (n < 0 || off[0] != 0) {
+      ctx->err = "mh_cluster_linkage: offsets must start at 0 and not decrease";
+      return MH_ERR_ARG;
+    }
+    if (n > LK_CAP) {
+      ctx->err = "mh_cluster_linkage: more than 1024 points in one problem";
+      return MH_ERR_CAPACITY;
+    }
+    need += 3 * (size_t)n * n;
+  }
+  if (total == 0) return MH_OK;
+  if (!corr_host || !depth_host || !label) {
+    ctx->err = "mh_cluster_linkage: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = ensure_linkage_scratch(ctx, need);
+  if (rc) return rc;
+  // device layout: corr | depth | off | members | label | cl_start (total + n_problems + 1) | ncl
+  const size_t b_corr = ((size_t)total * sizeof(mh_corr) + 15) & ~(size_t)15;
+  const size_t b_depth = (size_t)total * sizeof(mh_depth);
+  const size_t n_off = (size_t)n_problems + 1, n_start = (size_t)total + n_problems + 1;
+  const size_t ints = n_off + 2 * (size_t)total + n_start + n_problems;
+  if ((rc = ensure_scratch(ctx, b_corr + b_depth + ints * sizeof(int32_t) + 64))) return rc;
+  if ((rc = ensure_pinned(ctx, (2 * (size_t)total + n_start + n_problems) * sizeof(int32_t)))) return rc;
+  unsigned char* base = (unsigned char*)ctx->scratch;
+  mh_corr* d_corr = (mh_corr*)base;
+  float* d_depth = (float*)(base + b_corr);
+  int32_t* d_off = (int32_t*)(base + b_corr + b_depth);
+  int32_t* d_members = d_off + n_off;
+  int32_t* d_label = d_members + total;
+  int32_t* d_start = d_label + total;
+  int32_t* d_ncl = d_start + n_start;
+  hipStream_t s = ctx->stream;
+  MH_HIP(ctx, hipMemcpyAsync(d_corr, corr_host, (size_t)total * sizeof(mh_corr), hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(d_depth, depth_host, b_depth, hipMemcpyHostToDevice, s));
+  MH_HIP(ctx, hipMemcpyAsync(d_off, off, n_off * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  LinkageParams lp;
+  lp.cutoff = prm->cutoff;
+  lp.min_pts = prm->min_pts;
+  lp.use3d_filter = prm->use3d_filter;
+  lp.sigma2d = prm->sigma2d;
+  lp.sigma3d = prm->sigma3d;
+  launch_linkage_batch(d_corr, d_depth, d_off, n_problems, ctx->depth_img, lp, ctx->lk_scratch, ctx->lk_scratch_floats,
+                       d_members, d_start, d_ncl, d_label, s);
+  MH_HIP(ctx, hipGetLastError());
+  int32_t* hbuf = (int32_t*)ctx->pinned;
+  MH_HIP(ctx, hipMemcpyAsync(hbuf, d_members, (2 * (size_t)total + n_start + n_problems) * sizeof(int32_t),
+                             hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  const int32_t* h_members = hbuf;
+  const int32_t* h_label = hbuf + total;
+  const int32_t* h_start = h_label + total;
+  const int32_t* h_ncl = h_start + n_start;
+  for (int p = 0; p < n_problems; ++p) {
+    const int b = off[p], n = off[p + 1] - b;
+    n_clusters[p] = n > 0 ? h_ncl[p] : 0;
+    for (int i = 0; i < n; ++i) label[b + i] = h_label[b + i];
+    if (order) {
+      for (int i = 0; i < n; ++i) order[b + i] = -1;
+      if (n > 0) {
+        const int kept = h_start[b + p + h_ncl[p]];
+        for (int i = 0; i < kept; ++i) order[b + i] = h_members[b + i];
+      }
+    }
+  }
   return MH_OK;
 }
 

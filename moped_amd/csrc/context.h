@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.h"
+#include "steps.h"
 
 struct mh_ctx {
   int device = 0;
@@ -71,6 +72,12 @@ struct mh_ctx {
     uint8_t* keep1 = nullptr;       // device [max_q]
     int keep_cap = 0;
   } rules;
+
+  // moped3d CLUSTER_LINKAGE instead of mean shift (mh_frame_set_cluster_linkage)
+  bool linkage_on = false;
+  mh::LinkageParams linkage;
+  float* lk_scratch = nullptr;
+  size_t lk_scratch_floats = 0;
 
   bool timing = false;
   hipEvent_t ev[10] = {};

@@ -105,6 +105,25 @@ void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems
                             float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                             int32_t* ncl, int32_t* label, hipStream_t s);
 
+// ---- linkage (moped3d CLUSTER_LINKAGE_CPU; linkage.hip) -----------------------------------
+constexpr int LK_CAP = 1024;   // matches of one model
+struct LinkageParams {         // the constructor arguments used (config.hpp:45); average linkage only
+  float cutoff = 0.1f;
+  int min_pts = 7;             // clusters need MORE than this many members
+  int use3d_filter = 2;        // 0 none, 1 add, 2 multiply the model/world distance-consistency kernel
+  float sigma2d = -1.f, sigma3d = -1.f;   // -1: average nearest-neighbour distance
+};
+// Floats of scratch the models kernel needs for match lists of the given sizes: 3 n^2 each.
+// depth4: per match (wx, wy, wz, weight) aligned with corr.  Outputs as launch_meanshift_models.
+void launch_linkage_models(const mh_corr* corr, const float* depth4, const int32_t* model_off, int n_models,
+                           const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
+                           int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
+                           int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
+                           FrameCounts* counts, unsigned int* ticket, hipStream_t s);
+void launch_linkage_batch(const mh_corr* corr, const float* depth4, const int32_t* off, int n_problems,
+                          const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
+                          int32_t* members, int32_t* cl_start, int32_t* ncl, int32_t* label, hipStream_t s);
+
 // ---- pose ----------------------------------------------------------------------
 struct DevCam {
   float K[4];

