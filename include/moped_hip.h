@@ -242,6 +242,10 @@ int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float
  * NULL image switches depth off. */
 int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev,
                              int width, int height, int kind, float alpha, float cauchy_scale);
+/* The same for hosts that hold the maps in host memory (the STEP plugins): copies them into
+ * context-owned device buffers (4.9 MB + 1.2 MB for 640x480) and sets them. */
+int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, const float* fill_distance_host,
+                                  int width, int height, int kind, float alpha, float cauchy_scale);
 /* moped3d's rules on which features and matches reach CLUSTER, applied on the device inside the
  * frame (they need the depth map: mh_frame_set_depth_image):
  *  - DEPTHFILTER_CPU (moped3d/libmoped/src/depthfilter/DEPTHFILTER_CPU.hpp:117-254), ToFilter = 1

@@ -89,7 +89,7 @@ EXPORTS = [
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
-    "mh_frame_set_cluster_linkage", "mh_cluster_linkage",
+    "mh_frame_set_cluster_linkage", "mh_cluster_linkage", "mh_frame_set_depth_image_host",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
@@ -150,6 +150,7 @@ def load():
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
+    L.mh_frame_set_depth_image_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32]
     L.mh_frame_set_cluster_linkage.argtypes = [vp, C.POINTER(mh_linkage_params)]
     L.mh_cluster_linkage.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_linkage_params), vp, vp, vp]
     L.mh_frame_set_depth_rules.argtypes = [vp, C.POINTER(mh_depth_rules), vp]

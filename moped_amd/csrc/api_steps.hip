@@ -612,6 +612,32 @@ int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const flo
   return MH_OK;
 }
 
+int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, const float* fill_distance_host,
+                                  int width, int height, int kind, float alpha, float cauchy_scale) {
+  if (!ctx) return MH_ERR_ARG;
+  if (!depth_xyzn_host) return mh_frame_set_depth_image(ctx, nullptr, nullptr, 0, 0, 0, alpha, cauchy_scale);
+  if (width <= 0 || height <= 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  const size_t px = (size_t)width * height;
+  if (px > ctx->own_depth_px) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_depth) MH_HIP(ctx, hipFree(ctx->own_depth));
+    if (ctx->own_fill) MH_HIP(ctx, hipFree(ctx->own_fill));
+    ctx->own_depth = ctx->own_fill = nullptr;
+    ctx->own_depth_px = 0;
+    MH_HIP(ctx, hipMalloc(&ctx->own_depth, px * 4 * sizeof(float)));
+    MH_HIP(ctx, hipMalloc(&ctx->own_fill, px * sizeof(float)));
+    ctx->own_depth_px = px;
+  }
+  MH_HIP(ctx, hipMemcpyAsync(ctx->own_depth, depth_xyzn_host, px * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (fill_distance_host)
+    MH_HIP(ctx, hipMemcpyAsync(ctx->own_fill, fill_distance_host, px * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host maps may change after the call
+  return mh_frame_set_depth_image(ctx, ctx->own_depth, fill_distance_host ? ctx->own_fill : nullptr, width, height, kind,
+                                  alpha, cauchy_scale);
+}
+
 int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {
   if (!ctx) return MH_ERR_ARG;
   ctx->linkage_on = prm != nullptr;

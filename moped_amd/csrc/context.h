@@ -76,6 +76,9 @@ struct mh_ctx {
   // moped3d CLUSTER_LINKAGE instead of mean shift (mh_frame_set_cluster_linkage)
   bool linkage_on = false;
   mh::LinkageParams linkage;
+  float* own_depth = nullptr;     // device copies of a host depth / distance map (mh_frame_set_depth_image_host)
+  float* own_fill = nullptr;
+  size_t own_depth_px = 0;
   float* lk_scratch = nullptr;
   size_t lk_scratch_floats = 0;
 

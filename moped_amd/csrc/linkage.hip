@@ -22,6 +22,7 @@ namespace mh {
 namespace {
 
 constexpr int LK_THREADS = 1024;
+constexpr int LK_DLDS = 160;   // up to this many matches the clustering's similarity matrix stays in LDS
 
 struct LkLds {
   float uv[LK_CAP][2];
@@ -35,6 +36,7 @@ struct LkLds {
   float sigma2, sigma3, maxv;
   float best_v;
   int best_a, best_b;
+  float dmat[LK_DLDS * LK_DLDS];
 };
 
 __device__ __forceinline__ float sq_dist(const float* a, const float* b, int n) {   // Pt::sqEuclDist: d = pt - this
@@ -127,7 +129,7 @@ __device__ float wg_max(LkLds& L, float v) {
 
 __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const float4* __restrict__ depth4, int n,
                              const DepthImage& D, const LinkageParams& P, float* __restrict__ A,
-                             float* __restrict__ Dm, int32_t* __restrict__ mem, int32_t* __restrict__ members_out,
+                             float* Dm, int32_t* __restrict__ mem, int32_t* __restrict__ members_out,
                              int32_t member_base, int32_t* __restrict__ cl_start_out, int32_t* __restrict__ ncl_out,
                              int32_t* __restrict__ label_out) {
   const int tid = threadIdx.x;
@@ -248,6 +250,11 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
   }
   __threadfence_block();
   __syncthreads();
+  if (N <= LK_DLDS) {   // the agglomeration re-reads the matrix once per merge: keep it in LDS when it fits
+    for (int e = tid; e < N * N; e += LK_THREADS) L.dmat[e] = Dm[e];
+    Dm = L.dmat;
+    __syncthreads();
+  }
   // ---- hierarchicalCluster (:416-540) ----
   int removeValue = -1;
   for (int iter = 0; iter < 2 * N + 2; ++iter) {
@@ -263,12 +270,13 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
     const bool rv_listed = removeValue >= 0 && L.inlist[removeValue];
     float bv = -1.f;
     int ba = 0x7fffffff, bb = 0x7fffffff;
-    for (int a = tid; a < N; a += LK_THREADS) {
+    // one wavefront per row, lanes along it: every lane sees its candidates in scan order, so its
+    // running first-maximum is exact; the cross-lane reduction below breaks ties the same way
+    for (int a = (tid >> 6); a < N; a += LK_THREADS / 64) {
       if (!L.inlist[a] || a == removeValue || a == skip) continue;
       const float* row = Dm + (size_t)a * N;
-      for (int b = a + 1; b < N; ++b) {
-        if (!L.inlist[b]) continue;
-        if (b == removeValue && !(rv_listed && a < removeValue)) continue;   // (always a < b here; kept for clarity)
+      for (int b = a + 1 + (tid & 63); b < N; b += 64) {
+        if (!L.inlist[b]) continue;   // (the removed cluster is still listed in the scan right after its merge)
         const float v = row[b];
         if (v > bv) {
           bv = v;
