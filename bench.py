@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--n-vis", type=int, default=2)
     ap.add_argument("--depth-kind", type=int, default=0,
                     help="0 = moped2 residuals; 1/2 = moped3d back-projection / reprojection+depth (config 5)")
+    ap.add_argument("--moped3d-frontend", action="store_true",
+                    help="with --depth-kind: the frame takes the depth map itself and runs moped3d's shipped front end on "
+                         "the device (DEPTHFILTER, depth-adaptive ratio, DEPTHFILTER2, DEPTHMAP_PROP, CLUSTER_LINKAGE; "
+                         "moped3d/libmoped/src/config.hpp:41-45) instead of per-query depth attributes + mean shift")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,7 +149,21 @@ def main():
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
     work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
     depths = None
-    if args.depth_kind:
+    maps = None
+    if args.depth_kind and args.moped3d_frontend:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orclib   # only for the per-model ratio control points (host-side model metadata, outside the timed region)
+        maps = []
+        for i, f in enumerate(frames):
+            img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
+            maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
+        table = np.stack([orclib.adaptive_control_points(db.xyz[db.model_of == m].min(0), db.xyz[db.model_of == m].max(0),
+                                                         synth.K_DEFAULT, int((db.model_of == m).sum()))
+                          for m in range(db.n_models)])
+        for c in pipe.ctxs:
+            c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
+            c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45
+    elif args.depth_kind:
         depths = []
         for i, f in enumerate(frames):
             wpts, fill = synth.frame_depth(db, f, seed=i)
@@ -163,6 +181,9 @@ def main():
                 work[slot].copy_(pristine[b], non_blocking=True)   # restore raw descriptors (normalise is in place)
             if depths is not None:
                 pipe.ctxs[slot].frame_set_depth(depths[b].data_ptr(), args.depth_kind, 0.5)
+            if maps is not None:
+                pipe.ctxs[slot].frame_set_depth_image(maps[b][0].data_ptr(), maps[b][1].data_ptr(), 640, 480,
+                                                      args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
             pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + b + 1)
             if record and world == 1:
                 ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
@@ -207,7 +228,9 @@ def main():
         "config": {"workload": f"{args.models}-model DB ({db.n} descriptors), 640x480 frames, "
                                f"{Q} SIFT-like keypoints, {args.n_vis} planted objects, "
                                f"1024 P3P hypotheses x 4 replicas per cluster, MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2"
-                               + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}"),
+                               + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}")
+                               + ("" if not (args.depth_kind and args.moped3d_frontend) else
+                                  ", moped3d front end on the device (DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
                    "frames_per_step": n_frames, "frames_in_flight": args.depth,
                    "parallelism": f"model-shard x{world}" if world > 1 else "single GPU",
                    "objects_per_frame": det_per_frame},

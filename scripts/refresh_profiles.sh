@@ -8,6 +8,7 @@ cd $root
 timeout -k 10 300 python bench.py > $out/r01_bench_20models.json 2>$out/bench20.err || exit 1
 timeout -k 10 400 python bench.py --models 200 --steps 6 --warmup 2 > $out/r01_bench_200models.json 2>$out/bench200.err || exit 1
 timeout -k 10 300 python bench.py --models 50 --depth-kind 1 > $out/r01_bench_50models_depth.json 2>$out/bench50.err || exit 1
+timeout -k 10 300 python bench.py --models 50 --depth-kind 1 --moped3d-frontend > $out/r01_bench_50models_moped3d_frontend.json 2>$out/bench50f.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp20 -- python3 $root/bench.py --no-cpu-baseline > $out/r01_bench_20models_under_rocprof.json 2>/tmp/rp20.err || { tail /tmp/rp20.err; exit 1; }
 cp $(find /tmp/rp20 -name "*kernel_stats.csv" | head -1) $out/r01_bench_20models_kernel_stats.csv
@@ -25,6 +26,7 @@ python scripts/ms_bench.py > $out/r01_meanshift_bench.txt 2>&1
 python scripts/sift_probe.py > $out/r01_sift_probe.txt 2>&1
 python scripts/image_frame_bench.py 20 4 > $out/r01_image_frame_bench.txt 2>&1
 python scripts/host_step_timing.py > $out/r01_host_step_timing.txt 2>&1
+python scripts/linkage_bench.py > $out/r01_linkage_bench.txt 2>&1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpsift -- python3 $root/scripts/sift_probe.py > /tmp/rpsift.log 2>&1 && cp $(find /tmp/rpsift -name "*kernel_stats.csv" | head -1) $out/r01_sift_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpimg -- python3 $root/scripts/image_frame_bench.py 20 4 > /tmp/rpimg.log 2>&1 && cp $(find /tmp/rpimg -name "*kernel_stats.csv" | head -1) $out/r01_image_frame_kernel_stats.csv
