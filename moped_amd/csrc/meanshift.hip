@@ -138,7 +138,7 @@ __device__ __forceinline__ void fold_target(MsLds<ND>& L, int t, int lane) {
 // Rows with outward members use LDS stamps for the cross-lane parts (flag: targets of
 // members; st: positions written indirectly).
 template <int ND, int NP>
-__device__ __forceinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane,
+__device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane,
                                                 int& stamp) {
   int mpr[NP];
 #pragma unroll
@@ -406,12 +406,14 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
             m &= ~(1ull << r);
           }
         }
-      } else if (n <= 64 * 8) {
+      } else if (n <= 64 * 16) {
         if (wave == 0) {
           if (n <= 64 * 2) walk_block_regs<ND, 2>(L, i0, nrem, ne, lane, stamp);
           else if (n <= 64 * 4) walk_block_regs<ND, 4>(L, i0, nrem, ne, lane, stamp);
           else if (n <= 64 * 6) walk_block_regs<ND, 6>(L, i0, nrem, ne, lane, stamp);
-          else walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 8) walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 12) walk_block_regs<ND, 12>(L, i0, nrem, ne, lane, stamp);
+          else walk_block_regs<ND, 16>(L, i0, nrem, ne, lane, stamp);
         }
       } else if (wave == 0) {
         unsigned long long tb = lane < MS_WORDS ? L.tbw[lane] : 0ull;   // lane ps: target bits of positions [64 ps, 64 ps + 64)
