@@ -116,6 +116,68 @@ __global__ void half_kernel(const float* __restrict__ src, int scols, float* __r
   dst[(size_t)r * cols + c] = src[(size_t)(2 * r) * scols + 2 * c];
 }
 
+// The small octaves (<= SMALL_OCTAVE_PX pixels: 80x60 and below for a 640x480 frame) cost more in
+// launches than in arithmetic: one workgroup runs the whole rest of the blur chain -- every level of
+// every remaining octave and the subsampling between them -- out of LDS, with the same per-pixel
+// loops (taps in ascending order, replicated edges).
+constexpr int SMALL_OCTAVE_PX = 80 * 60;
+struct Taps5 {
+  Taps t[kScales + 2];
+};
+__global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int o_first, Taps5 T) {
+  __shared__ float cur[SMALL_OCTAVE_PX];   // image i - 1 of the octave
+  __shared__ float tmp[SMALL_OCTAVE_PX];   // its row-blurred version
+  const int tid = threadIdx.x;
+  for (int o = o_first; o < P.n_octaves; ++o) {
+    const SiftOctave& O = P.oct[o];
+    const int rows = O.rows, cols = O.cols, px = rows * cols;
+    if (o > o_first) {   // HalfImageSize (:390-408) of the previous octave's image `kScales`
+      const SiftOctave& V = P.oct[o - 1];
+      const float* src = V.gaus[kScales];
+      float* dst = O.gaus[0];
+      for (int e = tid; e < px; e += 1024) {
+        const float v = src[(size_t)(2 * (e / cols)) * V.cols + 2 * (e % cols)];
+        dst[e] = v;
+        cur[e] = v;
+      }
+    } else {
+      for (int e = tid; e < px; e += 1024) cur[e] = O.gaus[0][e];
+    }
+    __syncthreads();
+    for (int i = 1; i < kScales + 3; ++i) {
+      const Taps& t = T.t[i - 1];
+      const int w = t.n >> 1;
+      for (int e = tid; e < px; e += 1024) {
+        const int r = e / cols, c = e - r * cols;
+        const float* row = cur + r * cols;
+        float a = 0.f;
+        for (int j = 0; j < t.n; ++j) {
+          int x = c + j - w;
+          x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
+          a = __fadd_rn(a, __fmul_rn(row[x], t.k[j]));
+        }
+        tmp[e] = a;
+      }
+      __syncthreads();
+      float* dst = O.gaus[i];
+      float* dog = O.dog[i - 1];
+      for (int e = tid; e < px; e += 1024) {
+        const int r = e / cols, c = e - r * cols;
+        float a = 0.f;
+        for (int j = 0; j < t.n; ++j) {
+          int y = r + j - w;
+          y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
+          a = __fadd_rn(a, __fmul_rn(tmp[y * cols + c], t.k[j]));
+        }
+        dst[e] = a;
+        dog[e] = __fsub_rn(cur[e], a);
+        cur[e] = a;   // source of the next level (only this thread reads cur[e] in this phase)
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---- gradient / orientation (GradOriImages, :959-992) ---------------------------------------
 __global__ void grad_ori_kernel(SiftPyramid P) {
   const int o = blockIdx.z / kScales, index = 1 + blockIdx.z % kScales;
@@ -386,22 +448,51 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
 }
 
 // ---- descriptor (MakeKeypointSample / KeySample / AddSample / PlaceInIndex, :1424-1668) ---------
-// One wavefront per key.  Lane L owns descriptor entries 2L and 2L+1 (cell L/4 of the 4x4
-// grid, orientation bins 2(L%4) and 2(L%4)+1).  Samples are evaluated 64 at a time in raster
-// order and then folded one after the other, each lane taking its share of the sample's up to
-// eight contributions -- the same products, added in the same order, as the serial code.
-__global__ __launch_bounds__(64) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
+// Lane L of a wavefront owns descriptor entries 2L and 2L+1 (cell L/4 of the 4x4 grid, orientation
+// bins 2(L%4) and 2(L%4)+1).  Samples are evaluated 64 at a time in raster order and then folded
+// one after the other, each lane taking its share of the sample's up to eight contributions --
+// the same products, added in the same order, as the serial code.
+// Workgroups have four wavefronts.  With many keys each wavefront describes its own key; with few
+// (the chip would be mostly idle and the serial fold is what a key waits for) the four wavefronts
+// share ONE key, wavefront r folding only the samples that touch cell row r (2/5 of them): the
+// entries are independent, so the per-entry addition order is untouched.
+constexpr int DESC_WAVES = 4;
+constexpr int DESC_SHARE_BELOW = 1536;   // keys; below this the wavefronts of a workgroup share a key
+__global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
                                                       const int32_t* __restrict__ n_keys, int key_cap,
                                                       float* __restrict__ desc_out /* [key][128] */,
                                                       float* __restrict__ geo_out /* [key][4] col,row,scale,ori */) {
-  __shared__ float d_s[128];
-  __shared__ float scal_s;
-  const int lane = threadIdx.x;
+  __shared__ float d_all[DESC_WAVES][128];
+  __shared__ float scal_all[DESC_WAVES];
+  __shared__ int any_all[DESC_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
-  const int cell_r = lane >> 4, cell_c = (lane >> 2) & 3, ob0 = 2 * (lane & 3);
-  for (int ki = blockIdx.x; ki < n; ki += gridDim.x) {
-    const SiftKey k = keys[ki];
+  const bool share = n < DESC_SHARE_BELOW;
+  // shared key: wavefront `wave` owns cell row `wave` on its first 16 lanes, results meet in d_all[0]
+  const int cell_r = share ? wave : (lane >> 4);
+  const int cell_c = (lane >> 2) & 3, ob0 = 2 * (lane & 3);
+  const bool owner = !share || lane < 16;
+  float* const d_s = share ? d_all[0] : d_all[wave];
+  float& scal_s = share ? scal_all[0] : scal_all[wave];
+  int& any_s = share ? any_all[0] : any_all[wave];
+  // a key's 128 values belong to one wavefront, or (shared key) to the workgroup
+  auto sync_scope = [&]() {
+    if (share) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  const int entry = share ? (wave * 16 + lane) : lane;   // this lane's pair of entries: 2 entry, 2 entry + 1
+  const int k_first = share ? blockIdx.x : blockIdx.x * DESC_WAVES + wave;
+  const int k_step = share ? gridDim.x : gridDim.x * DESC_WAVES;
+  const int n_round = share ? n : ((n + DESC_WAVES - 1) / DESC_WAVES) * DESC_WAVES;   // whole workgroups reach the barriers
+  for (int kb = k_first - (share ? 0 : wave); kb < n_round; kb += k_step) {
+    const int ki = share ? kb : kb + wave;
+    const bool live = ki < n;
+    const SiftKey k = keys[live ? ki : 0];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
     const float* grad = O.grad[k.index - 1];
@@ -414,7 +505,7 @@ __global__ __launch_bounds__(64) void describe_kernel(SiftPyramid P, const SiftK
     const int win = (int)__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(frealsize, kSqrt2), 5.0f), 0.5f), 0.5f);
     const float fsr = __fmul_rn(sinang, firealsize), fcr = __fmul_rn(cosang, firealsize);
     const float fdrr = __fmul_rn(-fdrow, firealsize), fdcr = __fmul_rn(-fdcol, firealsize);
-    const int side = 2 * win + 1, total = side * side;
+    const int side = 2 * win + 1, total = live ? side * side : 0;
     float acc0 = 0.f, acc1 = 0.f;
     for (int base = 0; base < total; base += 64) {
       const int s = base + lane;
@@ -445,7 +536,8 @@ __global__ __launch_bounds__(64) void describe_kernel(SiftPyramid P, const SiftK
           of = __fsub_rn(oribin, (float)no);
         }
       }
-      unsigned long long m = __ballot(ok);
+      // shared key: only the samples that reach this wavefront's cell row (rows nr and nr + 1)
+      unsigned long long m = __ballot(ok && (!share || nr == cell_r - 1 || nr == cell_r));
       while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -455,7 +547,7 @@ __global__ __launch_bounds__(64) void describe_kernel(SiftPyramid P, const SiftK
         const float smag = RL_F(mag), srf = RL_F(rf), scf = RL_F(cf), sof = RL_F(of);
 #undef RL_F
         const int i = cell_r - snr, j = cell_c - snc;
-        if ((unsigned)i < 2u && (unsigned)j < 2u) {
+        if (owner && (unsigned)i < 2u && (unsigned)j < 2u) {
           const float rg = i == 0 ? __fmul_rn(smag, __fsub_rn(1.f, srf)) : __fmul_rn(smag, srf);
           const float cg = j == 0 ? __fmul_rn(rg, __fsub_rn(1.f, scf)) : __fmul_rn(rg, scf);
           const int k0 = (ob0 - sno) & 7, k1 = (ob0 + 1 - sno) & 7;
@@ -464,48 +556,59 @@ __global__ __launch_bounds__(64) void describe_kernel(SiftPyramid P, const SiftK
         }
       }
     }
-    __syncthreads();
-    d_s[2 * lane] = acc0;
-    d_s[2 * lane + 1] = acc1;
-    __syncthreads();
-    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527)
+    sync_scope();
+    if (owner) {
+      d_s[2 * entry] = acc0;
+      d_s[2 * entry + 1] = acc1;
+    }
+    sync_scope();
+    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527); one
+    // wavefront works on the 128 values (its own key's, or the shared key's on wavefront 0)
+    const bool norm_wave = !share || wave == 0;
     for (int pass = 0; pass < 2; ++pass) {
-      if (lane == 0) {
+      if (norm_wave && lane == 0) {
         float a = 0.f;
         for (int i = 0; i < 128; ++i) a = __fadd_rn(a, __fmul_rn(d_s[i], d_s[i]));
         scal_s = __fdiv_rn(1.f, sqrtf(a));
       }
-      __syncthreads();
-      const float sc = scal_s;
-      d_s[2 * lane] = __fmul_rn(d_s[2 * lane], sc);
-      d_s[2 * lane + 1] = __fmul_rn(d_s[2 * lane + 1], sc);
+      sync_scope();
       bool clamp = false;
-      if (pass == 0) {
-        if (d_s[2 * lane] > 0.2f) {
-          d_s[2 * lane] = 0.2f;
-          clamp = true;
+      if (norm_wave) {
+        const float sc = scal_s;
+        d_s[2 * lane] = __fmul_rn(d_s[2 * lane], sc);
+        d_s[2 * lane + 1] = __fmul_rn(d_s[2 * lane + 1], sc);
+        if (pass == 0) {
+          if (d_s[2 * lane] > 0.2f) {
+            d_s[2 * lane] = 0.2f;
+            clamp = true;
+          }
+          if (d_s[2 * lane + 1] > 0.2f) {
+            d_s[2 * lane + 1] = 0.2f;
+            clamp = true;
+          }
         }
-        if (d_s[2 * lane + 1] > 0.2f) {
-          d_s[2 * lane + 1] = 0.2f;
-          clamp = true;
-        }
+        const bool any_w = __ballot(clamp) != 0ull;
+        if (lane == 0) any_s = any_w ? 1 : 0;
       }
-      const bool any = __ballot(clamp) != 0ull;
-      __syncthreads();
+      sync_scope();
+      const bool any = any_s != 0;
+      sync_scope();
       if (!any) break;
     }
-    float* out = desc_out + (size_t)ki * 128;
-    out[2 * lane] = d_s[2 * lane];
-    out[2 * lane + 1] = d_s[2 * lane + 1];
-    if (lane == 0) {
-      const float fscale = O.fscale;
-      float* g = geo_out + (size_t)ki * 4;
-      g[0] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
-      g[1] = __fmul_rn(fscale, frow);
-      g[2] = __fmul_rn(fscale, fSize);
-      g[3] = ang;
+    if (live && norm_wave) {
+      float* out = desc_out + (size_t)ki * 128;
+      out[2 * lane] = d_s[2 * lane];
+      out[2 * lane + 1] = d_s[2 * lane + 1];
+      if (lane == 0) {
+        const float fscale = O.fscale;
+        float* g = geo_out + (size_t)ki * 4;
+        g[0] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
+        g[1] = __fmul_rn(fscale, frow);
+        g[2] = __fmul_rn(fscale, fSize);
+        g[3] = ang;
+      }
     }
-    __syncthreads();
+    sync_scope();
   }
 }
 
@@ -626,15 +729,28 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
   }
   const float fwidth = powf(2.0f, 1.0f / (float)kScales);
   const float fincsigma = sqrtf(fwidth * fwidth - 1.0f);
-  for (int o = 0; o < plan.n_octaves; ++o) {
-    const SiftOctave& O = P.oct[o];
+  // per-level kernels (they only depend on the level: sigma restarts at every octave, :410-438)
+  Taps5 T5;
+  {
     float sigma = kInitSigma;
+    for (int i = 1; i < kScales + 3; ++i) {
+      T5.t[i - 1] = make_taps(fincsigma * sigma);
+      sigma *= fwidth;
+    }
+  }
+  int o_small = plan.n_octaves;   // first octave the single-workgroup kernel takes over
+  for (int o = 1; o < plan.n_octaves; ++o)
+    if ((size_t)plan.rows[o] * plan.cols[o] <= (size_t)SMALL_OCTAVE_PX) {
+      o_small = o;
+      break;
+    }
+  for (int o = 0; o < o_small; ++o) {
+    const SiftOctave& O = P.oct[o];
     for (int i = 1; i < kScales + 3; ++i) {   // OctaveKeypoints (:410-438)
-      const Taps t = make_taps(fincsigma * sigma);
+      const Taps& t = T5.t[i - 1];
       hipLaunchKernelGGL(blur_rows_kernel, grid_for(O.rows, O.cols), tb, 0, s, O.gaus[i - 1], B.tmp, O.rows, O.cols, t);
       hipLaunchKernelGGL(blur_cols_kernel, grid_for(O.rows, O.cols), tb, 0, s, B.tmp, O.gaus[i], O.rows, O.cols, t,
                          (const float*)O.gaus[i - 1], O.dog[i - 1]);
-      sigma *= fwidth;
     }
     if (o + 1 < plan.n_octaves) {
       const SiftOctave& N = P.oct[o + 1];
@@ -642,13 +758,15 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
                          N.gaus[0], N.rows, N.cols);
     }
   }
+  if (o_small < plan.n_octaves)
+    hipLaunchKernelGGL(small_octaves_kernel, dim3(1), dim3(1024), 0, s, P, o_small, T5);
   const dim3 tb2(64, 4);
   const dim3 g2((O0.cols + 63) / 64, (O0.rows + 3) / 4, plan.n_octaves * kScales);
   hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P);
   hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, B.cand, B.counters + 0, B.cand_cap, B.counters + 2);
   hipLaunchKernelGGL(orient_kernel, dim3(1024), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
                      (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2);
-  hipLaunchKernelGGL(describe_kernel, dim3(2048), dim3(64), 0, s, P, (const SiftKey*)B.keys,
+  hipLaunchKernelGGL(describe_kernel, dim3(2048), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
                      (const int32_t*)(B.counters + 1), B.key_cap, B.desc_tmp, B.geo_tmp);
   hipLaunchKernelGGL(order_kernel, dim3(1024), dim3(64), 0, s, (const SiftKey*)B.keys,
                      (const int32_t*)(B.counters + 1), B.key_cap, (const float*)B.desc_tmp, (const float*)B.geo_tmp,

@@ -68,6 +68,22 @@ def test_hip_sift_other_sizes_and_no_doubling(ctx):
         assert np.abs(got[2][ok] - want[2][j[ok]]).max() < 5e-3
 
 
+def test_hip_sift_many_keypoints(ctx):
+    """More than 1536 keys: the descriptor kernel's one-key-per-wavefront mode (with fewer, the four
+    wavefronts of a workgroup share a key)."""
+    g0, g1 = GOLD["gray0"], GOLD["gray3"]
+    gray = np.ascontiguousarray(np.block([[g0, g1], [g1[::-1], g0[:, ::-1]]]))          # 1280 x 960 mosaic
+    want = orclib.sift(gray)
+    got = ctx.sift(gray)
+    n = len(want[0])
+    assert n > 1536
+    assert abs(len(got[0]) - n) <= max(2, n // 100)
+    ok, j = _agreement(got, want)
+    assert ok.sum() >= 0.99 * n
+    assert np.abs(got[2][ok] - want[2][j[ok]]).max() < 5e-3
+    assert np.array_equal(j[ok], np.sort(j[ok]))
+
+
 def test_hip_sift_flat_image_and_capacity(ctx):
     flat = np.full((64, 80), 128, np.uint8)
     assert len(ctx.sift(flat)[0]) == 0
