@@ -44,6 +44,9 @@ def parse():
                     help="with --depth-kind: the frame takes the depth map itself and runs moped3d's shipped front end on "
                          "the device (DEPTHFILTER, depth-adaptive ratio, DEPTHFILTER2, DEPTHMAP_PROP, CLUSTER_LINKAGE; "
                          "moped3d/libmoped/src/config.hpp:41-45) instead of per-query depth attributes + mean shift")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per MATCH launch and exchange with a sharded DB (default 4: a shard of ~12k rows does "
+                         "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,6 +117,10 @@ def main():
     sharded = world > 1 or args.force_exchange
     if args.depth <= 0:
         args.depth = 16 if sharded else 4
+    if args.batch <= 0:
+        args.batch = 4 if sharded else 1
+    if not sharded or args.depth_kind:
+        args.batch = 1
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
@@ -143,7 +150,7 @@ def main():
         params.pose1.error_threshold = 8.0
         params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
         params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
-    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q, params=params,
+    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q * args.batch, params=params,
                          force_exchange=args.force_exchange)
     pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
@@ -172,8 +179,24 @@ def main():
             d = capi.pack_depth(wpts, wgt)
             depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
     counts_host = torch.zeros(n_frames, dtype=torch.int32).pin_memory()
+    B = args.batch
+    if B > 1:
+        assert n_frames % B == 0
+        groups = n_frames // B
+        pristine_b = [torch.cat(pristine[g * B:(g + 1) * B]) for g in range(groups)]
+        uv_b = [torch.cat(uvs[g * B:(g + 1) * B]) for g in range(groups)]
+        work_b = [torch.empty_like(pristine_b[0]) for _ in range(args.depth)]
+
+    def run_step_batched(step):
+        for g in range(groups):
+            slot = (step * groups + g) % args.depth
+            with torch.cuda.stream(pipe.streams[slot]):
+                work_b[slot].copy_(pristine_b[g], non_blocking=True)
+            pipe.enqueue_batch(slot, work_b[slot], uv_b[g], B, [1000 * step + g * B + f + 1 for f in range(B)])
 
     def run_step(step, record=False):
+        if B > 1:
+            return run_step_batched(step)
         for b in range(n_frames):
             slot = b % args.depth
             s = pipe.streams[slot]
@@ -213,7 +236,10 @@ def main():
     fps = total_frames / dt
 
     # detections of the last step (sanity: the planted objects are found)
-    if world == 1:
+    if B > 1:
+        last_slot = ((args.steps - 1) * groups + groups - 1) % args.depth
+        det_per_frame = float(np.mean([len(o) for o in pipe.flush_objects_batch(last_slot, B)]))
+    elif world == 1:
         det_per_frame = float(counts_host.float().mean().item())
     else:
         objs = pipe.gather_objects((n_frames - 1) % args.depth)
@@ -231,7 +257,7 @@ def main():
                                + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}")
                                + ("" if not (args.depth_kind and args.moped3d_frontend) else
                                   ", moped3d front end on the device (DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
-                   "frames_per_step": n_frames, "frames_in_flight": args.depth,
+                   "frames_per_step": n_frames, "frames_in_flight": args.depth * B, "frames_per_match_launch": B,
                    "parallelism": f"model-shard x{world}" if world > 1 else "single GPU",
                    "objects_per_frame": det_per_frame},
     }

@@ -42,6 +42,7 @@ extern "C" {
 #endif
 
 #define MH_DESC_DIM 128
+#define MH_MAX_BATCH 8   /* frames one context can carry through one MATCH launch (mh_frame_enqueue_rest_batch) */
 #define MH_OK 0
 #define MH_ERR_ARG (-1)
 #define MH_ERR_HIP (-2)
@@ -311,6 +312,21 @@ int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32
 int mh_frame_enqueue_rest_strided(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
                                   int n_shards, int shard_stride_words, const mh_cam* cam,
                                   const mh_frame_params* prm, uint64_t seed);
+/* Frames in batches (small shards: one MATCH launch and one exchange for B frames).  The B frames'
+ * descriptors lie one after the other, so mh_frame_enqueue_match_local(ctx, q_desc, B * Q, top2) is
+ * the batched MATCH as it is: top2 = [3][B Q] words.  After the exchange, frame f of the batch is
+ *   mh_frame_enqueue_rest_batch(ctx, q_uv + 2 f Q, Q, gathered + f Q, W, shard_stride, B Q, f, ...)
+ * -- `plane_stride_words` = the distance between the idx / d1 / d2 planes of a shard's block (B Q),
+ * `slot` = f < MH_MAX_BATCH selects the result block the frame writes.  The frames of a batch run
+ * one after the other on the context's stream.  mh_frame_fetch_slot / mh_frame_result_copy_slots_dev
+ * are the per-slot forms of mh_frame_fetch / mh_frame_result_copy_dev (the latter packs the heads
+ * of slots 0..n_slots-1 one after the other). */
+int mh_frame_enqueue_rest_batch(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev, int n_shards,
+                                int shard_stride_words, int plane_stride_words, int slot, const mh_cam* cam,
+                                const mh_frame_params* prm, uint64_t seed);
+int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_objects, int32_t* n_objects,
+                        int32_t* counts);
+int mh_frame_result_copy_slots_dev(mh_ctx* ctx, void* dst_dev, int n_slots, int max_objects);
 /* Enqueues a device copy of the head of the context's result block {int32 n; int32 pad[3];
  * mh_object[max_objects]} -- the result of the last frame enqueued on this context, n = 0
  * before the first -- to dst_dev (16 + 40 max_objects bytes). */

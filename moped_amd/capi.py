@@ -66,6 +66,9 @@ DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
 
 # every symbol include/moped_hip.h declares
+MAX_BATCH = 8   # MH_MAX_BATCH
+
+
 class mh_linkage_params(C.Structure):
     _fields_ = [("cutoff", C.c_float), ("min_pts", C.c_int32), ("use3d_filter", C.c_int32), ("sigma2d", C.c_float),
                 ("sigma3d", C.c_float)]
@@ -90,6 +93,7 @@ EXPORTS = [
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
     "mh_frame_set_cluster_linkage", "mh_cluster_linkage", "mh_frame_set_depth_image_host",
+    "mh_frame_enqueue_rest_batch", "mh_frame_fetch_slot", "mh_frame_result_copy_slots_dev",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
@@ -157,6 +161,10 @@ def load():
     L.mh_frame_enqueue_rest_strided.argtypes = [vp, vp, i32, vp, i32, i32, C.POINTER(mh_cam),
                                                 C.POINTER(mh_frame_params), C.c_uint64]
     L.mh_frame_result_copy_dev.argtypes = [vp, vp, i32]
+    L.mh_frame_enqueue_rest_batch.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, C.POINTER(mh_cam),
+                                              C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_fetch_slot.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_int32), vp]
+    L.mh_frame_result_copy_slots_dev.argtypes = [vp, vp, i32, i32]
     L.mh_frame_fetch_matches.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_features_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.mh_frame_keypoints.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -538,6 +546,25 @@ class Context:
         self._ck(self.L.mh_frame_enqueue_rest_strided(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
                                                       stride_words, C.byref(c), C.byref(params), seed),
                  "mh_frame_enqueue_rest_strided")
+
+    def frame_enqueue_rest_batch(self, q_uv_ptr, Q, gathered_ptr, n_shards, stride_words, plane_words, slot, K, cam,
+                                 params: mh_frame_params, seed=1, _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_rest_batch(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
+                                                    stride_words, plane_words, slot, C.byref(c), C.byref(params), seed),
+                 "mh_frame_enqueue_rest_batch")
+
+    def frame_fetch_slot(self, slot, max_objects=4096):
+        objs = np.zeros(max_objects, OBJECT_DTYPE)
+        n = C.c_int32(0)
+        counts = np.zeros(4, np.int32)
+        self._ck(self.L.mh_frame_fetch_slot(self.h, slot, _ptr(objs), max_objects, C.byref(n), _ptr(counts)),
+                 "mh_frame_fetch_slot")
+        return objs[:min(n.value, max_objects)].copy(), counts
+
+    def frame_result_copy_slots_dev(self, dst_ptr, n_slots, max_objects):
+        self._ck(self.L.mh_frame_result_copy_slots_dev(self.h, C.c_void_p(dst_ptr), n_slots, max_objects),
+                 "mh_frame_result_copy_slots_dev")
 
     def frame_result_copy_dev(self, dst_ptr, max_objects):
         self._ck(self.L.mh_frame_result_copy_dev(self.h, C.c_void_p(dst_ptr), max_objects), "mh_frame_result_copy_dev")

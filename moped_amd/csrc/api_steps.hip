@@ -36,6 +36,7 @@ struct FrameState {
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
   uint64_t* seed_dev = nullptr;  // per-frame seed in device memory: only when the launch list is replayed as a graph
   int task_grid = 32;   // workgroups for the POSE/FILTER launches: follows the task count of the last fetched frame
+  int slot = 0;            // result / snap slot the next frame_rest writes (frames of a batch share the context)
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
   // hipGraph replay of the launch list (one graph per half of the frame)
   struct Graph {
@@ -120,9 +121,9 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->best, max_m);
   rc |= dev_alloc(ctx, fs->new_members, max_m);
   fs->result_bytes = 16 + sizeof(mh_object) * (size_t)max_objects;
-  rc |= dev_alloc(ctx, fs->result, fs->result_bytes);
-  if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes, ctx->stream));   // "0 objects" before the first frame
-  rc |= dev_alloc(ctx, fs->snap, 4);
+  rc |= dev_alloc(ctx, fs->result, fs->result_bytes * MH_MAX_BATCH);
+  if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes * MH_MAX_BATCH, ctx->stream));   // "0 objects" before the first frame
+  rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
   rc |= dev_alloc(ctx, fs->seed_dev, 1);
   rc |= dev_alloc(ctx, fs->tickets, 8);
   if (rc) return MH_ERR_HIP;
@@ -241,6 +242,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
   const int nm = ctx->n_models;
+  unsigned char* const result = fs->result + (size_t)fs->slot * fs->result_bytes;
+  int32_t* const snap = fs->snap + 4 * fs->slot;
   // Every workgroup of the POSE / FILTER launches needs a free compute unit to start even if
   // it has no task, and MATCH kernels of other frames keep all of them busy: launch about as
   // many workgroups as the previous frame had tasks (MH_TASK_GRID pins the number).
@@ -286,7 +289,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
-               gathered ? ctx->exchange_stride : 0);
+               gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   const bool have_depth = ctx->q_depth || ctx->depth_img.img;
@@ -298,25 +301,25 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     launch_linkage_models(fs->m_corr, reinterpret_cast<const float*>(fs->m_depth), fs->model_off, nm, ctx->depth_img,
                           ctx->linkage, ctx->lk_scratch, ctx->lk_scratch_floats, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
-                          fs->snap, fs->counts, fs->tickets + 0, s);
+                          snap, fs->counts, fs->tickets + 0, s);
   } else
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
-                          fs->n_clusters, fs->snap, fs->counts, fs->tickets + 0, s);
+                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s);
   stamp(ctx, 3);
   // POSE (+ slot count, snap[2] = objects after POSE)
   const float* depth4 = (ctx->q_depth || ctx->depth_img.img) ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
   launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
               fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
-              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, fs->snap + 2, grid}, s);
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     FilterBuffers fb = make_fb(ctx, fs, nm);
     // FILTER (snap[3] = objects kept)
     launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, fs->snap + 3, nullptr, grid}, s);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, snap + 3, nullptr, grid}, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
@@ -327,11 +330,11 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, fs->result, grid}, s);
+                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, result, grid}, s);
     stamp(ctx, 7);
   } else {
     for (int i = 5; i <= 7; ++i) stamp(ctx, i);
-    hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, fs->result, fs->n_slots,
+    hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, result, fs->n_slots,
                        fs->obj_valid, fs->obj_model, fs->obj_pose, fs->obj_score, fs->obj_npts,
                        fs->max_objects);
   }
@@ -1117,6 +1120,62 @@ int mh_frame_enqueue_rest_strided(mh_ctx* ctx, const float* q_uv_dev, int Q, con
   const int rc = mh_frame_enqueue_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
   ctx->exchange_stride = 0;
   return rc;
+}
+
+int mh_frame_enqueue_rest_batch(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev, int n_shards,
+                                int shard_stride_words, int plane_stride_words, int slot, const mh_cam* cam,
+                                const mh_frame_params* prm, uint64_t seed) {
+  if (!ctx || slot < 0 || slot >= MH_MAX_BATCH || plane_stride_words < Q || shard_stride_words < 3 * plane_stride_words)
+    return MH_ERR_ARG;
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  ctx->exchange_stride = shard_stride_words;
+  ctx->exchange_plane = plane_stride_words;
+  ctx->fs->slot = slot;
+  rc = mh_frame_enqueue_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
+  ctx->exchange_stride = 0;
+  ctx->exchange_plane = 0;
+  if (ctx->fs) ctx->fs->slot = 0;
+  return rc;
+}
+
+int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_objects, int32_t* n_objects,
+                        int32_t* counts) {
+  if (!ctx || !n_objects || !ctx->fs || slot < 0 || slot >= MH_MAX_BATCH) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  FrameState* fs = ctx->fs;
+  const unsigned char* result = fs->result + (size_t)slot * fs->result_bytes;
+  int32_t head[4];
+  int32_t snap[4] = {0, 0, 0, 0};
+  MH_HIP(ctx, hipMemcpyAsync(head, result, sizeof head, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap + 4 * slot, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_objects = head[0];
+  if (counts) std::memcpy(counts, snap, sizeof snap);
+  const int tasks = 4 * std::max(snap[1], snap[3]);
+  fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
+  const int take = head[0] < max_objects ? head[0] : max_objects;
+  if (take > 0 && objects_host)
+    MH_HIP(ctx, hipMemcpy(objects_host, result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
+  if (head[1]) {
+    ctx->err = "frame: capacity exceeded (flags " + std::to_string(head[1]) + ")";
+    return MH_ERR_CAPACITY;
+  }
+  return MH_OK;
+}
+
+int mh_frame_result_copy_slots_dev(mh_ctx* ctx, void* dst_dev, int n_slots, int max_objects) {
+  if (!ctx || !dst_dev || max_objects < 0 || n_slots <= 0 || n_slots > MH_MAX_BATCH) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1);
+  if (rc) return rc;
+  FrameState* fs = ctx->fs;
+  const size_t bytes = std::min(fs->result_bytes, 16 + sizeof(mh_object) * (size_t)max_objects);
+  MH_HIP(ctx, hipMemcpy2DAsync(dst_dev, bytes, fs->result, fs->result_bytes, bytes, (size_t)n_slots,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+  return MH_OK;
 }
 
 int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects) {

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
       out[r] = ob;
     }
     reinterpret_cast<int32_t*>(tail.result)[0] = kept;
+    reinterpret_cast<int32_t*>(tail.result)[1] = counts->error;   // sticky capacity flags of this frame
   }
 }
 

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
-    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride) {
+    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int base_s;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
       for (int k = 0; k < n_shards; ++k) {
         const size_t o = (size_t)k * shard_stride + q;   // shard k's [3][Q] block (+ what rides behind it)
         const int32_t i = gathered[o];
-        if (i >= 0) merge_top2(b1, b2, i1, gf[o + Q], gf[o + 2 * (size_t)Q], i);
+        if (i >= 0) merge_top2(b1, b2, i1, gf[o + plane_stride], gf[o + 2 * (size_t)plane_stride], i);
       }
       idx1[q] = i1;
       d1[q] = b1;
@@ -306,11 +306,11 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
-                  const DepthRules& rules, int shard_stride) {
+                  const DepthRules& rules, int shard_stride, int plane_stride) {
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
                      m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules,
-                     shard_stride > 0 ? shard_stride : 3 * Q);
+                     shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q);
 }
 
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {

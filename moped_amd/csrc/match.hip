@@ -403,7 +403,7 @@ int splits_for(int Q, int N) {
     return v > 0 ? v : TARGET_BLOCKS_DEFAULT;
   }();
   int S = (target + qgroups - 1) / qgroups;
-  if (S >= 8) S = (S + 7) / 8 * 8;  // whole splits per XCD (see match_kernel)
+  if (S >= 8) S = (S + 3) / 8 * 8;  // whole splits per XCD (see match_kernel); to the nearest multiple: fewer, longer workgroups win
   if (S > n_tiles) S = n_tiles;
   if (S < 1) S = 1;
   return S;

@@ -81,7 +81,8 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
-                  const DepthRules& rules = DepthRules(), int shard_stride = 0 /* words between shard blocks; 0 = 3 Q */);
+                  const DepthRules& rules = DepthRules(), int shard_stride = 0 /* words between shard blocks; 0 = 3 Q */,
+                  int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);

@@ -105,6 +105,72 @@ class FramePipeline:
             c.frame_enqueue_rest_strided(q_uv.data_ptr(), Q, gathered.data_ptr(), self.world, stride, self.K,
                                          self.cam, self.params, seed, _cam_struct=self._cam)
 
+    # ---- batches of frames (small shards) ----------------------------------------------------
+    def enqueue_batch(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, B: int, seeds):
+        """B frames through ONE MATCH launch and ONE exchange (a shard of a few thousand rows does not
+        fill the chip for the 3000 queries of one frame): q_desc [B*Q,128], q_uv [B*Q,2], the frames one
+        after the other; their CLUSTER..FILTER2 run one after the other on the slot's stream and leave
+        their objects in result slots 0..B-1.  Needs the exchange path (sharded DB or force_exchange)."""
+        assert self.exchange and 1 <= B <= capi.MAX_BATCH
+        c, s = self.ctxs[slot], self.streams[slot]
+        BQ = q_desc.shape[0]
+        Q = BQ // B
+        tail = B * self.EX2_WORDS
+        stride = 3 * BQ + tail
+        if self._local[slot] is None or self._ex_q[slot] != -BQ:
+            s.synchronize()
+            self._local[slot] = torch.zeros(stride, dtype=torch.int32, device=self.dev)
+            self._gather[slot] = torch.zeros(self.world * stride, dtype=torch.int32, device=self.dev)
+            self._ex_q[slot] = -BQ          # negative: batch layout
+            self._ex_b = B
+        local, gathered = self._local[slot], self._gather[slot]
+        with torch.cuda.stream(s):
+            c.frame_result_copy_slots_dev(local.data_ptr() + 12 * BQ, B, self.EX2_OBJECTS)   # exchange 2 of the slot's last batch
+            c.frame_enqueue_match_local(q_desc.data_ptr(), BQ, local.data_ptr())
+            _all_gather_into(gathered, local, self.group)
+            for f in range(B):
+                c.frame_enqueue_rest_batch(q_uv.data_ptr() + 8 * f * Q, Q, gathered.data_ptr() + 4 * f * Q, self.world,
+                                           stride, BQ, f, self.K, self.cam, self.params, int(seeds[f]),
+                                           _cam_struct=self._cam)
+
+    def fetch_batch(self, slot: int, B: int):
+        return [self.ctxs[slot].frame_fetch_slot(f) for f in range(B)]
+
+    def previous_objects_batch(self, slot: int):
+        """Objects of the B frames of the batch enqueued in `slot` BEFORE the current one, from all ranks."""
+        self.streams[slot].synchronize()
+        BQ, B = -self._ex_q[slot], self._ex_b
+        stride = 3 * BQ + B * self.EX2_WORDS
+        host = self._gather[slot].view(self.world, stride)[:, 3 * BQ:].contiguous().cpu().numpy()
+        out = []
+        for f in range(B):
+            objs = []
+            for r in range(self.world):
+                blk = host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]
+                n = min(int(blk[0]), self.EX2_OBJECTS)
+                objs.append(blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy())
+            out.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
+        return out
+
+    def flush_objects_batch(self, slot: int, B: int):
+        """Exchange 2 for the LAST batch of a slot (nothing follows to carry it): one small all-gather."""
+        c, s = self.ctxs[slot], self.streams[slot]
+        with torch.cuda.stream(s):
+            mine = torch.zeros(B * self.EX2_WORDS, dtype=torch.int32, device=self.dev)
+            c.frame_result_copy_slots_dev(mine.data_ptr(), B, self.EX2_OBJECTS)
+            out = _all_gather_flat(mine, self.world, self.group).view(self.world, B * self.EX2_WORDS)
+        s.synchronize()
+        host = out.cpu().numpy()
+        res = []
+        for f in range(B):
+            objs = []
+            for r in range(self.world):
+                blk = host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]
+                n = min(int(blk[0]), self.EX2_OBJECTS)
+                objs.append(blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy())
+            res.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
+        return res
+
     def previous_objects(self, slot: int):
         """Objects of the frame enqueued in `slot` BEFORE the current one, from all ranks, as they
         arrived with the current frame's exchange (no collective of its own).  Synchronises the slot."""

@@ -40,6 +40,13 @@ def _worker(rank, world, port, out_dir):
         res[f"objs{seed}"] = objs
         res[f"local{seed}"] = local
         res[f"counts{seed}"] = counts
+    # the same two frames as ONE batch: one MATCH launch over both frames' queries, one exchange
+    frs = [synth.make_frame(db, n_vis=3, seed=seed, Q=Q, pts_per_obj=120) for seed in (0, 1)]
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    quv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    pipe.enqueue_batch(0, qd, quv, 2, [5, 6])
+    merged = pipe.flush_objects_batch(0, 2)
+    res["batch0"], res["batch1"] = merged[0], merged[1]
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     pipe.close()
     dist.barrier()
@@ -58,6 +65,10 @@ def test_two_ranks_one_gpu_equals_single_context(tmp_path):
     pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=Q)
     dev = torch.device("cuda:0")
     z = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for r in range(world):   # both frames as one batch (one MATCH launch, one exchange): the same merged objects
+        for seed in (0, 1):
+            assert np.array_equal(z[r][f"batch{seed}"]["model"], z[r][f"objs{seed}"]["model"])
+            assert np.array_equal(z[r][f"batch{seed}"]["pose"], z[r][f"objs{seed}"]["pose"])
     for r in range(world):   # exchange 2 riding on the next frame's exchange 1 == the explicit gather
         assert np.array_equal(z[r]["prev0"]["model"], z[r]["objs0"]["model"])
         assert np.array_equal(z[r]["prev0"]["pose"], z[r]["objs0"]["pose"])
@@ -117,6 +128,24 @@ def _rccl_worker(rank, world, port, out_dir):
                 res[f"{tag}_gathered"] = pipe.gather_objects(i % 2)
             objs, counts = pipe.fetch(i % 2)
             res[f"{tag}_objs{i}"], res[f"{tag}_counts{i}"] = objs, counts
+        if force:
+            # frames 0..3 again as two batches of two (one MATCH launch + one exchange per batch): same objects
+            keep = []   # the inputs must outlive the enqueued work (torch would hand a freed tensor's memory out again)
+            def fresh(a, b):
+                keep.append(torch.cat([torch.from_numpy(frames[k].desc) for k in range(a, b)]).to(dev))
+                keep.append(torch.cat(uv[a:b]))
+                return keep[-2], keep[-1]
+            for g in range(2):
+                pipe.enqueue_batch(g, *fresh(2 * g, 2 * g + 2), 2, [2 * g + 5, 2 * g + 6])
+            for g in range(2):
+                for f, (objs, counts) in enumerate(pipe.fetch_batch(g, 2)):
+                    res[f"batch_objs{2 * g + f}"], res[f"batch_counts{2 * g + f}"] = objs, counts
+            # a second batch in slot 0 carries the first one's objects; the last batch is flushed explicitly
+            pipe.enqueue_batch(0, *fresh(2, 4), 2, [7, 8])
+            prev = pipe.previous_objects_batch(0)
+            res["batch_prev0"], res["batch_prev1"] = prev[0], prev[1]
+            fl = pipe.flush_objects_batch(0, 2)
+            res["batch_flush2"], res["batch_flush3"] = fl[0], fl[1]
         pipe.close()
     np.savez(os.path.join(out_dir, "rccl.npz"), **res)
     dist.barrier()
@@ -136,6 +165,13 @@ def test_rccl_exchange_path_world1_equals_direct(tmp_path):
         assert len(a) == len(b) and len(a) >= 3
         assert np.array_equal(a["model"], b["model"])
         assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["score"], b["score"])
+    for i in range(4):   # batches of two frames through one MATCH launch and one exchange: the same objects
+        a, b = z[f"direct_objs{i}"], z[f"batch_objs{i}"]
+        assert np.array_equal(z[f"direct_counts{i}"], z[f"batch_counts{i}"])
+        assert np.array_equal(a["model"], b["model"]) and np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["score"], b["score"])
+    for i in range(2):
+        assert np.array_equal(z[f"batch_prev{i}"]["pose"], z[f"direct_objs{i}"]["pose"])
+        assert np.array_equal(z[f"batch_flush{i + 2}"]["pose"], z[f"direct_objs{i + 2}"]["pose"])
     for i in range(2):   # the objects that rode on the next frame's exchange are the frame's own
         p = z[f"rccl_prev{i}"]
         assert np.array_equal(p["model"], z[f"rccl_objs{i}"]["model"]) and np.array_equal(p["pose"], z[f"rccl_objs{i}"]["pose"])
