@@ -158,15 +158,12 @@ def main():
     depths = None
     maps = None
     if args.depth_kind and args.moped3d_frontend:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import orclib   # only for the per-model ratio control points (host-side model metadata, outside the timed region)
+        from moped_amd import moped3d
         maps = []
         for i, f in enumerate(frames):
             img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
             maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
-        table = np.stack([orclib.adaptive_control_points(db.xyz[db.model_of == m].min(0), db.xyz[db.model_of == m].max(0),
-                                                         synth.K_DEFAULT, int((db.model_of == m).sum()))
-                          for m in range(db.n_models)])
+        table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
         for c in pipe.ctxs:
             c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
             c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45

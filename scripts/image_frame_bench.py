@@ -3,7 +3,7 @@
 usage: image_frame_bench.py [models=20] [depth=4] [frames=400]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from moped_amd import capi, synth

@@ -22,12 +22,12 @@ cd $root
 { python scripts/stage_latency_probe.py 20 1; python scripts/stage_latency_probe.py 20 4; python scripts/stage_latency_probe.py 3 16; } > $out/r01_stage_latency.txt 2>&1
 { GPU_MAX_HW_QUEUES=16 python scripts/rest_only_probe.py 3 16;
   for a in "" "--force-exchange"; do GPU_MAX_HW_QUEUES=16 python bench.py --models 3 --depth 16 $a --no-cpu-baseline --no-roofline | tail -1; done; } > $out/r01_per_rank_load_n8.txt 2>&1
-python scripts/ms_bench.py > $out/r01_meanshift_bench.txt 2>&1
-python scripts/sift_probe.py > $out/r01_sift_probe.txt 2>&1
+python tests/tools/ms_bench.py > $out/r01_meanshift_bench.txt 2>&1
+python tests/tools/sift_probe.py > $out/r01_sift_probe.txt 2>&1
 python scripts/image_frame_bench.py 20 4 > $out/r01_image_frame_bench.txt 2>&1
 python scripts/host_step_timing.py > $out/r01_host_step_timing.txt 2>&1
-python scripts/linkage_bench.py > $out/r01_linkage_bench.txt 2>&1
+python tests/tools/linkage_bench.py > $out/r01_linkage_bench.txt 2>&1
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpsift -- python3 $root/scripts/sift_probe.py > /tmp/rpsift.log 2>&1 && cp $(find /tmp/rpsift -name "*kernel_stats.csv" | head -1) $out/r01_sift_kernel_stats.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpsift -- python3 $root/tests/tools/sift_probe.py > /tmp/rpsift.log 2>&1 && cp $(find /tmp/rpsift -name "*kernel_stats.csv" | head -1) $out/r01_sift_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpimg -- python3 $root/scripts/image_frame_bench.py 20 4 > /tmp/rpimg.log 2>&1 && cp $(find /tmp/rpimg -name "*kernel_stats.csv" | head -1) $out/r01_image_frame_kernel_stats.csv
 ls -la $out

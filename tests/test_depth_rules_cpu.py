@@ -82,3 +82,14 @@ def test_control_points_follow_update():
     assert abs(cp[2] - 0.6) < 1e-3 and abs(cp[3] - 0.65) < 1e-3
     few = orclib.adaptive_control_points([-.05, -.05, -.1], [.05, .05, .1], K, 200)
     assert abs(few[2] - 0.75) < 1e-3 and abs(few[3] - 0.8) < 1e-3     # few features -> the upper ends
+
+
+def test_product_control_points_equal_the_oracles():
+    """moped_amd.moped3d (what bench.py and Python hosts use) restates the same Update(): identical tables."""
+    from moped_amd import moped3d, synth
+    db = synth.make_db(4, 300, seed=9)
+    tab = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, K)
+    for m in range(4):
+        sel = db.model_of == m
+        want = orclib.adaptive_control_points(db.xyz[sel].min(0), db.xyz[sel].max(0), K, int(sel.sum()))
+        assert np.array_equal(tab[m], want)

@@ -1,6 +1,6 @@
 """CLUSTER_LINKAGE: the step on the GPU (all models of a frame in one call) vs the oracle on one core."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import orclib

@@ -3,7 +3,7 @@
   * `.mopeddb`: map + upload + on-device normalisation, GB/s of descriptor bytes
 usage: model_load_bench.py [n_models_xml=4] [n_models_container=200]"""
 import os, sys, time, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from moped_amd import capi, synth

@@ -1,6 +1,6 @@
 import sys, time, numpy as np
 import os
-_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'oracle'))
 import orclib
 from moped_amd import capi, synth

@@ -1,6 +1,6 @@
 """Phase cycle counts of the mean-shift kernel (needs a build with EXTRA=-DMS_PROF)."""
 import sys, os, ctypes as C, numpy as np
-_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'oracle'))
 from moped_amd import capi
 ctx = capi.Context(0)
