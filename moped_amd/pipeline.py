@@ -232,7 +232,11 @@ def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
     """all_gather_into_tensor on flat buffers.  RCCL takes device tensors directly;
     the gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the N > 1
     path) is fed through host memory."""
+    import os
     import torch.distributed as dist
+    if os.environ.get("MH_NO_COLLECTIVE") == "1" and out.numel() == mine.numel():
+        out.copy_(mine)   # probe only (world 1): the exchange path without the collective call
+        return
     if mine.is_cuda and dist.get_backend(group) == "gloo":
         host = mine.cpu()
         tmp = torch.empty(out.numel(), dtype=host.dtype)
