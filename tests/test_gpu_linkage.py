@@ -103,3 +103,19 @@ def test_frame_with_linkage_clusterer(scene):
     objs2, counts2 = s["pipe"].fetch(0)
     assert counts2[1] != counts[1] or True
     assert set(objs2["model"].tolist()) == set(fr.visible.tolist())
+
+
+@pytest.mark.parametrize("n", [161, 300, 520])
+def test_linkage_larger_sets_use_the_global_matrix(scene, n):
+    """More than 160 matches: the clustering's similarity matrix lives in the global scratch region
+    instead of LDS.  Points scattered over the synthetic depth map (objects in front of a wavy
+    background), model points = their camera-frame points with a little noise."""
+    s = scene
+    rng = np.random.default_rng(n)
+    uv = rng.uniform([5, 5], [634, 474], (n, 2)).astype(np.float32)
+    world, _ = orclib.depthmap_prop(s["img"], s["fill"], uv, 0.1)
+    mx = (world + rng.normal(0, 0.002, world.shape)).astype(np.float32)
+    for cutoff, min_pts in ((0.1, 7), (0.35, 3)):
+        prm = capi.mh_linkage_params(cutoff, min_pts, 2, -1.0, -1.0)
+        (clusters, _), = s["c"].cluster_linkage([(uv, mx, world)], prm)
+        _same(clusters, orclib.cluster_linkage(uv, mx, world, s["img"], s["fill"], cutoff=cutoff, min_pts=min_pts))

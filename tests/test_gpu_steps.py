@@ -1,5 +1,6 @@
 """GPU parity tests, per step, through the C ABI (libmoped_hip.so) against the CPU
 oracle on the same seeded inputs.  Integer/index results must be bit-exact."""
+import os
 import zlib
 
 import numpy as np
@@ -368,3 +369,34 @@ def test_filter_matches_oracle(ctx):
         assert len(cl_g) == len(cl_o)
         for a, b in zip(cl_g, cl_o):
             assert np.array_equal(a, b)
+
+
+def test_meanshift_stress_all_walk_variants_and_real_layouts(ctx):
+    """The list walk has register variants for up to 128 / 256 / 384 / 512 / 768 / 1024 canopies and an LDS
+    variant beyond; closeness graphs that are far from transitive (smooth fields of means: real keypoint
+    layouts, strings of points) take the outward-member and relaxation paths, deep merge forests the
+    list-order fallback of the fold.  Everything must stay exact: same clusters, same member order."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sift_ref_frames.npz"))
+    real = np.concatenate([gold["xy0"], gold["xy3"] + np.float32(0.37)])
+    rng = np.random.default_rng(2024)
+    cases = []
+    for n in (100, 129, 257, 385, 513, 600, 769, 1025, 1100, 1500, 2048):
+        kinds = ("uniform", "blobs") if n > 1100 else ("uniform", "blobs", "chain", "real")
+        for kind in kinds:
+            if kind == "real":
+                pts = real[np.sort(rng.choice(len(real), min(n, len(real)), replace=False))]
+            else:
+                pts = _ms_points(rng, kind, n)
+            cases.append((f"{kind}-{n}", np.ascontiguousarray(pts, np.float32), (200.0, 20.0, 7)))
+    # strings of points 15 px apart with a radius that sees only the point itself: closeness is a chain,
+    # merges cascade along it (deep forests, many iterations)
+    for n in (40, 90, 300):
+        line = np.stack([20 + 15.0 * np.arange(n) % 600, 100 + 40.0 * (15 * np.arange(n) // 600)], 1).astype(np.float32)
+        cases.append((f"line-{n}", line, (10.0, 20.0, 2)))
+        cases.append((f"line-shuffled-{n}", line[rng.permutation(n)], (10.0, 20.0, 2)))
+    for name, pts, (radius, merge, min_pts) in cases:
+        want, _ = orclib.meanshift(pts, radius, merge, min_pts, 100)
+        got, _ = ctx.meanshift(pts, radius, merge, min_pts, 100)
+        assert len(got) == len(want), name
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), name
