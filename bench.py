@@ -44,6 +44,10 @@ def parse():
                     help="with --depth-kind: the frame takes the depth map itself and runs moped3d's shipped front end on "
                          "the device (DEPTHFILTER, depth-adaptive ratio, DEPTHFILTER2, DEPTHMAP_PROP, CLUSTER_LINKAGE; "
                          "moped3d/libmoped/src/config.hpp:41-45) instead of per-query depth attributes + mean shift")
+    ap.add_argument("--parallelism", choices=("models", "frames"), default="models",
+                    help="N > 1: 'models' (default, the north-star design) shards the DB by model with one all-gather per "
+                         "batch of frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: "
+                         "SURVEY 8(e)'s alternative for DBs too small to shard)")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per MATCH launch and exchange with a sharded DB (default 4: a shard of ~12k rows does "
                          "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
@@ -114,7 +118,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    sharded = world > 1 or args.force_exchange
+    by_frames = args.parallelism == "frames" and not args.force_exchange
+    sharded = (world > 1 and not by_frames) or args.force_exchange
     if args.depth <= 0:
         args.depth = 16 if sharded else 4
     if args.batch <= 0:
@@ -143,7 +148,11 @@ def main():
     db = synth.make_db(args.models, 5000)
     n_frames = max(args.frames_per_step, 1)
     frames = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_frames)]
-    shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
+    if by_frames:   # every rank holds the whole DB and works on its own frames
+        frames = [synth.make_frame(db, n_vis=args.n_vis, seed=1000 * rank + s, Q=Q) for s in range(n_frames)] if rank else frames
+        shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
+    else:
+        shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
     params = capi.default_frame_params()
     if args.depth_kind:
         # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
@@ -205,7 +214,7 @@ def main():
                 pipe.ctxs[slot].frame_set_depth_image(maps[b][0].data_ptr(), maps[b][1].data_ptr(), 640, 480,
                                                       args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
             pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + b + 1)
-            if record and world == 1:
+            if record and (world == 1 or by_frames):
                 ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
                 with torch.cuda.stream(s):
                     from moped_amd.pipeline import _wrap_int32
@@ -229,14 +238,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_frames = args.steps * n_frames
+    total_frames = args.steps * n_frames * (world if by_frames else 1)
     fps = total_frames / dt
 
     # detections of the last step (sanity: the planted objects are found)
     if B > 1:
         last_slot = ((args.steps - 1) * groups + groups - 1) % args.depth
         det_per_frame = float(np.mean([len(o) for o in pipe.flush_objects_batch(last_slot, B)]))
-    elif world == 1:
+    elif world == 1 or by_frames:
         det_per_frame = float(counts_host.float().mean().item())
     else:
         objs = pipe.gather_objects((n_frames - 1) % args.depth)
@@ -255,7 +264,8 @@ def main():
                                + ("" if not (args.depth_kind and args.moped3d_frontend) else
                                   ", moped3d front end on the device (DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
                    "frames_per_step": n_frames, "frames_in_flight": args.depth * B, "frames_per_match_launch": B,
-                   "parallelism": f"model-shard x{world}" if world > 1 else "single GPU",
+                   "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
+                                   f"model-shard x{world}" if world > 1 else "single GPU"),
                    "objects_per_frame": det_per_frame},
     }
 
