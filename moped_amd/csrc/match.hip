@@ -430,8 +430,25 @@ static int expected_queries(int Q, int q_expected) {
   if (q_expected <= 0 || q_expected > Q) return Q;
   return std::min(Q, std::max(q_expected, lo));
 }
+// the matrix-pipe variant (match_mfma.hip)
+int mfma_splits_for(int Q, int N);
+void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
+                       int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s);
+// Which kernel searches: the matrix-pipe one when there are enough queries to fill its 256-query
+// blocks (measured cross-over between 600 and 3000 queries), the VALU one below that.  Both give the
+// same bits.  MH_MATCH_MFMA = 0 / 1 pins the choice (A/B runs).
+bool match_uses_mfma(int q_expected) {
+  static const int pinned = [] {
+    const char* e = getenv("MH_MATCH_MFMA");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  return pinned >= 0 ? pinned == 1 : q_expected >= 1536;
+}
+
 size_t match_scratch_elems(int Q, int N) {
-  return (size_t)splits_for(expected_queries(Q, 1), N) * (size_t)(Q > 0 ? Q : 1);
+  const int e = expected_queries(Q, 1);
+  const int S = std::max(splits_for(e, N), mfma_splits_for(e, N));
+  return (size_t)S * (size_t)(Q > 0 ? Q : 1);
 }
 
 size_t match_pack_floats(int Q) { return (size_t)((Q + TQ - 1) / TQ) * TQ * (DIM + 1); }
@@ -442,6 +459,13 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
   if (Q <= 0) return;
   // the split count follows the number of queries expected (device-side counts: the caller's
   // estimate), the grid covers the capacity
+  if (N > 0 && match_uses_mfma(expected_queries(Q, q_expected))) {
+    const int Sm = mfma_splits_for(expected_queries(Q, q_expected), N);
+    launch_match_mfma(qn, qnorm, Q, db, dnorm, N, index_base, scratch, Sm, q_count, s);
+    hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, Sm, Q, q_count, idx1, d1,
+                       d2);
+    return;
+  }
   const int S = (N > 0) ? splits_for(expected_queries(Q, q_expected), N) : 0;
   if (S > 0) {
     const int n_groups = (Q + TQ - 1) / TQ;

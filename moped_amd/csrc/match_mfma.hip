@@ -1,0 +1,268 @@
+// MATCH on the matrix pipe: the same exact 2-NN search as match.hip, same canonical arithmetic,
+// same results bit for bit -- v_mfma_f32_32x32x2_f32 accumulates C + a0*b0 + a1*b1 as two fused
+// multiply-adds in k order (scripts/experiments/mfma_f32_chain.hip: 1024 / 1024 results identical
+// to the fmaf chain), so dot(q, d) over K = 128 is the chain the oracle computes.
+//
+// Shape: a wavefront owns 32 queries and keeps them in registers as the A operands of all 64
+// k-pairs (64 VGPRs: lane l holds q[l % 32][2 t + l / 32]).  The 128-row DB tile sits in LDS
+// (double buffered, rows 129 floats apart: the B operand read -- lane l takes
+// d[row block * 32 + l % 32][2 t + l / 32] -- touches 32 distinct banks per half wave).  Per tile a
+// wavefront issues 4 row blocks x 64 k-pairs = 256 MFMAs into four 32x32 accumulators; the
+// distances and the running top-2 fold (16 queries x 4 row blocks per lane, ascending rows) are
+// VALU work that runs beside the MFMAs of the SIMD's other wavefront.  Eight wavefronts (256
+// queries) share a tile; grid, split handling, XCD-aware block map and the per-split Top2 output
+// are match.hip's.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace mh {
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int MW = 8;                    // wavefronts per workgroup
+constexpr int MQ = 32 * MW;              // queries per workgroup (256)
+constexpr int M_THREADS = 64 * MW;
+constexpr int M_TILE = 128;              // DB rows per LDS tile
+constexpr int M_STRIDE = DIM + 1;        // floats between rows in LDS (odd: conflict-free B reads)
+constexpr int M_TILE_FLOATS = M_TILE * M_STRIDE;
+constexpr int M_TARGET_BLOCKS = 768;
+
+__device__ __forceinline__ void fold2(float& b1, float& b2, int& i1, float v, int idx) {
+  const bool lt = v < b1;
+  b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+  i1 = lt ? idx : i1;
+  b1 = lt ? v : b1;
+}
+struct Best2 {
+  float b1, b2;
+  int i1;
+};
+__device__ __forceinline__ void merge2(Best2& a, float ob1, float ob2, int oi1) {
+  const bool take = (ob1 < a.b1) || (ob1 == a.b1 && (unsigned)oi1 < (unsigned)a.i1);
+  const float lose1 = take ? a.b1 : ob1;
+  const float s2 = fminf(a.b2, ob2);
+  a.b2 = fminf(lose1, s2);
+  a.b1 = take ? ob1 : a.b1;
+  a.i1 = take ? oi1 : a.i1;
+}
+
+__global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
+    const float* __restrict__ qn, const float* __restrict__ qnorm, int Q, const float* __restrict__ db,
+    const float* __restrict__ dnorm, int N, int tiles_per_split, int n_splits, int32_t index_base,
+    Top2* __restrict__ partial, const int32_t* __restrict__ q_count) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 tiles
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  // XCD-aware (query block, split) map, as in match_kernel
+  const int nqb = gridDim.x / n_splits;
+  int qblock, split;
+  {
+    const int L = blockIdx.x;
+    if ((n_splits & 7) == 0) {
+      const int x = L & 7, j = L >> 3;
+      split = x + 8 * (j / nqb);
+      qblock = j % nqb;
+    } else {
+      split = L / nqb;
+      qblock = L % nqb;
+    }
+  }
+  const int Qe = q_count ? min(Q, *q_count) : Q;
+  if (qblock * MQ >= Qe) return;   // uniform over the workgroup
+  const int q0 = qblock * MQ + wave * 32;
+  const int n_tiles = (N + M_TILE - 1) / M_TILE;
+  const int tile_begin = split * tiles_per_split;
+  const int tile_end = min(tile_begin + tiles_per_split, n_tiles);
+
+  // ---- A operands: this lane's query row, every second coordinate starting at `half` ----
+  float A[64];
+  {
+    const int q = q0 + l32;
+    const bool live = q < Qe;
+    const float4* row = reinterpret_cast<const float4*>(qn + (size_t)(live ? q : 0) * DIM);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      float4 v = row[c];
+      if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      A[2 * c] = half ? v.y : v.x;
+      A[2 * c + 1] = half ? v.w : v.z;
+    }
+  }
+  // accumulator register r of a 32x32 block belongs to query (r / 4) * 8 + half * 4 + r % 4;
+  // the queries' norm terms wait in LDS (two broadcast reads per use instead of 16 registers)
+  float* const nq_s = lds + 2 * M_TILE_FLOATS + wave * 32;
+  if (lane < 32) nq_s[lane] = (q0 + lane < Qe) ? qnorm[q0 + lane] : 0.f;
+  float b1[16], b2[16];
+  int i1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    b1[r] = __builtin_inff();
+    b2[r] = __builtin_inff();
+    i1[r] = -1;
+  }
+
+  // ---- staging: a tile is 64 KB contiguous (the DB is padded to whole tiles), copied in four quarters
+  // of 32 rows so that only two 16-byte registers per thread are in flight: per quarter thread t takes
+  // 2 x 16 B at (quarter base) + t * 16 + i * 8 KB = row (t >> 5) + 16 i, coordinates 4 (t & 31) .. + 3
+  float4 st[2];
+  const int st_row = tid >> 5, st_k = (tid & 31) * 4;
+  auto stage_load = [&](int tile, int qt) {
+    const char* tb = reinterpret_cast<const char*>(db) + (size_t)tile * (M_TILE * DIM * 4) + (size_t)qt * (32 * DIM * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st[i] = *reinterpret_cast<const float4*>(tb + (size_t)tid * 16 + (size_t)i * (M_THREADS * 16));
+  };
+  auto stage_store = [&](int buf, int qt) {
+    float* d = lds + buf * M_TILE_FLOATS + (qt * 32 + st_row) * M_STRIDE + st_k;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* p = d + i * 16 * M_STRIDE;
+      p[0] = st[i].x;
+      p[1] = st[i].y;
+      p[2] = st[i].z;
+      p[3] = st[i].w;
+    }
+  };
+  if (tile_begin < tile_end) {   // the first tile: all eight 16-byte loads in flight at once
+    float4 f[8];
+    const char* tb = reinterpret_cast<const char*>(db) + (size_t)tile_begin * (M_TILE * DIM * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float4*>(tb + (size_t)tid * 16 + (size_t)i * (M_THREADS * 16));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* p = lds + (st_row + 16 * i) * M_STRIDE + st_k;
+      p[0] = f[i].x;
+      p[1] = f[i].y;
+      p[2] = f[i].z;
+      p[3] = f[i].w;
+    }
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const bool more = tile + 1 < tile_end;
+    const float* B = lds + buf * M_TILE_FLOATS + l32 * M_STRIDE + half;
+    // two passes of 64 rows: two 32x32 accumulators live at a time; each pass in two segments of 32
+    // k-pairs, a quarter of the next tile in flight during each
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float dn[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) dn[rb] = dnorm[tile * M_TILE + (2 * h + rb) * 32 + l32];   // +inf on padding rows
+      v16f acc[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+      // B operands one k-pair ahead of the MFMAs that use them; the scheduling fence keeps the
+      // compiler from hoisting all the LDS reads of the pass to its top (and spilling)
+      const float* Bh = B + (2 * h) * 32 * M_STRIDE;
+      float bc0 = Bh[0], bc1 = Bh[32 * M_STRIDE];
+#pragma unroll
+      for (int seg = 0; seg < 2; ++seg) {
+#ifndef MM_NOSTAGE   // experiment: MM_NOSTAGE keeps re-using the first tile (results are wrong)
+        if (more) stage_load(tile + 1, 2 * h + seg);
+#endif
+#pragma unroll
+        for (int tt = 0; tt < 32; ++tt) {
+          const int t = seg * 32 + tt;
+          float bn0 = 0.f, bn1 = 0.f;
+          if (t + 1 < 64) {
+            bn0 = Bh[2 * (t + 1)];
+            bn1 = Bh[32 * M_STRIDE + 2 * (t + 1)];
+          }
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], bc0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], bc1, acc[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bc0 = bn0;
+          bc1 = bn1;
+        }
+#ifndef MM_NOSTAGE
+        if (more) stage_store(buf ^ 1, 2 * h + seg);
+#endif
+      }
+      // distances + fold, rows ascending within the lane
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int row = tile * M_TILE + (2 * h + rb) * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifdef MM_NOFOLD   // experiment: no distance / fold work (results are wrong)
+          b1[r] += acc[rb][r];
+#else
+          const float d = fmaxf(fmaf(-2.f, acc[rb][r], nq_s[(r >> 2) * 8 + half * 4 + (r & 3)] + dn[rb]), 0.f);
+          fold2(b1[r], b2[r], i1[r], d, row);
+#endif
+        }
+      }
+    }
+#ifndef MM_NOSTAGE
+    __syncthreads();
+    buf ^= 1;
+#endif
+  }
+
+  // ---- the 32 lanes of a half hold different rows for the same 16 queries: min-reduce, write ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    Best2 s = {b1[r], b2[r], i1[r]};
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+      const float ob1 = __shfl_xor(s.b1, off);
+      const float ob2 = __shfl_xor(s.b2, off);
+      const int oi1 = __shfl_xor(s.i1, off);
+      if (oi1 >= 0) merge2(s, ob1, ob2, oi1);
+    }
+    const int qi = q0 + (r >> 2) * 8 + half * 4 + (r & 3);
+    if (l32 == 0 && qi < Qe) {
+      Top2 o;
+      o.d1 = s.b1;
+      o.d2 = s.b2;
+      o.i1 = (s.i1 >= 0) ? s.i1 + index_base : -1;
+      o.pad = 0;
+      partial[(size_t)split * Q + qi] = o;
+    }
+  }
+}
+
+}  // namespace
+
+int mfma_splits_for(int Q, int N) {
+  const int qblocks = (Q + MQ - 1) / MQ;
+  const int n_tiles = (N + M_TILE - 1) / M_TILE;
+  static const int target = [] {
+    const char* e = getenv("MH_MATCH_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : M_TARGET_BLOCKS;
+  }();
+  int S = (target + qblocks - 1) / qblocks;
+  if (S >= 8) S = (S + 3) / 8 * 8;
+  if (S > n_tiles) S = n_tiles;
+  if (S < 1) S = 1;
+  return S;
+}
+
+// Same contract as the VALU path of launch_match (match.hip) from the normalised queries on.
+void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
+                       int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s) {
+  const int qblocks = (Q + MQ - 1) / MQ;
+  const int n_tiles = (N + M_TILE - 1) / M_TILE;
+  const int tiles_per_split = (n_tiles + S - 1) / S;
+  const size_t lds_bytes = (2 * M_TILE_FLOATS + MQ) * sizeof(float);   // two tiles + the queries' norm terms
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks * S), dim3(M_THREADS), lds_bytes, s, qn, qnorm, Q, db, dnorm, N,
+                     tiles_per_split, S, index_base, scratch, q_count);
+}
+
+}  // namespace mh
