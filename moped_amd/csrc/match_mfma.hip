@@ -50,6 +50,13 @@ __device__ __forceinline__ void merge2(Best2& a, float ob1, float ob2, int oi1) 
   a.i1 = take ? oi1 : a.i1;
 }
 
+#ifdef MM_PROF   // phase timing build (make EXTRA=-DMM_PROF): cycles of thread 0 per phase, summed over workgroups
+__device__ unsigned long long g_mm_prof[8];
+#define MM_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_mm_prof[k], now_ - t_prof); t_prof = now_; } } while (0)
+#else
+#define MM_T(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
     const float* __restrict__ qn, const float* __restrict__ qnorm, int Q, const float* __restrict__ db,
     const float* __restrict__ dnorm, int N, int tiles_per_split, int n_splits, int32_t index_base,
@@ -75,6 +82,10 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
   }
   const int Qe = q_count ? min(Q, *q_count) : Q;
   if (qblock * MQ >= Qe) return;   // uniform over the workgroup
+#ifdef MM_PROF
+  unsigned long long t_prof = clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_mm_prof[7], 1ull);
+#endif
   const int q0 = qblock * MQ + wave * 32;
   const int n_tiles = (N + M_TILE - 1) / M_TILE;
   const int tile_begin = split * tiles_per_split;
@@ -94,6 +105,7 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
       A[2 * c + 1] = half ? v.w : v.z;
     }
   }
+  MM_T(0);
   // accumulator register r of a 32x32 block belongs to query (r / 4) * 8 + half * 4 + r % 4;
   // the queries' norm terms wait in LDS (two broadcast reads per use instead of 16 registers)
   float* const nq_s = lds + 2 * M_TILE_FLOATS + wave * 32;
@@ -143,11 +155,42 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
     }
   }
   __syncthreads();
+  MM_T(1);
+
+  // distances + fold of one pass (two row blocks), rows ascending within the lane
+  auto fold_pass = [&](const v16f (&a)[2], const float (&dnv)[2], int row0) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int row = row0 + rb * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#ifdef MM_NOFOLD   // experiment: no distance / fold work (results are wrong)
+        b1[r] += a[rb][r];
+#else
+        const float d = fmaxf(fmaf(-2.f, a[rb][r], nq_s[(r >> 2) * 8 + half * 4 + (r & 3)] + dnv[rb]), 0.f);
+        fold2(b1[r], b2[r], i1[r], d, row);
+#endif
+      }
+    }
+  };
+  // The two wavefronts of a SIMD would reach their folds together and leave the matrix pipe idle
+  // meanwhile.  The later four wavefronts (4..7: second wavefront of each SIMD) therefore postpone the fold
+  // of a tile's second pass to the start of the next tile: they fold while the others multiply and
+  // vice versa.  Per lane the rows still arrive in ascending order.
+  const bool late = wave >= MW / 2;
+  v16f acc[2];
+  float dn_kept[2] = {0.f, 0.f};
+  int row_kept = 0;
+  bool pending = false;
 
   int buf = 0;
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     const bool more = tile + 1 < tile_end;
     const float* B = lds + buf * M_TILE_FLOATS + l32 * M_STRIDE + half;
+    if (pending) {
+      fold_pass(acc, dn_kept, row_kept);
+      pending = false;
+    }
     // two passes of 64 rows: two 32x32 accumulators live at a time; each pass in two segments of 32
     // k-pairs, a quarter of the next tile in flight during each
 #pragma unroll
@@ -155,7 +198,6 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
       float dn[2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) dn[rb] = dnorm[tile * M_TILE + (2 * h + rb) * 32 + l32];   // +inf on padding rows
-      v16f acc[2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -163,7 +205,9 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
       // B operands one k-pair ahead of the MFMAs that use them; the scheduling fence keeps the
       // compiler from hoisting all the LDS reads of the pass to its top (and spilling)
       const float* Bh = B + (2 * h) * 32 * M_STRIDE;
+      // B operands two k-pairs ahead of the MFMAs that use them
       float bc0 = Bh[0], bc1 = Bh[32 * M_STRIDE];
+      float bd0 = Bh[2], bd1 = Bh[32 * M_STRIDE + 2];
 #pragma unroll
       for (int seg = 0; seg < 2; ++seg) {
 #ifndef MM_NOSTAGE   // experiment: MM_NOSTAGE keeps re-using the first tile (results are wrong)
@@ -173,33 +217,30 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
         for (int tt = 0; tt < 32; ++tt) {
           const int t = seg * 32 + tt;
           float bn0 = 0.f, bn1 = 0.f;
-          if (t + 1 < 64) {
-            bn0 = Bh[2 * (t + 1)];
-            bn1 = Bh[32 * M_STRIDE + 2 * (t + 1)];
+          if (t + 2 < 64) {
+            bn0 = Bh[2 * (t + 2)];
+            bn1 = Bh[32 * M_STRIDE + 2 * (t + 2)];
           }
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], bc0, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], bc1, acc[1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          bc0 = bn0;
-          bc1 = bn1;
+          bc0 = bd0;
+          bc1 = bd1;
+          bd0 = bn0;
+          bd1 = bn1;
         }
 #ifndef MM_NOSTAGE
         if (more) stage_store(buf ^ 1, 2 * h + seg);
 #endif
       }
-      // distances + fold, rows ascending within the lane
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const int row = tile * M_TILE + (2 * h + rb) * 32 + l32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-#ifdef MM_NOFOLD   // experiment: no distance / fold work (results are wrong)
-          b1[r] += acc[rb][r];
-#else
-          const float d = fmaxf(fmaf(-2.f, acc[rb][r], nq_s[(r >> 2) * 8 + half * 4 + (r & 3)] + dn[rb]), 0.f);
-          fold2(b1[r], b2[r], i1[r], d, row);
-#endif
-        }
+      const int row0 = tile * M_TILE + (2 * h) * 32 + l32;
+      if (h == 1 && late) {
+        dn_kept[0] = dn[0];
+        dn_kept[1] = dn[1];
+        row_kept = row0;
+        pending = true;
+      } else {
+        fold_pass(acc, dn, row0);
       }
     }
 #ifndef MM_NOSTAGE
@@ -207,16 +248,31 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
     buf ^= 1;
 #endif
   }
+  if (pending) fold_pass(acc, dn_kept, row_kept);
 
-  // ---- the 32 lanes of a half hold different rows for the same 16 queries: min-reduce, write ----
+  MM_T(2);
+  // ---- the 32 lanes of a half hold different rows for the same 16 queries: min-reduce (the merge
+  // is commutative and associative: any tree gives the same top-2), four DPP steps inside the rows
+  // of 16 lanes and one cross-row exchange, then lane 0 of each half writes ----
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     Best2 s = {b1[r], b2[r], i1[r]};
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-      const float ob1 = __shfl_xor(s.b1, off);
-      const float ob2 = __shfl_xor(s.b2, off);
-      const int oi1 = __shfl_xor(s.i1, off);
+#define MM_DPP_STEP(CTRL)                                                                                   \
+    {                                                                                                       \
+      const float ob1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s.b1), CTRL, 0xF, 0xF, false)); \
+      const float ob2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s.b2), CTRL, 0xF, 0xF, false)); \
+      const int oi1 = __builtin_amdgcn_update_dpp(0, s.i1, CTRL, 0xF, 0xF, false);                          \
+      if (oi1 >= 0) merge2(s, ob1, ob2, oi1);                                                               \
+    }
+    MM_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]
+    MM_DPP_STEP(0x4E)    // quad_perm [2,3,0,1]
+    MM_DPP_STEP(0x141)   // row_half_mirror
+    MM_DPP_STEP(0x140)   // row_mirror
+#undef MM_DPP_STEP
+    {
+      const float ob1 = __shfl_xor(s.b1, 16);
+      const float ob2 = __shfl_xor(s.b2, 16);
+      const int oi1 = __shfl_xor(s.i1, 16);
       if (oi1 >= 0) merge2(s, ob1, ob2, oi1);
     }
     const int qi = q0 + (r >> 2) * 8 + half * 4 + (r & 3);
@@ -229,9 +285,21 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
       partial[(size_t)split * Q + qi] = o;
     }
   }
+  MM_T(3);
 }
 
 }  // namespace
+
+#ifdef MM_PROF
+extern "C" int mh_debug_mm_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mm_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 int mfma_splits_for(int Q, int N) {
   const int qblocks = (Q + MQ - 1) / MQ;
