@@ -297,16 +297,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"match_kernel_{args.models}m_{Q}q")
+                traffic = json.load(open(tpath)).get(f"match_{args.models}m_{Q}q")
             except Exception:
                 traffic = None
         out["roofline"] = {
-            "kernel": "match_kernel (+ combine_splits_kernel, <1% of the time)",
+            "kernel": "match_mfma_kernel (+ combine_splits_kernel, <1% of the time)",
             "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-            "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s FP32 peak, "
-                    "which is the same number for the vector and the f32-input MFMA pipes; the kernel issues "
-                    "v_pk_fma_f32 (VALU) -- no MFMA instruction is used",
+            "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s dense FP32 MFMA peak; "
+                    "the kernel issues v_mfma_f32_32x32x2_f32, whose accumulation is bit-identical to the canonical fmaf "
+                    "chain (index-exact parity with the oracle kept); MH_MATCH_MFMA=0 selects the VALU kernel (v_pk_fma_f32)",
             "ms_per_launch": round(t_ms, 4),
             "measured": "HIP events around 20 back-to-back launches on one stream after the timed region "
                         "(one kernel on the chip at a time); in the timed region `frames_in_flight` frames "
