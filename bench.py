@@ -35,8 +35,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=3000)
     ap.add_argument("--frames-per-step", type=int, default=16)
     ap.add_argument("--depth", type=int, default=0,
-                    help="frames in flight per GPU (default: 4 on one GPU, where MATCH saturates the chip; "
-                         "16 with a sharded DB, where the per-rank frame is short and latency-bound)")
+                    help="frame slots (streams) per GPU (default: 4 on one GPU, where MATCH saturates the chip; "
+                         "32 with a sharded DB, where the per-rank frame is short and latency-bound)")
     ap.add_argument("--n-vis", type=int, default=2)
     ap.add_argument("--depth-kind", type=int, default=0,
                     help="0 = moped2 residuals; 1/2 = moped3d back-projection / reprojection+depth (config 5)")
@@ -49,7 +49,7 @@ def parse():
                          "batch of frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: "
                          "SURVEY 8(e)'s alternative for DBs too small to shard)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per MATCH launch and exchange with a sharded DB (default 4: a shard of ~12k rows does "
+                    help="frames per MATCH launch and exchange with a sharded DB (default 8: a shard of ~12k rows does "
                          "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
@@ -121,9 +121,9 @@ def main():
     by_frames = args.parallelism == "frames" and not args.force_exchange
     sharded = (world > 1 and not by_frames) or args.force_exchange
     if args.depth <= 0:
-        args.depth = 16 if sharded else 4
+        args.depth = 32 if sharded else 4
     if args.batch <= 0:
-        args.batch = 4 if sharded else 1
+        args.batch = 8 if sharded else 1
     if not sharded or args.depth_kind:
         args.batch = 1
     if args.depth > 4:

@@ -432,6 +432,7 @@ static int expected_queries(int Q, int q_expected) {
 }
 // the matrix-pipe variant (match_mfma.hip)
 int mfma_splits_for(int Q, int N);
+int mfma_max_splits(int N);
 void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
                        int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s);
 // Which kernel searches: the matrix-pipe one when there are enough queries to fill its 256-query
@@ -447,7 +448,7 @@ bool match_uses_mfma(int q_expected) {
 
 size_t match_scratch_elems(int Q, int N) {
   const int e = expected_queries(Q, 1);
-  const int S = std::max(splits_for(e, N), mfma_splits_for(e, N));
+  const int S = std::max(splits_for(e, N), mfma_max_splits(N));
   return (size_t)S * (size_t)(Q > 0 ? Q : 1);
 }
 

@@ -29,7 +29,6 @@ constexpr int M_THREADS = 64 * MW;
 constexpr int M_TILE = 128;              // DB rows per LDS tile
 constexpr int M_STRIDE = DIM + 1;        // floats between rows in LDS (odd: conflict-free B reads)
 constexpr int M_TILE_FLOATS = M_TILE * M_STRIDE;
-constexpr int M_TARGET_BLOCKS = 768;
 
 __device__ __forceinline__ void fold2(float& b1, float& b2, int& i1, float v, int idx) {
   const bool lt = v < b1;
@@ -59,7 +58,7 @@ __device__ unsigned long long g_mm_prof[8];
 
 __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
     const float* __restrict__ qn, const float* __restrict__ qnorm, int Q, const float* __restrict__ db,
-    const float* __restrict__ dnorm, int N, int tiles_per_split, int n_splits, int32_t index_base,
+    const float* __restrict__ dnorm, int N, int tiles_base, int tiles_rem, int n_splits, int32_t index_base,
     Top2* __restrict__ partial, const int32_t* __restrict__ q_count) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 tiles
   const int tid = threadIdx.x;
@@ -88,8 +87,9 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
 #endif
   const int q0 = qblock * MQ + wave * 32;
   const int n_tiles = (N + M_TILE - 1) / M_TILE;
-  const int tile_begin = split * tiles_per_split;
-  const int tile_end = min(tile_begin + tiles_per_split, n_tiles);
+  // split s takes tiles_base tiles, the first tiles_rem splits one more
+  const int tile_begin = split * tiles_base + min(split, tiles_rem);
+  const int tile_end = min(tile_begin + tiles_base + (split < tiles_rem ? 1 : 0), n_tiles);
 
   // ---- A operands: this lane's query row, every second coordinate starting at `half` ----
   float A[64];
@@ -301,19 +301,29 @@ extern "C" int mh_debug_mm_prof(unsigned long long out[8], int reset) {
 }
 #endif
 
+// How many splits of the DB: enough workgroups for three rounds over the chip's CUs (a workgroup owns a CU:
+// two tiles of LDS, 8 x 223 VGPRs).  Fewer, longer workgroups would save pipeline fills (one round of 21 splits
+// at config 1: measured 4% SLOWER, and 20% slower on an 8-way shard) - with several frames in flight the tail
+// of one launch overlaps the next frame's kernels, and short workgroups let the latency-bound steps of the other
+// streams in.  MH_MATCH_SPLITS pins the count, MH_MATCH_BLOCKS the workgroup target (sweeps).
+constexpr int M_MAX_SPLITS = 128;
+constexpr int M_TARGET_BLOCKS = 768;
+int mfma_max_splits(int N) { return std::max(1, std::min((N + M_TILE - 1) / M_TILE, M_MAX_SPLITS)); }
 int mfma_splits_for(int Q, int N) {
   const int qblocks = (Q + MQ - 1) / MQ;
-  const int n_tiles = (N + M_TILE - 1) / M_TILE;
+  static const int pinned = [] {
+    const char* e = getenv("MH_MATCH_SPLITS");
+    return e ? atoi(e) : 0;
+  }();
   static const int target = [] {
     const char* e = getenv("MH_MATCH_BLOCKS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : M_TARGET_BLOCKS;
+    return e ? atoi(e) : 0;
   }();
-  int S = (target + qblocks - 1) / qblocks;
-  if (S >= 8) S = (S + 3) / 8 * 8;
-  if (S > n_tiles) S = n_tiles;
-  if (S < 1) S = 1;
-  return S;
+  const int s_max = mfma_max_splits(N);
+  if (pinned > 0) return std::min(pinned, s_max);
+  int S = ((target > 0 ? target : M_TARGET_BLOCKS) + qblocks - 1) / qblocks;
+  if (S >= 8) S = (S + 3) / 8 * 8;   // whole splits per XCD
+  return std::max(1, std::min(S, s_max));
 }
 
 // Same contract as the VALU path of launch_match (match.hip) from the normalised queries on.
@@ -321,7 +331,6 @@ void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* 
                        int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s) {
   const int qblocks = (Q + MQ - 1) / MQ;
   const int n_tiles = (N + M_TILE - 1) / M_TILE;
-  const int tiles_per_split = (n_tiles + S - 1) / S;
   const size_t lds_bytes = (2 * M_TILE_FLOATS + MQ) * sizeof(float);   // two tiles + the queries' norm terms
   static bool attr_set = false;
   if (!attr_set) {
@@ -330,7 +339,7 @@ void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* 
     attr_set = true;
   }
   hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks * S), dim3(M_THREADS), lds_bytes, s, qn, qnorm, Q, db, dnorm, N,
-                     tiles_per_split, S, index_base, scratch, q_count);
+                     n_tiles / S, n_tiles % S, S, index_base, scratch, q_count);
 }
 
 }  // namespace mh
