@@ -38,7 +38,7 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
                                                     int min_points, float min_score,
                                                     int32_t* n_slots_dev, int32_t* n_clusters_dev,
                                                     FrameCounts* counts, FilterTail tail) {
-  __shared__ float err_s[FT];
+  __shared__ double term_s[FT];
   __shared__ float score_s;
   __shared__ int cnt_s, kept_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
         const mh_corr c = fb.corr[b + i];
         e = reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v);
       }
-      err_s[tid] = e;
+      // score += 1./(err+1.) over the in-cluster matches, in list order: the quotients in parallel, the
+      // Float += double chain by one thread (adding 0. leaves a float unchanged)
+      term_s[tid] = e < feature_distance ? 1. / ((double)e + 1.) : 0.;
       __syncthreads();
       if (tid == 0) {
         const int cnt = min(FT, n - base);
-        for (int j = 0; j < cnt; ++j)
-          if (err_s[j] < feature_distance)
-            score = (float)((double)score + 1. / ((double)err_s[j] + 1.));  // score += 1./(err+1.)
+        for (int j = 0; j < cnt; ++j) score = (float)((double)score + term_s[j]);
       }
       __syncthreads();
     }

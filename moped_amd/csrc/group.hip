@@ -10,6 +10,7 @@ namespace {
 
 constexpr int GROUP_THREADS = 1024;
 constexpr int GROUP_MAX_MODELS = 8192;  // LDS histogram
+constexpr int GROUP_LDS_M = 2048;       // accepted matches whose (model, pixel) wait in LDS for the rank / representative scans
 
 __device__ __forceinline__ bool accepted(int32_t idx, float d1, float d2, float ratio) {
   // squared distances, fp32 division, exactly `ds[0]/ds[1] < Ratio` (:165)
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int base_s;
+  __shared__ int model_s[GROUP_LDS_M];
+  __shared__ float2 uv_s[GROUP_LDS_M];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int m = tid; m <= n_models; m += GROUP_THREADS) hist[m] = 0;
   if (tid == 0) {
@@ -222,11 +225,21 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   }
   __syncthreads();
 
-  // (c) stable placement: rank among earlier accepted entries of the same model
+  // (c) stable placement: rank among earlier accepted entries of the same model (the scans of (c) and
+  // (d) read LDS copies: every lane of a wavefront asks for the same j, a broadcast)
+  const bool in_lds = M <= GROUP_LDS_M;
+  if (in_lds) {
+    for (int i = tid; i < M; i += GROUP_THREADS) model_s[i] = acc_model[i];
+    __syncthreads();
+  }
   for (int i = tid; i < M; i += GROUP_THREADS) {
     const int model = acc_model[i];
     int rank = 0;
-    for (int j = 0; j < i; ++j) rank += (acc_model[j] == model);
+    if (in_lds) {
+      for (int j = 0; j < i; ++j) rank += (model_s[j] == model);
+    } else {
+      for (int j = 0; j < i; ++j) rank += (acc_model[j] == model);
+    }
     const int dst = hist[model] + rank;
     const int q = acc_q[i];
     const int32_t li = idx1[q] - index_base;
@@ -239,6 +252,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     c.y = db_xyz[3 * (size_t)li + 1];
     c.z = db_xyz[3 * (size_t)li + 2];
     m_corr[dst] = c;
+    if (in_lds) uv_s[dst] = make_float2(c.u, c.v);
     if (q_depth) {
       m_depth[dst] = q_depth[q];
     } else if (dimg.img) {
@@ -265,13 +279,24 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
 
   // (d) representative of each image coordinate
   for (int i = tid; i < M; i += GROUP_THREADS) {
-    const float u = m_corr[i].u, v = m_corr[i].v;
     int rep = i;
-    for (int j = 0; j < i; ++j)
-      if (m_corr[j].u == u && m_corr[j].v == v) {
-        rep = j;
-        break;
+    if (in_lds) {
+      const float2 p = uv_s[i];
+      for (int j = 0; j < i; ++j) {
+        const float2 o = uv_s[j];
+        if (o.x == p.x && o.y == p.y) {
+          rep = j;
+          break;
+        }
       }
+    } else {
+      const float u = m_corr[i].u, v = m_corr[i].v;
+      for (int j = 0; j < i; ++j)
+        if (m_corr[j].u == u && m_corr[j].v == v) {
+          rep = j;
+          break;
+        }
+    }
     m_rep[i] = rep;
     if (best) best[i] = 0ull;
   }

@@ -47,39 +47,55 @@ __device__ __forceinline__ float dot_chain_lds(const float* a, const float* b) {
 constexpr int NORM_ROWS = 64;
 constexpr int NORM_STRIDE = DIM + 1;
 
+constexpr int NORM_THREADS = 256;   // four wavefronts move the slab (16-byte accesses, all in flight); the first does the rows
+
 template <bool NORMALIZE>
-__global__ __launch_bounds__(NORM_ROWS) void normalize_kernel(float* __restrict__ desc,
-                                                             float* __restrict__ norm_out, int n,
-                                                             const int32_t* __restrict__ n_dev) {
+__global__ __launch_bounds__(NORM_THREADS) void normalize_kernel(float* __restrict__ desc,
+                                                                float* __restrict__ norm_out, int n,
+                                                                const int32_t* __restrict__ n_dev) {
   __shared__ float tile[NORM_ROWS * NORM_STRIDE];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * NORM_ROWS;
   if (n_dev) n = min(n, *n_dev);   // row count known only on the device (features extracted there)
   const int rows = min(NORM_ROWS, n - (int)row0);
   if (rows <= 0) return;
-  const float* src = desc + row0 * DIM;
-  for (int i = 0; i < DIM; ++i) {
-    int e = i * NORM_ROWS + t;  // element of the block's [rows x 128] slab
-    int r = e >> 7, c = e & 127;
-    tile[r * NORM_STRIDE + c] = (r < rows) ? src[e] : 0.f;
+  constexpr int PER_THREAD = NORM_ROWS * DIM / 4 / NORM_THREADS;   // float4s of the [rows x 128] slab per thread
+  const float4* src = reinterpret_cast<const float4*>(desc + row0 * DIM);
+  float4 v[PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < PER_THREAD; ++i) {
+    const int e = i * NORM_THREADS + t;   // float4 index: row e / 32, columns 4 (e % 32) ..
+    v[i] = (e >> 5) < rows ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < PER_THREAD; ++i) {
+    const int e = i * NORM_THREADS + t;
+    float* d = tile + (e >> 5) * NORM_STRIDE + (e & 31) * 4;
+    d[0] = v[i].x;
+    d[1] = v[i].y;
+    d[2] = v[i].z;
+    d[3] = v[i].w;
   }
   __syncthreads();
-  float* mine = tile + t * NORM_STRIDE;
-  if (NORMALIZE) {
-    float s = 0.f;
-    for (int x = 0; x < DIM; ++x) s = __fadd_rn(s, __fmul_rn(mine[x], mine[x]));
-    const float inv = (float)(1.0 / (double)sqrtf(s));
-    for (int x = 0; x < DIM; ++x) mine[x] = __fmul_rn(mine[x], inv);
+  if (t < NORM_ROWS) {
+    float* mine = tile + t * NORM_STRIDE;
+    if (NORMALIZE) {
+      float s = 0.f;
+      for (int x = 0; x < DIM; ++x) s = __fadd_rn(s, __fmul_rn(mine[x], mine[x]));
+      const float inv = (float)(1.0 / (double)sqrtf(s));
+      for (int x = 0; x < DIM; ++x) mine[x] = __fmul_rn(mine[x], inv);
+    }
+    const float nn = dot_chain_lds(mine, mine);
+    if (t < rows && norm_out) norm_out[row0 + t] = nn;
   }
-  const float nn = dot_chain_lds(mine, mine);
-  if (t < rows && norm_out) norm_out[row0 + t] = nn;
   if (NORMALIZE) {
     __syncthreads();
-    float* dst = desc + row0 * DIM;
-    for (int i = 0; i < DIM; ++i) {
-      int e = i * NORM_ROWS + t;
-      int r = e >> 7, c = e & 127;
-      if (r < rows) dst[e] = tile[r * NORM_STRIDE + c];
+    float4* dst = reinterpret_cast<float4*>(desc + row0 * DIM);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int e = i * NORM_THREADS + t;
+      const float* d = tile + (e >> 5) * NORM_STRIDE + (e & 31) * 4;
+      if ((e >> 5) < rows) dst[e] = make_float4(d[0], d[1], d[2], d[3]);
     }
   }
 }
@@ -365,10 +381,15 @@ __global__ void combine_splits_kernel(const Top2* __restrict__ partial, int S, i
   if (q >= Q) return;
   Best s = {__builtin_inff(), __builtin_inff(), -1};
   if (q_count && q >= *q_count) S = 0;   // no such query in this frame: "no neighbour"
-  for (int k = 0; k < S; ++k) {
-    const Top2 p = partial[(size_t)k * Q + q];
-    if (p.i1 < 0) continue;
-    merge(s, p.d1, p.d2, p.i1);
+  // eight partial results in flight per step (the merge itself is a short dependent chain)
+  for (int k0 = 0; k0 < S; k0 += 8) {
+    Top2 p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      p[j] = (k0 + j < S) ? partial[(size_t)(k0 + j) * Q + q] : Top2{__builtin_inff(), __builtin_inff(), -1};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (p[j].i1 >= 0) merge(s, p[j].d1, p[j].d2, p[j].i1);
   }
   idx1[q] = s.i1;
   d1[q] = s.b1;
@@ -414,13 +435,13 @@ int splits_for(int Q, int N) {
 void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s, const int32_t* n_dev) {
   if (n <= 0) return;
   const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
-  hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks), dim3(NORM_ROWS), 0, s, desc, norm_out, n, n_dev);
+  hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks), dim3(NORM_THREADS), 0, s, desc, norm_out, n, n_dev);
 }
 
 void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s) {
   if (n <= 0) return;
   const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
-  hipLaunchKernelGGL(normalize_kernel<false>, dim3(blocks), dim3(NORM_ROWS), 0, s,
+  hipLaunchKernelGGL(normalize_kernel<false>, dim3(blocks), dim3(NORM_THREADS), 0, s,
                      const_cast<float*>(desc), norm_out, n, (const int32_t*)nullptr);
 }
 
@@ -463,7 +484,7 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
   if (N > 0 && match_uses_mfma(expected_queries(Q, q_expected))) {
     const int Sm = mfma_splits_for(expected_queries(Q, q_expected), N);
     launch_match_mfma(qn, qnorm, Q, db, dnorm, N, index_base, scratch, Sm, q_count, s);
-    hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, Sm, Q, q_count, idx1, d1,
+    hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, Sm, Q, q_count, idx1, d1,
                        d2);
     return;
   }
@@ -488,7 +509,7 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
     hipLaunchKernelGGL(match_kernel, dim3(qgroups * S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
                        db, dnorm, N, tiles_per_split, S, index_base, scratch, q_count);
   }
-  hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 255) / 256), dim3(256), 0, s, scratch, S, Q,
+  hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, S, Q,
                      q_count, idx1, d1, d2);
 }
 
