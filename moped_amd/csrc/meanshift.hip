@@ -30,9 +30,16 @@ namespace {
 
 #ifdef MS_PROF   // phase timing build (make EXTRA=-DMS_PROF): cycles of thread 0 per phase, summed over calls
 __device__ unsigned long long g_ms_prof[8];
+__device__ unsigned long long g_ms_stat[8];   // walk: rows, rows with outward members, -, rows with a hit, relaxation rounds, cycles per row class
+#ifdef MS_STATS   // (perturbs the timing: every update is a global read-modify-write)
+#define MS_STAT(k, v) do { if (lane == 0) g_ms_stat[k] += (v); } while (0)
+#else
+#define MS_STAT(k, v) do { } while (0)
+#endif
 #define MS_T(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); g_ms_prof[k] += now_ - t_prof; t_prof = now_; } } while (0)
 #else
 #define MS_T(k) do { } while (0)
+#define MS_STAT(k, v) do { } while (0)
 #endif
 
 constexpr int MS_THREADS = 1024;   // one workgroup per point set owns a CU (LDS): use its 16 wavefronts
@@ -138,8 +145,8 @@ __device__ __forceinline__ void fold_target(MsLds<ND>& L, int t, int lane) {
 // Rows with outward members use LDS stamps for the cross-lane parts (flag: targets of
 // members; st: positions written indirectly).
 template <int ND, int NP>
-__device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane,
-                                                int& stamp) {
+__device__ __forceinline__ int walk_block_impl(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane,
+                                               int stamp) {   // the stamp counter by value: by reference it lives in scratch
   int mpr[NP];
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
@@ -149,6 +156,9 @@ __device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, uns
   for (unsigned long long rows = ne; rows; rows &= rows - 1ull) {
     const int r = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rows));
     const int i = i0 + r;
+#ifdef MS_STATS
+    const unsigned long long t_row = clock64();
+#endif
     // loads are unconditional (clamped indices) so that each batch is one LDS round trip
     unsigned long long W[NP], TW[NP];
 #pragma unroll
@@ -165,7 +175,15 @@ __device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, uns
       out[u] = mem[u] && t != pos && !((TW[u] >> (t & 63)) & 1ull);
       any_out_l |= out[u];
     }
+    MS_STAT(0, 1);
+#ifdef MS_STATS
+    int row_class = 5;
+#endif
     if (__ballot(any_out_l) != 0ull) {
+#ifdef MS_STATS
+      row_class = 6;
+#endif
+      MS_STAT(1, 1);
       // is an outward member the target of another member?
       ++stamp;
 #pragma unroll
@@ -181,6 +199,10 @@ __device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, uns
 #pragma unroll
       for (int u = 0; u < NP; ++u) stv[u] = mem[u] ? 1 : 0;
       if (__ballot(hit) != 0ull) {
+        MS_STAT(3, 1);
+#ifdef MS_STATS
+        row_class = 7;
+#endif
         // ov relaxation: ov(j) = exists j' in S_i, !ov(j'), m[j'] == j (j' != j).  The sweep above
         // (every member flags its pointer) was its first round.
 #pragma unroll
@@ -201,6 +223,7 @@ __device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, uns
               ch |= s1 != stv[u];
               stv[u] = s1;
             }
+          MS_STAT(4, 1);
           if (__ballot(ch) == 0ull) break;
         }
       }
@@ -219,16 +242,29 @@ __device__ __noinline__ void walk_block_regs(MsLds<ND>& L, int i0, int nrem, uns
 #pragma unroll
     for (int u = 0; u < NP; ++u)
       if (mem[u]) mpr[u] = i;
+    MS_STAT(row_class, clock64() - t_row);
   }
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     const int pos = u * 64 + lane;
     if (pos < nrem) L.mp[pos] = mpr[u];
   }
+  return stamp;
+}
+// Inlined for the sizes a frame's models usually have; the large ones stay functions of their own (inlined, their
+// register arrays push the whole kernel over the 128 VGPRs a 1024-thread workgroup allows), at the price of the
+// call and of one dynamic-LDS table lookup per LDS base address.
+template <int ND, int NP>
+__device__ __forceinline__ int walk_block_regs(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane, int stamp) {
+  return walk_block_impl<ND, NP>(L, i0, nrem, ne, lane, stamp);
+}
+template <int ND, int NP>
+__device__ __noinline__ int walk_block_regs_call(MsLds<ND>& L, int i0, int nrem, unsigned long long ne, int lane, int stamp) {
+  return walk_block_impl<ND, NP>(L, i0, nrem, ne, lane, stamp);
 }
 
 template <int ND>
-__device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int pts_stride, int n,
+__device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int pts_stride, int n,
                                float radius, float merge, int min_pts, int max_iter,
                                int32_t* __restrict__ members_out, int32_t member_base,
                                int32_t* __restrict__ cl_start_out, int32_t* __restrict__ ncl_out,
@@ -408,12 +444,12 @@ __device__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int 
         }
       } else if (n <= 64 * 16) {
         if (wave == 0) {
-          if (n <= 64 * 2) walk_block_regs<ND, 2>(L, i0, nrem, ne, lane, stamp);
-          else if (n <= 64 * 4) walk_block_regs<ND, 4>(L, i0, nrem, ne, lane, stamp);
-          else if (n <= 64 * 6) walk_block_regs<ND, 6>(L, i0, nrem, ne, lane, stamp);
-          else if (n <= 64 * 8) walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
-          else if (n <= 64 * 12) walk_block_regs<ND, 12>(L, i0, nrem, ne, lane, stamp);
-          else walk_block_regs<ND, 16>(L, i0, nrem, ne, lane, stamp);
+          if (n <= 64 * 2) stamp = walk_block_regs<ND, 2>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 4) stamp = walk_block_regs<ND, 4>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 6) stamp = walk_block_regs<ND, 6>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 8) stamp = walk_block_regs<ND, 8>(L, i0, nrem, ne, lane, stamp);
+          else if (n <= 64 * 12) stamp = walk_block_regs_call<ND, 12>(L, i0, nrem, ne, lane, stamp);
+          else stamp = walk_block_regs_call<ND, 16>(L, i0, nrem, ne, lane, stamp);
         }
       } else if (wave == 0) {
         unsigned long long tb = lane < MS_WORDS ? L.tbw[lane] : 0ull;   // lane ps: target bits of positions [64 ps, 64 ps + 64)
@@ -800,6 +836,14 @@ void set_lds_attr(K kernel, size_t bytes) {
 }  // namespace
 
 #ifdef MS_PROF
+extern "C" int mh_debug_ms_stat(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ms_stat), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ms_stat), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int mh_debug_ms_prof(unsigned long long out[8], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ms_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {

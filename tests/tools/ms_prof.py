@@ -13,6 +13,10 @@ def prof(pts, label):
     ctx.meanshift(pts); L.mh_debug_ms_prof(out, 1)
     tot = sum(out)
     print(f"{label} n={len(pts)}: total {tot} cycles  " + "  ".join(f"{nm}={v}" for nm, v in zip(names, out) if v))
+    st = (C.c_ulonglong * 8)()
+    if hasattr(L, "mh_debug_ms_stat"):
+        L.mh_debug_ms_stat(st, 1)
+        print(f"   (two calls) walk rows {st[0]} with outward {st[1]} outward members {st[2]} hit rows {st[3]} relax rounds {st[4]}; cycles in plain rows {st[5]}, outward rows {st[6]}, hit rows {st[7]}")
 for n in (150, 300, 600):
     prof(rng.normal([320, 240], 6, size=(n, 2)).astype(np.float32), "tight")
     prof(rng.normal([320, 240], 40, size=(n, 2)).astype(np.float32), "blob40")
