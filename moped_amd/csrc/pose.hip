@@ -36,7 +36,7 @@ DevCam make_devcam(const mh_cam& cam) {
 
 namespace {
 
-constexpr int POSE_THREADS = 1024;
+constexpr int POSE_THREADS = 512;
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -684,7 +684,7 @@ __device__ void pose_task(
   PP_T(0);
 
   // ---- hypotheses: one per lane ------------------------------------------------------
-  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : POSE_THREADS;
+  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : 1024;
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
   auto hypothesis = [&](const int h) {

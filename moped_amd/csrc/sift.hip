@@ -336,17 +336,6 @@ __global__ void detect_kernel(SiftPyramid P, SiftCandidate* __restrict__ cand, i
 }
 
 // ---- orientation (AssignOriHist, :1274-1382) ---------------------------------------------------
-__device__ __forceinline__ void smooth_hist(float* h) {  // SmoothHistogram (:1395-1408), 36 bins
-  const float first = h[0];
-  float prev = h[35];
-  for (int i = 0; i < 35; ++i) {
-    const float org = h[i];
-    h[i] = __fmul_rn(__fadd_rn(__fadd_rn(prev, org), h[i + 1]), 0.33333333f);
-    prev = org;
-  }
-  h[35] = __fmul_rn(__fadd_rn(__fadd_rn(prev, h[35]), first), 0.3333333f);
-}
-
 // One wavefront per candidate.  Samples are visited 64 at a time in raster order; lane b < 36
 // owns histogram bin b and adds the chunk's contributions to it in that order, so every bin
 // sums exactly like the serial loop.
@@ -354,7 +343,6 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
                                                     const int32_t* __restrict__ n_cand, int cand_cap,
                                                     SiftKey* __restrict__ keys, int32_t* __restrict__ n_keys,
                                                     int key_cap, int32_t* __restrict__ overflow) {
-  __shared__ float hist_s[36];
   const int lane = threadIdx.x;
   int n = *n_cand;
   if (n > cand_cap) n = cand_cap;
@@ -404,46 +392,54 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
         if (lane == b) h = __fadd_rn(h, x);
       }
     }
-    __syncthreads();
-    if (lane < 36) hist_s[lane] = h;
-    __syncthreads();
-    if (lane == 0) {
-      float hist[36];
-      for (int i = 0; i < 36; ++i) hist[i] = hist_s[i];
-      for (int i = 0; i < 6; ++i) smooth_hist(hist);
-      float fmax = 0.f;
-      for (int i = 0; i < 36; ++i)
-        if (hist[i] > fmax) fmax = hist[i];
-      fmax = __fmul_rn(fmax, 0.8f);
-      const float foriadd = 0.5f * 2 * kPi / 36.0f - kPi, forimult = 2 * kPi / 36.0f;
-      for (int i = 0; i < 36; ++i) {
-        const int prev = i == 0 ? 35 : i - 1, next = i == 35 ? 0 : i + 1;
-        if (hist[i] <= hist[prev] || hist[i] <= hist[next] || hist[i] < fmax) continue;
-        float f0 = hist[prev], f1 = hist[i], f2 = hist[next];  // InterpPeak (:1384-1393)
-        if (f1 < 0) {
-          f0 = -f0;
-          f1 = -f1;
-          f2 = -f2;
+    // SmoothHistogram x 6 (:1395-1408): every new bin is (previous + own) + next of the OLD values (the serial
+    // loop carries the old left neighbour along and has not reached the right one yet; bin 35 closes the ring
+    // with the old bin 0 and its own, shorter, constant), so the 36 lanes smooth their bins side by side.
+    const int lp = lane == 0 ? 35 : lane - 1, ln = lane >= 35 ? 0 : lane + 1;
+    for (int it = 0; it < 6; ++it) {
+      const float hp = __shfl(h, lp), hn = __shfl(h, ln);
+      h = __fmul_rn(__fadd_rn(__fadd_rn(hp, h), hn), lane == 35 ? 0.3333333f : 0.33333333f);
+    }
+    float fmax = lane < 36 ? h : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fmax = fmaxf(fmax, __shfl_xor(fmax, off));
+    fmax = fmaxf(fmax, 0.f);
+    fmax = __fmul_rn(fmax, 0.8f);
+    const float foriadd = 0.5f * 2 * kPi / 36.0f - kPi, forimult = 2 * kPi / 36.0f;
+    {
+      const float hp = __shfl(h, lp), hn = __shfl(h, ln);
+      const bool is_peak = lane < 36 && !(h <= hp || h <= hn || h < fmax);
+      const unsigned long long pm = __ballot(is_peak);
+      if (pm != 0ull) {
+        int at0 = 0;
+        if (lane == 0) at0 = atomicAdd(n_keys, __popcll(pm));   // slots in any order: order_kernel sorts by q.order
+        at0 = __builtin_amdgcn_readfirstlane(at0);
+        if (is_peak) {
+          const int at = at0 + __popcll(pm & ((1ull << lane) - 1ull));
+          if (at >= key_cap) {
+            *overflow = 1;
+          } else {
+            float f0 = hp, f1 = h, f2 = hn;  // InterpPeak (:1384-1393)
+            if (f1 < 0) {
+              f0 = -f0;
+              f1 = -f1;
+              f2 = -f2;
+            }
+            const float peak = __fdiv_rn(__fmul_rn(0.5f, __fsub_rn(f0, f2)),
+                                         __fadd_rn(__fsub_rn(f0, __fmul_rn(2.0f, f1)), f2));
+            SiftKey q;
+            q.octave = k.octave;
+            q.index = k.index;
+            q.order = ((unsigned long long)k.octave << 40) | ((unsigned long long)k.key << 8) | (unsigned)lane;
+            q.fsize = fSize;
+            q.frow = frow;
+            q.fcol = fcol;
+            q.ori = __fadd_rn(__fmul_rn(__fadd_rn((float)lane, peak), forimult), foriadd);
+            keys[at] = q;
+          }
         }
-        const float peak = __fdiv_rn(__fmul_rn(0.5f, __fsub_rn(f0, f2)),
-                                     __fadd_rn(__fsub_rn(f0, __fmul_rn(2.0f, f1)), f2));
-        const int at = atomicAdd(n_keys, 1);
-        if (at >= key_cap) {
-          *overflow = 1;
-          break;
-        }
-        SiftKey q;
-        q.octave = k.octave;
-        q.index = k.index;
-        q.order = ((unsigned long long)k.octave << 40) | ((unsigned long long)k.key << 8) | (unsigned)i;
-        q.fsize = fSize;
-        q.frow = frow;
-        q.fcol = fcol;
-        q.ori = __fadd_rn(__fmul_rn(__fadd_rn((float)i, peak), forimult), foriadd);
-        keys[at] = q;
       }
     }
-    __syncthreads();
   }
 }
 
