@@ -251,32 +251,43 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
   if (pending) fold_pass(acc, dn_kept, row_kept);
 
   MM_T(2);
-  // ---- the 32 lanes of a half hold different rows for the same 16 queries: min-reduce (the merge
-  // is commutative and associative: any tree gives the same top-2), four DPP steps inside the rows
-  // of 16 lanes and one cross-row exchange, then lane 0 of each half writes ----
+  // ---- the 32 lanes of a half hold different rows for the same 16 queries: min-reduce over the lanes (the
+  // merge is commutative and associative: any tree gives the same top-2).  A halving butterfly: in every
+  // step a lane keeps one half of its queries and hands the other half to a partner that keeps those, so
+  // the merges number 8 + 4 + 2 + 1 (+ 1 across the two rows of 16) per lane instead of 16 x 5.  Partners:
+  // lane ^ 1, lane ^ 2 (quad permutes), lane -/+ 4 and lane -/+ 8 inside the row of 16 (row rotations: the
+  // sender differs from the receiver in exactly the bit that decides what each keeps), lane ^ 16 at the end.
+  // A lane with bits b0..b3 ends with accumulator register r = 8 b0 + 4 b1 + 2 b2 + b3. ----
+  Best2 v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    Best2 s = {b1[r], b2[r], i1[r]};
-#define MM_DPP_STEP(CTRL)                                                                                   \
-    {                                                                                                       \
-      const float ob1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s.b1), CTRL, 0xF, 0xF, false)); \
-      const float ob2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s.b2), CTRL, 0xF, 0xF, false)); \
-      const int oi1 = __builtin_amdgcn_update_dpp(0, s.i1, CTRL, 0xF, 0xF, false);                          \
-      if (oi1 >= 0) merge2(s, ob1, ob2, oi1);                                                               \
-    }
-    MM_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]
-    MM_DPP_STEP(0x4E)    // quad_perm [2,3,0,1]
-    MM_DPP_STEP(0x141)   // row_half_mirror
-    MM_DPP_STEP(0x140)   // row_mirror
-#undef MM_DPP_STEP
-    {
-      const float ob1 = __shfl_xor(s.b1, 16);
-      const float ob2 = __shfl_xor(s.b2, 16);
-      const int oi1 = __shfl_xor(s.i1, 16);
-      if (oi1 >= 0) merge2(s, ob1, ob2, oi1);
-    }
+  for (int r = 0; r < 16; ++r) v[r] = Best2{b1[r], b2[r], i1[r]};
+#define MM_HALVE(CNT, BIT, CTRL)                                                                              \
+  {                                                                                                          \
+    const bool up = (l32 & (BIT)) != 0;                                                                      \
+    _Pragma("unroll") for (int j = 0; j < (CNT) / 2; ++j) {                                                  \
+      const Best2 send = up ? v[j] : v[j + (CNT) / 2];                                                       \
+      Best2 keep = up ? v[j + (CNT) / 2] : v[j];                                                             \
+      const float ob1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send.b1), CTRL, 0xF, 0xF, false)); \
+      const float ob2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send.b2), CTRL, 0xF, 0xF, false)); \
+      const int oi1 = __builtin_amdgcn_update_dpp(0, send.i1, CTRL, 0xF, 0xF, false);                        \
+      if (oi1 >= 0) merge2(keep, ob1, ob2, oi1);                                                             \
+      v[j] = keep;                                                                                           \
+    }                                                                                                        \
+  }
+  MM_HALVE(16, 1, 0xB1)    // quad_perm [1,0,3,2]
+  MM_HALVE(8, 2, 0x4E)     // quad_perm [2,3,0,1]
+  MM_HALVE(4, 4, 0x124)    // row_ror:4
+  MM_HALVE(2, 8, 0x128)    // row_ror:8
+#undef MM_HALVE
+  {
+    Best2 s = v[0];
+    const float ob1 = __shfl_xor(s.b1, 16);
+    const float ob2 = __shfl_xor(s.b2, 16);
+    const int oi1 = __shfl_xor(s.i1, 16);
+    if (oi1 >= 0) merge2(s, ob1, ob2, oi1);
+    const int r = ((l32 & 1) << 3) | ((l32 & 2) << 1) | ((l32 & 4) >> 1) | ((l32 & 8) >> 3);
     const int qi = q0 + (r >> 2) * 8 + half * 4 + (r & 3);
-    if (l32 == 0 && qi < Qe) {
+    if (l32 < 16 && qi < Qe) {
       Top2 o;
       o.d1 = s.b1;
       o.d2 = s.b2;
