@@ -91,6 +91,13 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
   const int tile_begin = split * tiles_base + min(split, tiles_rem);
   const int tile_end = min(tile_begin + tiles_base + (split < tiles_rem ? 1 : 0), n_tiles);
 
+  // the first tile's eight 16-byte loads go out before the A operands' 32: one trip to memory for both
+  float4 f[8];
+  if (tile_begin < tile_end) {
+    const char* tb = reinterpret_cast<const char*>(db) + (size_t)tile_begin * (M_TILE * DIM * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float4*>(tb + (size_t)threadIdx.x * 16 + (size_t)i * (M_THREADS * 16));
+  }
   // ---- A operands: this lane's query row, every second coordinate starting at `half` ----
   float A[64];
   {
@@ -140,11 +147,7 @@ __global__ __launch_bounds__(M_THREADS) void match_mfma_kernel(
       p[3] = st[i].w;
     }
   };
-  if (tile_begin < tile_end) {   // the first tile: all eight 16-byte loads in flight at once
-    float4 f[8];
-    const char* tb = reinterpret_cast<const char*>(db) + (size_t)tile_begin * (M_TILE * DIM * 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const float4*>(tb + (size_t)tid * 16 + (size_t)i * (M_THREADS * 16));
+  if (tile_begin < tile_end) {   // the first tile (its loads left before the A operands')
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float* p = lds + (st_row + 16 * i) * M_STRIDE + st_k;
