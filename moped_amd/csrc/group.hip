@@ -10,6 +10,12 @@ namespace {
 
 constexpr int GROUP_THREADS = 1024;
 constexpr int GROUP_MAX_MODELS = 8192;  // LDS histogram
+#ifdef GROUP_PROF   // phase timing build (EXTRA=-DGROUP_PROF): cycles of thread 0 per phase
+__device__ unsigned long long g_group_prof[8];
+#define GP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_group_prof[k] += now_ - t_prof; t_prof = now_; } } while (0)
+#else
+#define GP_T(k) do { } while (0)
+#endif
 constexpr int GROUP_LDS_M = 2048;       // accepted matches whose (model, pixel) wait in LDS for the rank / representative scans
 
 __device__ __forceinline__ bool accepted(int32_t idx, float d1, float d2, float ratio) {
@@ -77,10 +83,14 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride) {
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
+  __shared__ int pass_cnt[2][GROUP_THREADS / 64];
   __shared__ int base_s;
-  __shared__ int model_s[GROUP_LDS_M];
-  __shared__ float2 uv_s[GROUP_LDS_M];
+  __shared__ __attribute__((aligned(16))) int model_s[GROUP_LDS_M];
+  __shared__ __attribute__((aligned(16))) float2 uv_s[GROUP_LDS_M];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GROUP_PROF
+  unsigned long long t_prof = clock64();
+#endif
   for (int m = tid; m <= n_models; m += GROUP_THREADS) hist[m] = 0;
   if (tid == 0) {
     base_s = 0;
@@ -105,52 +115,76 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   }
   __syncthreads();
 
-  // (a) ordered compaction, 1024 queries per pass
-  for (int q0 = 0; q0 < Q; q0 += GROUP_THREADS) {
-    const int q = q0 + tid;
-    bool ok = false;
-    int model = 0;
-    if (q < Q) {
-      const int32_t gi = idx1[q];
-      const int32_t li = gi - index_base;
-      if (gi >= 0 && li >= 0 && li < N && !(rules.keep1 && !rules.keep1[q])) {
-        model = db_model[li];
-        float rq = ratio;
-        bool reachable = true;
-        if (rules.ratio_table) {
-          // the feature's pixel (:447-450; clamped to the map, the reference clamps to [0, width])
-          int x = (int)q_uv[2 * q], y = (int)q_uv[2 * q + 1];
-          x = x < 0 ? 0 : (x >= dimg.w ? dimg.w - 1 : x);
-          y = y < 0 ? 0 : (y >= dimg.h ? dimg.h - 1 : y);
-          const float depth = dimg.img[(size_t)y * dimg.w + x].z;
-          reachable = !(depth > rules.max_depth);   // "Don't even bother searching" (:457-460)
-          const float fill = dimg.fill ? dimg.fill[(size_t)y * dimg.w + x] : 0.f;
-          rq = adjusted_ratio(depth, fill, rules.ratio_table[model], rules);
+  GP_T(0);
+  // (a) ordered compaction, 1024 queries per pass; the acceptance tests of four passes (dependent global
+  // loads: idx1 -> the row's model, d1, d2) are evaluated together so that their latencies overlap
+  constexpr int PASSES = 4;
+  int base = 0, pass_no = 0;
+  for (int q00 = 0; q00 < Q; q00 += PASSES * GROUP_THREADS) {
+    bool okv[PASSES];
+    int modelv[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int q = q00 + ps * GROUP_THREADS + tid;
+      bool ok = false;
+      int model = 0;
+      if (q < Q) {
+        const int32_t gi = idx1[q];
+        const int32_t li = gi - index_base;
+        if (gi >= 0 && li >= 0 && li < N && !(rules.keep1 && !rules.keep1[q])) {
+          model = db_model[li];
+          float rq = ratio;
+          bool reachable = true;
+          if (rules.ratio_table) {
+            // the feature's pixel (:447-450; clamped to the map, the reference clamps to [0, width])
+            int x = (int)q_uv[2 * q], y = (int)q_uv[2 * q + 1];
+            x = x < 0 ? 0 : (x >= dimg.w ? dimg.w - 1 : x);
+            y = y < 0 ? 0 : (y >= dimg.h ? dimg.h - 1 : y);
+            const float depth = dimg.img[(size_t)y * dimg.w + x].z;
+            reachable = !(depth > rules.max_depth);   // "Don't even bother searching" (:457-460)
+            const float fill = dimg.fill ? dimg.fill[(size_t)y * dimg.w + x] : 0.f;
+            rq = adjusted_ratio(depth, fill, rules.ratio_table[model], rules);
+          }
+          ok = reachable && accepted(gi, d1[q], d2[q], rq);
         }
-        ok = reachable && accepted(gi, d1[q], d2[q], rq);
+      }
+      okv[ps] = ok;
+      modelv[ps] = model;
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int q = q00 + ps * GROUP_THREADS + tid;
+      if (q00 + ps * GROUP_THREADS >= Q) break;   // uniform
+      const bool ok = okv[ps];
+      const int model = modelv[ps];
+      // one barrier per pass: the wavefronts' counts alternate between two buffers, every thread sums them
+      // itself and carries the running base in a register
+      const unsigned long long bal = __ballot(ok);
+      int* const cnt = pass_cnt[pass_no & 1];
+      ++pass_no;
+      if (lane == 0) cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int before = base, tot = 0;
+#pragma unroll
+      for (int w = 0; w < GROUP_THREADS / 64; ++w) {
+        const int c = cnt[w];
+        if (w < wave) before += c;
+        tot += c;
+      }
+      base += tot;
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (ok && pos < max_m) {
+        acc_q[pos] = q;
+        acc_model[pos] = model;
+        atomicAdd(&hist[model], 1);
       }
     }
-    const unsigned long long bal = __ballot(ok);
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int before = base_s;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (ok && pos < max_m) {
-      acc_q[pos] = q;
-      acc_model[pos] = model;
-      atomicAdd(&hist[model], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int tot = 0;
-      for (int w = 0; w < GROUP_THREADS / 64; ++w) tot += wave_cnt[w];
-      base_s += tot;
-    }
-    __syncthreads();
   }
-  int M = base_s;
+  __threadfence_block();
+  __syncthreads();
+  int M = base;
   if (M > max_m) M = max_m;
+  GP_T(1);
 
   // (a') DEPTHFILTER with ToFilter = 2 (moped3d DEPTHFILTER_CPU.hpp:212-249): per model, the
   // density of its matches over the image patches, dilated, must exceed Density where the
@@ -210,6 +244,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     M = base_s;
   }
 
+  GP_T(2);
   // (b) exclusive scan of the histogram (single thread: n_models is small)
   if (tid == 0) {
     int run = 0;
@@ -225,6 +260,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   }
   __syncthreads();
 
+  GP_T(3);
   // (c) stable placement: rank among earlier accepted entries of the same model (the scans of (c) and
   // (d) read LDS copies: every lane of a wavefront asks for the same j, a broadcast)
   const bool in_lds = M <= GROUP_LDS_M;
@@ -236,7 +272,13 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     const int model = acc_model[i];
     int rank = 0;
     if (in_lds) {
-      for (int j = 0; j < i; ++j) rank += (model_s[j] == model);
+      const int4* m4 = reinterpret_cast<const int4*>(model_s);   // four entries per LDS read
+      int j = 0;
+      for (; j + 4 <= i; j += 4) {
+        const int4 v = m4[j >> 2];
+        rank += (v.x == model) + (v.y == model) + (v.z == model) + (v.w == model);
+      }
+      for (; j < i; ++j) rank += (model_s[j] == model);
     } else {
       for (int j = 0; j < i; ++j) rank += (acc_model[j] == model);
     }
@@ -277,17 +319,28 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
   __threadfence_block();
   __syncthreads();
 
+  GP_T(4);
   // (d) representative of each image coordinate
   for (int i = tid; i < M; i += GROUP_THREADS) {
     int rep = i;
     if (in_lds) {
       const float2 p = uv_s[i];
-      for (int j = 0; j < i; ++j) {
-        const float2 o = uv_s[j];
+      const float4* u4 = reinterpret_cast<const float4*>(uv_s);   // two entries per LDS read
+      int j = 0;
+      for (; j + 2 <= i; j += 2) {
+        const float4 o = u4[j >> 1];
         if (o.x == p.x && o.y == p.y) {
           rep = j;
           break;
         }
+        if (o.z == p.x && o.w == p.y) {
+          rep = j + 1;
+          break;
+        }
+      }
+      if (rep == i && j < i && j + 1 == i) {
+        const float2 o = uv_s[j];
+        if (o.x == p.x && o.y == p.y) rep = j;
       }
     } else {
       const float u = m_corr[i].u, v = m_corr[i].v;
@@ -300,8 +353,21 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     m_rep[i] = rep;
     if (best) best[i] = 0ull;
   }
+  GP_T(5);
 }
 
+#ifdef GROUP_PROF
+}  // namespace
+extern "C" int mh_debug_group_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_group_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace {
+#endif
 // m_rep for caller-provided match lists (per-step FILTER entry point).
 __global__ void rep_kernel(const mh_corr* __restrict__ corr, int M, int32_t* __restrict__ rep_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
