@@ -108,6 +108,58 @@ __global__ void blur_cols_kernel(const float* __restrict__ src, float* __restric
   if (dog) dog[o] = __fsub_rn(prev[o], a);
 }
 
+// Both passes of one pyramid level in one launch: a workgroup blurs a 64 x 32 tile out of LDS -- the tile and a
+// halo of w pixels (replicated edges applied while loading), the row pass over the tile's rows and the halo rows
+// above and below, then the column pass.  Every output pixel sees the same products added in the same order as
+// with the two kernels above (taps ascending, the intermediate row-blurred values are the same numbers).
+constexpr int BT_X = 64, BT_Y = 32, BT_MAXW = 16, BT_THREADS = 256;
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                int rows, int cols, Taps t,
+                                                                const float* __restrict__ prev, float* __restrict__ dog) {
+  __shared__ float in_s[(BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW)];
+  __shared__ __attribute__((aligned(8))) float row_s[(BT_Y + 2 * BT_MAXW) * BT_X];
+  const int tid = threadIdx.x;
+  const int w = t.n >> 1;
+  const int c0 = blockIdx.x * BT_X, r0 = blockIdx.y * BT_Y;
+  const int in_w = BT_X + 2 * w, in_h = BT_Y + 2 * w;
+  for (int e = tid; e < in_w * in_h; e += BT_THREADS) {
+    const int yy = e / in_w, xx = e - yy * in_w;
+    int y = r0 - w + yy, x = c0 - w + xx;
+    y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
+    x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
+    in_s[e] = src[(size_t)y * cols + x];
+  }
+  __syncthreads();
+  // two outputs per packed instruction (the products and sums round like the scalar ones): the row pass pairs
+  // two rows of the same column, the column pass two neighbouring columns (one 8-byte LDS read per tap)
+  for (int e = tid; e < (in_h >> 1) * BT_X; e += BT_THREADS) {   // in_h is even
+    const int yy = 2 * (e / BT_X), x = e % BT_X;
+    const float* r0p = in_s + yy * in_w + x;
+    const float* r1p = r0p + in_w;
+    v2f a = {0.f, 0.f};
+    for (int j = 0; j < t.n; ++j) a = a + v2f{r0p[j], r1p[j]} * v2f{t.k[j], t.k[j]};
+    row_s[yy * BT_X + x] = a.x;
+    row_s[(yy + 1) * BT_X + x] = a.y;
+  }
+  __syncthreads();
+  for (int e = tid; e < BT_Y * (BT_X / 2); e += BT_THREADS) {
+    const int y = e / (BT_X / 2), x = 2 * (e % (BT_X / 2));
+    const int r = r0 + y, c = c0 + x;
+    if (r >= rows || c >= cols) continue;
+    const float* col = row_s + y * BT_X + x;
+    v2f a = {0.f, 0.f};
+    for (int j = 0; j < t.n; ++j) a = a + *reinterpret_cast<const v2f*>(col + j * BT_X) * v2f{t.k[j], t.k[j]};
+    const size_t o = (size_t)r * cols + c;
+    dst[o] = a.x;
+    if (dog) dog[o] = __fsub_rn(prev[o], a.x);
+    if (c + 1 < cols) {
+      dst[o + 1] = a.y;
+      if (dog) dog[o + 1] = __fsub_rn(prev[o + 1], a.y);
+    }
+  }
+}
+
 // HalfImageSize (:390-408)
 __global__ void half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -714,13 +766,19 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
   const SiftOctave& O0 = P.oct[0];
   const dim3 tb(256);
   auto grid_for = [](int rows, int cols) { return dim3((cols + 255) / 256, rows); };
-  hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
-                     O0.gaus[0], O0.rows, O0.cols);
   const float fnew = double_size ? 1.0f : 0.5f;
-  if (kInitSigma > fnew) {  // :325-327, in place through the scratch image
-    const Taps t = make_taps(sqrtf(kInitSigma * kInitSigma - fnew * fnew));
-    hipLaunchKernelGGL(blur_rows_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, O0.gaus[0], B.tmp, O0.rows, O0.cols, t);
-    hipLaunchKernelGGL(blur_cols_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, B.tmp, O0.gaus[0], O0.rows, O0.cols, t,
+  const bool init_blur = kInitSigma > fnew;   // :325-327
+  const Taps t0 = init_blur ? make_taps(sqrtf(kInitSigma * kInitSigma - fnew * fnew)) : Taps{};
+  const bool init_fused = init_blur && (t0.n >> 1) <= BT_MAXW;
+  // the prepared image goes to the scratch image when the fused blur can write octave 0's first level from there
+  hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
+                     init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols);
+  if (init_fused) {
+    hipLaunchKernelGGL(blur_level_kernel, dim3((O0.cols + BT_X - 1) / BT_X, (O0.rows + BT_Y - 1) / BT_Y), dim3(BT_THREADS), 0, s,
+                       (const float*)B.tmp, O0.gaus[0], O0.rows, O0.cols, t0, (const float*)nullptr, (float*)nullptr);
+  } else if (init_blur) {   // in place through the scratch image
+    hipLaunchKernelGGL(blur_rows_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, O0.gaus[0], B.tmp, O0.rows, O0.cols, t0);
+    hipLaunchKernelGGL(blur_cols_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, B.tmp, O0.gaus[0], O0.rows, O0.cols, t0,
                        (const float*)nullptr, (float*)nullptr);
   }
   const float fwidth = powf(2.0f, 1.0f / (float)kScales);
@@ -744,6 +802,12 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
     const SiftOctave& O = P.oct[o];
     for (int i = 1; i < kScales + 3; ++i) {   // OctaveKeypoints (:410-438)
       const Taps& t = T5.t[i - 1];
+      if ((t.n >> 1) <= BT_MAXW) {
+        hipLaunchKernelGGL(blur_level_kernel, dim3((O.cols + BT_X - 1) / BT_X, (O.rows + BT_Y - 1) / BT_Y), dim3(BT_THREADS), 0,
+                           s, (const float*)O.gaus[i - 1], O.gaus[i], O.rows, O.cols, t, (const float*)O.gaus[i - 1],
+                           O.dog[i - 1]);
+        continue;
+      }
       hipLaunchKernelGGL(blur_rows_kernel, grid_for(O.rows, O.cols), tb, 0, s, O.gaus[i - 1], B.tmp, O.rows, O.cols, t);
       hipLaunchKernelGGL(blur_cols_kernel, grid_for(O.rows, O.cols), tb, 0, s, B.tmp, O.gaus[i], O.rows, O.cols, t,
                          (const float*)O.gaus[i - 1], O.dog[i - 1]);
