@@ -500,11 +500,13 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
 // bins 2(L%4) and 2(L%4)+1).  Samples are evaluated 64 at a time in raster order and then folded
 // one after the other, each lane taking its share of the sample's up to eight contributions --
 // the same products, added in the same order, as the serial code.
-// Workgroups have four wavefronts.  With many keys each wavefront describes its own key; with few
-// (the chip would be mostly idle and the serial fold is what a key waits for) the four wavefronts
-// share ONE key, wavefront r folding only the samples that touch cell row r (2/5 of them): the
-// entries are independent, so the per-entry addition order is untouched.
-constexpr int DESC_WAVES = 4;
+// Workgroups have eight wavefronts.  With many keys each wavefront describes its own key; with few
+// (the chip would be mostly idle and the serial fold is what a key waits for) the eight wavefronts
+// share ONE key, wavefront (r, h) folding only the samples that touch cell row r and cell columns
+// 2h, 2h + 1 (about a quarter of them) on its first eight lanes: the entries are independent, so the
+// per-entry addition order is untouched.  (Four wavefronts, a cell row each: 0.86 ms per frame instead
+// of 0.83; sixteen, a cell each: 1.01 -- every wavefront evaluates all the samples.)
+constexpr int DESC_WAVES = 8;
 constexpr int DESC_SHARE_BELOW = 1536;   // keys; below this the wavefronts of a workgroup share a key
 __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
                                                       const int32_t* __restrict__ n_keys, int key_cap,
@@ -517,10 +519,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
   const bool share = n < DESC_SHARE_BELOW;
-  // shared key: wavefront `wave` owns cell row `wave` on its first 16 lanes, results meet in d_all[0]
-  const int cell_r = share ? wave : (lane >> 4);
-  const int cell_c = (lane >> 2) & 3, ob0 = 2 * (lane & 3);
-  const bool owner = !share || lane < 16;
+  // shared key: wavefront `wave` owns cell row wave / 2, columns 2 (wave % 2) + {0, 1} on its first 8 lanes;
+  // results meet in d_all[0]
+  const int cell_r = share ? (wave >> 1) : (lane >> 4);
+  const int col_lo = 2 * (wave & 1);                       // shared key: this wavefront's two cell columns
+  const int cell_c = share ? col_lo + ((lane >> 2) & 1) : ((lane >> 2) & 3), ob0 = 2 * (lane & 3);
+  const bool owner = !share || lane < 8;
   float* const d_s = share ? d_all[0] : d_all[wave];
   float& scal_s = share ? scal_all[0] : scal_all[wave];
   int& any_s = share ? any_all[0] : any_all[wave];
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
       __builtin_amdgcn_wave_barrier();
     }
   };
-  const int entry = share ? (wave * 16 + lane) : lane;   // this lane's pair of entries: 2 entry, 2 entry + 1
+  const int entry = share ? ((cell_r * 4 + cell_c) * 4 + (lane & 3)) : lane;   // this lane's pair of entries: 2 entry, 2 entry + 1
   const int k_first = share ? blockIdx.x : blockIdx.x * DESC_WAVES + wave;
   const int k_step = share ? gridDim.x : gridDim.x * DESC_WAVES;
   const int n_round = share ? n : ((n + DESC_WAVES - 1) / DESC_WAVES) * DESC_WAVES;   // whole workgroups reach the barriers
@@ -584,8 +588,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
           of = __fsub_rn(oribin, (float)no);
         }
       }
-      // shared key: only the samples that reach this wavefront's cell row (rows nr and nr + 1)
-      unsigned long long m = __ballot(ok && (!share || nr == cell_r - 1 || nr == cell_r));
+      // shared key: only the samples that reach this wavefront's cells (rows nr, nr + 1; columns nc, nc + 1)
+      unsigned long long m = __ballot(ok && (!share || ((nr == cell_r - 1 || nr == cell_r) && nc >= col_lo - 1 && nc <= col_lo + 1)));
       while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
