@@ -57,7 +57,11 @@ def test_hip_sift_other_sizes_and_no_doubling(ctx):
     rng = np.random.default_rng(3)
     base = GOLD["gray0"]
     for gray, dbl in ((base[40:300, 100:420], True), (base[::2, ::2].copy(), True), (base, False),
-                      ((rng.random((97, 131)) * 255).astype(np.uint8), True)):
+                      ((rng.random((97, 131)) * 255).astype(np.uint8), True),
+                      (base[100:133, 0:400], True),        # a strip: blur tiles thinner than their halo
+                      (base[200:224, 300:340], True)):     # smaller than one blur tile
+        if gray.shape[0] < 40 and len(orclib.sift(np.ascontiguousarray(gray), double_size=dbl)[0]) == 0:
+            continue
         gray = np.ascontiguousarray(gray)
         want = orclib.sift(gray, double_size=dbl)
         got = ctx.sift(gray, double_size=dbl)
