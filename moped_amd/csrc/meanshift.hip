@@ -758,7 +758,7 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
   const int m = blockIdx.x;
   const int b = m < n_models ? model_off[m] : 0;
   int n = m < n_models ? model_off[m + 1] - b : 0;
-  if (n <= 0) {
+  if (n <= 0 || n < min_pts) {   // fewer points than MinPts: no canopy can reach the emission threshold (:151-157)
     if (threadIdx.x == 0 && m < n_models) ncl[m] = 0;
   } else {
     if (n > MS_CAP) {
