@@ -99,3 +99,28 @@ def test_growing_query_count_reallocates(ctx, sift):
         objs, counts = pipe.fetch(0)
         assert fr.visible[0] in objs["model"].tolist()
     pipe.close()
+
+
+def test_frame_capacities_are_errors_not_faults():
+    """A frame whose clusters / objects exceed what mh_reserve set aside: fetch reports MH_ERR_CAPACITY (sticky flags in the
+    result header), nothing faults, and the context keeps working with larger capacities afterwards."""
+    import torch
+    from moped_amd import synth
+    db = synth.make_db(8, 2000)
+    fr = synth.make_frame(db, n_vis=6, seed=4, Q=3000, pts_per_obj=150)
+    dev = torch.device("cuda:0")
+    q = torch.from_numpy(fr.desc).to(dev)
+    uv = torch.from_numpy(fr.uv).to(dev)
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    prm = capi.default_frame_params()
+    c.reserve(3000, max_clusters=2, max_objects=4)          # six planted objects: > 2 clusters, > 4 object slots
+    qa, qb = q.clone(), q.clone()                            # MATCH normalises in place
+    c.frame_enqueue(qa.data_ptr(), uv.data_ptr(), 3000, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, 5)
+    with pytest.raises(capi.MhError, match="capacity"):
+        c.frame_fetch()
+    c.reserve(3000, max_clusters=1024, max_objects=4096)
+    c.frame_enqueue(qb.data_ptr(), uv.data_ptr(), 3000, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, 5)
+    objs, counts = c.frame_fetch()
+    assert set(objs["model"].tolist()) == set(fr.visible.tolist())
+    c.close()
