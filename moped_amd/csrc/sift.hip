@@ -176,24 +176,50 @@ constexpr int SMALL_OCTAVE_PX = 80 * 60;
 struct Taps5 {
   Taps t[kScales + 2];
 };
+// Octaves that fit get their two images with replicated borders of SO_PAD pixels (left / right of the source
+// image, above / below the row-blurred one), so the tap loops read straight through without clamping an index per
+// tap; the others run the clamped loops.
+constexpr int SO_PAD = 12, SO_CAP = 6912;
 __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int o_first, Taps5 T) {
-  __shared__ float cur[SMALL_OCTAVE_PX];   // image i - 1 of the octave
-  __shared__ float tmp[SMALL_OCTAVE_PX];   // its row-blurred version
+  __shared__ float cur[SO_CAP];   // image i - 1 of the octave: [px], or [rows][cols + 2 SO_PAD]
+  __shared__ float tmp[SO_CAP];   // its row-blurred version:   [px], or [rows + 2 SO_PAD][cols]
   const int tid = threadIdx.x;
+  int wmax = 0;
+  for (int i = 0; i < kScales + 2; ++i) wmax = max(wmax, T.t[i].n >> 1);
   for (int o = o_first; o < P.n_octaves; ++o) {
     const SiftOctave& O = P.oct[o];
     const int rows = O.rows, cols = O.cols, px = rows * cols;
+    const int cs = cols + 2 * SO_PAD;
+    const bool padded = wmax <= SO_PAD && rows * cs <= SO_CAP && (rows + 2 * SO_PAD) * cols <= SO_CAP;
+    // cur[at(r, c)], with its left / right borders when padded
+    auto put_cur = [&](int r, int c, float v) {
+      if (!padded) {
+        cur[r * cols + c] = v;
+        return;
+      }
+      float* row = cur + r * cs;
+      row[SO_PAD + c] = v;
+      if (c == 0)
+        for (int h = 0; h < SO_PAD; ++h) row[h] = v;
+      if (c == cols - 1)
+        for (int h = 0; h < SO_PAD; ++h) row[SO_PAD + cols + h] = v;
+    };
+    const float* src0 = O.gaus[0];
     if (o > o_first) {   // HalfImageSize (:390-408) of the previous octave's image `kScales`
       const SiftOctave& V = P.oct[o - 1];
       const float* src = V.gaus[kScales];
       float* dst = O.gaus[0];
       for (int e = tid; e < px; e += 1024) {
-        const float v = src[(size_t)(2 * (e / cols)) * V.cols + 2 * (e % cols)];
+        const int r = e / cols, c = e - r * cols;
+        const float v = src[(size_t)(2 * r) * V.cols + 2 * c];
         dst[e] = v;
-        cur[e] = v;
+        put_cur(r, c, v);
       }
     } else {
-      for (int e = tid; e < px; e += 1024) cur[e] = O.gaus[0][e];
+      for (int e = tid; e < px; e += 1024) {
+        const int r = e / cols, c = e - r * cols;
+        put_cur(r, c, src0[e]);
+      }
     }
     __syncthreads();
     for (int i = 1; i < kScales + 3; ++i) {
@@ -201,14 +227,24 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
       const int w = t.n >> 1;
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
-        const float* row = cur + r * cols;
         float a = 0.f;
-        for (int j = 0; j < t.n; ++j) {
-          int x = c + j - w;
-          x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
-          a = __fadd_rn(a, __fmul_rn(row[x], t.k[j]));
+        if (padded) {
+          const float* row = cur + r * cs + SO_PAD + c - w;
+          for (int j = 0; j < t.n; ++j) a = __fadd_rn(a, __fmul_rn(row[j], t.k[j]));
+          tmp[(r + SO_PAD) * cols + c] = a;
+          if (r == 0)
+            for (int h = 0; h < SO_PAD; ++h) tmp[h * cols + c] = a;
+          if (r == rows - 1)
+            for (int h = 0; h < SO_PAD; ++h) tmp[(rows + SO_PAD + h) * cols + c] = a;
+        } else {
+          const float* row = cur + r * cols;
+          for (int j = 0; j < t.n; ++j) {
+            int x = c + j - w;
+            x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
+            a = __fadd_rn(a, __fmul_rn(row[x], t.k[j]));
+          }
+          tmp[e] = a;
         }
-        tmp[e] = a;
       }
       __syncthreads();
       float* dst = O.gaus[i];
@@ -216,14 +252,20 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
         float a = 0.f;
-        for (int j = 0; j < t.n; ++j) {
-          int y = r + j - w;
-          y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
-          a = __fadd_rn(a, __fmul_rn(tmp[y * cols + c], t.k[j]));
+        if (padded) {
+          const float* col = tmp + (r + SO_PAD - w) * cols + c;
+          for (int j = 0; j < t.n; ++j) a = __fadd_rn(a, __fmul_rn(col[j * cols], t.k[j]));
+        } else {
+          for (int j = 0; j < t.n; ++j) {
+            int y = r + j - w;
+            y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
+            a = __fadd_rn(a, __fmul_rn(tmp[y * cols + c], t.k[j]));
+          }
         }
+        const float old = padded ? cur[r * cs + SO_PAD + c] : cur[e];
         dst[e] = a;
-        dog[e] = __fsub_rn(cur[e], a);
-        cur[e] = a;   // source of the next level (only this thread reads cur[e] in this phase)
+        dog[e] = __fsub_rn(old, a);
+        put_cur(r, c, a);   // source of the next level (nobody reads cur in this phase but the owner of a pixel)
       }
       __syncthreads();
     }
