@@ -22,9 +22,10 @@ cd $root
 { python scripts/stage_latency_probe.py 20 1; python scripts/stage_latency_probe.py 20 4; python scripts/stage_latency_probe.py 3 16; } > $out/r01_stage_latency.txt 2>&1
 { GPU_MAX_HW_QUEUES=16 python scripts/rest_only_probe.py 3 16;
   # the per-rank load of N = 8 / 4 / 2 GPUs on one GPU: a DB of 20/N models behind the exchange path
-  # (defaults: 32 slots x 8 frames per MATCH launch), then 16 x 4, then frame by frame
+  # (defaults: 16 slots x 8 frames per MATCH launch), then 32 x 8, 16 x 4, frame by frame
   for a in "--models 3 --force-exchange" "--models 5 --force-exchange" "--models 10 --force-exchange" \
-           "--models 3 --force-exchange --depth 16 --batch 4" "--models 3 --force-exchange --depth 16 --batch 1" "--models 3 --depth 16"; do
+           "--models 3 --force-exchange --depth 32" "--models 3 --force-exchange --depth 16 --batch 4" \
+           "--models 3 --force-exchange --depth 16 --batch 1" "--models 3 --depth 16"; do
     echo "bench.py $a"; python bench.py $a --no-cpu-baseline --no-roofline | tail -1; done; } > $out/r01_per_rank_load_n8.txt 2>&1
 python tests/tools/ms_bench.py > $out/r01_meanshift_bench.txt 2>&1
 python tests/tools/sift_probe.py > $out/r01_sift_probe.txt 2>&1
