@@ -27,6 +27,8 @@ cd $root
            "--models 3 --force-exchange --depth 32" "--models 3 --force-exchange --depth 16 --batch 4" \
            "--models 3 --force-exchange --depth 16 --batch 1" "--models 3 --depth 16"; do
     echo "bench.py $a"; python bench.py $a --no-cpu-baseline --no-roofline | tail -1; done; } > $out/r01_per_rank_load_n8.txt 2>&1
+# the same for the 200-model DB (BASELINE configs[3]): per-rank load of 2 / 4 / 8 GPUs
+{ for a in "--models 100 --steps 6" "--models 50 --steps 10" "--models 25"; do echo "bench.py $a --force-exchange"; python bench.py $a --force-exchange --no-cpu-baseline --no-roofline | tail -1; done; } > $out/r01_per_rank_load_200models.txt 2>&1
 python tests/tools/ms_bench.py > $out/r01_meanshift_bench.txt 2>&1
 python tests/tools/sift_probe.py > $out/r01_sift_probe.txt 2>&1
 python scripts/image_frame_bench.py 20 4 > $out/r01_image_frame_bench.txt 2>&1
