@@ -43,6 +43,7 @@ extern "C" {
 
 #define MH_DESC_DIM 128
 #define MH_MAX_BATCH 8   /* frames one context can carry through one MATCH launch (mh_frame_enqueue_rest_batch) */
+#define MH_MAX_MODELS 8192   /* models a context's frames can address (sharded: the global count); more -> MH_ERR_CAPACITY */
 #define MH_OK 0
 #define MH_ERR_ARG (-1)
 #define MH_ERR_HIP (-2)
@@ -71,7 +72,8 @@ int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects);
 
 /* desc_host: N x 128 row-major, ALREADY L2-normalised by the caller (the
  * reference normalises model descriptors in place in Update(), :94);
- * model_of_host[N]: model index of each row (local to this context, 0..n_models-1);
+ * model_of_host[N]: model index of each row, 0..n_models-1 (a shard passes global model
+ * ids and the global n_models); a value outside that range -> MH_ERR_ARG;
  * xyz_host: N x 3 model coordinates.  index_base: value added to row numbers in
  * every index this context reports (global row id of row 0 when the DB is a
  * shard).  Re-upload after modelsUpdated(). */

@@ -152,6 +152,12 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
     if (ctx) ctx->err = "mh_db_upload: bad argument";
     return MH_ERR_ARG;
   }
+  // every later kernel indexes per-model tables with these values
+  for (int i = 0; i < N; ++i)
+    if (model_of_host[i] < 0 || model_of_host[i] >= n_models) {
+      ctx->err = "mh_db_upload: model_of value outside [0, n_models)";
+      return MH_ERR_ARG;
+    }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -159,6 +165,8 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
   // +inf norm terms (a padding row can never enter a top-2)
   const size_t Npad = ((size_t)N + 127) / 128 * 128;
   if (Npad > ctx->db_cap) {
+    ctx->db_cap = 0;   // until every array has its new size
+    ctx->N = 0;
     int rc;
     if ((rc = realloc_dev(ctx, ctx->db_desc, Npad * DIM))) return rc;
     if ((rc = realloc_dev(ctx, ctx->db_norm, Npad))) return rc;

@@ -54,6 +54,8 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
   st->cap = cap;
   if (sift_plan(width, height, double_size, &st->plan) == 0) {
     ctx->err = "mh_sift: image too small (both sides must exceed 12 pixels after scaling)";
+    free_sift(st);   // no half-built state: the next call with this geometry fails the same way
+    ctx->sift = nullptr;
     return MH_ERR_ARG;
   }
   size_t owner = 0;
@@ -75,7 +77,12 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
   rc |= alloc(ctx, st->xy, (size_t)cap * 2);
   rc |= alloc(ctx, st->scale_ori, (size_t)cap * 2);
   rc |= alloc(ctx, st->n_dev, 1);
-  return rc ? MH_ERR_HIP : MH_OK;
+  if (rc) {
+    free_sift(st);
+    ctx->sift = nullptr;
+    return MH_ERR_HIP;
+  }
+  return MH_OK;
 }
 
 }  // namespace

@@ -126,7 +126,11 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
   rc |= dev_alloc(ctx, fs->seed_dev, 1);
   rc |= dev_alloc(ctx, fs->tickets, 8);
-  if (rc) return MH_ERR_HIP;
+  if (rc) {   // a half-built state must not look valid to the next call
+    free_fs(fs);
+    ctx->fs = nullptr;
+    return MH_ERR_HIP;
+  }
   MH_HIP(ctx, hipMemsetAsync(fs->tickets, 0, 8 * sizeof(unsigned int), ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->best, 0, sizeof(unsigned long long) * max_m, ctx->stream));
   MH_HIP(ctx, hipMemsetAsync(fs->obj_valid, 0, sizeof(int32_t) * max_objects, ctx->stream));
@@ -167,7 +171,7 @@ __global__ void set_scalar_kernel(int32_t* p, int32_t v) { *p = v; }
 __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots,
                                    const int32_t* obj_valid, const int32_t* obj_model,
                                    const float* obj_pose, const float* obj_score,
-                                   const int32_t* obj_npts, int max_objects) {
+                                   const int32_t* obj_npts, int max_objects, const FrameCounts* counts) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   mh_object* out = reinterpret_cast<mh_object*>(result + 16);
   int k = 0;
@@ -182,6 +186,7 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
     out[k++] = ob;
   }
   reinterpret_cast<int32_t*>(result)[0] = k;
+  reinterpret_cast<int32_t*>(result)[1] = counts->error;   // capacity flags, as the last FILTER launch reports them
 }
 
 bool graphs_enabled();
@@ -242,6 +247,12 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
   const int nm = ctx->n_models;
+  // group_kernel keeps one LDS histogram bin per model: every entry point (fused, sharded, batched)
+  // comes through here, so the bound is checked here and not in the callers
+  if (nm > MH_MAX_MODELS) {
+    ctx->err = "more than 8192 models per context";
+    return MH_ERR_CAPACITY;
+  }
   unsigned char* const result = fs->result + (size_t)fs->slot * fs->result_bytes;
   int32_t* const snap = fs->snap + 4 * fs->slot;
   // Every workgroup of the POSE / FILTER launches needs a free compute unit to start even if
@@ -336,7 +347,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     for (int i = 5; i <= 7; ++i) stamp(ctx, i);
     hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(1), 0, s, result, fs->n_slots,
                        fs->obj_valid, fs->obj_model, fs->obj_pose, fs->obj_score, fs->obj_npts,
-                       fs->max_objects);
+                       fs->max_objects, fs->counts);
   }
   stamp(ctx, 8);
   MH_HIP(ctx, hipGetLastError());
@@ -529,6 +540,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   std::vector<int32_t> h_members(std::max(total, 1)), h_model(n_clusters, 0), h_begin(n_clusters), h_count(n_clusters);
   for (int i = 0; i < total; ++i) h_members[i] = i;
   for (int c = 0; c < n_clusters; ++c) {
+    h_model[c] = c;   // the step-level call has no models: every cluster its own (keys the task's random stream)
     h_begin[c] = cluster_off[c];
     h_count[c] = cluster_off[c + 1] - cluster_off[c];
   }
@@ -975,10 +987,6 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   if (!ctx || Q <= 0 || !q_desc_dev || !q_uv_dev || !cam || !prm) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  if (ctx->n_models > 8192) {
-    ctx->err = "more than 8192 models per context";
-    return MH_ERR_CAPACITY;
-  }
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   ctx->feat_count_dev = nullptr;
@@ -1002,10 +1010,6 @@ int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int 
   if (!ctx || !gray_dev || width <= 0 || height <= 0 || max_keypoints <= 0 || !cam || !prm) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  if (ctx->n_models > 8192) {
-    ctx->err = "more than 8192 models per context";
-    return MH_ERR_CAPACITY;
-  }
   const int Q = max_keypoints;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 
 #include "../../include/moped_hip.h"
@@ -10,6 +11,26 @@
 namespace mh {
 
 constexpr int DIM = MH_DESC_DIM;
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize,
+// and a function's attributes belong to the device that is current when they are set: one
+// `DynLds` per kernel remembers the devices done (bit per device id), so a second device in the
+// process -- or a second host thread -- gets the attribute before its first launch too.  Setting
+// it twice from two racing threads is harmless.
+struct DynLds {
+  std::atomic<unsigned long long> done[4];   // device ids 0..255
+  template <typename K>
+  void ensure(K kernel, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::atomic<unsigned long long>& word = done[(dev >> 6) & 3];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (word.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+    word.fetch_or(bit, std::memory_order_release);
+  }
+};
 
 // ---- match ------------------------------------------------------------------
 // Per-query local result of one DB split / shard.

@@ -472,12 +472,8 @@ __global__ __launch_bounds__(LK_THREADS) void linkage_batch_kernel(
 
 template <typename K>
 void set_lds(K kernel) {
-  static bool done = false;
-  if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)sizeof(LkLds));
-    done = true;
-  }
+  static DynLds attr;   // one per kernel (template instantiation)
+  attr.ensure(kernel, sizeof(LkLds));
 }
 
 }  // namespace

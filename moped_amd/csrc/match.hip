@@ -500,12 +500,8 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
     const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
     const int tiles_per_split = (n_tiles + S - 1) / S;
     const size_t lds_bytes = 2 * TILE_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_set = true;
-    }
+    static DynLds attr;
+    attr.ensure(match_kernel, lds_bytes);
     hipLaunchKernelGGL(match_kernel, dim3(qgroups * S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
                        db, dnorm, N, tiles_per_split, S, index_base, scratch, q_count);
   }

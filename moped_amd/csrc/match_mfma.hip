@@ -346,12 +346,8 @@ void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* 
   const int qblocks = (Q + MQ - 1) / MQ;
   const int n_tiles = (N + M_TILE - 1) / M_TILE;
   const size_t lds_bytes = (2 * M_TILE_FLOATS + MQ) * sizeof(float);   // two tiles + the queries' norm terms
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
-    attr_set = true;
-  }
+  static DynLds attr;
+  attr.ensure(match_mfma_kernel, lds_bytes);
   hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks * S), dim3(M_THREADS), lds_bytes, s, qn, qnorm, Q, db, dnorm, N,
                      n_tiles / S, n_tiles % S, S, index_base, scratch, q_count);
 }

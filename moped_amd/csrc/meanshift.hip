@@ -827,11 +827,6 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_batch_kernel(
                      cl_start + b + p, ncl + p, label + b, nullptr);
 }
 
-template <typename K>
-void set_lds_attr(K kernel, size_t bytes) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
 
 }  // namespace
 
@@ -859,11 +854,8 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
                              FrameCounts* counts, unsigned int* ticket, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    set_lds_attr(meanshift_models_kernel, sizeof(MsLds<2>));
-    once = true;
-  }
+  static DynLds attr;
+  attr.ensure(meanshift_models_kernel, sizeof(MsLds<2>));
   // an empty database still gets one workgroup: it publishes "0 clusters"
   hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
@@ -873,12 +865,9 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,
                              int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                              int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    set_lds_attr(meanshift_single_kernel<2>, sizeof(MsLds<2>));
-    set_lds_attr(meanshift_single_kernel<3>, sizeof(MsLds<3>));
-    once = true;
-  }
+  static DynLds attr2, attr3;
+  attr2.ensure(meanshift_single_kernel<2>, sizeof(MsLds<2>));
+  attr3.ensure(meanshift_single_kernel<3>, sizeof(MsLds<3>));
   if (dim == 3)
     hipLaunchKernelGGL(meanshift_single_kernel<3>, dim3(1), dim3(MS_THREADS), sizeof(MsLds<3>), s,
                        pts, n, radius, merge, min_pts, max_iter, members, cl_start, ncl, label, iters);
@@ -891,12 +880,9 @@ void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems
                             float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                             int32_t* ncl, int32_t* label, hipStream_t s) {
   if (n_problems <= 0) return;
-  static bool once = false;
-  if (!once) {
-    set_lds_attr(meanshift_batch_kernel<2>, sizeof(MsLds<2>));
-    set_lds_attr(meanshift_batch_kernel<3>, sizeof(MsLds<3>));
-    once = true;
-  }
+  static DynLds attr2, attr3;
+  attr2.ensure(meanshift_batch_kernel<2>, sizeof(MsLds<2>));
+  attr3.ensure(meanshift_batch_kernel<3>, sizeof(MsLds<3>));
   if (dim == 3)
     hipLaunchKernelGGL(meanshift_batch_kernel<3>, dim3(n_problems), dim3(MS_THREADS), sizeof(MsLds<3>), s,
                        pts, off, radius, merge, min_pts, max_iter, members, cl_start, ncl, label);

@@ -544,10 +544,14 @@ int mh_models_load(mh_model_set** out, const char* path) {
   bool ok = bytes >= sizeof h;
   if (ok) {
     memcpy(&h, b, sizeof h);
+    // offsets first, then sizes against what is left behind them: no sum can wrap
+    auto fits = [&](uint64_t off, uint64_t count, uint64_t elem) {
+      return off <= bytes && count <= (bytes - off) / elem;
+    };
     ok = memcmp(h.magic, "MOPEDDB1", 8) == 0 && h.version == 1 && h.dim == (uint32_t)DIM && h.file_bytes <= bytes &&
-         h.off_models + (uint64_t)h.n_models * sizeof(DbModelRecord) <= bytes && h.off_names + h.names_bytes <= bytes &&
-         h.off_xyz % 16 == 0 && h.off_desc % 16 == 0 && h.off_xyz + h.n_rows * 12 <= bytes &&
-         h.off_desc + h.n_rows * (uint64_t)DIM * 4 <= bytes && h.n_rows < (1ull << 31);
+         h.n_rows < (1ull << 31) && fits(h.off_models, h.n_models, sizeof(DbModelRecord)) &&
+         fits(h.off_names, h.names_bytes, 1) && h.off_xyz % 16 == 0 && h.off_desc % 16 == 0 &&
+         fits(h.off_xyz, h.n_rows, 12) && fits(h.off_desc, h.n_rows, (uint64_t)DIM * 4);
   }
   if (!ok) {
     delete s;
@@ -564,7 +568,8 @@ int mh_models_load(mh_model_set** out, const char* path) {
   for (uint32_t i = 0; i < h.n_models; ++i) {
     DbModelRecord r;
     memcpy(&r, b + h.off_models + (size_t)i * sizeof r, sizeof r);
-    if (r.row_begin != run || r.row_begin + r.n_rows > h.n_rows || (uint64_t)r.name_off + r.name_len > h.names_bytes) {
+    if (r.row_begin != run || r.n_rows > h.n_rows - run || r.name_off > h.names_bytes ||
+        r.name_len > h.names_bytes - r.name_off) {
       delete s;
       return MH_ERR_ARG;
     }

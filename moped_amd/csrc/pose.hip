@@ -687,8 +687,19 @@ __device__ void pose_task(
   const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : 1024;
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
+  // The random stream of a task is keyed by (model id, number of the cluster among its model's
+  // clusters, replica) and not by the cluster's row in this context's table: a rank that holds a
+  // shard of the models numbers its rows differently, its objects must still be the ones the
+  // single-context frame reports (model ids are global, a model's clusters keep their order).
+  int ordinal = 0;
+  {
+    const int model = cl_model[cluster];
+    while (ordinal < cluster && cl_model[cluster - ordinal - 1] == model) ++ordinal;
+  }
+  const uint64_t task_key = (seed ^ (seed_dev ? *seed_dev : 0ull)) ^ ((uint64_t)(cl_model[cluster] + 1) << 48) ^
+                            ((uint64_t)(ordinal + 1) << 36) ^ ((uint64_t)(replica + 1) << 32);
   auto hypothesis = [&](const int h) {
-    uint64_t st = (seed ^ (seed_dev ? *seed_dev : 0ull)) ^ ((uint64_t)(cluster + 1) << 40) ^ ((uint64_t)(replica + 1) << 32) ^ (uint64_t)h;
+    uint64_t st = task_key ^ (uint64_t)h;
     splitmix64(st);
     // 4 correspondences with pairwise distinct image coordinates (:76-98)
     int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
@@ -924,12 +935,8 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
                              const PoseTail& tail, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pose_kernel<KIND>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLds<KIND>));
-    once = true;
-  }
+  static DynLds attr;   // one per KIND (this function is a template)
+  attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
   const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
   hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster))), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,

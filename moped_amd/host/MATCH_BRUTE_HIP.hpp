@@ -91,15 +91,22 @@ class MATCH_BRUTE_HIP : public MopedAlg {
       for (int j = 0; j < MH_DESC_DIM; ++j) corresp[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
     vector<int32_t> nn(Q);
     if (mh_match(ctx, &packed[0], Q, Ratio, &nn[0], 0, 0, 0) != MH_OK) { HipSession::warn("mh_match"); return; }
+    // the slot's contract (:165-176): matches[model] in ascending query order.  Two passes:
+    // count per model, size each list once, then fill.
+    vector<size_t> fill(models->size(), 0);
+    for (int i = 0; i < Q; ++i)
+      if (nn[i] >= 0) ++fill[correspModel[nn[i]]];
+    for (size_t m = 0; m < fill.size(); ++m) {
+      const size_t had = matches[m].size();
+      matches[m].resize(had + fill[m]);
+      fill[m] = had;
+    }
     for (int i = 0; i < Q; ++i) {
       if (nn[i] < 0) continue;
-      const int m = correspModel[nn[i]];
-      if (matches[m].capacity() < 1000) matches[m].reserve(1000);
-      matches[m].resize(matches[m].size() + 1);
-      FrameData::Match& match = matches[m].back();
-      match.imageIdx = corresp[i].imageIdx;
-      match.coord3D = *correspFeat[nn[i]];
-      match.coord2D = corresp[i].coord2D;
+      FrameData::Match& out = matches[correspModel[nn[i]]][fill[correspModel[nn[i]]]++];
+      out.imageIdx = corresp[i].imageIdx;
+      out.coord2D = corresp[i].coord2D;
+      out.coord3D = *correspFeat[nn[i]];
     }
   }
 };

@@ -1,10 +1,12 @@
-// Clean-room declaration of the libmoped types the STEP plugins are written
-// against, for building OUTSIDE a libmoped tree (the GPU box has no reference).
-// Inside libmoped, include the real <moped.hpp> and <util.hpp> instead and do not
-// include this file: the plugin headers only use the members declared here, with
-// the reference's names and meaning (include/moped.hpp:84-290, src/util.hpp:68-201).
-// Written from the interface description in SURVEY.md 8(a) A15 -- no reference
-// code is copied; only what the four HIP steps touch is declared.
+// Stand-in declaration of the libmoped types the STEP plugins are written against, for
+// building OUTSIDE a libmoped tree (the GPU box has no reference).  Inside libmoped,
+// include the real <moped.hpp> and <util.hpp> instead and do NOT include this file: it is
+// test scaffolding, not something a libmoped maintainer takes.
+// It mirrors an interface, so names, member order and meaning are the reference's by
+// necessity (include/moped.hpp:84-290, src/util.hpp:68-201, read as text); only what the
+// HIP steps and the test harness touch is declared, and the pipeline container below is
+// our own implementation of the same contract (first-seen step order, first capable
+// algorithm of a step; util.hpp:151-201).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -151,35 +153,38 @@ class MopedAlg {
 };
 
 struct MopedStep : public vector<shared_ptr<MopedAlg> > {
+  // the reference's fall-back hook: the first algorithm of the step that is capable
   MopedAlg* getAlg() {
-    for (size_t i = 0; i < size(); ++i)
-      if ((*this)[i]->isCapable()) return (*this)[i].get();
+    for (iterator it = begin(); it != end(); ++it)
+      if ((*it)->isCapable()) return it->get();
     return 0;
   }
 };
 
+// Steps in first-seen order of their names; several algorithms may share a step name.
 struct MopedPipeline : public vector<MopedStep> {
-  map<string, int> fromStepNameToIndex;
+  vector<string> stepNames;   // stepNames[i] names (*this)[i]
+
+  int stepIndex(const string& name) {
+    for (size_t i = 0; i < stepNames.size(); ++i)
+      if (stepNames[i] == name) return (int)i;
+    stepNames.push_back(name);
+    push_back(MopedStep());
+    return (int)stepNames.size() - 1;
+  }
   void addAlg(string stepName, MopedAlg* alg) {
-    int step;
-    if (fromStepNameToIndex.find(stepName) == fromStepNameToIndex.end()) {
-      step = (int)fromStepNameToIndex.size();
-      fromStepNameToIndex[stepName] = step;
-    } else {
-      step = fromStepNameToIndex[stepName];
-    }
-    if (step >= (int)size()) resize(step + 1);
-    alg->setStepNameAndAlg(stepName, (int)(*this)[step].size());
-    (*this)[step].push_back(shared_ptr<MopedAlg>(alg));
+    MopedStep& step = (*this)[stepIndex(stepName)];
+    alg->setStepNameAndAlg(stepName, (int)step.size());
+    step.push_back(shared_ptr<MopedAlg>(alg));   // the pipeline owns its algorithms
   }
   list<MopedAlg*> getAlgs(bool onlyActive = false) {
     list<MopedAlg*> out;
-    for (size_t s = 0; s < size(); ++s) {
-      if (!onlyActive) {
-        for (size_t a = 0; a < (*this)[s].size(); ++a) out.push_back((*this)[s][a].get());
-      } else if ((*this)[s].getAlg()) {
-        out.push_back((*this)[s].getAlg());
+    for (iterator st = begin(); st != end(); ++st) {
+      if (onlyActive) {
+        if (MopedAlg* a = st->getAlg()) out.push_back(a);
+        continue;
       }
+      for (MopedStep::iterator a = st->begin(); a != st->end(); ++a) out.push_back(a->get());
     }
     return out;
   }

@@ -68,6 +68,7 @@ class FramePipeline:
         self._local = [None] * depth    # send block per slot: [3][Q] words of exchange 1 + the result block riding along
         self._gather = [None] * depth   # receive block: W of those
         self._ex_q = [0] * depth
+        self._inputs = [None] * depth   # the slot's current input tensors: its stream may still be reading them
         self._cam = capi.make_cam(self.K, self.cam)
 
     # Exchange 2 rides on exchange 1: behind its [3][Q] top-2 words every rank sends the result block
@@ -75,6 +76,16 @@ class FramePipeline:
     # frame carries both exchanges of SURVEY 8(e).  EX2_OBJECTS objects per rank and frame.
     EX2_OBJECTS = 62
     EX2_WORDS = (16 + EX2_OBJECTS * capi.OBJECT_DTYPE.itemsize) // 4
+
+    def _unpack_block(self, blk: np.ndarray) -> np.ndarray:
+        """One rank's piggy-backed result block {n, flags, pad, pad, objects...} -> object array.
+        The block carries at most EX2_OBJECTS objects: a frame with more, or one whose capacity flags
+        are set, is an error here and not a silently shortened list (gather_objects() has no limit)."""
+        n, flags = int(blk[0]), int(blk[1])
+        if n > self.EX2_OBJECTS or flags != 0:
+            raise RuntimeError(f"exchange 2: a rank reported {n} objects (block holds {self.EX2_OBJECTS}), "
+                               f"capacity flags {flags}; use gather_objects() for this frame")
+        return blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy()
 
     # ---- single frame in slot i ------------------------------------------------------
     def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
@@ -85,6 +96,7 @@ class FramePipeline:
         waiting on the legacy default stream serialises every frame behind it)."""
         c, s = self.ctxs[slot], self.streams[slot]
         Q = q_desc.shape[0]
+        self._inputs[slot] = (q_desc, q_uv)   # kept until the slot's next enqueue (stream order: the old ones are done by then)
         if after is not None:
             s.wait_stream(after)
         if not self.exchange:
@@ -113,6 +125,7 @@ class FramePipeline:
         their objects in result slots 0..B-1.  Needs the exchange path (sharded DB or force_exchange)."""
         assert self.exchange and 1 <= B <= capi.MAX_BATCH
         c, s = self.ctxs[slot], self.streams[slot]
+        self._inputs[slot] = (q_desc, q_uv)
         BQ = q_desc.shape[0]
         Q = BQ // B
         tail = B * self.EX2_WORDS
@@ -146,9 +159,7 @@ class FramePipeline:
         for f in range(B):
             objs = []
             for r in range(self.world):
-                blk = host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]
-                n = min(int(blk[0]), self.EX2_OBJECTS)
-                objs.append(blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy())
+                objs.append(self._unpack_block(host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]))
             out.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
         return out
 
@@ -165,9 +176,7 @@ class FramePipeline:
         for f in range(B):
             objs = []
             for r in range(self.world):
-                blk = host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]
-                n = min(int(blk[0]), self.EX2_OBJECTS)
-                objs.append(blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy())
+                objs.append(self._unpack_block(host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]))
             res.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
         return res
 
@@ -180,9 +189,7 @@ class FramePipeline:
         host = self._gather[slot].view(self.world, stride)[:, 3 * Q:].contiguous().cpu().numpy()
         objs = []
         for r in range(self.world):
-            n = min(int(host[r, 0]), self.EX2_OBJECTS)
-            blk = host[r, 4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE)
-            objs.append(blk.copy())
+            objs.append(self._unpack_block(host[r]))
         return np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE)
 
     def fetch(self, slot: int):
@@ -232,11 +239,7 @@ def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
     """all_gather_into_tensor on flat buffers.  RCCL takes device tensors directly;
     the gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the N > 1
     path) is fed through host memory."""
-    import os
     import torch.distributed as dist
-    if os.environ.get("MH_NO_COLLECTIVE") == "1" and out.numel() == mine.numel():
-        out.copy_(mine)   # probe only (world 1): the exchange path without the collective call
-        return
     if mine.is_cuda and dist.get_backend(group) == "gloo":
         host = mine.cpu()
         tmp = torch.empty(out.numel(), dtype=host.dtype)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, n_models):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orclib
@@ -24,7 +24,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     base, _, _ = synth.load_sift_fixture()
-    db = synth.make_db(5, 300, seed=11)
+    db = synth.make_db(n_models, 300, seed=11)
     dbn = orclib.normalize(db.desc)
     qn = orclib.normalize(base[:500])
     sh = ShardedDB(dbn, db.xyz, db.model_of, db.n_models, rank, world)
@@ -43,15 +43,16 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_model_sharded_match_equals_single_rank(tmp_path, world):
+# (8, 16): BASELINE configs[3]'s world size; (8, 5): more ranks than models, three ranks own nothing
+@pytest.mark.parametrize("world,n_models", [(2, 5), (3, 5), (8, 16), (8, 5)])
+def test_model_sharded_match_equals_single_rank(tmp_path, world, n_models):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orclib
     from moped_amd import synth
-    port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + world + n_models
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_models), nprocs=world, join=True)
     base, _, _ = synth.load_sift_fixture()
-    db = synth.make_db(5, 300, seed=11)
+    db = synth.make_db(n_models, 300, seed=11)
     dbn = orclib.normalize(db.desc)
     qn = orclib.normalize(base[:500])
     oi, o1, o2 = orclib.match_2nn(dbn, qn)

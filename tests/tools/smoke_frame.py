@@ -1,14 +1,14 @@
 """One small frame through the HIP path on cuda:0, checked against the CPU oracle.
-Called by __graft_entry__.smoke(); the oracle is the checker here, never the
-thing that produces the result."""
+Called by __graft_entry__.smoke().  Lives under tests/ because it imports oracle/ (the
+checker): nothing inside the moped_amd package does."""
 import numpy as np
 
 
 def run(n_models: int = 4, pts_per_model: int = 1500, Q: int = 800, verbose: bool = True):
     import torch
     import orclib  # oracle/ (test infrastructure)
-    from . import capi, synth
-    from .pipeline import FramePipeline, ShardedDB
+    from moped_amd import capi, synth
+    from moped_amd.pipeline import FramePipeline, ShardedDB
 
     db = synth.make_db(n_models, pts_per_model)
     fr = synth.make_frame(db, n_vis=2, seed=3, Q=Q, pts_per_obj=120)
