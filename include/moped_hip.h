@@ -80,6 +80,12 @@ int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects);
 int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
                  const float* xyz_host, int N, int n_models, int32_t index_base);
 int mh_db_size(const mh_ctx* ctx, int* N, int* n_models);
+/* Let `dst` use the database `src` holds: same device, no copy -- one upload and one HBM copy per GPU
+ * however many contexts (frames in flight) work against it.  The analogue of the ONE kd-tree every
+ * frame of the reference searches (MATCH_ANN_CPU.hpp:70,106).  The store lives as long as its last
+ * user; a later mh_db_upload into either context gives that context a new store of its own and leaves
+ * the other one's untouched.  Frames already enqueued on `dst` finish on its old database first. */
+int mh_db_share(mh_ctx* dst, mh_ctx* src);
 
 /* ---- MATCH ---------------------------------------------------------------- */
 
@@ -93,6 +99,21 @@ int mh_normalize(mh_ctx* ctx, float* desc_host, int n);
  * ratio test; d1/d2 (optional) = best / second-best squared distance. */
 int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio,
              int32_t* nn_idx, int32_t* nn_raw, float* d1, float* d2);
+
+/* How MATCH ran on this context since the last reset: stats[0] = candidate rows the exact stage evaluated,
+ * stats[1] = queries searched by brute force inside it (candidate list overflow, or a query the f16
+ * screen cannot represent), stats[2] = queries through the two-stage path, stats[3] = 1 if a MATCH of
+ * `Q` queries against the current DB takes the two-stage path (f16 screen + exact rescoring), 0 if it
+ * takes the exact kernels.  Synchronises the context's stream. */
+int mh_match_stats(mh_ctx* ctx, int Q, uint32_t stats[4], int reset);
+/* Which kernels search: -1 (default) = the two-stage path when the work is large enough (Q x N >= 8e6,
+ * N >= 4096) and every DB row is finite and inside f16's range, 0 = always the exact f32 kernels,
+ * 1 = the two-stage path whenever the DB allows.  The results are the same bits either way. */
+int mh_match_set_mode(mh_ctx* ctx, int mode);
+/* The two-stage path's error model (host arithmetic, no device needed): a row can be one of a query's
+ * two nearest only if its f16 screen value exceeds T - mh_screen_margin(dot(q,q), max row norm), T =
+ * any lower bound of the second largest screen value.  Exposed so that tests can check the bound. */
+float mh_screen_margin(float qq, float dmax);
 
 /* Device-pointer forms for a model-sharded DB: local top-2 of this shard
  * (idx carries index_base; -1 when the shard is empty), then the merge of S

@@ -99,7 +99,7 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin",
 ]
 
 _lib = None
@@ -195,6 +195,11 @@ def load():
                                         C.POINTER(mh_frame_params), C.c_uint64]
     L.mh_frame_fetch.argtypes = [vp, vp, i32, C.POINTER(C.c_int32), vp]
     L.mh_frame_result_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.mh_db_share.argtypes = [vp, vp]
+    L.mh_match_stats.argtypes = [vp, i32, vp, i32]
+    L.mh_match_set_mode.argtypes = [vp, i32]
+    L.mh_screen_margin.argtypes = [f32, f32]
+    L.mh_screen_margin.restype = f32
     L.mh_enable_timing.argtypes = [vp, i32]
     L.mh_timing.argtypes = [vp, C.POINTER(mh_times)]
     _lib = L
@@ -292,6 +297,21 @@ class Context:
         xyz = np.ascontiguousarray(xyz, np.float32)
         self._ck(self.L.mh_db_upload(self.h, _ptr(desc), _ptr(model_of), _ptr(xyz), desc.shape[0],
                                      n_models, index_base), "mh_db_upload")
+
+    def db_share(self, src: "Context"):
+        """Use the database `src` holds (no copy; one store per GPU for all frames in flight)."""
+        self._ck(self.L.mh_db_share(self.h, src.h), "mh_db_share")
+
+    def match_set_mode(self, mode: int):
+        """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible."""
+        self._ck(self.L.mh_match_set_mode(self.h, int(mode)), "mh_match_set_mode")
+
+    def match_stats(self, Q=0, reset=False) -> dict:
+        """Two-stage MATCH statistics since the last reset + which path Q queries would take."""
+        st = np.zeros(4, np.uint32)
+        self._ck(self.L.mh_match_stats(self.h, int(Q), _ptr(st), int(reset)), "mh_match_stats")
+        return {"candidates": int(st[0]), "brute_force_queries": int(st[1]), "queries": int(st[2]),
+                "two_stage": bool(st[3])}
 
     def normalize(self, desc):
         d = np.ascontiguousarray(desc, np.float32).copy()

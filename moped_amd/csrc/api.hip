@@ -1,7 +1,10 @@
 // C ABI of libmoped_hip.so: context, model database, MATCH entry points.
 // (CLUSTER / POSE / FILTER / frame entry points live in api_steps.hip.)
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "context.h"
 #include "steps.h"
@@ -39,6 +42,26 @@ int ensure_pinned(mh_ctx* ctx, size_t bytes) {
   return MH_OK;
 }
 
+static void free_screen_bufs(mh_ctx* ctx) {
+  ScreenBufs& b = ctx->sbuf;
+  for (void* p : {(void*)b.qh, (void*)b.qbad, (void*)b.part, (void*)b.tau, (void*)b.ovf_cnt, (void*)b.recs, (void*)b.ovf, (void*)b.stats})
+    if (p) hipFree(p);
+  b = ScreenBufs();
+}
+
+// the context's view of its store
+static void bind_store(mh_ctx* ctx) {
+  const DbStore* st = ctx->store.get();
+  ctx->N = st ? st->N : 0;
+  ctx->n_models = st ? st->n_models : 0;
+  ctx->index_base = st ? st->index_base : 0;
+  ctx->db_desc = st ? st->desc : nullptr;
+  ctx->db_norm = st ? st->norm : nullptr;
+  ctx->db_xyz = st ? st->xyz : nullptr;
+  ctx->db_model = st ? st->model : nullptr;
+  ctx->sdb = st ? st->screen : ScreenDb();
+}
+
 int ensure_match_scratch(mh_ctx* ctx, int Q) {
   const size_t need_pack = match_pack_floats(Q);
   if (need_pack > ctx->match_pack_cap) {
@@ -49,12 +72,49 @@ int ensure_match_scratch(mh_ctx* ctx, int Q) {
     ctx->match_pack_cap = need_pack;
   }
   size_t need = match_scratch_elems(Q, ctx->N > 0 ? ctx->N : 1);
-  if (need <= ctx->match_scratch_cap) return MH_OK;
-  if (ctx->match_scratch) MH_HIP(ctx, hipFree(ctx->match_scratch));
-  ctx->match_scratch = nullptr;
-  ctx->match_scratch_cap = 0;
-  MH_HIP(ctx, hipMalloc(&ctx->match_scratch, need * sizeof(Top2)));
-  ctx->match_scratch_cap = need;
+  if (need > ctx->match_scratch_cap) {
+    if (ctx->match_scratch) MH_HIP(ctx, hipFree(ctx->match_scratch));
+    ctx->match_scratch = nullptr;
+    ctx->match_scratch_cap = 0;
+    MH_HIP(ctx, hipMalloc(&ctx->match_scratch, need * sizeof(Top2)));
+    ctx->match_scratch_cap = need;
+  }
+  // the screen's scratch (only for a DB the screen can serve)
+  const int q_pad = screen_q_pad(Q);
+  if (ctx->sdb.usable && q_pad > ctx->sbuf.q_pad) {
+    ScreenBufs& b = ctx->sbuf;
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_screen_bufs(ctx);
+    const size_t slots = (size_t)q_pad * screen_rec_slots();
+    MH_HIP(ctx, hipMalloc(&b.qh, (size_t)q_pad * DIM * sizeof(_Float16)));
+    MH_HIP(ctx, hipMalloc(&b.qbad, (size_t)q_pad));
+    MH_HIP(ctx, hipMalloc(&b.part, (size_t)screen_max_splits_a() * q_pad * sizeof(float2)));
+    MH_HIP(ctx, hipMalloc(&b.tau, (size_t)q_pad * sizeof(float)));
+    MH_HIP(ctx, hipMalloc(&b.recs, slots * sizeof(uint2)));
+    MH_HIP(ctx, hipMalloc(&b.ovf_cnt, (size_t)q_pad * sizeof(int32_t)));
+    MH_HIP(ctx, hipMalloc(&b.ovf, (size_t)q_pad * SCREEN_OVF_CAP * sizeof(uint2)));
+    MH_HIP(ctx, hipMalloc(&b.stats, (size_t)q_pad * 3 * sizeof(unsigned int)));
+    MH_HIP(ctx, hipMemsetAsync(b.recs, 0, slots * sizeof(uint2), ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(b.ovf_cnt, 0, (size_t)q_pad * sizeof(int32_t), ctx->stream));
+    MH_HIP(ctx, hipMemsetAsync(b.stats, 0, (size_t)q_pad * 3 * sizeof(unsigned int), ctx->stream));
+    b.ovf_cap = SCREEN_OVF_CAP;
+    b.q_pad = q_pad;   // only now: a failed allocation above leaves q_pad = 0 and the next call starts over
+  }
+  return MH_OK;
+}
+
+int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* idx1, float* d1, float* d2,
+              const int32_t* q_count, int q_expected) {
+  if (Q <= 0) return MH_OK;
+  int rc = ensure_match_scratch(ctx, Q);
+  if (rc) return rc;
+  const int qe = (q_expected > 0 && q_expected < Q) ? q_expected : Q;
+  if (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(qe, ctx->N, ctx->match_mode))
+    launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->sdb, ctx->sbuf, idx1, d1,
+                        d2, ctx->stream, q_count, q_expected);
+  else
+    launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->match_scratch,
+                 ctx->match_pack, idx1, d1, d2, ctx->stream, q_count, q_expected);
   return MH_OK;
 }
 
@@ -114,7 +174,9 @@ void mh_destroy(mh_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   mh_free_frame_state(ctx);
   mh_free_sift_state(ctx);
-  void* ptrs[] = {ctx->db_desc, ctx->db_norm, ctx->db_xyz, ctx->db_model, ctx->q_desc, ctx->q_norm,
+  free_screen_bufs(ctx);
+  ctx->store.reset();   // the DB goes with its last user
+  void* ptrs[] = {ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
                   ctx->scratch, ctx->match_pack, ctx->rules.ratio_table, ctx->rules.inv_size, ctx->rules.cnt,
                   ctx->rules.keep1, ctx->lk_scratch, ctx->own_depth, ctx->own_fill};
@@ -161,40 +223,91 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // rows are padded to whole 128-row tiles for the match kernel: zero descriptors,
+  // rows are padded to whole 128-row tiles for the match kernels: zero descriptors,
   // +inf norm terms (a padding row can never enter a top-2)
   const size_t Npad = ((size_t)N + 127) / 128 * 128;
-  if (Npad > ctx->db_cap) {
-    ctx->db_cap = 0;   // until every array has its new size
-    ctx->N = 0;
-    int rc;
-    if ((rc = realloc_dev(ctx, ctx->db_desc, Npad * DIM))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_norm, Npad))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_xyz, Npad * 3))) return rc;
-    if ((rc = realloc_dev(ctx, ctx->db_model, Npad))) return rc;
-    ctx->db_cap = Npad;
+  if (!ctx->store || ctx->store.use_count() > 1) {   // other contexts read the old store: leave it alone
+    ctx->store = std::make_shared<DbStore>();
+    ctx->store->device = ctx->device;
   }
-  ctx->N = N;
-  ctx->n_models = n_models;
-  ctx->index_base = index_base;
+  DbStore* st = ctx->store.get();
+  st->N = 0;
+  st->screen = ScreenDb();
+  bind_store(ctx);
+  if (Npad > st->cap) {
+    st->cap = 0;   // until every array has its new size
+    int rc;
+    if ((rc = realloc_dev(ctx, st->desc, Npad * DIM))) return rc;
+    if ((rc = realloc_dev(ctx, st->norm, Npad))) return rc;
+    if ((rc = realloc_dev(ctx, st->xyz, Npad * 3))) return rc;
+    if ((rc = realloc_dev(ctx, st->model, Npad))) return rc;
+    st->cap = Npad;
+  }
+  st->n_models = n_models;
+  st->index_base = index_base;
   if (N > 0) {
-    MH_HIP(ctx, hipMemcpyAsync(ctx->db_desc, desc_host, (size_t)N * DIM * sizeof(float),
+    MH_HIP(ctx, hipMemcpyAsync(st->desc, desc_host, (size_t)N * DIM * sizeof(float),
                                hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(ctx->db_xyz, xyz_host, (size_t)N * 3 * sizeof(float),
+    MH_HIP(ctx, hipMemcpyAsync(st->xyz, xyz_host, (size_t)N * 3 * sizeof(float),
                                hipMemcpyHostToDevice, ctx->stream));
-    MH_HIP(ctx, hipMemcpyAsync(ctx->db_model, model_of_host, (size_t)N * sizeof(int32_t),
+    MH_HIP(ctx, hipMemcpyAsync(st->model, model_of_host, (size_t)N * sizeof(int32_t),
                                hipMemcpyHostToDevice, ctx->stream));
     if (Npad > (size_t)N) {
-      MH_HIP(ctx, hipMemsetAsync(ctx->db_desc + (size_t)N * DIM, 0, (Npad - N) * DIM * sizeof(float), ctx->stream));
-      MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->db_norm + N), 0x7F800000, Npad - N, ctx->stream));
+      MH_HIP(ctx, hipMemsetAsync(st->desc + (size_t)N * DIM, 0, (Npad - N) * DIM * sizeof(float), ctx->stream));
+      MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(st->norm + N), 0x7F800000, Npad - N, ctx->stream));
     }
     if (normalize)
-      launch_normalize(ctx->db_desc, ctx->db_norm, N, ctx->stream);   // A1 on the device, like Update() (:94)
+      launch_normalize(st->desc, st->norm, N, ctx->stream);   // A1 on the device, like Update() (:94)
     else
-      launch_row_norms(ctx->db_desc, ctx->db_norm, N, ctx->stream);
+      launch_row_norms(st->desc, st->norm, N, ctx->stream);
     MH_HIP(ctx, hipGetLastError());
+    // the screen's f16 image + what it needs to know about the rows (match_screen.hip)
+    if (screen_wanted(1 << 30, N)) {
+      const size_t need_h = screen_db_half_elems(N);
+      if (need_h > st->cap_h) {
+        st->cap_h = 0;
+        int rc;
+        if ((rc = realloc_dev(ctx, st->desc_h, need_h))) return rc;
+        if ((rc = realloc_dev(ctx, st->neg_h, need_h / DIM))) return rc;
+        st->cap_h = need_h;
+      }
+      if (!st->stats) MH_HIP(ctx, hipMalloc(&st->stats, 4 * sizeof(unsigned int)));
+      MH_HIP(ctx, hipMemsetAsync(st->stats, 0, 4 * sizeof(unsigned int), ctx->stream));
+      launch_db_to_half(st->desc, st->norm, N, st->desc_h, st->neg_h, st->stats, ctx->stream);
+      MH_HIP(ctx, hipGetLastError());
+      unsigned int h[4] = {0, 0, 0, 0};
+      MH_HIP(ctx, hipMemcpyAsync(h, st->stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      float dd_max, x_max;
+      std::memcpy(&dd_max, &h[0], 4);
+      std::memcpy(&x_max, &h[1], 4);
+      st->screen.dbh = st->desc_h;
+      st->screen.dneg = st->neg_h;
+      st->screen.dmax = std::sqrt(dd_max);
+      st->screen.usable = h[2] == 0 && x_max < 60000.f;   // (a NaN coordinate reads as a huge bit pattern: not < 60000)
+    }
   }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  st->N = N;
+  bind_store(ctx);
+  return MH_OK;
+}
+
+int mh_db_share(mh_ctx* dst, mh_ctx* src) {
+  if (!dst || !src || !src->store) {
+    if (dst) dst->err = "mh_db_share: the source context holds no database";
+    return MH_ERR_ARG;
+  }
+  if (dst == src) return MH_OK;
+  if (dst->device != src->device) {
+    dst->err = "mh_db_share: contexts on different devices";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(dst, hipSetDevice(dst->device));
+  if (dst->stream) MH_HIP(dst, hipStreamSynchronize(dst->stream));   // frames of dst still reading its old DB
+  if (src->stream) MH_HIP(src, hipStreamSynchronize(src->stream));   // the upload into src has completed (it is synchronous) -- cheap
+  dst->store = src->store;
+  bind_store(dst);
   return MH_OK;
 }
 
@@ -237,10 +350,8 @@ int mh_match_local_dev(mh_ctx* ctx, const float* qn_dev, const float* qnorm_dev,
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = ensure_match_scratch(ctx, Q);
+  int rc = ctx_match(ctx, qn_dev, qnorm_dev, Q, idx1_dev, d1_dev, d2_dev);
   if (rc) return rc;
-  launch_match(qn_dev, qnorm_dev, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->match_pack, idx1_dev, d1_dev, d2_dev, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;
 }
@@ -272,8 +383,7 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
   MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_host, (size_t)Q * DIM * sizeof(float),
                              hipMemcpyHostToDevice, ctx->stream));
   launch_row_norms(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
-  launch_match(ctx->q_desc, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+  if ((rc = ctx_match(ctx, ctx->q_desc, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
   // the reference's acceptance test on squared distances (MATCH_ANN_CPU.hpp:165)
   int32_t* d_acc = (int32_t*)ctx->scratch;
   launch_accept(ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, ratio, d_acc, ctx->stream);
@@ -291,6 +401,36 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
   if (nn_raw) std::memcpy(nn_raw, h_raw, (size_t)Q * 4);
   if (d1) std::memcpy(d1, h_d1, (size_t)Q * 4);
   if (d2) std::memcpy(d2, h_d2, (size_t)Q * 4);
+  return MH_OK;
+}
+
+float mh_screen_margin(float qq, float dmax) { return screen_margin_host(qq, dmax); }
+
+int mh_match_set_mode(mh_ctx* ctx, int mode) {
+  if (!ctx || mode < -1 || mode > 1) return MH_ERR_ARG;
+  ctx->match_mode = mode;
+  return MH_OK;
+}
+
+int mh_match_stats(mh_ctx* ctx, int Q, uint32_t stats[4], int reset) {
+  if (!ctx || !stats) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  if (Q > 0) {
+    int rc = ensure_match_scratch(ctx, Q);
+    if (rc) return rc;
+    stats[3] = (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(Q, ctx->N, ctx->match_mode)) ? 1u : 0u;
+  }
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->sbuf.stats) {
+    std::vector<unsigned int> h((size_t)ctx->sbuf.q_pad * 3);
+    MH_HIP(ctx, hipMemcpy(h.data(), ctx->sbuf.stats, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    unsigned long long sum[3] = {0, 0, 0};
+    for (size_t i = 0; i < h.size(); ++i) sum[i % 3] += h[i];
+    for (int k = 0; k < 3; ++k) stats[k] = (uint32_t)std::min<unsigned long long>(sum[k], 0xFFFFFFFFull);
+    if (reset) MH_HIP(ctx, hipMemset(ctx->sbuf.stats, 0, h.size() * sizeof(unsigned int)));
+  }
   return MH_OK;
 }
 

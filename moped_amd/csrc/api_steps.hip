@@ -998,8 +998,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   return run_graphed(ctx, ctx->fs->g_full, key, [&]() -> int {
     stamp(ctx, 0);
     launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-    launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-                 ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream);
+    if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2)) return rc_m;
     stamp(ctx, 1);
     return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
   });
@@ -1019,9 +1018,8 @@ int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int 
   ctx->feat_count_dev = n_dev;
   stamp(ctx, 0);
   launch_normalize(ctx->q_desc, ctx->q_norm, Q, ctx->stream, n_dev);
-  launch_match(ctx->q_desc, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-               ctx->match_scratch, ctx->match_pack, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, ctx->stream, n_dev,
-               ctx->feat_expected);
+  if ((rc = ctx_match(ctx, ctx->q_desc, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, n_dev, ctx->feat_expected)))
+    return rc;
   stamp(ctx, 1);
   return frame_rest(ctx, ctx->q_uv, Q, nullptr, 0, cam, prm, seed);
 }
@@ -1055,8 +1053,7 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
   return run_graphed(ctx, ctx->fs->g_local, key, [&]() -> int {
     stamp(ctx, 0);
     launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-    launch_match(q_desc_dev, ctx->q_norm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base,
-                 ctx->match_scratch, ctx->match_pack, top2_dev, d1, d1 + Q, ctx->stream);
+    if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, top2_dev, d1, d1 + Q)) return rc_m;
     MH_HIP(ctx, hipGetLastError());
     return MH_OK;
   });

@@ -2,11 +2,41 @@
 // MATCH_ANN_CPU keeps between frames, MATCH_ANN_CPU.hpp:70) plus the per-frame
 // device buffers.  Everything lives in HBM; host pointers only at the C ABI.
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "common.h"
+#include "screen.h"
 #include "steps.h"
+
+// The model database in HBM.  Contexts (= frames in flight) of one device may share one store
+// (mh_db_share): one upload and one copy per GPU instead of one per frame slot, and one set of lines in
+// the Infinity Cache for all frames in flight.  A store that is shared is never resized or rewritten:
+// an upload into a context whose store has other users gives that context a fresh store.
+struct DbStore {
+  int device = 0;
+  int N = 0, n_models = 0;
+  int32_t index_base = 0;
+  float* desc = nullptr;       // [rows padded to 128][128], zero padding rows
+  float* norm = nullptr;       // [padded] dot(d,d), +inf on padding rows
+  float* xyz = nullptr;        // [padded][3]
+  int32_t* model = nullptr;    // [padded]
+  size_t cap = 0;              // rows allocated
+  _Float16* desc_h = nullptr;  // f16 image for the screen (match_screen.hip)
+  float* neg_h = nullptr;      // [padded] -norm/2: the screen's accumulator seeds
+  size_t cap_h = 0;            // elements allocated
+  unsigned int* stats = nullptr;
+  mh::ScreenDb screen;
+  ~DbStore() {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    hipSetDevice(device);
+    for (void* p : {(void*)desc, (void*)norm, (void*)xyz, (void*)model, (void*)desc_h, (void*)neg_h, (void*)stats})
+      if (p) hipFree(p);
+    if (have) hipSetDevice(cur);
+  }
+};
 
 struct mh_ctx {
   int device = 0;
@@ -14,14 +44,17 @@ struct mh_ctx {
   hipStream_t stream = nullptr;
   std::string err;
 
-  // ---- model database (resident) ----
+  // ---- model database (resident; the arrays belong to `store`, these are its pointers) ----
+  std::shared_ptr<DbStore> store;
   int N = 0, n_models = 0;
   int32_t index_base = 0;
   float* db_desc = nullptr;      // [N][128]
   float* db_norm = nullptr;      // [N]
   float* db_xyz = nullptr;       // [N][3]
   int32_t* db_model = nullptr;   // [N]
-  size_t db_cap = 0;
+  mh::ScreenDb sdb;
+  mh::ScreenBufs sbuf;           // the screen's per-frame scratch
+  int match_mode = -1;           // mh_match_set_mode
 
   // ---- per-frame buffers ----
   int max_q = 0, max_clusters = 0, max_objects = 0;
@@ -104,6 +137,10 @@ int ensure_frame_buffers(mh_ctx* ctx, int Q);
 int ensure_scratch(mh_ctx* ctx, size_t bytes);
 int ensure_pinned(mh_ctx* ctx, size_t bytes);
 int ensure_match_scratch(mh_ctx* ctx, int Q);
+// MATCH of Q normalised queries against the context's DB on its stream: exact (idx1, d1, d2) per query, by the
+// two-stage screen when it pays and the DB allows it, else by the exact kernels (bit-identical results either way).
+int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* idx1, float* d1, float* d2,
+              const int32_t* q_count = nullptr, int q_expected = 0);
 int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
               float* desc_dev, float* xy_dev, int32_t** n_dev_out);
 

@@ -1,0 +1,727 @@
+// MATCH in two stages: an f16 matrix-pipe SCREEN of all (query, row) pairs, then the canonical f32
+// arithmetic only on the few rows per query that can still be one of its two nearest.  Results --
+// (idx1, d1, d2) per query -- are bit for bit those of match.hip / match_mfma.hip (and of the oracle):
+// the screen only decides WHICH rows get the exact treatment, and it errs on the side of too many.
+//
+// Replaces the kd-tree search of MATCH_ANN_CPU::process (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:
+// 155-165) like the exact kernels do; what changes is the cost: 2*128*Q*N flops on
+// v_mfma_f32_32x32x16_f16 (16x the f32 rate) instead of on v_mfma_f32_32x32x2_f32.
+//
+// Why it is exact.  Canonical distance (match.hip): a(q,r) = max(0, fmaf(-2, p, qq + dd_r)) with p the
+// f32 fmaf chain of dot(q, d_r).  Ranking by a is ranking by w(q,r) = p - dd_r / 2 (a = qq - 2w up to
+// f32 rounding).  The screen computes w~ = sum_k f16(q_k) f16(d_rk) - dd_r / 2 with f32 accumulation
+// (the -dd_r/2 term is the accumulator's initial value, exact).  With u = 2^-11 (f16 unit roundoff)
+//     |w~ - w| <= E(q) = (2u + u^2) |q| Dmax            rounding of both operands (Cauchy-Schwarz)
+//                      + 2^-25 sqrt(128) (|q| + Dmax)    f16 subnormal range (absolute 2^-25 per element)
+//                      + 3e-5 (|q| Dmax + Dmax^2 / 2)    136 f32 accumulations on either side + the chain's own rounding
+// where Dmax = max_r |d_r| (taken at upload).  Let T be any value known to be <= the second largest w~
+// over distinct rows (pass A: the second largest over a SAMPLE of the rows).  A row r that is one of the
+// two nearest by a satisfies w_r >= (second largest w) - slack, hence w~_r >= T - 2E - slack.  Pass B emits
+// every row above tau = T - (2E + slack); pass C evaluates the canonical distance of the emitted rows and
+// folds the exact top-2 (ties -> lower row, second best = second smallest value), which is the global
+// answer because every row it did not see is strictly farther than the two it reports.  A query whose
+// candidate list overflows, or whose descriptor is not finite / too large for f16, is searched by brute
+// force inside pass C: the screen can be slow, never wrong.  The bound is exercised by
+// tests/test_gpu_screen.py (near-ties inside the bound, duplicates, zero rows, unnormalised rows) and
+// its arithmetic by tests/test_screen_bound_cpu.py.
+//
+// Shape (gfx950).  A workgroup = 4 wavefronts, 2 workgroups per CU.  A wavefront keeps 64 queries in
+// registers as the B operands of all 8 k-steps (2 blocks x 8 x 4 VGPRs); the f16 DB streams through
+// LDS in 128-row tiles (32 KB, double buffered, filled by global_load_lds_dwordx4 with the 16-byte
+// chunks of row r stored at chunk position c ^ (r & 15), so the A-operand ds_read_b128 of 16 lanes
+// touch all 64 banks once).  Queries sit on the accumulator's lane axis, rows on its register axis:
+// a lane's 16 values of a 32x32 block are 16 rows of ONE query, so the running maxima are lane-local
+// v_max3_f32 (8 per block) and only a lane with a hit looks at individual values.
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "screen.h"
+
+namespace mh {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define MH_AS1 __attribute__((address_space(1)))
+#define MH_AS3 __attribute__((address_space(3)))
+
+constexpr int SC_WAVES = 8;                        // one workgroup per CU, two wavefronts per SIMD
+constexpr int SC_THREADS = 64 * SC_WAVES;
+constexpr int SC_QPAD = 3 * 1024;                  // the query image is padded to whole workgroups of every kernel width (256, 512, 768)
+constexpr int SC_TILE = 128;                       // DB rows per LDS tile (= the DB's row padding)
+constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
+constexpr int SC_LDS_BYTES = 2 * SC_TILE_BYTES + 2 * SC_TILE * 4;   // two tiles + their -dd/2 terms
+static_assert(SC_TILE == 128 && DIM == 128, "tile image and chunk swizzle assume 128 x 128");
+
+// error model of the screen (see the header comment)
+__host__ __device__ inline float screen_margin(float qq, float dmax) {
+  const float nq = sqrtf(fmaxf(qq, 0.f));
+  const float E = 0.000978f * nq * dmax + 4e-7f * (nq + dmax) + 3e-5f * (nq * dmax + 0.5f * dmax * dmax);
+  return 2.f * E + 2e-6f * (qq + dmax * dmax);
+}
+
+// ---- f16 images ------------------------------------------------------------------------------
+// DB: [n_pad][128] f16 (round to nearest), dneg[n_pad] = -dd/2, + statistics over the real rows: max dd, max |x|, any non-finite dd.
+__global__ __launch_bounds__(256) void db_to_half_kernel(const float* __restrict__ db, const float* __restrict__ dnorm, int N,
+                                                         size_t n_chunks, _Float16* __restrict__ dbh, float* __restrict__ dneg,
+                                                         unsigned int* __restrict__ stats) {
+  __shared__ unsigned int red[3];
+  if (threadIdx.x < 3) red[threadIdx.x] = 0;
+  __syncthreads();
+  float x_max = 0.f, dd_max = 0.f;
+  unsigned int bad = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_chunks; i += (size_t)gridDim.x * blockDim.x) {   // one 8-element chunk
+    const float4 a = reinterpret_cast<const float4*>(db)[2 * i], b = reinterpret_cast<const float4*>(db)[2 * i + 1];
+    half8 h;
+    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+    reinterpret_cast<half8*>(dbh)[i] = h;
+    const int row = (int)(i >> 4);
+    if ((i & 15) == 0) dneg[row] = -0.5f * dnorm[row];   // the accumulators' initial values; -inf on padding rows
+    if (row < N) {
+      // (fmaxf drops NaNs: a NaN coordinate shows in the row's norm term)
+      x_max = fmaxf(x_max, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                                 fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+      if ((i & 15) == 0) {
+        const float dd = dnorm[row];
+        if (!(dd >= 0.f) || dd == __builtin_inff()) bad = 1;
+        else dd_max = fmaxf(dd_max, dd);
+      }
+    }
+  }
+  // non-negative floats order like their bit patterns
+  atomicMax(&red[0], __float_as_uint(dd_max));
+  atomicMax(&red[1], __float_as_uint(x_max));
+  if (bad) atomicOr(&red[2], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&stats[0], red[0]);
+    atomicMax(&stats[1], red[1]);
+    if (red[2]) atomicOr(&stats[2], 1u);
+  }
+}
+
+// Queries of the frame: f16 rows (zero rows up to the padded count) + a flag for queries the screen
+// cannot vouch for (non-finite norm term, or a coordinate outside f16's range).
+__global__ void screen_prepare_kernel(const float* __restrict__ qn, const float* __restrict__ qnorm, int Q,
+                                      const int32_t* __restrict__ q_count, int q_pad, _Float16* __restrict__ qh,
+                                      uint8_t* __restrict__ qbad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element chunk; 16 consecutive threads = one row
+  if (i >= q_pad * 16) return;
+  const int row = i >> 4;
+  const int Qe = q_count ? min(Q, *q_count) : Q;
+  half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+  float m = 0.f;
+  if (row < Qe) {
+    const float4 a = reinterpret_cast<const float4*>(qn)[2 * (size_t)i], b = reinterpret_cast<const float4*>(qn)[2 * (size_t)i + 1];
+    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+    m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+              fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+  }
+  reinterpret_cast<half8*>(qh)[i] = h;
+  // row maximum over its 16 threads (fmaxf drops NaNs: a NaN coordinate shows in the norm term instead)
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((i & 15) == 0) {
+    bool bad = false;
+    if (row < Qe) {
+      const float qq = qnorm[row];
+      bad = !(qq >= 0.f) || qq == __builtin_inff() || !(m < 60000.f);
+    }
+    qbad[row] = bad ? 1 : 0;
+  }
+}
+
+// ---- passes A and B ------------------------------------------------------------------------------
+// MODE 0 (pass A): top-2 VALUES of w~ per (split, query) over the sampled tiles -> part[split][q].
+// MODE 1 (pass B): every row with w~ > tau(q) -> the query's candidate records {row0, bits}: rows
+//                  row0 + (r & 3) + 8 (r >> 2) for the set bits r.  A lane owns the sub-list (query, split, half)
+//                  -- `sub_cap` slots nobody else writes, no atomics; a sub-list that is full spills into the
+//                  query's overflow list (atomic append, rare).  bits = 0 marks an empty slot.
+constexpr int SC_SLOTS_MAX = 512;   // record slots per query: 2 halves x splits x sub_cap <= this
+
+#ifdef SC_PROF   // experiment build (make EXTRA=-DSC_PROF ...): switch parts of passes A/B off (results are wrong then)
+// and stamp a workgroup's time; scripts/screen_prof.py
+__device__ unsigned long long g_sc_prof[8];
+__device__ unsigned long long g_sc_trace[2][1024];   // (event << 56 | cycles since the workgroup's start) of wavefronts 0 and 4 of workgroup 3
+static int g_sc_ablate = 0;
+#define SC_ABL(bit) ((A.ablate >> (bit)) & 1)
+#define SC_EV(e) do { if (tracing && n_ev < 1024) { g_sc_trace[wave >> 2][n_ev++] = ((unsigned long long)(e) << 56) | (__builtin_amdgcn_s_memtime() - t_start); } } while (0)
+#else
+#define SC_ABL(bit) 0
+#define SC_EV(e) do { } while (0)
+#endif
+
+struct ScreenArgs {
+  const _Float16* qh;
+  const _Float16* dbh;
+  const float* dneg;     // [padded rows] -dd/2, -inf on padding rows
+  const float* qnorm;
+  const uint8_t* qbad;
+  const int32_t* q_count;
+  float2* part;          // pass A's output, [n_splits_a][q_pad]
+  const float* tau;      // pass B's input, [q_pad] (screen_tau_kernel)
+  uint2* recs;           // [q_pad][SC_SLOTS_MAX], empty (bits 0) on entry of pass B (pass C re-empties)
+  int32_t* ovf_cnt;      // [q_pad], zero on entry
+  uint2* ovf;            // [q_pad][ovf_cap]
+  int Q, q_pad, ovf_cap, sub_cap;
+  int n_sel, tile_first, tile_stride;   // the pass covers tiles tile_first + j * tile_stride, j < n_sel
+  int tiles_base, tiles_rem, n_splits;  // split s takes tiles_base selected tiles, the first tiles_rem one more
+  int n_splits_a;
+  float dmax;
+  int ablate;            // SC_PROF builds only: 1 = no finish(), 2 = stage only the first tile, 4 = no MFMAs
+};
+
+// Between the passes: a query's threshold from pass A's per-split top-2 values.  tau = +inf for queries that do not
+// exist in this frame or that the screen cannot vouch for (pass B then leaves them no records; pass C searches the
+// latter by brute force).  One thread per query; the splits' values of neighbouring queries are neighbours in memory.
+__global__ void screen_tau_kernel(const float2* __restrict__ part, int n_splits_a, int q_pad, int Q,
+                                  const int32_t* __restrict__ q_count, const float* __restrict__ qnorm,
+                                  const uint8_t* __restrict__ qbad, float dmax, float* __restrict__ tau) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= q_pad) return;
+  const int Qe = q_count ? min(Q, *q_count) : Q;
+  float t = __builtin_inff();
+  if (q < Qe && !qbad[q]) {
+    float B = -__builtin_inff(), S = -__builtin_inff();
+    for (int s0 = 0; s0 < n_splits_a; s0 += 8) {
+      float2 p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        p[j] = (s0 + j < n_splits_a) ? part[(size_t)(s0 + j) * q_pad + q] : make_float2(-__builtin_inff(), -__builtin_inff());
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        S = fmaxf(fminf(B, p[j].x), fmaxf(S, p[j].y));
+        B = fmaxf(B, p[j].x);
+      }
+    }
+    t = S - screen_margin(qnorm[q], dmax);
+  }
+  tau[q] = t;
+}
+
+// Four LDS-DMA pieces (1 KB each: 16 bytes per lane to lds_i + lane * 16) in one statement: the source of piece i
+// is base_i + voff (the same per-lane offset for all four), M0 is saved once.  Issued as asm so that hipcc neither
+// counts the transfers nor waits for them before the next ds_read (it would: vmcnt(0) at the first LDS read after a
+// __builtin_amdgcn_global_load_lds).  Completion: the s_waitcnt vmcnt(0) + barrier that end every tile.
+__device__ __forceinline__ void dma16x4(unsigned voff, const void* b0, const void* b1, const void* b2, const void* b3,
+                                        unsigned l0, unsigned l1, unsigned l2, unsigned l3) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+      "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(l0), "s"(l1), "s"(l2), "s"(l3)
+      : "memory");
+}
+__device__ __forceinline__ void dma4(unsigned voff, const void* base, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+template <int MODE, int NQB>
+__global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs A) {
+  constexpr int QW = 32 * NQB;            // queries per wavefront
+  constexpr int QB = QW * SC_WAVES;       // queries per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const unsigned lds_base = (unsigned)(uintptr_t)(MH_AS3 unsigned char*)lds;
+  // XCD-aware (query block, split) map as in match.hip: workgroups are dealt round-robin to the 8 XCDs, so
+  // giving XCD x the splits x, x + 8, ... keeps a split's rows in one L2
+  const int nqb = gridDim.x / A.n_splits;
+  int qblock, split;
+  {
+    const int L = blockIdx.x;
+    if ((A.n_splits & 7) == 0) {
+      const int x = L & 7, j = L >> 3;
+      split = x + 8 * (j / nqb);
+      qblock = j % nqb;
+    } else {
+      split = L / nqb;
+      qblock = L % nqb;
+    }
+  }
+  const int Qe = A.q_count ? min(A.Q, *A.q_count) : A.Q;
+  if (qblock * QB >= Qe) return;   // uniform over the workgroup
+  const int q0 = qblock * QB + wave * QW;
+  const int sel_begin = split * A.tiles_base + min(split, A.tiles_rem);
+  const int sel_end = min(sel_begin + A.tiles_base + (split < A.tiles_rem ? 1 : 0), A.n_sel);
+
+  // ---- staging: one tile = 32 pieces of 1 KB (64 lanes x 16 B, lane-linear in LDS); wavefront w brings pieces
+  // w, w + 8, w + 16, w + 24.  Chunk g = 64 piece + lane of the LDS image is row g >> 4, position g & 15, and holds
+  // source chunk (g & 15) ^ (row & 15); row & 15 = (4 w + (lane >> 4)) & 15 for all four pieces of a wavefront, so one
+  // per-lane offset serves them and the pieces differ by 8 KB in a scalar base.  The rows' -dd/2 terms (512 B per tile)
+  // come the same way: wavefronts 0 and 1, 4 bytes per lane.
+  const unsigned voff = (unsigned)(wave * 1024 + (lane >> 4) * 256 + (((lane & 15) ^ ((wave * 4 + (lane >> 4)) & 15)) << 4));
+  const unsigned voff_dd = (unsigned)((wave * 64 + lane) * 4);
+  auto stage = [&](int sel, int buf) {
+    const int tile = A.tile_first + sel * A.tile_stride;
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(A.dbh) + (size_t)tile * SC_TILE_BYTES;
+    const unsigned l = lds_base + buf * SC_TILE_BYTES + wave * 1024;
+    dma16x4(voff, tb, tb + 8192, tb + 16384, tb + 24576, l, l + 8192, l + 16384, l + 24576);
+    if (wave < 2)
+      dma4(voff_dd, A.dneg + (size_t)tile * SC_TILE, lds_base + 2 * SC_TILE_BYTES + buf * (SC_TILE * 4) + wave * 256);
+  };
+
+#ifdef SC_PROF
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long t_wait = 0;
+  const bool tracing = MODE == 1 && blockIdx.x == 3 && (wave == 0 || wave == 4) && lane == 0;
+  int n_ev = 0;
+#endif
+  if (sel_begin < sel_end) stage(sel_begin, 0);
+  // ---- B operands: this lane's query of each block, k = 16 s + 8 half .. + 7 of every k-step s ----
+  half8 bq[NQB][8];
+#pragma unroll
+  for (int nb = 0; nb < NQB; ++nb) {
+    const _Float16* row = A.qh + (size_t)(q0 + nb * 32 + l32) * DIM + 8 * half;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bq[nb][s] = *reinterpret_cast<const half8*>(row + 16 * s);
+  }
+  // ---- per-query state ----
+  float b1[NQB], b2[NQB], tau[NQB];
+  int n_rec[NQB];
+#pragma unroll
+  for (int nb = 0; nb < NQB; ++nb) {
+    b1[nb] = -__builtin_inff();
+    b2[nb] = -__builtin_inff();
+    tau[nb] = __builtin_inff();
+    n_rec[nb] = 0;
+    if (MODE == 1) tau[nb] = A.tau[q0 + nb * 32 + l32];
+  }
+  // vmcnt(0) as a builtin, not asm: hipcc must KNOW that the B operands (and everything else) have arrived, or it
+  // keeps counted vmcnt waits for them inside the tile loop -- where they would wait for the LDS-DMA of the next tile
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  // what a lane does with one finished 32 x 32 block: 16 rows of one of its queries
+  auto finish = [&](const v16f& acc, int nb, int row0) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        b2[nb] = __builtin_amdgcn_fmed3f(b1[nb], b2[nb], acc[r]);
+        b1[nb] = fmaxf(b1[nb], acc[r]);
+      }
+    } else {
+      float m = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);   // -> 8 v_max3_f32
+      if (m > tau[nb]) {
+        // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tau[nb] - acc[r]), 31);
+        const int q = q0 + nb * 32 + l32;
+        const uint2 rec = make_uint2((unsigned)row0, bits);
+        if (n_rec[nb] < A.sub_cap) {
+          A.recs[(size_t)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb]] = rec;
+          ++n_rec[nb];
+        } else {
+          const int pos = atomicAdd(&A.ovf_cnt[q], 1);
+          if (pos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + pos] = rec;
+        }
+      }
+    }
+  };
+
+  const int swz = l32 & 15;
+  int buf = 0;
+  v16f pend;            // pass B: the block whose MFMAs were issued last is finished behind the next block's MFMAs
+  int pend_row0 = 0;
+  bool have_pend = false;
+  for (int sel = sel_begin; sel < sel_end; ++sel) {
+    const bool more = sel + 1 < sel_end;
+    SC_EV(1);   // tile begins
+    if (more && !SC_ABL(1)) stage(sel + 1, buf ^ 1);
+    SC_EV(2);   // staging issued
+    const unsigned char* T = lds + (SC_ABL(1) ? 0 : buf) * SC_TILE_BYTES;
+    const float* ddp = reinterpret_cast<const float*>(lds + 2 * SC_TILE_BYTES + buf * (SC_TILE * 4));
+    const int row_tile = (A.tile_first + sel * A.tile_stride) * SC_TILE;
+#pragma unroll(MODE == 0 ? 1 : SC_TILE / 32)   // (pass A unrolled: 123 spilled registers at three query blocks)
+    for (int rb = 0; rb < SC_TILE / 32; ++rb) {
+      // A operands: row rb * 32 + l32, k-step s -> chunk 2 s + half, stored at position chunk ^ (row & 15)
+      half8 a[8];
+      const unsigned char* rowp = T + (rb * 32 + l32) * 256;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const half8*>(rowp + (((2 * s + half) ^ swz) << 4));
+      // accumulator register r belongs to row (r & 3) + 8 (r >> 2) + 4 half of the block: its -dd/2 goes in as C
+      v16f init;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(ddp + rb * 32 + 8 * g + 4 * half);
+        init[4 * g] = v.x;
+        init[4 * g + 1] = v.y;
+        init[4 * g + 2] = v.z;
+        init[4 * g + 3] = v.w;
+      }
+      const int row0 = row_tile + rb * 32 + 4 * half;
+      SC_EV(3);   // LDS reads of the row block issued (the stamp's own lgkmcnt(0) also waits for them)
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) {
+        v16f acc = init;
+        if (!SC_ABL(2)) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[nb][s], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) acc[s] += (float)a[s][nb];
+        }
+        if (MODE == 1) {
+          // a block is finished behind the NEXT block's MFMAs: its values are out of the pipe by then, and the
+          // vector instructions issue while the matrix pipe works
+          __builtin_amdgcn_sched_barrier(0);
+          SC_EV(4);   // chain issued
+          if (have_pend && !SC_ABL(0)) finish(pend, (nb + NQB - 1) % NQB, pend_row0);
+          __builtin_amdgcn_sched_barrier(0);
+          SC_EV(5);   // previous block finished
+          pend = acc;
+          pend_row0 = row0;
+          have_pend = true;
+        } else {
+          // (fenced: left alone, the scheduler overlaps several blocks' accumulators and spills)
+          __builtin_amdgcn_sched_barrier(0);
+          finish(acc, nb, row0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#ifdef SC_PROF
+    const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
+#endif
+    SC_EV(6);   // tile's work issued
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the next tile have landed
+    SC_EV(7);   // own pieces landed
+    __syncthreads();   // everybody's pieces have; nobody reads `buf` any more
+    SC_EV(8);   // barrier passed
+#ifdef SC_PROF
+    t_wait += __builtin_amdgcn_s_memtime() - t_w0;
+#endif
+    buf ^= 1;
+  }
+  if (MODE == 1 && have_pend) finish(pend, NQB - 1, pend_row0);
+#ifdef SC_PROF
+  if (MODE == 1 && tid == 0) {
+    atomicAdd(&g_sc_prof[0], __builtin_amdgcn_s_memtime() - t_start);       // shader cycles of the workgroup
+    atomicAdd(&g_sc_prof[1], __builtin_amdgcn_s_memrealtime() - r_start);   // 100 MHz ticks
+    atomicAdd(&g_sc_prof[2], t_wait);                                       // cycles in the end-of-tile wait + barrier
+    atomicAdd(&g_sc_prof[3], (unsigned long long)(sel_end - sel_begin));
+    atomicAdd(&g_sc_prof[4], 1ull);
+    if (SC_ABL(0)) A.part[0].x = b1[0] + pend[3];
+  }
+#endif
+
+  if (MODE == 0) {
+    // the two halves of the wavefront hold different rows of the same queries
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb) {
+      const float ob = __shfl_xor(b1[nb], 32), os = __shfl_xor(b2[nb], 32);
+      const float S = fmaxf(fminf(b1[nb], ob), fmaxf(b2[nb], os));
+      const float B = fmaxf(b1[nb], ob);
+      const int q = q0 + nb * 32 + l32;
+      if (half == 0 && q < A.q_pad) A.part[(size_t)split * A.q_pad + q] = make_float2(B, S);
+    }
+  }
+}
+
+// ---- pass C: canonical arithmetic on the candidates ------------------------------------------------
+struct Best {
+  float b1, b2;
+  int i1;
+};
+// one more row into a running top-2; rows arrive in any order: lower row wins a tie on the best distance,
+// b2 = second smallest value.  A first row at distance +inf leaves "none" (i1 = -1) as the exact kernels do.
+__device__ __forceinline__ void take(Best& a, float d, int row) {
+  const bool better = d < a.b1 || (d == a.b1 && a.i1 >= 0 && row < a.i1);
+  const float lose = better ? a.b1 : d;
+  a.b2 = fminf(a.b2, lose);
+  a.b1 = better ? d : a.b1;
+  a.i1 = better ? row : a.i1;
+}
+__device__ __forceinline__ void merge(Best& a, float ob1, float ob2, int oi1) {   // match.hip's merge
+  const bool take_o = (ob1 < a.b1) || (ob1 == a.b1 && (unsigned)oi1 < (unsigned)a.i1);
+  const float lose1 = take_o ? a.b1 : ob1;
+  const float s2 = fminf(a.b2, ob2);
+  a.b2 = fminf(lose1, s2);
+  a.b1 = take_o ? ob1 : a.b1;
+  a.i1 = take_o ? oi1 : a.i1;
+}
+
+// One wavefront per query; every lane runs the canonical chain of one candidate row at a time:
+// dot = fmaf chain over k = 0..127 from 0, dist = max(0, fmaf(-2, dot, qq + dd)).  The query's coordinates are
+// wave-uniform (LDS broadcast reads), the row comes straight from HBM / the Infinity Cache, 16 bytes per load.
+constexpr int RS_WAVES = 4;          // queries per workgroup
+constexpr int RS_MAXC = 1024;        // candidate rows a query may have before it is searched by brute force
+
+__device__ __forceinline__ float exact_dist(const float* __restrict__ q_lds, const float* __restrict__ row, float nq, float dn) {
+  float s = 0.f;
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll 2
+  for (int c = 0; c < DIM / 16; ++c) {   // 64 bytes x 4 in flight per step
+    const float4 x0 = r4[4 * c], x1 = r4[4 * c + 1], x2 = r4[4 * c + 2], x3 = r4[4 * c + 3];
+    const float4 y0 = *reinterpret_cast<const float4*>(q_lds + 16 * c), y1 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 4);
+    const float4 y2 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 8), y3 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 12);
+    s = fmaf(y0.x, x0.x, s); s = fmaf(y0.y, x0.y, s); s = fmaf(y0.z, x0.z, s); s = fmaf(y0.w, x0.w, s);
+    s = fmaf(y1.x, x1.x, s); s = fmaf(y1.y, x1.y, s); s = fmaf(y1.z, x1.z, s); s = fmaf(y1.w, x1.w, s);
+    s = fmaf(y2.x, x2.x, s); s = fmaf(y2.y, x2.y, s); s = fmaf(y2.z, x2.z, s); s = fmaf(y2.w, x2.w, s);
+    s = fmaf(y3.x, x3.x, s); s = fmaf(y3.y, x3.y, s); s = fmaf(y3.z, x3.z, s); s = fmaf(y3.w, x3.w, s);
+  }
+  return fmaxf(fmaf(-2.f, s, nq + dn), 0.f);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {   // LDS written by some lanes of this wavefront, read by others
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
+    const float* __restrict__ qn, const float* __restrict__ qnorm, const uint8_t* __restrict__ qbad, int Q,
+    const int32_t* __restrict__ q_count, const float* __restrict__ db, const float* __restrict__ dnorm, int N,
+    int32_t index_base, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
+    int ovf_cap, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
+    unsigned int* __restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
+  __shared__ int cand_s[RS_WAVES][RS_MAXC];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.x * RS_WAVES + wave;
+  if (q >= Q) return;
+  const int Qe = q_count ? min(Q, *q_count) : Q;
+  if (q >= Qe) {   // no such query in this frame: "no neighbour", like combine_splits_kernel (pass B left it no records)
+    if (lane == 0) {
+      idx1[q] = -1;
+      d1[q] = __builtin_inff();
+      d2[q] = __builtin_inff();
+    }
+    return;
+  }
+  const float nq = qnorm[q];
+  {
+    const float2 v = reinterpret_cast<const float2*>(qn + (size_t)q * DIM)[lane];
+    q_s[wave][2 * lane] = v.x;
+    q_s[wave][2 * lane + 1] = v.y;
+  }
+  // ---- records -> candidate row list in LDS; the slots read are emptied for the next frame ----
+  const int n_ovf = ovf_cnt[q];
+  bool brute = n_ovf > ovf_cap || qbad[q];
+  int n_cand = 0;
+  uint2* mine = recs + (size_t)q * SC_SLOTS_MAX;
+  if (!brute) {
+    for (int base = 0; base < n_slots + n_ovf; base += 64) {
+      const int j = base + lane;
+      uint2 rec = make_uint2(0u, 0u);
+      if (j < n_slots) {
+        rec = mine[j];
+        if (rec.y) mine[j] = make_uint2(0u, 0u);
+      } else if (j < n_slots + n_ovf) {
+        rec = ovf[(size_t)q * ovf_cap + (j - n_slots)];
+      }
+      unsigned bits = rec.y & 0xFFFFu;
+      const int cnt = __popc(bits);
+      int pre = cnt;   // inclusive prefix over the lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(pre, d);
+        if (lane >= d) pre += o;
+      }
+      const int total = __shfl(pre, 63);
+      int w = n_cand + pre - cnt;
+      while (bits) {
+        const int r = __builtin_ctz(bits);
+        bits &= bits - 1;
+        if (w < RS_MAXC) cand_s[wave][w] = (int)rec.x + (r & 3) + 8 * (r >> 2);
+        ++w;
+      }
+      n_cand += total;
+    }
+    if (n_cand > RS_MAXC) brute = true;
+  } else if (n_ovf > ovf_cap) {
+    for (int j = lane; j < n_slots; j += 64) mine[j] = make_uint2(0u, 0u);   // the lists overflowed: empty every slot
+  }
+  if (n_ovf && lane == 0) ovf_cnt[q] = 0;
+  wave_lds_sync();
+
+  Best best = {__builtin_inff(), __builtin_inff(), -1};
+  const int n_rows = brute ? N : n_cand;
+  for (int k = lane; k < n_rows; k += 64) {
+    const int row = brute ? k : cand_s[wave][k];
+    if (row >= 0 && row < N) take(best, exact_dist(q_s[wave], db + (size_t)row * DIM, nq, dnorm[row]), row);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float ob1 = __shfl_xor(best.b1, d), ob2 = __shfl_xor(best.b2, d);
+    const int oi1 = __shfl_xor(best.i1, d);
+    if (oi1 >= 0) merge(best, ob1, ob2, oi1);
+  }
+  if (lane == 0) {
+    idx1[q] = best.i1 >= 0 ? best.i1 + index_base : -1;
+    d1[q] = best.b1;
+    d2[q] = best.b2;
+    if (stats) {   // per-query tallies (this wavefront is the query's only writer; launches are stream ordered): no atomics
+      stats[3 * q] += (unsigned)n_cand;
+      stats[3 * q + 1] += brute ? 1u : 0u;
+      stats[3 * q + 2] += 1u;
+    }
+  }
+}
+
+int env_int(const char* name, int def) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : def;
+}
+
+}  // namespace
+
+#ifdef SC_PROF
+extern "C" int mh_debug_screen_trace(unsigned long long* out /* [2][1024] */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_trace), 2 * 1024 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mh_debug_screen_prof(unsigned long long out[8], int reset, int ablate) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sc_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  g_sc_ablate = ablate;
+  return 0;
+}
+#endif
+
+// ---- host side -----------------------------------------------------------------------------------
+float screen_margin_host(float qq, float dmax) { return screen_margin(qq, dmax); }
+
+size_t screen_db_half_elems(int N) { return ((size_t)N + SC_TILE - 1) / SC_TILE * SC_TILE * DIM; }
+
+void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh, float* dneg, unsigned int* stats,
+                       hipStream_t s) {
+  const size_t n_chunks = screen_db_half_elems(N) / 8;
+  if (n_chunks == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n_chunks + 255) / 256, 2048);
+  hipLaunchKernelGGL(db_to_half_kernel, dim3(blocks), dim3(256), 0, s, db, dnorm, N, n_chunks, dbh, dneg, stats);
+}
+
+size_t screen_rec_slots() { return SC_SLOTS_MAX; }
+
+int screen_q_pad(int Q) { return (Q + SC_QPAD - 1) / SC_QPAD * SC_QPAD; }
+int screen_max_splits_a() { return 64; }
+
+// When the screen pays: enough (query, row) pairs to be bound by arithmetic rather than by its launches, and
+// enough rows for pass A's sample to mean something.  MH_MATCH_SCREEN = 0 / 1 pins the choice for the process
+// (A/B runs; bench.py records it), mh_match_set_mode for a context.
+bool screen_wanted(int q_expected, int N, int mode) {
+  static const int pinned = env_int("MH_MATCH_SCREEN", -1);
+  if (mode < 0) mode = pinned;
+  if (mode == 0 || N < 4096) return false;
+  if (mode == 1) return true;
+  return (double)q_expected * (double)N >= 8e6;
+}
+
+namespace {
+
+template <int NQB>
+void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blocks_a, int blocks_b, int* n_slots_out,
+                   hipStream_t s) {
+  constexpr int QB = 32 * NQB * SC_WAVES;
+  static DynLds attr0, attr1;
+  attr0.ensure(screen_kernel<0, NQB>, SC_LDS_BYTES);
+  attr1.ensure(screen_kernel<1, NQB>, SC_LDS_BYTES);
+  const int nqb = (Q + QB - 1) / QB;        // the grid covers the capacity ...
+  const int nqb_e = (qe + QB - 1) / QB;     // ... the splits are sized for the queries expected
+  auto splits_for = [&](int n_sel, int target, int s_max) {
+    int S = std::max(1, target / nqb_e);
+    S = std::min(std::min(S, n_sel), s_max);
+    if (S >= 8) S = S / 8 * 8;   // whole splits per XCD
+    return std::max(S, 1);
+  };
+  // pass A: every `stride`-th tile, starting in the middle of the first stride
+  const int stride = n_tiles >= 4 * sample ? sample : 1;
+  const int n_sel_a = (n_tiles + stride - 1) / stride;
+  const int Sa = splits_for(n_sel_a, blocks_a, screen_max_splits_a());
+  a.n_sel = n_sel_a;
+  a.tile_first = std::min(stride / 2, n_tiles - 1 - (n_sel_a - 1) * stride);
+  if (a.tile_first < 0) a.tile_first = 0;
+  a.tile_stride = stride;
+  a.n_splits = Sa;
+  a.tiles_base = n_sel_a / Sa;
+  a.tiles_rem = n_sel_a % Sa;
+  a.n_splits_a = Sa;
+  hipLaunchKernelGGL((screen_kernel<0, NQB>), dim3(nqb * Sa), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(screen_tau_kernel, dim3((a.q_pad + 255) / 256), dim3(256), 0, s, a.part, Sa, a.q_pad, a.Q, a.q_count,
+                     a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
+  // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
+  const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
+  a.n_sel = n_tiles;
+  a.tile_first = 0;
+  a.tile_stride = 1;
+  a.n_splits = Sb;
+  a.tiles_base = n_tiles / Sb;
+  a.tiles_rem = n_tiles % Sb;
+  a.sub_cap = std::max(1, std::min(4, SC_SLOTS_MAX / (2 * Sb)));
+  hipLaunchKernelGGL((screen_kernel<1, NQB>), dim3(nqb * Sb), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  *n_slots_out = 2 * Sb * a.sub_cap;
+}
+
+}  // namespace
+
+void launch_match_screen(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
+                         int32_t index_base, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
+                         float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
+  static const int sample = std::max(1, env_int("MH_SCREEN_SAMPLE", 8));      // pass A looks at every `sample`-th tile
+  static const int blocks_b = std::max(1, env_int("MH_SCREEN_BLOCKS", 256));  // one workgroup per CU, one round
+  static const int blocks_a = std::max(1, env_int("MH_SCREEN_BLOCKS_A", 256));
+  static const int nqb_pin = env_int("MH_SCREEN_NQB", 0);
+  const int q_pad = screen_q_pad(Q);
+  const int qe = (q_expected > 0 && q_expected < Q) ? std::max(q_expected, std::min(Q, 256)) : Q;
+  const int n_tiles = (N + SC_TILE - 1) / SC_TILE;
+
+  hipLaunchKernelGGL(screen_prepare_kernel, dim3((q_pad * 16 + 255) / 256), dim3(256), 0, s, qn, qnorm, Q, q_count, q_pad,
+                     sb.qh, sb.qbad);
+  ScreenArgs a;
+  a.qh = sb.qh;
+  a.dbh = sdb.dbh;
+  a.dneg = sdb.dneg;
+  a.qnorm = qnorm;
+  a.qbad = sb.qbad;
+  a.q_count = q_count;
+  a.part = sb.part;
+  a.tau = sb.tau;
+  a.recs = sb.recs;
+  a.ovf_cnt = sb.ovf_cnt;
+  a.ovf = sb.ovf;
+  a.ovf_cap = sb.ovf_cap;
+  a.sub_cap = 1;
+  a.Q = Q;
+  a.q_pad = q_pad;
+  a.dmax = sdb.dmax;
+#ifdef SC_PROF
+  a.ablate = g_sc_ablate;
+#else
+  a.ablate = 0;
+#endif
+  // queries per workgroup: 768 when there are enough of them to give every CU work that way, else 512 / 256
+  int nqb_sel = qe > 1536 ? 3 : (qe > 640 ? 2 : 1);
+  if (nqb_pin >= 1 && nqb_pin <= 3) nqb_sel = nqb_pin;
+  int n_slots = 0;
+  if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
+  else if (nqb_sel == 2) launch_passes<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
+  else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
+  // pass C
+  hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
+                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, idx1, d1, d2,
+                     sb.stats);
+}
+
+}  // namespace mh

@@ -56,10 +56,12 @@ class FramePipeline:
             c = capi.Context(device)
             s = torch.cuda.Stream(device=self.dev)
             c.set_stream(s.cuda_stream)   # before any work: the context then never creates a stream of its own
-            if normalized is None:
+            if i == 0:
                 # model descriptors are L2-normalised once, like Update() (MATCH_ANN_CPU.hpp:94)
                 normalized = c.normalize(db.desc) if db.desc.shape[0] else db.desc
-            c.db_upload(normalized, db.model_of, db.xyz, db.n_models, index_base=db.row_lo)
+                c.db_upload(normalized, db.model_of, db.xyz, db.n_models, index_base=db.row_lo)
+            else:
+                c.db_share(self.ctxs[0])   # one store per GPU: every frame in flight searches the same copy
             c.reserve(max_queries)
             self.ctxs.append(c)
             self.streams.append(s)
