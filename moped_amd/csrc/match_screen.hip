@@ -54,7 +54,11 @@ constexpr int SC_THREADS = 64 * SC_WAVES;
 constexpr int SC_QPAD = 3 * 1024;                  // the query image is padded to whole workgroups of every kernel width (256, 512, 768)
 constexpr int SC_TILE = 128;                       // DB rows per LDS tile (= the DB's row padding)
 constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
-constexpr int SC_LDS_BYTES = 2 * SC_TILE_BYTES + 2 * SC_TILE * 4;   // two tiles + their -dd/2 terms
+constexpr int SC_RECBUF = 96;                      // records a wavefront parks in LDS before they go to memory
+constexpr int SC_GROUP = 1;                        // tiles per barrier: the wavefronts of a workgroup drift apart within a group
+constexpr int SC_NBUF = 2 * SC_GROUP;              // (a hit costs its wavefront ~300 cycles), every barrier makes seven wait for the slowest
+constexpr int SC_LDS_TILES = SC_NBUF * SC_TILE_BYTES + SC_NBUF * SC_TILE * 4;   // the tiles + their -dd/2 terms
+constexpr int SC_LDS_BYTES = SC_LDS_TILES + SC_WAVES * (SC_RECBUF * 16 + 16);   // + the wavefronts' record buffers and counters
 static_assert(SC_TILE == 128 && DIM == 128, "tile image and chunk swizzle assume 128 x 128");
 
 // error model of the screen (see the header comment)
@@ -273,16 +277,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     const unsigned l = lds_base + buf * SC_TILE_BYTES + wave * 1024;
     dma16x4(voff, tb, tb + 8192, tb + 16384, tb + 24576, l, l + 8192, l + 16384, l + 24576);
     if (wave < 2)
-      dma4(voff_dd, A.dneg + (size_t)tile * SC_TILE, lds_base + 2 * SC_TILE_BYTES + buf * (SC_TILE * 4) + wave * 256);
+      dma4(voff_dd, A.dneg + (size_t)tile * SC_TILE, lds_base + SC_NBUF * SC_TILE_BYTES + buf * (SC_TILE * 4) + wave * 256);
   };
 
 #ifdef SC_PROF
   const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
   unsigned long long t_wait = 0;
-  const bool tracing = MODE == 1 && blockIdx.x == 3 && (wave == 0 || wave == 4) && lane == 0;
-  int n_ev = 0;
 #endif
-  if (sel_begin < sel_end) stage(sel_begin, 0);
+#pragma unroll
+  for (int j = 0; j < SC_GROUP; ++j)
+    if (sel_begin + j < sel_end) stage(sel_begin + j, j);
   // ---- B operands: this lane's query of each block, k = 16 s + 8 half .. + 7 of every k-step s ----
   half8 bq[NQB][8];
 #pragma unroll
@@ -307,111 +311,169 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
-  // what a lane does with one finished 32 x 32 block: 16 rows of one of its queries
-  auto finish = [&](const v16f& acc, int nb, int row0) {
-    if (MODE == 0) {
+  // ---- what a lane does with one finished 32 x 32 block: 16 rows of one of its queries ----
+  // pass A: running top-2 values
+  auto fold_a = [&](const v16f& acc, int nb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        b2[nb] = __builtin_amdgcn_fmed3f(b1[nb], b2[nb], acc[r]);
-        b1[nb] = fmaxf(b1[nb], acc[r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      b2[nb] = __builtin_amdgcn_fmed3f(b1[nb], b2[nb], acc[r]);
+      b1[nb] = fmaxf(b1[nb], acc[r]);
+    }
+  };
+  // pass B, rare part: this lane has rows above its query's threshold -> one record.  The record does not go to
+  // memory now: the s_waitcnt vmcnt(0) that ends every tile (it is there for the LDS-DMA) would wait for the store's
+  // round trip too, and the tile's barrier would hand that wait to all eight wavefronts.  It is parked in the
+  // wavefront's LDS buffer {destination slot, row0, bits} and written out when the workgroup is done.
+  uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16));
+  int* const reccnt = reinterpret_cast<int*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16) + SC_RECBUF * 16);
+  auto emit = [&](const v16f& acc, int nb, int row0) {
+    // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tau[nb] - acc[r]), 31);
+    const int q = q0 + nb * 32 + l32;
+    if (n_rec[nb] < A.sub_cap) {
+      const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb];
+      ++n_rec[nb];
+      const int pos = atomicAdd(reccnt, 1);   // LDS: the lanes with a hit get consecutive places
+      if (pos < SC_RECBUF) recbuf[pos] = make_uint4(dst, (unsigned)row0, bits, 0u);
+      else A.recs[dst] = make_uint2((unsigned)row0, bits);   // buffer full (a few dozen hits per wavefront are usual)
     } else {
-      float m = acc[0];
+      // the lane's sub-list is full: the query's overflow list (rare)
+      const int pos = atomicAdd(&A.ovf_cnt[q], 1);
+      if (pos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + pos] = make_uint2((unsigned)row0, bits);
+    }
+  };
+  if (MODE == 1 && lane == 0) *reccnt = 0;   // (read by this wavefront only, after its own LDS operations in order)
+
+  const int swz = l32 & 15;
+  // A operands of a row block: row rb * 32 + l32, k-step s -> chunk 2 s + half, stored at position chunk ^ (row & 15);
+  // accumulator register r belongs to row (r & 3) + 8 (r >> 2) + 4 half of the block: its -dd/2 goes in as C
+  auto load_rb = [&](const unsigned char* T, const float* ddp, int rb, half8 (&a)[8], v16f& init) {
+    const unsigned char* rowp = T + (rb * 32 + l32) * 256;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);   // -> 8 v_max3_f32
-      if (m > tau[nb]) {
-        // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
-        unsigned bits = 0;
+    for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const half8*>(rowp + (((2 * s + half) ^ swz) << 4));
 #pragma unroll
-        for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tau[nb] - acc[r]), 31);
-        const int q = q0 + nb * 32 + l32;
-        const uint2 rec = make_uint2((unsigned)row0, bits);
-        if (n_rec[nb] < A.sub_cap) {
-          A.recs[(size_t)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb]] = rec;
-          ++n_rec[nb];
-        } else {
-          const int pos = atomicAdd(&A.ovf_cnt[q], 1);
-          if (pos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + pos] = rec;
-        }
-      }
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(ddp + rb * 32 + 8 * g + 4 * half);
+      init[4 * g] = v.x;
+      init[4 * g + 1] = v.y;
+      init[4 * g + 2] = v.z;
+      init[4 * g + 3] = v.w;
     }
   };
 
-  const int swz = l32 & 15;
-  int buf = 0;
-  v16f pend;            // pass B: the block whose MFMAs were issued last is finished behind the next block's MFMAs
-  int pend_row0 = 0;
-  bool have_pend = false;
-  for (int sel = sel_begin; sel < sel_end; ++sel) {
-    const bool more = sel + 1 < sel_end;
-    SC_EV(1);   // tile begins
-    if (more && !SC_ABL(1)) stage(sel + 1, buf ^ 1);
-    SC_EV(2);   // staging issued
-    const unsigned char* T = lds + (SC_ABL(1) ? 0 : buf) * SC_TILE_BYTES;
-    const float* ddp = reinterpret_cast<const float*>(lds + 2 * SC_TILE_BYTES + buf * (SC_TILE * 4));
+#ifdef SC_PROF
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  int side = 0;         // which half of the LDS buffers holds the current group of tiles
+  v16f pend;            // pass B: the block whose MFMAs were issued last; looked at behind the next block's MFMAs
+  int pend_row0 = 0;    // (its query block is (nb + NQB - 1) % NQB when block nb is issued: a constant after unrolling --
+  bool have_pend = false;   // a run-time index would put tau[] and n_rec[] into scratch memory)
+  for (int grp = sel_begin; grp < sel_end; grp += SC_GROUP) {
+    const bool more = grp + SC_GROUP < sel_end;
+    if (!SC_ABL(1)) {
+#pragma unroll
+      for (int j = 0; j < SC_GROUP; ++j)
+        if (grp + SC_GROUP + j < sel_end) stage(grp + SC_GROUP + j, (side ^ 1) * SC_GROUP + j);
+    }
+#pragma unroll 1
+    for (int j = 0; j < SC_GROUP; ++j) {
+    const int sel = grp + j;
+    if (sel >= sel_end) break;
+    const int buf = SC_ABL(1) ? 0 : side * SC_GROUP + j;
+    const unsigned char* T = lds + buf * SC_TILE_BYTES;
+    const float* ddp = reinterpret_cast<const float*>(lds + SC_NBUF * SC_TILE_BYTES + buf * (SC_TILE * 4));
     const int row_tile = (A.tile_first + sel * A.tile_stride) * SC_TILE;
-#pragma unroll(MODE == 0 ? 1 : SC_TILE / 32)   // (pass A unrolled: 123 spilled registers at three query blocks)
-    for (int rb = 0; rb < SC_TILE / 32; ++rb) {
-      // A operands: row rb * 32 + l32, k-step s -> chunk 2 s + half, stored at position chunk ^ (row & 15)
-      half8 a[8];
-      const unsigned char* rowp = T + (rb * 32 + l32) * 256;
+    if (MODE == 0) {
+#pragma unroll 1   // (pass A unrolled: 123 spilled registers at three query blocks)
+      for (int rb = 0; rb < SC_TILE / 32; ++rb) {
+        half8 a[8];
+        v16f init;
+        load_rb(T, ddp, rb, a, init);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const half8*>(rowp + (((2 * s + half) ^ swz) << 4));
-      // accumulator register r belongs to row (r & 3) + 8 (r >> 2) + 4 half of the block: its -dd/2 goes in as C
-      v16f init;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(ddp + rb * 32 + 8 * g + 4 * half);
-        init[4 * g] = v.x;
-        init[4 * g + 1] = v.y;
-        init[4 * g + 2] = v.z;
-        init[4 * g + 3] = v.w;
-      }
-      const int row0 = row_tile + rb * 32 + 4 * half;
-      SC_EV(3);   // LDS reads of the row block issued (the stamp's own lgkmcnt(0) also waits for them)
-#pragma unroll
-      for (int nb = 0; nb < NQB; ++nb) {
-        v16f acc = init;
-        if (!SC_ABL(2)) {
+        for (int nb = 0; nb < NQB; ++nb) {
+          v16f acc = init;
 #pragma unroll
           for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], bq[nb][s], acc, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) acc[s] += (float)a[s][nb];
+          __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler overlaps several blocks' accumulators and spills)
+          fold_a(acc, nb);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == 1) {
-          // a block is finished behind the NEXT block's MFMAs: its values are out of the pipe by then, and the
-          // vector instructions issue while the matrix pipe works
+      }
+    } else {
+      // Software pipeline: while the MFMAs of block b are issued, (1) the A operands of the NEXT row block arrive from
+      // LDS and (2) the maximum over the 16 values of block b - 1 is taken, two values per MFMA -- vector instructions
+      // in the shadow of the matrix pipe.  Only a lane whose maximum beats its threshold looks at single values.
+      half8 a_cur[8], a_nxt[8];
+      v16f init_cur, init_nxt;
+      load_rb(T, ddp, 0, a_cur, init_cur);
+#pragma unroll
+      for (int rb = 0; rb < SC_TILE / 32; ++rb) {
+        if (rb + 1 < SC_TILE / 32) load_rb(T, ddp, rb + 1, a_nxt, init_nxt);
+        const int row0 = row_tile + rb * 32 + 4 * half;
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          const int pnb = (nb + NQB - 1) % NQB;
+          v16f acc = init_cur;
+          float m = -__builtin_inff();
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            if (!SC_ABL(2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[s], bq[nb][s], acc, 0, 0, 0);
+            // (nothing behind the first MFMA: the pending block's last values are still in the pipe)
+            if (have_pend && s >= 1) {
+              if (s == 1) m = fmaxf(fmaxf(pend[0], pend[1]), pend[2]);
+              else if (s < 7) m = fmaxf(fmaxf(m, pend[2 * s - 1]), pend[2 * s]);
+              else m = fmaxf(fmaxf(fmaxf(m, pend[13]), pend[14]), pend[15]);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {   // pin the interleave: one MFMA, then the vector instructions of its shadow
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
-          SC_EV(4);   // chain issued
-          if (have_pend && !SC_ABL(0)) finish(pend, (nb + NQB - 1) % NQB, pend_row0);
+          if (have_pend && !SC_ABL(0) && m > tau[pnb]) emit(pend, pnb, pend_row0);
           __builtin_amdgcn_sched_barrier(0);
-          SC_EV(5);   // previous block finished
           pend = acc;
           pend_row0 = row0;
           have_pend = true;
-        } else {
-          // (fenced: left alone, the scheduler overlaps several blocks' accumulators and spills)
-          __builtin_amdgcn_sched_barrier(0);
-          finish(acc, nb, row0);
-          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rb + 1 < SC_TILE / 32) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) a_cur[s] = a_nxt[s];
+          init_cur = init_nxt;
         }
       }
     }
+    }   // tiles of the group
 #ifdef SC_PROF
     const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
 #endif
-    SC_EV(6);   // tile's work issued
-    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the next tile have landed
-    SC_EV(7);   // own pieces landed
-    __syncthreads();   // everybody's pieces have; nobody reads `buf` any more
-    SC_EV(8);   // barrier passed
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the next group have landed
+    __syncthreads();   // everybody's pieces have; nobody reads this group's buffers any more
 #ifdef SC_PROF
     t_wait += __builtin_amdgcn_s_memtime() - t_w0;
 #endif
-    buf ^= 1;
+    side ^= 1;
   }
-  if (MODE == 1 && have_pend) finish(pend, NQB - 1, pend_row0);
+  if (MODE == 1 && have_pend) {
+    float m = pend[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, pend[r]);
+    if (m > tau[NQB - 1]) emit(pend, NQB - 1, pend_row0);
+  }
+  if (MODE == 1) {
+    // the parked records to their slots
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = min(*reccnt, SC_RECBUF);
+    for (int j = lane; j < n; j += 64) {
+      const uint4 e = recbuf[j];
+      A.recs[e.x] = make_uint2(e.y, e.z);
+    }
+  }
 #ifdef SC_PROF
   if (MODE == 1 && tid == 0) {
     atomicAdd(&g_sc_prof[0], __builtin_amdgcn_s_memtime() - t_start);       // shader cycles of the workgroup
@@ -419,6 +481,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     atomicAdd(&g_sc_prof[2], t_wait);                                       // cycles in the end-of-tile wait + barrier
     atomicAdd(&g_sc_prof[3], (unsigned long long)(sel_end - sel_begin));
     atomicAdd(&g_sc_prof[4], 1ull);
+    atomicAdd(&g_sc_prof[5], t_loop - t_start);                             // prologue
     if (SC_ABL(0)) A.part[0].x = b1[0] + pend[3];
   }
 #endif
@@ -711,8 +774,9 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
 #else
   a.ablate = 0;
 #endif
-  // queries per workgroup: 768 when there are enough of them to give every CU work that way, else 512 / 256
-  int nqb_sel = qe > 1536 ? 3 : (qe > 640 ? 2 : 1);
+  // queries per workgroup: 512, or 256 for small frames (768 = three query blocks per wavefront does not fit
+  // pass B's registers beside the prefetched A operands: selectable for experiments only)
+  int nqb_sel = qe > 640 ? 2 : 1;
   if (nqb_pin >= 1 && nqb_pin <= 3) nqb_sel = nqb_pin;
   int n_slots = 0;
   if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);

@@ -40,7 +40,7 @@ for abl in (0, 1, 2, 4, 3, 6, 7):
     s.synchronize()
     L.mh_debug_screen_prof(out, 1, abl)
     n = max(out[4], 1)
-    cyc, real, wait, tiles = out[0] / n, out[1] / n, out[2] / n, out[3] / n
+    cyc, real, wait, tiles, pro = out[0] / n, out[1] / n, out[2] / n, out[3] / n, out[5] / n
     print(f"ablate {abl} ({names[abl]:>24}): match stage {e0.elapsed_time(e1) / reps * 1e3:7.1f} us | pass-B workgroup: {cyc:9.0f} cycles "
-          f"= {real / 100:6.1f} us -> {cyc / max(real, 1) * 100:5.0f} MHz; {tiles:4.1f} tiles, {cyc / max(tiles, 1):6.0f} cycles per tile, "
+          f"= {real / 100:6.1f} us -> {cyc / max(real, 1) * 100:5.0f} MHz; prologue {pro:6.0f}; {tiles:4.1f} tiles, {(cyc - pro) / max(tiles, 1):6.0f} cycles per tile, "
           f"{wait / max(tiles, 1):6.0f} of them in the end-of-tile wait + barrier", flush=True)
