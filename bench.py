@@ -5,8 +5,8 @@ FILTER2 path on MI355X, BASELINE.json's metric.
     python bench.py --gpus N --steps K --warmup W
 
 A step = one batch of `--frames-per-step` synthetic 640x480 frames (~3k SIFT
-keypoints, 2 planted objects) against an N-model database, inputs resident in
-HBM, `--depth` frames in flight per GPU.  With N > 1 (one process per GPU under
+keypoints, 2 planted objects; `--frame-pool` distinct frames in turn) against an
+N-model database, inputs resident in HBM, `--depth` frames in flight per GPU.  With N > 1 (one process per GPU under
 torch.distributed.run) the model database is sharded by model over the ranks
 and every frame does the two small exchanges of SURVEY.md 8(e) over RCCL; the
 total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32-input MFMA peak
+PEAK_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA (the F16 forms take the same cycles)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -33,11 +34,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--models", type=int, default=20, help="models in the DB (5000 points each)")
     ap.add_argument("--queries", type=int, default=3000)
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=1024,
+                    help="frames per step (20 steps = 20,480 frames: a timed region of seconds, not milliseconds)")
+    ap.add_argument("--frame-pool", type=int, default=32, help="distinct synthetic frames the steps cycle through")
     ap.add_argument("--depth", type=int, default=0,
-                    help="frame slots (streams) per GPU (default: 4 on one GPU, where MATCH saturates the chip; "
-                         "16 with a sharded DB, where the per-rank frame is short and latency-bound: one stream per "
-                         "hardware queue -- 32 are 7% faster on most boxes and 2.4x slower on some)")
+                    help="frame slots (streams) per GPU (default 16: one stream per hardware queue; a frame is a chain of "
+                         "~13 short launches, most of them latency bound -- 32 are faster on most boxes and 2.4x slower on some)")
+    ap.add_argument("--no-adaptive", action="store_true",
+                    help="POSE evaluates all 1024 hypotheses of every (cluster, replica) task instead of stopping after 256 "
+                         "when the inlier ratio allows it")
+    ap.add_argument("--h2d-steps", type=int, default=3,
+                    help="steps of the secondary measurement with the descriptors in pinned host memory (0 = skip)")
     ap.add_argument("--n-vis", type=int, default=2)
     ap.add_argument("--depth-kind", type=int, default=0,
                     help="0 = moped2 residuals; 1/2 = moped3d back-projection / reprojection+depth (config 5)")
@@ -128,7 +135,7 @@ def main():
     sharded = (world > 1 and not by_frames) or args.force_exchange
     depth_given = args.depth > 0
     if args.depth <= 0:
-        args.depth = 16 if sharded else 4
+        args.depth = 16
     if args.batch <= 0:
         args.batch = 8 if sharded else 1
     if not sharded or args.depth_kind:
@@ -154,13 +161,20 @@ def main():
     Q = args.queries
     db = synth.make_db(args.models, 5000)
     n_frames = max(args.frames_per_step, 1)
-    frames = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_frames)]
+    n_pool = max(1, min(args.frame_pool, n_frames))
+    if args.batch > 1:
+        n_pool = max(args.batch, n_pool // args.batch * args.batch)
+        n_frames = max(n_pool, n_frames // n_pool * n_pool)
+    frames = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]
     if by_frames:   # every rank holds the whole DB and works on its own frames
-        frames = [synth.make_frame(db, n_vis=args.n_vis, seed=1000 * rank + s, Q=Q) for s in range(n_frames)] if rank else frames
+        frames = [synth.make_frame(db, n_vis=args.n_vis, seed=1000 * rank + s, Q=Q) for s in range(n_pool)] if rank else frames
         shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
     else:
         shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
     params = capi.default_frame_params()
+    if args.no_adaptive:
+        params.pose1.n_hypotheses = -abs(params.pose1.n_hypotheses)
+        params.pose2.n_hypotheses = -abs(params.pose2.n_hypotheses)
     if args.depth_kind:
         # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
         params.pose1.error_threshold = 8.0
@@ -191,13 +205,14 @@ def main():
             wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
             d = capi.pack_depth(wpts, wgt)
             depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
-    counts_host = torch.zeros(n_frames, dtype=torch.int32).pin_memory()
+    counts_host = torch.zeros(n_pool, dtype=torch.int32).pin_memory()
     B = args.batch
     if B > 1:
-        assert n_frames % B == 0
+        assert n_pool % B == 0 and n_frames % B == 0
         groups = n_frames // B
-        pristine_b = [torch.cat(pristine[g * B:(g + 1) * B]) for g in range(groups)]
-        uv_b = [torch.cat(uvs[g * B:(g + 1) * B]) for g in range(groups)]
+        pool_groups = n_pool // B
+        pristine_b = [torch.cat(pristine[g * B:(g + 1) * B]) for g in range(pool_groups)]
+        uv_b = [torch.cat(uvs[g * B:(g + 1) * B]) for g in range(pool_groups)]
         work_b = [torch.empty_like(pristine_b[0]) for _ in range(args.depth)]
 
     active_slots = [args.depth]   # slots in use (the calibration below may settle on fewer)
@@ -205,25 +220,30 @@ def main():
     def run_step_batched(step):
         for g in range(groups):
             slot = (step * groups + g) % active_slots[0]
+            pg = g % pool_groups
             with torch.cuda.stream(pipe.streams[slot]):
-                work_b[slot].copy_(pristine_b[g], non_blocking=True)
-            pipe.enqueue_batch(slot, work_b[slot], uv_b[g], B, [1000 * step + g * B + f + 1 for f in range(B)])
+                work_b[slot].copy_(pristine_b[pg], non_blocking=True)
+            pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
 
-    def run_step(step, record=False):
+    host_desc = None   # --h2d-steps: the same descriptors in pinned host memory
+
+    def run_step(step, record=False, from_host=False):
         if B > 1:
             return run_step_batched(step)
-        for b in range(n_frames):
-            slot = b % args.depth
+        for f in range(n_frames):
+            b = f % n_pool
+            slot = f % args.depth
             s = pipe.streams[slot]
             with torch.cuda.stream(s):
-                work[slot].copy_(pristine[b], non_blocking=True)   # restore raw descriptors (normalise is in place)
+                # fresh raw descriptors (normalise is in place): from HBM (the headline) or over PCIe from pinned memory
+                work[slot].copy_(host_desc[b] if from_host else pristine[b], non_blocking=True)
             if depths is not None:
                 pipe.ctxs[slot].frame_set_depth(depths[b].data_ptr(), args.depth_kind, 0.5)
             if maps is not None:
                 pipe.ctxs[slot].frame_set_depth_image(maps[b][0].data_ptr(), maps[b][1].data_ptr(), 640, 480,
                                                       args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
-            pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + b + 1)
-            if record and (world == 1 or by_frames):
+            pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + f + 1)
+            if record and f >= n_frames - n_pool and (world == 1 or by_frames):
                 ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
                 with torch.cuda.stream(s):
                     from moped_amd.pipeline import _wrap_int32
@@ -280,6 +300,13 @@ def main():
         objs = pipe.gather_objects((n_frames - 1) % args.depth)
         det_per_frame = float(len(objs))
 
+    # what POSE actually evaluated (device-side counters of the last frame of every slot)
+    ctr = [c.frame_counters() for c in pipe.ctxs[:active_slots[0] if B > 1 else args.depth]]
+    R_ = params.pose1.max_objects_per_cluster
+    hyp_per_task = float(np.sum([c["hypotheses"] for c in ctr]) / max(1, np.sum([c["pose_tasks"] for c in ctr])))
+    ms = pipe.ctxs[0].match_stats(Q * B)
+    overrides = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MH_") or k == "GPU_MAX_HW_QUEUES"}
+
     out = {
         "metric": "detections/sec (frames/s) 640x480 ~3k SIFT vs N models",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -288,64 +315,121 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.models}-model DB ({db.n} descriptors), 640x480 frames, "
                                f"{Q} SIFT-like keypoints, {args.n_vis} planted objects, "
-                               f"1024 P3P hypotheses x 4 replicas per cluster, MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2"
+                               f"up to {abs(params.pose1.n_hypotheses)} P3P hypotheses x {R_} replicas per cluster "
+                               f"({'all evaluated' if args.no_adaptive else 'adaptive stop after 256'}: {hyp_per_task:.0f} evaluated per "
+                               f"(cluster, replica) task), MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2"
                                + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}")
                                + ("" if not (args.depth_kind and args.moped3d_frontend) else
                                   ", moped3d front end on the device (DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
-                   "frames_per_step": n_frames, "frames_in_flight": (active_slots[0] if B > 1 else args.depth) * B, "frames_per_match_launch": B,
+                   "frames_per_step": n_frames, "distinct_frames": n_pool, "timed_seconds": round(dt, 3),
+                   "frames_in_flight": (active_slots[0] if B > 1 else args.depth) * B, "frames_per_match_launch": B,
                    "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
                                    f"model-shard x{world}" if world > 1 else "single GPU"),
-                   "objects_per_frame": det_per_frame},
+                   "objects_per_frame": det_per_frame,
+                   "hypotheses_per_task": round(hyp_per_task, 1), "hypotheses_per_frame": round(float(np.mean([c["hypotheses"] for c in ctr])), 1),
+                   "match": ("two-stage: f16 MFMA screen + canonical f32 arithmetic on the candidates (bit-identical to the exact kernels)"
+                             if ms["two_stage"] else "exact f32 kernels"),
+                   "env_overrides": overrides},
     }
 
-    # ---- roofline of the dominant kernel (match), measured live with HIP events ----
+    # ---- secondary: the same frames with the descriptors in pinned HOST memory (1.5 MB over PCIe per frame, the copy
+    # on the frame's own stream, overlapped with the other frames in flight).  Never `value`.
+    if rank == 0 and world == 1 and B == 1 and args.h2d_steps > 0:
+        host_desc = [torch.from_numpy(f.desc).pin_memory() for f in frames]
+        run_step(-500, from_host=True)
+        sync_all()
+        t0h = time.perf_counter()
+        for k in range(args.h2d_steps):
+            run_step(-501 - k, from_host=True)
+        sync_all()
+        dth = time.perf_counter() - t0h
+        out["h2d_inclusive"] = {"value": round(args.h2d_steps * n_frames / dth, 2), "unit": "frames/s", "steps": args.h2d_steps,
+                                "note": "descriptors start in pinned host memory: one 1.5 MB hipMemcpyAsync per frame on the frame's "
+                                        "stream (keypoint coordinates resident); a reported figure, not the metric's `value`"}
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the stream it is launched on ----
     if rank == 0 and not args.no_roofline:
         c, s = pipe.ctxs[0], pipe.streams[0]
-        qn = pristine[0].clone()
-        qnorm = torch.empty(Q, dtype=torch.float32, device=dev)
-        idx = torch.empty(Q, dtype=torch.int32, device=dev)
-        d1 = torch.empty(Q, dtype=torch.float32, device=dev)
-        d2 = torch.empty(Q, dtype=torch.float32, device=dev)
+        Qr = Q * B
+        qn = (pristine_b[0] if B > 1 else pristine[0]).clone()
+        qnorm = torch.empty(Qr, dtype=torch.float32, device=dev)
+        idx = torch.empty(Qr, dtype=torch.int32, device=dev)
+        d1 = torch.empty(Qr, dtype=torch.float32, device=dev)
+        d2 = torch.empty(Qr, dtype=torch.float32, device=dev)
+        n_local = shard.desc.shape[0]
+        flops = 2.0 * 128 * Qr * n_local                # one multiply-add per (query, row, coordinate)
+        reps = 20
+        two_stage = c.match_stats(Qr)["two_stage"]
+        c.enable_timing(True)
+        stage = np.zeros(5)
         with torch.cuda.stream(s):
-            c.normalize_dev(qn.data_ptr(), qnorm.data_ptr(), Q)
+            c.normalize_dev(qn.data_ptr(), qnorm.data_ptr(), Qr)
             for _ in range(3):
-                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Q, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
+                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+        s.synchronize()
+        c.match_stats(reset=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s):   # 20 launch sequences back to back; the library records its own events around every kernel
             e0.record(s)
             for _ in range(reps):
-                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Q, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
             e1.record(s)
         s.synchronize()
-        t_ms = e0.elapsed_time(e1) / reps
-        n_local = shard.desc.shape[0]
-        flops = 2.0 * 128 * Q * n_local                 # fmaf chain: one FMA per (query, row, dim)
-        b_alg = 512.0 * n_local + 512.0 * Q + 12.0 * Q    # DB once + queries once + (idx,d1,d2)
-        ach_tf = flops / (t_ms * 1e-3) / 1e12
+        t_stage = e0.elapsed_time(e1)
+        if two_stage:
+            stage = np.array(list(c.match_timing().values())) * reps
+        c.enable_timing(False)
+        t_stage /= reps
+        stage /= reps
+        st = c.match_stats()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"match_{args.models}m_{Q}q")
+                traffic = json.load(open(tpath)).get(f"{'screen_b' if two_stage else 'match'}_{args.models}m_{Qr}q")
             except Exception:
                 traffic = None
-        out["roofline"] = {
-            "kernel": "match_mfma_kernel (+ combine_splits_kernel, <1% of the time)",
-            "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-            "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s dense FP32 MFMA peak; "
-                    "the kernel issues v_mfma_f32_32x32x2_f32, whose accumulation is bit-identical to the canonical fmaf "
-                    "chain (index-exact parity with the oracle kept); MH_MATCH_MFMA=0 selects the VALU kernel (v_pk_fma_f32)",
-            "ms_per_launch": round(t_ms, 4),
-            "measured": "HIP events around 20 back-to-back launches on one stream after the timed region "
-                        "(one kernel on the chip at a time); in the timed region `frames_in_flight` frames "
-                        "share the chip, so rocprof's per-kernel wall durations there are longer by the "
-                        "overlap -- profiles/*_depth1_kernel_stats.csv is the same command with --depth 1",
-            "whole_pipeline_tflops_per_gpu": round(flops * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
-            "hbm": {"achieved": round(b_alg / (t_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(b_alg / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                    "algorithmic_bytes": int(b_alg)},
-        }
+        if two_stage:
+            t_b = float(stage[3])
+            ach_tf = flops / (t_b * 1e-3) / 1e12
+            rec_bytes = 8.0 * st["candidates"] / max(st["queries"], 1) * Qr / 1.3   # ~1.3 rows per record
+            b_alg = 256.0 * n_local + 256.0 * Qr + rec_bytes      # f16 DB once + f16 queries once + candidate records
+            out["roofline"] = {
+                "kernel": "screen_kernel<1> = pass B of the two-stage MATCH: f16 x f16 -> f32 on v_mfma_f32_32x32x16_f16 over every "
+                          "(query, row) pair",
+                "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                "ms_per_launch": round(t_b, 4),
+                "algorithmic_flops": int(flops),
+                "note": "compute bound (SURVEY F10): 2*128*Q*N flops per launch against the dense F16 MFMA peak of the dtype the "
+                        "kernel multiplies in.  The match STAGE delivers exact f32 results (bit-identical to the f32 kernels and the "
+                        "oracle); its five kernels per launch, ms: "
+                        + ", ".join(f"{k} {v:.4f}" for k, v in zip(("query image", "pass A", "thresholds", "pass B", "pass C"), stage)),
+                "match_stage": {"ms_per_launch": round(t_stage, 4), "kernels_ms": [round(float(v), 4) for v in stage],
+                                "candidate_rows_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
+                                "brute_force_queries": st["brute_force_queries"],
+                                "f32_equivalent_tflops": round(flops / (t_stage * 1e-3) / 1e12, 1)},
+                "measured": "HIP events recorded by libmoped_hip.so on the launching stream around every kernel of the stage "
+                            "(mh_match_timing), 20 launch sequences after the timed region, one kernel on the chip at a time; "
+                            "profiles/r02_*_depth1_kernel_stats.* is the same command under rocprofv3 with --depth 1",
+                "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
+                "hbm": {"achieved": round(b_alg / (t_b * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(b_alg / (t_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
+            }
+        else:
+            ach_tf = flops / (t_stage * 1e-3) / 1e12
+            b_alg = 512.0 * n_local + 512.0 * Qr + 12.0 * Qr    # DB once + queries once + (idx,d1,d2)
+            out["roofline"] = {
+                "kernel": "match_mfma_kernel / match_kernel (+ combine_splits_kernel, <1% of the time): the exact f32 search",
+                "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                "ms_per_launch": round(t_stage, 4),
+                "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s dense FP32 MFMA peak",
+                "measured": "HIP events around 20 launches on one stream after the timed region (one kernel on the chip at a time)",
+                "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),
+                "hbm": {"achieved": round(b_alg / (t_stage * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(b_alg / (t_stage * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
+            }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(db, frames, args)
     if rank == 0:

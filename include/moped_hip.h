@@ -429,6 +429,19 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
 
 /* ---- timing --------------------------------------------------------------------- */
 
+/* Device-side counters of the last frame that ran on the context (synchronises its stream):
+ * out[0] accepted matches, [1] clusters, [2..4] reserved, [5] (cluster, replica) tasks of POSE + POSE2 that
+ * evaluated hypotheses, [6] capacity flags, [7] P3P hypotheses those tasks evaluated -- POSE stops after the
+ * first 256 of a task's n_hypotheses when the inlier ratio they reached makes a better all-inlier sample
+ * unlikely; n_hypotheses < 0 in mh_pose_params means "-n_hypotheses, all of them". */
+int mh_frame_counters(mh_ctx* ctx, int32_t out[8]);
+/* GPU time of the kernels of the two-stage MATCH on this context, after mh_enable_timing(ctx, 1): the mean over
+ * the launch sequences since the previous call (at most the last 32; synchronises the context's stream):
+ * ms[0] query image (f16), [1] pass A (thresholds from a sample of the rows), [2] threshold merge,
+ * [3] pass B (the f16 screen of every (query, row) pair: the dominant kernel), [4] pass C (canonical
+ * f32 arithmetic on the candidates).  MH_ERR_ARG if no two-stage MATCH has run with timing on. */
+int mh_match_timing(mh_ctx* ctx, float ms[5]);
+
 typedef struct {
   float match_ms, group_ms, cluster_ms, pose1_ms, filter1_ms, pose2_ms, filter2_ms, total_ms;
 } mh_times;

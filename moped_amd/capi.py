@@ -99,7 +99,7 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin", "mh_frame_counters", "mh_match_timing",
 ]
 
 _lib = None
@@ -198,6 +198,8 @@ def load():
     L.mh_db_share.argtypes = [vp, vp]
     L.mh_match_stats.argtypes = [vp, i32, vp, i32]
     L.mh_match_set_mode.argtypes = [vp, i32]
+    L.mh_frame_counters.argtypes = [vp, vp]
+    L.mh_match_timing.argtypes = [vp, vp]
     L.mh_screen_margin.argtypes = [f32, f32]
     L.mh_screen_margin.restype = f32
     L.mh_enable_timing.argtypes = [vp, i32]
@@ -301,6 +303,19 @@ class Context:
     def db_share(self, src: "Context"):
         """Use the database `src` holds (no copy; one store per GPU for all frames in flight)."""
         self._ck(self.L.mh_db_share(self.h, src.h), "mh_db_share")
+
+    def frame_counters(self) -> dict:
+        """Device-side counters of the last frame on this context (see mh_frame_counters)."""
+        c = np.zeros(8, np.int32)
+        self._ck(self.L.mh_frame_counters(self.h, _ptr(c)), "mh_frame_counters")
+        names = ("matches", "clusters", "r2", "r3", "r4", "pose_tasks", "error", "hypotheses")
+        return dict(zip(names, (int(v) for v in c)))
+
+    def match_timing(self) -> dict:
+        """Per-kernel GPU times (ms) of the last two-stage MATCH (after enable_timing)."""
+        t = np.zeros(5, np.float32)
+        self._ck(self.L.mh_match_timing(self.h, _ptr(t)), "mh_match_timing")
+        return dict(zip(("prepare_ms", "pass_a_ms", "thresholds_ms", "pass_b_ms", "pass_c_ms"), (float(v) for v in t)))
 
     def match_set_mode(self, mode: int):
         """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible."""

@@ -109,10 +109,16 @@ int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* 
   int rc = ensure_match_scratch(ctx, Q);
   if (rc) return rc;
   const int qe = (q_expected > 0 && q_expected < Q) ? q_expected : Q;
-  if (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(qe, ctx->N, ctx->match_mode))
+  if (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(qe, ctx->N, ctx->match_mode)) {
+    ctx->sbuf.ev = nullptr;
+    if (ctx->timing && ctx->ev_made) {   // one event set per launch sequence, a ring of them (mh_match_timing)
+      ctx->sbuf.ev = ctx->mev[ctx->mev_next];
+      ctx->mev_next = (ctx->mev_next + 1) % mh_ctx::MEV_SETS;
+      ++ctx->mev_used;
+    }
     launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->sdb, ctx->sbuf, idx1, d1,
                         d2, ctx->stream, q_count, q_expected);
-  else
+  } else
     launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->match_scratch,
                  ctx->match_pack, idx1, d1, d2, ctx->stream, q_count, q_expected);
   return MH_OK;
@@ -185,6 +191,8 @@ void mh_destroy(mh_ctx* ctx) {
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ev_made)
     for (auto& e : ctx->ev) hipEventDestroy(e);
+    for (auto& set : ctx->mev)
+      for (auto& e : set) hipEventDestroy(e);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -440,9 +448,31 @@ int mh_enable_timing(mh_ctx* ctx, int on) {
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   if (on && !ctx->ev_made) {
     for (auto& e : ctx->ev) MH_HIP(ctx, hipEventCreate(&e));
+    for (auto& set : ctx->mev)
+      for (auto& e : set) MH_HIP(ctx, hipEventCreate(&e));
     ctx->ev_made = true;
   }
   ctx->timing = on != 0;
+  ctx->mev_next = ctx->mev_used = 0;
+  return MH_OK;
+}
+
+int mh_match_timing(mh_ctx* ctx, float ms[5]) {
+  if (!ctx || !ms || !ctx->timing || !ctx->ev_made || ctx->mev_used == 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = std::min(ctx->mev_used, (int)mh_ctx::MEV_SETS);
+  double sum[5] = {0, 0, 0, 0, 0};
+  for (int k = 0; k < n; ++k) {
+    const int set = ((ctx->mev_next - 1 - k) % mh_ctx::MEV_SETS + mh_ctx::MEV_SETS) % mh_ctx::MEV_SETS;
+    for (int i = 0; i < 5; ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ctx->mev[set][i], ctx->mev[set][i + 1]) != hipSuccess) return MH_ERR_HIP;
+      sum[i] += t;
+    }
+  }
+  for (int i = 0; i < 5; ++i) ms[i] = (float)(sum[i] / n);
+  ctx->mev_used = 0;
   return MH_OK;
 }
 

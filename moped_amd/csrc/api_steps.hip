@@ -1215,6 +1215,16 @@ int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes) {
   return MH_OK;
 }
 
+int mh_frame_counters(mh_ctx* ctx, int32_t out[8]) {
+  if (!ctx || !out || !ctx->fs) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  static_assert(sizeof(FrameCounts) == 8 * sizeof(int32_t), "mh_frame_counters hands the block out as 8 words");
+  MH_HIP(ctx, hipMemcpyAsync(out, ctx->fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MH_OK;
+}
+
 int mh_timing(mh_ctx* ctx, mh_times* out) {
   if (!ctx || !out || !ctx->timing || !ctx->ev_made) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));

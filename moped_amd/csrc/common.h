@@ -101,12 +101,10 @@ struct DepthImage {
 struct FrameCounts {
   int32_t n_matches;
   int32_t n_clusters;
-  int32_t n_objects;     // objects currently in the list
-  int32_t n_obj_pose1;   // after POSE
-  int32_t n_obj_filter1; // after FILTER
-  int32_t n_obj_pose2;   // objects added by POSE2
+  int32_t reserved[3];   // (object counts live in the frame's snap[] / result block)
+  int32_t n_pose_tasks;  // (cluster, replica) tasks of POSE + POSE2 that evaluated hypotheses
   int32_t error;         // sticky capacity/overflow flags
-  int32_t pad;
+  int32_t n_hyp;         // P3P hypotheses evaluated by POSE + POSE2 (all tasks of the frame)
 };
 
 }  // namespace mh

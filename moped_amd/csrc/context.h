@@ -118,6 +118,9 @@ struct mh_ctx {
 
   bool timing = false;
   hipEvent_t ev[10] = {};
+  static constexpr int MEV_SETS = 32;
+  hipEvent_t mev[MEV_SETS][6] = {};   // around the kernels of the two-stage MATCH, one set per launch sequence (mh_match_timing)
+  int mev_next = 0, mev_used = 0;     // ring position, sets recorded since the last mh_match_timing
   bool ev_made = false;
 };
 

@@ -696,7 +696,7 @@ namespace {
 
 template <int NQB>
 void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blocks_a, int blocks_b, int* n_slots_out,
-                   hipStream_t s) {
+                   hipEvent_t* ev, hipStream_t s) {
   constexpr int QB = 32 * NQB * SC_WAVES;
   static DynLds attr0, attr1;
   attr0.ensure(screen_kernel<0, NQB>, SC_LDS_BYTES);
@@ -722,8 +722,10 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   a.tiles_rem = n_sel_a % Sa;
   a.n_splits_a = Sa;
   hipLaunchKernelGGL((screen_kernel<0, NQB>), dim3(nqb * Sa), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  if (ev) hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(screen_tau_kernel, dim3((a.q_pad + 255) / 256), dim3(256), 0, s, a.part, Sa, a.q_pad, a.Q, a.q_count,
                      a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
+  if (ev) hipEventRecord(ev[3], s);
   // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
   const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
   a.n_sel = n_tiles;
@@ -732,8 +734,10 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   a.n_splits = Sb;
   a.tiles_base = n_tiles / Sb;
   a.tiles_rem = n_tiles % Sb;
-  a.sub_cap = std::max(1, std::min(4, SC_SLOTS_MAX / (2 * Sb)));
+  // (few splits = long sub-streams: a lane sees many of its query's candidates, its sub-list must hold them)
+  a.sub_cap = std::max(1, std::min(48, SC_SLOTS_MAX / (2 * Sb)));
   hipLaunchKernelGGL((screen_kernel<1, NQB>), dim3(nqb * Sb), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  if (ev) hipEventRecord(ev[4], s);
   *n_slots_out = 2 * Sb * a.sub_cap;
 }
 
@@ -750,8 +754,10 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   const int qe = (q_expected > 0 && q_expected < Q) ? std::max(q_expected, std::min(Q, 256)) : Q;
   const int n_tiles = (N + SC_TILE - 1) / SC_TILE;
 
+  if (sb.ev) hipEventRecord(sb.ev[0], s);
   hipLaunchKernelGGL(screen_prepare_kernel, dim3((q_pad * 16 + 255) / 256), dim3(256), 0, s, qn, qnorm, Q, q_count, q_pad,
                      sb.qh, sb.qbad);
+  if (sb.ev) hipEventRecord(sb.ev[1], s);
   ScreenArgs a;
   a.qh = sb.qh;
   a.dbh = sdb.dbh;
@@ -779,13 +785,14 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   int nqb_sel = qe > 640 ? 2 : 1;
   if (nqb_pin >= 1 && nqb_pin <= 3) nqb_sel = nqb_pin;
   int n_slots = 0;
-  if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
-  else if (nqb_sel == 2) launch_passes<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
-  else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, s);
+  if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
+  else if (nqb_sel == 2) launch_passes<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
+  else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
                      q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, idx1, d1, d2,
                      sb.stats);
+  if (sb.ev) hipEventRecord(sb.ev[5], s);
 }
 
 }  // namespace mh

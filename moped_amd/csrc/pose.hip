@@ -684,7 +684,9 @@ __device__ void pose_task(
   PP_T(0);
 
   // ---- hypotheses: one per lane ------------------------------------------------------
-  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : 1024;
+  // n_hypotheses < 0: that many, all of them (no adaptive stop after the first 256)
+  const bool always_all = prm.n_hypotheses < 0;
+  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : (always_all ? -prm.n_hypotheses : 1024);
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
   // The random stream of a task is keyed by (model id, number of the cluster among its model's
@@ -785,11 +787,19 @@ __device__ void pose_task(
   for (int h = tid; h < HA; h += POSE_THREADS) hypothesis(h);
   PP_T(1);
   unsigned long long gkey = wg_argmax();
+  if (H <= HA && tid == 0) {
+    atomicAdd(&counts->n_hyp, HA);
+    atomicAdd(&counts->n_pose_tasks, 1);
+  }
   if (H > HA) {
     const int cnt_a = (int)(gkey >> 32);
     const float w = (float)cnt_a / (float)k;
     const float w4 = w * w * w * w;
-    const bool settled = cnt_a > prm.min_n_pts_object && powf(1.f - w4, (float)HA) < 1e-3f;
+    const bool settled = !always_all && cnt_a > prm.min_n_pts_object && powf(1.f - w4, (float)HA) < 1e-3f;
+    if (tid == 0) {   // what was evaluated (bench.py reports it)
+      atomicAdd(&counts->n_hyp, settled ? HA : H);
+      atomicAdd(&counts->n_pose_tasks, 1);
+    }
     if (!settled) {
       for (int h = HA + tid; h < H; h += POSE_THREADS) hypothesis(h);
       __syncthreads();   // everybody has read wave_best of the first stage

@@ -24,6 +24,7 @@ struct ScreenBufs {
   int32_t* ovf_cnt = nullptr;      // [q_pad] records in the query's overflow list; zero between frames
   uint2* ovf = nullptr;            // [q_pad][ovf_cap]
   int ovf_cap = 0, q_pad = 0;
+  hipEvent_t* ev = nullptr;        // optional [6]: recorded around prepare / pass A / thresholds / pass B / pass C (mh_match_timing)
   unsigned int* stats = nullptr;   // optional [q_pad][3] per-query tallies: candidate rows, brute-force searches, searches
 };
 

@@ -239,6 +239,33 @@ void residuals_depth(int mode, const float* p7, const float* uv, const float* xy
   }
 }
 
+// lmFuncQuat with every correspondence in its own image (LmData::image, …REPROJECTION_CPU.hpp:100-138,
+// 213-237): cams[img[i]] is the camera of point i.  Same arithmetic as residuals() per point.
+void residuals_images(const float* p7, const float* uv, const float* xyz, const int32_t* img, int n,
+                      const Camera* cams, float* hx) {
+  float q[4] = {p7[0], p7[1], p7[2], p7[3]};
+  quat_normalize(q);
+  Mat34 T;
+  tm_init(T, q, p7 + 4);
+  for (int i = 0; i < n; i++) {
+    const Camera& c = cams[img[i]];
+    float p[3];
+    tm_apply(T, xyz + 3 * i, p);
+    tm_apply_inv(c.TM, p, p);
+    float u = p[0] / p[2] * c.K[0] + c.K[2];
+    float v = p[1] / p[2] * c.K[1] + c.K[3];
+    if (p[2] < 0) {
+      hx[2 * i] = -p[2] + 10;
+      hx[2 * i + 1] = -p[2] + 10;
+    } else {
+      float du = u - uv[2 * i];
+      float dv = v - uv[2 * i + 1];
+      hx[2 * i] = du * du;
+      hx[2 * i + 1] = dv * dv;
+    }
+  }
+}
+
 struct LmProblem {
   const float* uv;
   const float* xyz;
@@ -249,9 +276,13 @@ struct LmProblem {
   const float* world;
   const float* wgt;
   float alpha;
+  // mode 0 with several images: img[i] selects the camera of point i out of cam[0..] (nullptr = one camera)
+  const int32_t* img = nullptr;
   int per_item() const { return mode == 0 ? 2 : (mode == 1 ? 2 : 3); }
   void eval(const float* p, float* hx) const {
-    if (mode == 0)
+    if (mode == 0 && img)
+      residuals_images(p, uv, xyz, img, npts, cam, hx);
+    else if (mode == 0)
       residuals(p, uv, xyz, npts, *cam, hx);
     else
       residuals_depth(mode, p, uv, xyz, world, wgt, npts, *cam, alpha, hx);
@@ -984,6 +1015,292 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
     // list order is preserved by the erase; clusters[m] receive kept objects of model m in list order
     std::vector<int> kept_of(n_obj, -1);
     for (int k = 0; k < kept; k++) kept_of[order[k]] = k;
+    for (int o = 0; o < n_obj; o++)
+      if (keep[o]) {
+        nobj.push_back(objects[o]);
+        score_out.push_back(score[o]);
+      }
+    for (int k = 0; k < kept; k++)
+      clusters[om[order[k]]].push_back(std::vector<int>(members.begin() + off[k], members.begin() + off[k + 1]));
+    objects.swap(nobj);
+    return kept;
+  };
+  run_pose(fp->pose1);
+  const int n_pose1 = (int)objects.size();
+  std::vector<float> scores;
+  int n_f1 = n_pose1;
+  if (fp->run_stage2) {
+    n_f1 = run_filter(fp->f1_min_points, fp->f1_feature_distance, fp->f1_min_score, scores);
+    run_pose(fp->pose2);
+    run_filter(fp->f2_min_points, fp->f2_feature_distance, fp->f2_min_score, scores);
+  } else {
+    scores.assign(objects.size(), 0.f);
+  }
+  if (counts) {
+    counts[0] = M;
+    counts[1] = ncl;
+    counts[2] = n_pose1;
+    counts[3] = n_f1;
+  }
+  const int n_out = std::min((int)objects.size(), max_obj);
+  for (int o = 0; o < n_out; o++) {
+    obj_model[o] = objects[o].model;
+    memcpy(obj_pose + 7 * (size_t)o, objects[o].pose, 28);
+    obj_score[o] = scores[o];
+  }
+  return (int)objects.size();
+}
+
+
+// ===========================================================================
+// Frames with several images (cameras).  The reference carries the image with every
+// feature / match / correspondence: CLUSTER runs MeanShift per image in image order
+// (CLUSTER_MEAN_SHIFT_CPU.hpp:186-196), POSE projects every correspondence through its own
+// image (…REPROJECTION_CPU.hpp:100-138, 213-237) and never samples two correspondences with the
+// same (image, coord2D) (:76-98), FILTER projects every match through its image and keys the
+// ownership map by (coord2D, image) (FILTER_PROJECTION_CPU.hpp:89-141).  With one image these
+// functions are the single-image ones above, operation for operation.
+// ===========================================================================
+static int test_all_points_images(const float* pose7, const float* uv, const float* xyz, const int32_t* img,
+                                  int n, const Camera* cams, float thr, uint8_t* inlier) {
+  Mat34 T;
+  tm_init(T, pose7, pose7 + 4);
+  int cnt = 0;
+  for (int i = 0; i < n; i++) {
+    float p[2];
+    project_one(T, cams[img[i]], xyz + 3 * i, p);
+    p[0] -= uv[2 * i];
+    p[1] -= uv[2 * i + 1];
+    float err = p[0] * p[0] + p[1] * p[1];
+    bool in = err < thr;
+    if (inlier) inlier[i] = in;
+    cnt += in;
+  }
+  return cnt;
+}
+
+static float optimize_camera_images(float* pose7, const float* uv, const float* xyz, const int32_t* img, int n,
+                                    const Camera* cams, int itmax) {
+  float p[7];
+  memcpy(p, pose7, sizeof p);
+  LmProblem f = {uv, xyz, n, cams, 0, NULL, NULL, 0.f};
+  f.img = img;
+  float info[3];
+  int ret = lm_dif(f, p, itmax, info);
+  if (ret < 0) return (float)ret;
+  quat_normalize(p);
+  memcpy(pose7, p, sizeof p);
+  return info[1];
+}
+
+static std::vector<Camera> make_cameras(const float* Ks, const float* cam_poses, int n_images) {
+  std::vector<Camera> cams(n_images > 0 ? n_images : 1);
+  for (int i = 0; i < n_images; i++) camera_init(cams[i], Ks + 4 * i, cam_poses + 7 * i);
+  return cams;
+}
+
+int orc_project_test_images(const float pose7[7], const float* uv, const float* xyz, const int32_t* img, int n,
+                            const float* Ks, const float* cam_poses, int n_images, float thr, uint8_t* inlier) {
+  std::vector<Camera> cams = make_cameras(Ks, cam_poses, n_images);
+  return test_all_points_images(pose7, uv, xyz, img, n, &cams[0], thr, inlier);
+}
+
+int orc_ransac_images(const float* uv, const float* xyz, const int32_t* img, int k, const float* Ks,
+                      const float* cam_poses, int n_images, const orc_pose_params* prm, float pose7[7]) {
+  std::vector<Camera> cams = make_cameras(Ks, cam_poses, n_images);
+  std::vector<float> suv, sxyz;
+  std::vector<int32_t> simg;
+  std::vector<uint8_t> inl(k);
+  for (int it = 0; it < prm->max_ransac_tests; it++) {
+    std::vector<std::pair<float, int> > keyed(k);
+    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)rand(), i);
+    std::sort(keyed.begin(), keyed.end());
+    std::map<std::pair<int, std::pair<float, float> >, int> used;   // (image, coord2D) (:79)
+    suv.clear();
+    sxyz.clear();
+    simg.clear();
+    size_t pos = 0;
+    while ((int)used.size() < prm->n_pts_align && pos < keyed.size()) {
+      int i = keyed[pos++].second;
+      std::pair<int, std::pair<float, float> > key(img[i], std::make_pair(uv[2 * i], uv[2 * i + 1]));
+      if (!used[key]++) {
+        suv.push_back(uv[2 * i]);
+        suv.push_back(uv[2 * i + 1]);
+        for (int x = 0; x < 3; x++) sxyz.push_back(xyz[3 * i + x]);
+        simg.push_back(img[i]);
+      }
+    }
+    if ((int)used.size() != prm->n_pts_align) return 0;
+    for (int j = 0; j < 4; j++) pose7[j] = (float)((rand() & 255) / 256.);
+    pose7[4] = 0.f;
+    pose7[5] = 0.f;
+    pose7[6] = 0.5f;
+    int lm = (int)optimize_camera_images(pose7, &suv[0], &sxyz[0], &simg[0], (int)simg.size(), &cams[0],
+                                         prm->max_lm_tests);
+    if (lm == -1) continue;
+    int cnt = test_all_points_images(pose7, uv, xyz, img, k, &cams[0], prm->error_threshold, &inl[0]);
+    if (cnt > prm->min_n_pts_object) {
+      suv.clear();
+      sxyz.clear();
+      simg.clear();
+      for (int i = 0; i < k; i++)
+        if (inl[i]) {
+          suv.push_back(uv[2 * i]);
+          suv.push_back(uv[2 * i + 1]);
+          for (int x = 0; x < 3; x++) sxyz.push_back(xyz[3 * i + x]);
+          simg.push_back(img[i]);
+        }
+      optimize_camera_images(pose7, &suv[0], &sxyz[0], &simg[0], cnt, &cams[0], prm->max_lm_tests);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+int orc_filter_images(const float* uv, const int32_t* img, const float* xyz, const int32_t* model_off, int n_models,
+                      const int32_t* obj_model, const float* obj_pose, int n_obj, const float* Ks,
+                      const float* cam_poses, int n_images, int min_points, float feature_distance,
+                      float min_score, float* score, uint8_t* keep, int32_t* out_order, int32_t* cl_members,
+                      int32_t* cl_off) {
+  std::vector<Camera> cams = make_cameras(Ks, cam_poses, n_images);
+  typedef std::pair<std::pair<float, float>, int> Key;   // (coord2D, image) (:89)
+  std::map<Key, std::pair<float, int> > best;
+  for (int m = 0; m < n_models; m++) {
+    for (int o = 0; o < n_obj; o++) {
+      if (obj_model[o] != m) continue;
+      Mat34 T;
+      tm_init(T, obj_pose + 7 * o, obj_pose + 7 * o + 4);
+      std::vector<int> cl;
+      float sc = 0;
+      for (int i = model_off[m]; i < model_off[m + 1]; i++) {
+        float p[2];
+        project_one(T, cams[img[i]], xyz + 3 * i, p);
+        p[0] -= uv[2 * i];
+        p[1] -= uv[2 * i + 1];
+        float err = p[0] * p[0] + p[1] * p[1];
+        if (err < feature_distance) {
+          cl.push_back(i);
+          sc += 1. / (err + 1.);
+        }
+      }
+      score[o] = sc;
+      for (size_t j = 0; j < cl.size(); j++) {
+        Key key(std::make_pair(uv[2 * cl[j]], uv[2 * cl[j] + 1]), img[cl[j]]);
+        std::map<Key, std::pair<float, int> >::iterator itb = best.find(key);
+        if (itb == best.end()) itb = best.insert(std::make_pair(key, std::make_pair(0.f, -1))).first;
+        if (itb->second.first < sc) itb->second = std::make_pair(sc, o);
+      }
+    }
+  }
+  std::vector<std::vector<int> > newcl(n_obj);
+  for (int m = 0; m < n_models; m++)
+    for (int i = model_off[m]; i < model_off[m + 1]; i++) {
+      std::map<Key, std::pair<float, int> >::iterator itb = best.find(Key(std::make_pair(uv[2 * i], uv[2 * i + 1]), img[i]));
+      if (itb == best.end()) continue;
+      int o = itb->second.second;
+      if (o >= 0 && obj_model[o] == m) newcl[o].push_back(i - model_off[m]);
+    }
+  int kept = 0, w = 0;
+  for (int o = 0; o < n_obj; o++) keep[o] = 0;
+  for (int m = 0; m < n_models; m++)
+    for (int o = 0; o < n_obj; o++) {
+      if (obj_model[o] != m) continue;
+      if ((int)newcl[o].size() < min_points || score[o] < min_score) continue;
+      keep[o] = 1;
+      out_order[kept] = o;
+      cl_off[kept++] = w;
+      for (size_t j = 0; j < newcl[o].size(); j++) cl_members[w++] = newcl[o][j];
+    }
+  cl_off[kept] = w;
+  return kept;
+}
+
+// orc_frame_rest for a frame whose features come from n_images images: q_img[Q] = image of every
+// feature, Ks [n_images][4], cam_poses [n_images][7].  counts as orc_frame_rest.
+int orc_frame_rest_images(const float* q_uv, const int32_t* q_img, const int32_t* idx1, const float* d1,
+                          const float* d2, int Q, float ratio, const int32_t* model_of, const float* db_xyz,
+                          int n_models, const float* Ks, const float* cam_poses, int n_images,
+                          const orc_frame_params* fp, int32_t* obj_model, float* obj_pose, float* obj_score,
+                          int max_obj, int32_t* counts) {
+  std::vector<int32_t> out_q(Q > 0 ? Q : 1), model_off(n_models + 1);
+  const int M = orc_match_accept(idx1, d1, d2, Q, ratio, model_of, n_models, &out_q[0], &model_off[0]);
+  std::vector<float> uv(2 * (size_t)std::max(M, 1)), xyz(3 * (size_t)std::max(M, 1));
+  std::vector<int32_t> img(std::max(M, 1));
+  for (int i = 0; i < M; i++) {
+    const int q = out_q[i];
+    uv[2 * i] = q_uv[2 * q];
+    uv[2 * i + 1] = q_uv[2 * q + 1];
+    img[i] = q_img[q];
+    const int r = idx1[q];
+    for (int x = 0; x < 3; x++) xyz[3 * i + x] = db_xyz[3 * (size_t)r + x];
+  }
+  // CLUSTER: per model, per image in image order; cluster members = match indices inside the model
+  std::vector<std::vector<std::vector<int> > > clusters(n_models);
+  for (int m = 0; m < n_models; m++) {
+    const int b = model_off[m], n = model_off[m + 1] - b;
+    for (int im = 0; im < n_images; im++) {
+      std::vector<float> pts;
+      std::vector<int> which;
+      for (int k = 0; k < n; k++)
+        if (img[b + k] == im) {
+          pts.push_back(uv[2 * (size_t)(b + k)]);
+          pts.push_back(uv[2 * (size_t)(b + k) + 1]);
+          which.push_back(k);
+        }
+      const int np = (int)which.size();
+      if (np == 0) continue;
+      std::vector<int32_t> members(np), off(np + 2);
+      const int k = orc_meanshift(&pts[0], np, 2, fp->ms_radius, fp->ms_merge, fp->ms_min_pts, fp->ms_max_iter,
+                                  &members[0], &off[0], NULL);
+      for (int c = 0; c < k; c++) {
+        std::vector<int> cl;
+        for (int j = off[c]; j < off[c + 1]; j++) cl.push_back(which[members[j]]);
+        clusters[m].push_back(cl);
+      }
+    }
+  }
+  int ncl = 0;
+  for (int m = 0; m < n_models; m++) ncl += (int)clusters[m].size();
+  struct Obj {
+    int model;
+    float pose[7];
+  };
+  std::vector<Obj> objects;
+  auto run_pose = [&](const orc_pose_params& pp) {
+    for (int m = 0; m < n_models; m++)
+      for (size_t c = 0; c < clusters[m].size(); c++)
+        for (int r = 0; r < pp.max_objects_per_cluster; r++) {
+          const std::vector<int>& cl = clusters[m][c];
+          std::vector<float> cuv(2 * cl.size()), cxyz(3 * cl.size());
+          std::vector<int32_t> cimg(cl.size());
+          for (size_t i = 0; i < cl.size(); i++) {
+            const int g = model_off[m] + cl[i];
+            cuv[2 * i] = uv[2 * g];
+            cuv[2 * i + 1] = uv[2 * g + 1];
+            for (int x = 0; x < 3; x++) cxyz[3 * i + x] = xyz[3 * g + x];
+            cimg[i] = img[g];
+          }
+          Obj o;
+          o.model = m;
+          if (orc_ransac_images(&cuv[0], &cxyz[0], &cimg[0], (int)cl.size(), Ks, cam_poses, n_images, &pp, o.pose))
+            objects.push_back(o);
+        }
+  };
+  auto run_filter = [&](int min_points, float fdist, float min_score, std::vector<float>& score_out) {
+    const int n_obj = (int)objects.size();
+    std::vector<int32_t> om(std::max(n_obj, 1)), order(std::max(n_obj, 1)), members(std::max(M, 1)), off(n_obj + 2);
+    std::vector<float> op(7 * (size_t)std::max(n_obj, 1)), score(std::max(n_obj, 1));
+    std::vector<uint8_t> keep(std::max(n_obj, 1));
+    for (int o = 0; o < n_obj; o++) {
+      om[o] = objects[o].model;
+      memcpy(&op[7 * (size_t)o], objects[o].pose, 28);
+    }
+    const int kept = orc_filter_images(&uv[0], &img[0], &xyz[0], &model_off[0], n_models, &om[0], &op[0], n_obj, Ks,
+                                       cam_poses, n_images, min_points, fdist, min_score, &score[0], &keep[0],
+                                       &order[0], &members[0], &off[0]);
+    std::vector<Obj> nobj;
+    score_out.clear();
+    for (int m = 0; m < n_models; m++) clusters[m].clear();
     for (int o = 0; o < n_obj; o++)
       if (keep[o]) {
         nobj.push_back(objects[o]);

@@ -166,6 +166,23 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
                    int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
                    int32_t* counts);
 
+/* ---- frames with several images (cameras): every feature / match / correspondence carries its image.
+ * Ks [n_images][4], cam_poses [n_images][7]; with one image these are the functions above. ---- */
+int orc_project_test_images(const float pose7[7], const float* uv, const float* xyz, const int32_t* img, int n,
+                            const float* Ks, const float* cam_poses, int n_images, float thr, uint8_t* inlier);
+int orc_ransac_images(const float* uv, const float* xyz, const int32_t* img, int k, const float* Ks,
+                      const float* cam_poses, int n_images, const orc_pose_params* prm, float pose7[7]);
+int orc_filter_images(const float* uv, const int32_t* img, const float* xyz, const int32_t* model_off, int n_models,
+                      const int32_t* obj_model, const float* obj_pose, int n_obj, const float* Ks,
+                      const float* cam_poses, int n_images, int min_points, float feature_distance,
+                      float min_score, float* score, uint8_t* keep, int32_t* out_order, int32_t* cl_members,
+                      int32_t* cl_off);
+int orc_frame_rest_images(const float* q_uv, const int32_t* q_img, const int32_t* idx1, const float* d1,
+                          const float* d2, int Q, float ratio, const int32_t* model_of, const float* db_xyz,
+                          int n_models, const float* Ks, const float* cam_poses, int n_images,
+                          const orc_frame_params* fp, int32_t* obj_model, float* obj_pose, float* obj_score,
+                          int max_obj, int32_t* counts);
+
 /* N2  SIFT extraction as FEAT_SIFT_CPU runs it (feat/FEAT_SIFT_CPU.hpp:78-112 over libsiftfast
  * 1.1, plain-C arithmetic; see sift_oracle.cpp).  gray = h x w bytes; keypoints in the
  * reference's list order: xy[i] = (col, row), scale_ori[i] = (scale, orientation) (optional),
