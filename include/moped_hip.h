@@ -43,6 +43,7 @@ extern "C" {
 
 #define MH_DESC_DIM 128
 #define MH_MAX_BATCH 8   /* frames one context can carry through one MATCH launch (mh_frame_enqueue_rest_batch) */
+#define MH_MAX_IMAGES 8    /* images (cameras) of one frame (mh_frame_set_images, mh_*_images) */
 #define MH_MAX_MODELS 8192   /* models a context's frames can address (sharded: the global count); more -> MH_ERR_CAPACITY */
 #define MH_OK 0
 #define MH_ERR_ARG (-1)
@@ -182,6 +183,13 @@ typedef struct {
 int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster_off,
                    int n_clusters, const mh_cam* cam, const mh_pose_params* prm,
                    uint64_t seed, mh_pose_out* out_host, int32_t* n_out);
+/* The same with every correspondence in its own image (LmData::image, …REPROJECTION_CPU.hpp:213-237; POSE2's
+ * clusters, rewritten by FILTER, mix images): image_of_host[i] in [0, n_images), cams[n_images].  A minimal
+ * sample is drawn inside one image; inliers and the refinement use every point's own camera; two
+ * correspondences with the same (image, coord2D) are never sampled together (:76-98). */
+int mh_pose_ransac_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image_of_host,
+                          const int32_t* cluster_off, int n_clusters, const mh_cam* cams, int n_images,
+                          const mh_pose_params* prm, uint64_t seed, mh_pose_out* out_host, int32_t* n_out);
 
 /* moped3d (Kinect) variants: every correspondence also carries the camera-frame point
  * read from the depth map and its Cauchy weight (Match.depthData.coord3D and
@@ -218,6 +226,13 @@ int mh_project_test(mh_ctx* ctx, const float pose[7], const mh_corr* corr_host, 
  * order.  score[n_obj], keep[n_obj]; the rewritten clusters of kept objects in
  * (model, list) order: out_order[kept] object indices, cl_off[kept+1] /
  * cl_members (match index inside its model). */
+/* The same for a frame whose matches come from n_images images (FILTER_PROJECTION_CPU.hpp:100-141: every match
+ * is projected through *images[match.imageIdx], the ownership map is keyed by (coord2D, image)):
+ * image_of_host[i] = image of match i (same order as corr_host), cams[n_images].  n_images == 1: mh_filter. */
+int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image_of_host, const int32_t* model_off,
+                     int n_models, const int32_t* obj_model, const float* obj_pose, int n_obj, const mh_cam* cams,
+                     int n_images, int min_points, float feature_distance, float min_score, float* score,
+                     uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off, int32_t* n_kept);
 int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, int n_models,
               const int32_t* obj_model, const float* obj_pose, int n_obj, const mh_cam* cam,
               int min_points, float feature_distance, float min_score,
@@ -252,6 +267,14 @@ typedef struct {
  * synchronisation.  Results stay on the device until mh_frame_fetch. */
 int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
                      const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):
+ * q_image_dev[Q] = image of every query of the frames enqueued from now on (device memory, read when a frame
+ * runs), cams[n_images] their cameras.  CLUSTER then runs per (model, image) in image order
+ * (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195), POSE / FILTER project every correspondence through its own image; the
+ * `cam` argument of mh_frame_enqueue* is ignored.  n_images <= 1 or NULL: back to one image.  Not together with the
+ * moped3d depth steps (single camera). */
+int mh_frame_set_images(mh_ctx* ctx, const int32_t* q_image_dev, const mh_cam* cams, int n_images);
+
 /* Per-query depth attributes for the next frames (device pointer, [Q] mh_depth, in query
  * order; NULL switches back to the 2-D residuals).  POSE and POSE2 of the frame then use
  * the MH_DEPTH_* residuals `kind` with `alpha`. */

@@ -99,7 +99,8 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin", "mh_frame_counters", "mh_match_timing",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
+    "mh_pose_ransac_images",
 ]
 
 _lib = None
@@ -199,6 +200,11 @@ def load():
     L.mh_match_stats.argtypes = [vp, i32, vp, i32]
     L.mh_match_set_mode.argtypes = [vp, i32]
     L.mh_frame_counters.argtypes = [vp, vp]
+    L.mh_frame_set_images.argtypes = [vp, vp, vp, i32]
+    L.mh_filter_images.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f32, f32,
+                                   vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.mh_pose_ransac_images.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.POINTER(mh_pose_params),
+                                        C.c_uint64, vp, C.POINTER(C.c_int32)]
     L.mh_match_timing.argtypes = [vp, vp]
     L.mh_screen_margin.argtypes = [f32, f32]
     L.mh_screen_margin.restype = f32
@@ -213,6 +219,14 @@ def make_cam(K, cam) -> mh_cam:
     c.K[:] = [float(x) for x in K]
     c.cam[:] = [float(x) for x in cam]
     return c
+
+
+def make_cams(Ks, cams):
+    """Array of mh_cam for a frame with several images: Ks [n,4], cams [n,7]."""
+    arr = (mh_cam * len(Ks))()
+    for i, (K, c) in enumerate(zip(Ks, cams)):
+        arr[i] = make_cam(K, c)
+    return arr
 
 
 def make_pose_params(n_hypotheses=1024, max_objects_per_cluster=4, n_pts_align=5,
@@ -405,6 +419,28 @@ class Context:
                                        C.byref(params), seed, _ptr(out), C.byref(n_out)), "mh_pose_ransac")
         return out[:n_out.value].copy()
 
+    def pose_ransac_images(self, corr, image_of, cluster_off, Ks, cams, params: mh_pose_params, seed=1):
+        """pose_ransac with every correspondence in its own image (Ks [n,4], cams [n,7])."""
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        image_of = np.ascontiguousarray(image_of, np.int32)
+        cluster_off = np.ascontiguousarray(cluster_off, np.int32)
+        ncl = len(cluster_off) - 1
+        R = max(params.max_objects_per_cluster, 1)
+        out = np.zeros(max(ncl * R, 1), POSE_OUT_DTYPE)
+        n_out = C.c_int32(0)
+        arr = make_cams(Ks, cams)
+        self._ck(self.L.mh_pose_ransac_images(self.h, _ptr(corr), _ptr(image_of), _ptr(cluster_off), ncl, arr, len(Ks),
+                                              C.byref(params), seed, _ptr(out), C.byref(n_out)), "mh_pose_ransac_images")
+        return out[:n_out.value].copy()
+
+    def frame_set_images(self, q_image_ptr, Ks=None, cams=None):
+        """Frames with several images: q_image_ptr = device int32[Q] (image of every query); 0 / None: one image again."""
+        if not q_image_ptr or Ks is None or len(Ks) <= 1:
+            self._ck(self.L.mh_frame_set_images(self.h, None, None, 1), "mh_frame_set_images")
+            return
+        arr = make_cams(Ks, cams)
+        self._ck(self.L.mh_frame_set_images(self.h, C.c_void_p(q_image_ptr), arr, len(Ks)), "mh_frame_set_images")
+
     def pose_ransac_depth(self, corr, depth, cluster_off, K, cam, params: mh_pose_params, kind, alpha=0.5, seed=1):
         corr = np.ascontiguousarray(corr, CORR_DTYPE)
         depth = np.ascontiguousarray(depth, DEPTH_DTYPE)
@@ -477,6 +513,31 @@ class Context:
                                   _ptr(obj_pose), n_obj, C.byref(c), min_points, feature_distance,
                                   min_score, _ptr(score), _ptr(keep), _ptr(order), _ptr(members),
                                   _ptr(off), C.byref(kept)), "mh_filter")
+        k = kept.value
+        clusters = [members[off[i]:off[i + 1]].copy() for i in range(k)]
+        return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters
+
+    def filter_images(self, corr, image_of, model_off, obj_model, obj_pose, Ks, cams, min_points, feature_distance,
+                      min_score):
+        """filter() for matches that come from several images (image_of[i] = image of match i)."""
+        corr = np.ascontiguousarray(corr, CORR_DTYPE)
+        image_of = np.ascontiguousarray(image_of, np.int32)
+        model_off = np.ascontiguousarray(model_off, np.int32)
+        obj_model = np.ascontiguousarray(obj_model, np.int32)
+        obj_pose = np.ascontiguousarray(obj_pose, np.float32)
+        n_obj = obj_model.shape[0]
+        M = corr.shape[0]
+        score = np.zeros(max(n_obj, 1), np.float32)
+        keep = np.zeros(max(n_obj, 1), np.uint8)
+        order = np.zeros(max(n_obj, 1), np.int32)
+        members = np.zeros(max(M, 1), np.int32)
+        off = np.zeros(n_obj + 2, np.int32)
+        kept = C.c_int32(0)
+        arr = make_cams(Ks, cams)
+        self._ck(self.L.mh_filter_images(self.h, _ptr(corr), _ptr(image_of), _ptr(model_off), len(model_off) - 1,
+                                         _ptr(obj_model), _ptr(obj_pose), n_obj, arr, len(Ks), min_points,
+                                         feature_distance, min_score, _ptr(score), _ptr(keep), _ptr(order),
+                                         _ptr(members), _ptr(off), C.byref(kept)), "mh_filter_images")
         k = kept.value
         clusters = [members[off[i]:off[i + 1]].copy() for i in range(k)]
         return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters

@@ -18,6 +18,9 @@ struct FrameState {
   // group
   int32_t *acc_q = nullptr, *acc_model = nullptr, *m_q = nullptr, *m_model = nullptr, *m_rep = nullptr;
   mh_corr* m_corr = nullptr;
+  // several images: image of every match; the matches again in (model, image, query) order for CLUSTER / POSE
+  int32_t *m_img = nullptr, *mi_img = nullptr, *off2 = nullptr;
+  mh_corr* mi_corr = nullptr;
   mh_depth* m_depth = nullptr;     // per match, when the frame carries depth attributes
   int32_t* model_off = nullptr;
   // cluster
@@ -62,7 +65,8 @@ void free_fs(FrameState* fs) {
                   fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
                   fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
                   fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw,
-                  fs->m_depth,    fs->seed_dev,    fs->tickets};
+                  fs->m_depth,    fs->seed_dev,    fs->tickets,    fs->m_img,      fs->mi_img,
+                  fs->off2,       fs->mi_corr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (FrameState::Graph* g : {&fs->g_full, &fs->g_local, &fs->g_rest})
@@ -101,6 +105,10 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   rc |= dev_alloc(ctx, fs->m_rep, max_m);
   rc |= dev_alloc(ctx, fs->m_corr, max_m);
   rc |= dev_alloc(ctx, fs->m_depth, max_m);
+  rc |= dev_alloc(ctx, fs->m_img, max_m);
+  rc |= dev_alloc(ctx, fs->mi_img, max_m);
+  rc |= dev_alloc(ctx, fs->mi_corr, max_m);
+  rc |= dev_alloc(ctx, fs->off2, (size_t)n_models + 1);
   rc |= dev_alloc(ctx, fs->model_off, (size_t)n_models + 1);
   rc |= dev_alloc(ctx, fs->ms_members, max_m);
   rc |= dev_alloc(ctx, fs->ms_cl_start, (size_t)max_m + n_models + 1);
@@ -144,6 +152,9 @@ FilterBuffers make_fb(const mh_ctx* ctx, const FrameState* fs, int n_models) {
   FilterBuffers fb;
   fb.corr = fs->m_corr;
   fb.m_rep = fs->m_rep;
+  fb.m_img = nullptr;
+  fb.cams = nullptr;
+  fb.n_images = 1;
   fb.model_off = fs->model_off;
   fb.n_models = n_models;
   fb.max_m = fs->max_m;
@@ -268,6 +279,11 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     seed_dev = fs->seed_dev;
     seed = 0;
   }
+  const bool multi = ctx->q_img && ctx->n_images > 1 && ctx->cams_dev;
+  if (multi && (ctx->q_depth || ctx->depth_img.img || ctx->linkage_on)) {
+    ctx->err = "frames with several images: the moped3d depth steps are single-camera";
+    return MH_ERR_ARG;
+  }
   // moped3d depth rules: patch maps of this frame's depth image, DEPTHFILTER on the features
   DepthRules rules;
   if (ctx->rules.on && ctx->depth_img.img) {
@@ -313,21 +329,41 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                           ctx->linkage, ctx->lk_scratch, ctx->lk_scratch_floats, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
                           snap, fs->counts, fs->tickets + 0, s);
+  } else if (multi) {
+    // MeanShift per (model, image) in image order (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195)
+    launch_image_split(fs->m_corr, fs->m_q, fs->m_model, fs->model_off, nm, ctx->q_img, ctx->n_images, fs->counts,
+                       fs->m_img, fs->m_rep, fs->mi_corr, fs->mi_img, fs->off2, s);
+    launch_meanshift_models(fs->mi_corr, fs->off2, nm * ctx->n_images, prm->ms_radius, prm->ms_merge,
+                            prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
+                            fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
+                            fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, ctx->n_images);
   } else
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
                           fs->n_clusters, snap, fs->counts, fs->tickets + 0, s);
   stamp(ctx, 3);
+  PoseImages img1, img2;   // POSE works on the (model, image, query) copy, POSE2 on FILTER's clusters over the match lists
+  if (multi) {
+    img1.cams = img2.cams = ctx->cams_dev;
+    img1.n_images = img2.n_images = ctx->n_images;
+    img1.img_of = fs->mi_img;
+    img2.img_of = fs->m_img;
+  }
   // POSE (+ slot count, snap[2] = objects after POSE)
   const float* depth4 = (ctx->q_depth || ctx->depth_img.img) ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
-  launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model, fs->cl_begin,
-              fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
+  launch_pose(multi ? fs->mi_corr : fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model,
+              fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
-              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s);
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s, img1);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     FilterBuffers fb = make_fb(ctx, fs, nm);
+    if (multi) {
+      fb.m_img = fs->m_img;
+      fb.cams = ctx->cams_dev;
+      fb.n_images = ctx->n_images;
+    }
     // FILTER (snap[3] = objects kept)
     launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
                   fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, snap + 3, nullptr, grid}, s);
@@ -337,7 +373,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                 fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
@@ -361,7 +397,8 @@ int prepare_frame(mh_ctx* ctx, int Q) {
   const int want_m = ctx->fs ? ctx->fs->max_m : 0;
   const int mc = ctx->fs ? ctx->fs->max_clusters : 1024;
   const int mo = ctx->fs ? ctx->fs->max_objects : 4096;
-  return ensure_fs(ctx, std::max(want_m, ctx->max_q), mc, mo, ctx->n_models);
+  // (several images: CLUSTER's per-"model" tables hold one entry per (model, image) pair)
+  return ensure_fs(ctx, std::max(want_m, ctx->max_q), mc, mo, ctx->n_models * (ctx->n_images > 1 ? ctx->n_images : 1));
 }
 
 }  // namespace
@@ -518,11 +555,22 @@ int mh_meanshift_batch(mh_ctx* ctx, const float* pts_host, const int32_t* off, i
   return MH_OK;
 }
 
+// the frame's cameras into the context's device table
+static int upload_cams(mh_ctx* ctx, const mh_cam* cams, int n_images) {
+  if (!ctx->cams_dev) MH_HIP(ctx, hipMalloc(&ctx->cams_dev, sizeof(DevCam) * MH_MAX_IMAGES));
+  DevCam h[MH_MAX_IMAGES];
+  for (int i = 0; i < n_images; ++i) h[i] = make_devcam(cams[i]);
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // frames in flight still read the old table
+  MH_HIP(ctx, hipMemcpy(ctx->cams_dev, h, sizeof(DevCam) * n_images, hipMemcpyHostToDevice));
+  return MH_OK;
+}
+
 static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host, int kind,
                             float alpha, const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
                             const mh_pose_params* prm, uint64_t seed, mh_pose_out* out_host,
-                            int32_t* n_out) {
-  if (!ctx || n_clusters < 0 || !cam || !prm || !n_out || (n_clusters > 0 && (!corr_host || !cluster_off || !out_host))) {
+                            int32_t* n_out, const int32_t* image_of_host = nullptr, int n_images = 1) {
+  if (!ctx || n_clusters < 0 || !cam || !prm || !n_out || (n_clusters > 0 && (!corr_host || !cluster_off || !out_host)) ||
+      n_images < 1 || n_images > MH_MAX_IMAGES) {
     if (ctx) ctx->err = "mh_pose_ransac: bad argument";
     return MH_ERR_ARG;
   }
@@ -544,6 +592,19 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
     h_begin[c] = cluster_off[c];
     h_count[c] = cluster_off[c + 1] - cluster_off[c];
   }
+  PoseImages images;
+  if (image_of_host && n_images > 1) {   // every correspondence in its own image: cam[0..n_images)
+    for (int i = 0; i < total; ++i)
+      if (image_of_host[i] < 0 || image_of_host[i] >= n_images) {
+        ctx->err = "mh_pose_ransac_images: image index outside [0, n_images)";
+        return MH_ERR_ARG;
+      }
+    if ((rc = upload_cams(ctx, cam, n_images))) return rc;
+    MH_HIP(ctx, hipMemcpyAsync(fs->m_img, image_of_host, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    images.cams = ctx->cams_dev;
+    images.img_of = fs->m_img;
+    images.n_images = n_images;
+  }
   MH_HIP(ctx, hipMemcpyAsync(fs->m_corr, corr_host, (size_t)total * sizeof(mh_corr), hipMemcpyHostToDevice, s));
   if (depth_host)
     MH_HIP(ctx, hipMemcpyAsync(fs->m_depth, depth_host, (size_t)total * sizeof(mh_depth), hipMemcpyHostToDevice, s));
@@ -557,7 +618,8 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   const DevCam dc = make_devcam(*cam);
   launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
               fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, nullptr, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
-              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0}, s);
+              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0}, s,
+              images);
   MH_HIP(ctx, hipGetLastError());
   std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
   std::vector<float> pose((size_t)7 * n_obj), err(n_obj);
@@ -587,6 +649,14 @@ int mh_pose_ransac(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* cluster
                           out_host, n_out);
 }
 
+int mh_pose_ransac_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image_of_host,
+                          const int32_t* cluster_off, int n_clusters, const mh_cam* cams, int n_images,
+                          const mh_pose_params* prm, uint64_t seed, mh_pose_out* out_host, int32_t* n_out) {
+  if (n_clusters > 0 && n_images > 1 && !image_of_host) return MH_ERR_ARG;
+  return pose_ransac_impl(ctx, corr_host, nullptr, MH_DEPTH_NONE, 0.f, cluster_off, n_clusters, cams, prm, seed,
+                          out_host, n_out, image_of_host, n_images);
+}
+
 int mh_pose_ransac_depth(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* depth_host,
                          const int32_t* cluster_off, int n_clusters, const mh_cam* cam,
                          const mh_pose_params* prm, int kind, float alpha, uint64_t seed,
@@ -595,6 +665,25 @@ int mh_pose_ransac_depth(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* 
   if (n_clusters > 0 && !depth_host) return MH_ERR_ARG;
   return pose_ransac_impl(ctx, corr_host, depth_host, kind, alpha, cluster_off, n_clusters, cam, prm, seed,
                           out_host, n_out);
+}
+
+int mh_frame_set_images(mh_ctx* ctx, const int32_t* q_image_dev, const mh_cam* cams, int n_images) {
+  if (!ctx) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  if (!q_image_dev || !cams || n_images <= 1) {   // back to one image: the camera of mh_frame_enqueue*
+    ctx->q_img = nullptr;
+    ctx->n_images = 1;
+    return MH_OK;
+  }
+  if (n_images > MH_MAX_IMAGES) {
+    ctx->err = "mh_frame_set_images: more than MH_MAX_IMAGES images";
+    return MH_ERR_CAPACITY;
+  }
+  if (int rc = upload_cams(ctx, cams, n_images)) return rc;
+  ctx->q_img = q_image_dev;
+  ctx->n_images = n_images;
+  return MH_OK;
 }
 
 int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float alpha) {
@@ -833,7 +922,17 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
               int min_points, float feature_distance, float min_score, float* score,
               uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off,
               int32_t* n_kept) {
-  if (!ctx || !model_off || n_models <= 0 || n_obj < 0 || !cam || !n_kept) return MH_ERR_ARG;
+  return mh_filter_images(ctx, corr_host, nullptr, model_off, n_models, obj_model, obj_pose, n_obj, cam, 1, min_points,
+                          feature_distance, min_score, score, keep, out_order, cl_members, cl_off, n_kept);
+}
+
+int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image_of_host, const int32_t* model_off,
+                     int n_models, const int32_t* obj_model, const float* obj_pose, int n_obj, const mh_cam* cam,
+                     int n_images, int min_points, float feature_distance, float min_score, float* score,
+                     uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off, int32_t* n_kept) {
+  if (!ctx || !model_off || n_models <= 0 || n_obj < 0 || !cam || !n_kept || n_images < 1 || n_images > MH_MAX_IMAGES ||
+      (n_images > 1 && !image_of_host))
+    return MH_ERR_ARG;
   *n_kept = 0;
   if (cl_off) cl_off[0] = 0;
   if (n_obj == 0) return MH_OK;
@@ -845,8 +944,18 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   FrameState* fs = ctx->fs;
   hipStream_t s = ctx->stream;
   std::vector<int32_t> ones(n_obj, 1);
+  const bool multi = image_of_host && n_images > 1;
+  if (multi) {
+    for (int i = 0; i < M; ++i)
+      if (image_of_host[i] < 0 || image_of_host[i] >= n_images) {
+        ctx->err = "mh_filter_images: image index outside [0, n_images)";
+        return MH_ERR_ARG;
+      }
+    if ((rc = upload_cams(ctx, cam, n_images))) return rc;
+    MH_HIP(ctx, hipMemcpyAsync(fs->m_img, image_of_host, (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  }
   MH_HIP(ctx, hipMemcpyAsync(fs->m_corr, corr_host, (size_t)M * sizeof(mh_corr), hipMemcpyHostToDevice, s));
-  launch_rep(fs->m_corr, M, fs->m_rep, s);
+  launch_rep(fs->m_corr, M, fs->m_rep, s, multi ? fs->m_img : nullptr);
   MH_HIP(ctx, hipMemcpyAsync(fs->model_off, model_off, (size_t)(n_models + 1) * 4, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->obj_model, obj_model, (size_t)n_obj * 4, hipMemcpyHostToDevice, s));
   MH_HIP(ctx, hipMemcpyAsync(fs->obj_pose, obj_pose, (size_t)n_obj * 28, hipMemcpyHostToDevice, s));
@@ -856,6 +965,11 @@ int mh_filter(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* model_off, i
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, n_obj);
   FilterBuffers fb = make_fb(ctx, fs, n_models);
   fb.max_objects = n_obj;  // grid size; arrays are at least this large
+  if (multi) {
+    fb.m_img = fs->m_img;
+    fb.cams = ctx->cams_dev;
+    fb.n_images = n_images;
+  }
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
                 fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0}, s);
   MH_HIP(ctx, hipGetLastError());

@@ -84,6 +84,11 @@ struct mh_ctx {
   int exchange_plane = 0;             // words between the idx / d1 / d2 planes of one shard's block (0 = Q)
   int exchange_stride = 0;            // words between the shards' blocks of the gathered exchange buffer (0 = 3 Q)
 
+  // frames with several images (mh_frame_set_images): image of every query + the cameras; n_images == 1 = off
+  const int32_t* q_img = nullptr;     // device, [Q]
+  mh::DevCam* cams_dev = nullptr;     // device, [MH_MAX_IMAGES]
+  int n_images = 1;
+
   // optional depth attributes of the current queries (moped3d residuals)
   const mh_depth* q_depth = nullptr;
   int depth_kind = 0;

@@ -41,8 +41,16 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
   __shared__ double term_s[FT];
   __shared__ float score_s;
   __shared__ int cnt_s, kept_s;
+  __shared__ DevCam cams_s[MH_MAX_IMAGES];   // several images: every match is projected through its own image's camera
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_slots = *n_slots_dev;
+  const bool multi = fb.m_img != nullptr;
+  if (multi) {
+    for (int i = tid; i < fb.n_images * (int)(sizeof(DevCam) / 4); i += FT)
+      reinterpret_cast<float*>(cams_s)[i] = reinterpret_cast<const float*>(fb.cams)[i];
+    __syncthreads();
+  }
+  auto cam_of = [&](int match) -> const DevCam& { return multi ? cams_s[fb.m_img[match]] : cam; };
   // ---- F1 ----
   for (int o = blockIdx.x; o < n_slots; o += gridDim.x) {
     __syncthreads();
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
       float e = __builtin_inff();
       if (i < n) {
         const mh_corr c = fb.corr[b + i];
-        e = reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v);
+        e = reproj_err2(T.r, T.t, cam_of(b + i), c.x, c.y, c.z, c.u, c.v);
       }
       // score += 1./(err+1.) over the in-cluster matches, in list order: the quotients in parallel, the
       // Float += double chain by one thread (adding 0. leaves a float unchanged)
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(FT) void filter_kernel(FilterBuffers fb, DevCam cam
     const unsigned long long key = pack_best(score, o);
     for (int i = tid; i < n; i += FT) {
       const mh_corr c = fb.corr[b + i];
-      if (reproj_err2(T.r, T.t, cam, c.x, c.y, c.z, c.u, c.v) < feature_distance)
+      if (reproj_err2(T.r, T.t, cam_of(b + i), c.x, c.y, c.z, c.u, c.v) < feature_distance)
         atomicMax(&fb.best[fb.m_rep[b + i]], key);
     }
   }

@@ -369,13 +369,65 @@ extern "C" int mh_debug_group_prof(unsigned long long out[8], int reset) {
 namespace {
 #endif
 // m_rep for caller-provided match lists (per-step FILTER entry point).
-__global__ void rep_kernel(const mh_corr* __restrict__ corr, int M, int32_t* __restrict__ rep_out) {
+// See launch_image_split (steps.h).  One workgroup; frames with several images are the exception, the work is
+// O(matches x matches-of-a-model) and nothing here is tuned.
+__global__ __launch_bounds__(GROUP_THREADS) void image_split_kernel(
+    const mh_corr* __restrict__ m_corr, const int32_t* __restrict__ m_q, const int32_t* __restrict__ m_model,
+    const int32_t* __restrict__ model_off, int n_models, const int32_t* __restrict__ q_img, int n_images,
+    const FrameCounts* __restrict__ counts, int32_t* __restrict__ m_img, int32_t* __restrict__ m_rep,
+    mh_corr* __restrict__ mi_corr, int32_t* __restrict__ mi_img, int32_t* __restrict__ off2) {
+  const int tid = threadIdx.x;
+  const int M = counts->n_matches;
+  for (int i = tid; i < M; i += GROUP_THREADS) {
+    int im = q_img[m_q[i]];
+    im = im < 0 ? 0 : (im >= n_images ? n_images - 1 : im);
+    m_img[i] = im;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // representative of every (coord2D, image)
+  for (int i = tid; i < M; i += GROUP_THREADS) {
+    const float u = m_corr[i].u, v = m_corr[i].v;
+    const int im = m_img[i];
+    int rep = i;
+    for (int j = 0; j < i; ++j)
+      if (m_corr[j].u == u && m_corr[j].v == v && m_img[j] == im) {
+        rep = j;
+        break;
+      }
+    m_rep[i] = rep;
+  }
+  // first row of every (model, image) set
+  for (int vm = tid; vm <= n_models * n_images; vm += GROUP_THREADS) {
+    if (vm == n_models * n_images) {
+      off2[vm] = M;
+      continue;
+    }
+    const int m = vm / n_images, im = vm % n_images;
+    const int b = model_off[m], e = model_off[m + 1];
+    int before = 0;
+    for (int j = b; j < e; ++j) before += m_img[j] < im;
+    off2[vm] = b + before;
+  }
+  // stable placement inside the model's slice: by image, then in list (= query) order
+  for (int i = tid; i < M; i += GROUP_THREADS) {
+    const int m = m_model[i], im = m_img[i];
+    const int b = model_off[m], e = model_off[m + 1];
+    int dst = b;
+    for (int j = b; j < e; ++j) dst += (m_img[j] < im) || (m_img[j] == im && j < i);
+    mi_corr[dst] = m_corr[i];
+    mi_img[dst] = im;
+  }
+}
+
+__global__ void rep_kernel(const mh_corr* __restrict__ corr, const int32_t* __restrict__ img, int M,
+                           int32_t* __restrict__ rep_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const float u = corr[i].u, v = corr[i].v;
   int rep = i;
   for (int j = 0; j < i; ++j)
-    if (corr[j].u == u && corr[j].v == v) {
+    if (corr[j].u == u && corr[j].v == v && (!img || img[j] == img[i])) {
       rep = j;
       break;
     }
@@ -404,9 +456,16 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                      shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q);
 }
 
-void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s) {
+void launch_image_split(const mh_corr* m_corr, const int32_t* m_q, const int32_t* m_model, const int32_t* model_off,
+                        int n_models, const int32_t* q_img, int n_images, const FrameCounts* counts, int32_t* m_img,
+                        int32_t* m_rep, mh_corr* mi_corr, int32_t* mi_img, int32_t* off2, hipStream_t s) {
+  hipLaunchKernelGGL(image_split_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, m_corr, m_q, m_model, model_off, n_models,
+                     q_img, n_images, counts, m_img, m_rep, mi_corr, mi_img, off2);
+}
+
+void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s, const int32_t* img) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(rep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, corr, M, rep);
+  hipLaunchKernelGGL(rep_kernel, dim3((M + 255) / 256), dim3(256), 0, s, corr, img, M, rep);
 }
 
 }  // namespace mh

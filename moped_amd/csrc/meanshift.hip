@@ -752,7 +752,9 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
     float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start, int32_t* ncl,
     int max_clusters, int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
     int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out, int32_t* __restrict__ snap,
-    FrameCounts* counts, unsigned int* ticket) {
+    FrameCounts* counts, unsigned int* ticket, int models_div) {
+  // models_div > 1: the "models" are (model, image) pairs in (model, image) order -- MeanShift runs per image
+  // (CLUSTER_MEAN_SHIFT_CPU.hpp:194-195) -- and the cluster table names the real model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MsLds<2>& L = *reinterpret_cast<MsLds<2>*>(smem);
   const int m = blockIdx.x;
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
         atomicOr(&counts->error, ERR_CLUSTER_CAP);
         break;
       }
-      cl_model[k] = mm;
+      cl_model[k] = mm / models_div;
       cl_begin[k] = bb + st[c];
       cl_count[k] = st[c + 1] - st[c];
       ++k;
@@ -853,13 +855,14 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s) {
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div) {
   static DynLds attr;
   attr.ensure(meanshift_models_kernel, sizeof(MsLds<2>));
   // an empty database still gets one workgroup: it publishes "0 clusters"
   hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
-                     max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket);
+                     max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket,
+                     models_div > 0 ? models_div : 1);
 }
 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,

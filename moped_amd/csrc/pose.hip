@@ -283,7 +283,15 @@ __device__ void rot_to_quat(const float* r, float* q) {
 // reference's squared errors so the result sits at the minimiser levmar converges to.
 // A point is pts[PS*i ..] = u,v, x,y,z [, wx,wy,wz, cauchyWeight].
 constexpr int MAX_ROWS = 4;
-template <int KIND> struct PointStride { static constexpr int value = (KIND == 0) ? 5 : 9; };
+// KIND 3 = KIND 0's residuals with every correspondence in its own image (several cameras): a point carries
+// its image number behind x,y,z and every projection goes through that image's camera (LmData::image,
+// …REPROJECTION_CPU.hpp:213-237).
+template <int KIND> struct PointStride { static constexpr int value = (KIND == 0) ? 5 : ((KIND == 3) ? 6 : 9); };
+// the camera of a point: `cams` is ONE camera for KIND 0..2, the frame's camera table for KIND 3
+template <int KIND>
+__device__ __forceinline__ const DevCam& cam_of(const DevCam* cams, const float* p) {
+  return KIND == 3 ? cams[__float_as_int(p[5])] : cams[0];
+}
 
 struct Accum {
   float H[21];  // upper triangle of J^T J
@@ -319,10 +327,10 @@ __device__ __forceinline__ int residual_rows(const float* R, const float* t, con
   c[0] = wx * cam.Rc[0] + wy * cam.Rc[3] + wz * cam.Rc[6];
   c[1] = wx * cam.Rc[1] + wy * cam.Rc[4] + wz * cam.Rc[7];
   c[2] = wx * cam.Rc[2] + wy * cam.Rc[5] + wz * cam.Rc[8];
-  constexpr int NR = (KIND == 0) ? 2 : ((KIND == 1) ? 4 : 3);      // rows in phase 0
+  constexpr int NR = (KIND == 0 || KIND == 3) ? 2 : ((KIND == 1) ? 4 : 3);      // rows in phase 0
   const int nrows = (phase == 0) ? NR : ((KIND == 2) ? 3 : 2);   // the reference's row count in phase 1
   float w3 = 0.f, w2 = 1.f;
-  if (KIND != 0) {
+  if (KIND == 1 || KIND == 2) {
     w3 = (1.f - alpha) * p[8];
     w2 = 1.f - w3;
   }
@@ -338,7 +346,7 @@ __device__ __forceinline__ int residual_rows(const float* R, const float* t, con
     }
     return nrows;
   }
-  if (KIND == 0 || KIND == 2) {
+  if (KIND == 0 || KIND == 2 || KIND == 3) {
     const float iz = 1.f / c[2];
     const float du = c[0] * iz * cam.K[0] + cam.K[2] - p[0];
     const float dv = c[1] * iz * cam.K[1] + cam.K[3] - p[1];
@@ -441,13 +449,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Sum of squared residuals over the inlier list at pose (R,t); all 64 lanes return it.
 template <int KIND>
-__device__ float lm_cost(const float* R, const float* t, const DevCam& cam, const float* pts,
+__device__ float lm_cost(const float* R, const float* t, const DevCam* cams, const float* pts,
                          const int* list, int n, float alpha, int phase, int lane) {
   constexpr int PS = PointStride<KIND>::value;
   float c = 0.f;
   for (int i = lane; i < n; i += 64) {
     float r[MAX_ROWS];
-    const int nr = residual_rows<KIND>(R, t, cam, pts + PS * list[i], alpha, phase, r, nullptr, false);
+    const float* p = pts + PS * list[i];
+    const int nr = residual_rows<KIND>(R, t, cam_of<KIND>(cams, p), p, alpha, phase, r, nullptr, false);
     for (int a = 0; a < nr; ++a) c += r[a] * r[a];
   }
   return wave_sum(c);
@@ -519,10 +528,10 @@ __device__ bool solve6(const float* Hp, const float* g, float mu, float* x) {
 
 // Runs on one full wavefront; pose in/out is wave-uniform.
 template <int KIND>
-__device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* pts, const int* list,
+__device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* pts, const int* list,
                            int n, float alpha, int phase, int iters, int lane) {
   constexpr int PS = PointStride<KIND>::value;
-  float cost = lm_cost<KIND>(R, t, cam, pts, list, n, alpha, phase, lane);
+  float cost = lm_cost<KIND>(R, t, cams, pts, list, n, alpha, phase, lane);
   float mu = -1.f, nu = 2.f;
   for (int it = 0; it < iters; ++it) {
     Accum acc;
@@ -530,7 +539,8 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
     for (int i = 0; i < 6; ++i) acc.g[i] = 0.f;
     for (int i = lane; i < n; i += 64) {
       float r[MAX_ROWS], J[MAX_ROWS][6];
-      const int nr = residual_rows<KIND>(R, t, cam, pts + PS * list[i], alpha, phase, r, J, true);
+      const float* p = pts + PS * list[i];
+      const int nr = residual_rows<KIND>(R, t, cam_of<KIND>(cams, p), p, alpha, phase, r, J, true);
       for (int row = 0; row < nr; ++row) {
         int k = 0;
         for (int a = 0; a < 6; ++a) {
@@ -557,7 +567,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam& cam, const float* p
         float Rn[9], tn[3];
         rotate_left(dx, R, Rn);
         for (int i = 0; i < 3; ++i) tn[i] = t[i] + dx[3 + i];
-        const float c2 = lm_cost<KIND>(Rn, tn, cam, pts, list, n, alpha, phase, lane);
+        const float c2 = lm_cost<KIND>(Rn, tn, cams, pts, list, n, alpha, phase, lane);
         float dL = 0.f;
         for (int i = 0; i < 6; ++i) dL += dx[i] * (mu * dx[i] - acc.g[i]);
         const float dF = cost - c2;
@@ -597,6 +607,7 @@ struct PoseLds {
   float best_pose[12];
   int n_distinct;
   int n_inl;
+  DevCam cams[MH_MAX_IMAGES];       // KIND 3: the frame's cameras
 };
 
 // One (cluster, replica) task, executed by a whole workgroup.  Every early exit is
@@ -607,7 +618,8 @@ __device__ void pose_task(
     const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
     const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
-    const int32_t* __restrict__ cl_count, const DevCam& cam,
+    const int32_t* __restrict__ cl_count, const DevCam& cam1, const DevCam* __restrict__ cam_table,
+    const int32_t* __restrict__ img_of, int n_images,
     const mh_pose_params& prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
     const int obj_base, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
@@ -631,6 +643,13 @@ __device__ void pose_task(
     if (tid == 0) atomicOr(&counts->error, ERR_POSE_CAP);
     k = POSE_MAX_PTS;
   }
+  // the camera(s): one (KIND 0..2) or the frame's table in LDS (KIND 3)
+  const DevCam* cams = &cam1;
+  if (KIND == 3) {
+    for (int i = tid; i < n_images * (int)(sizeof(DevCam) / 4); i += POSE_THREADS)
+      reinterpret_cast<float*>(L.cams)[i] = reinterpret_cast<const float*>(cam_table)[i];
+    cams = L.cams;
+  }
   for (int i = tid; i < k; i += POSE_THREADS) {
     const int mi = members[begin + i];
     const mh_corr c = corr[mi];
@@ -640,7 +659,8 @@ __device__ void pose_task(
     p[2] = c.x;
     p[3] = c.y;
     p[4] = c.z;
-    if (KIND != 0) {
+    if (KIND == 3) p[5] = __int_as_float(img_of[mi]);
+    if (KIND == 1 || KIND == 2) {
       const float4 d = depth[mi];
       p[5] = d.x;
       p[6] = d.y;
@@ -665,7 +685,9 @@ __device__ void pose_task(
       const int i = w / per, part = w - i * per;
       const float ui = L.pts[PS * i], vi = L.pts[PS * i + 1];
       bool dup = false;
-      for (int j = part; j < i; j += per) dup |= (L.pts[PS * j] == ui) & (L.pts[PS * j + 1] == vi);
+      for (int j = part; j < i; j += per)
+        dup |= (L.pts[PS * j] == ui) & (L.pts[PS * j + 1] == vi) &
+               (KIND != 3 || __float_as_int(L.pts[PS * j + 5]) == __float_as_int(L.pts[PS * i + 5]));
       if (dup) L.list[i] = 1;
     }
     __syncthreads();
@@ -705,7 +727,10 @@ __device__ void pose_task(
     splitmix64(st);
     // 4 correspondences with pairwise distinct image coordinates (:76-98)
     int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
+    // (several cameras: P3P needs its three points and the one that picks the root in ONE image -- the
+    // image of the first draw; a candidate from another image counts like a repeated coordinate)
     auto same_uv = [&](int a, int b) {
+      if (KIND == 3 && __float_as_int(L.pts[PS * a + 5]) != __float_as_int(L.pts[PS * b + 5])) return true;
       return L.pts[PS * a] == L.pts[PS * b] && L.pts[PS * a + 1] == L.pts[PS * b + 1];
     };
     i0 = (int)(splitmix64(st) % (uint64_t)k);
@@ -725,6 +750,7 @@ __device__ void pose_task(
     }
     if (i3 < 0) return;
     double X[3][3], y[3][3];
+    const DevCam& cam = cam_of<KIND>(cams, L.pts + PS * i0);   // the sample's camera
     auto load = [&](int s, int pi) {
       const float* p = L.pts + PS * pi;
       X[s][0] = p[2];
@@ -757,7 +783,7 @@ __device__ void pose_task(
     int cnt = 0;
     for (int i = 0; i < k; ++i) {
       const float* p = L.pts + PS * i;
-      cnt += reproj_err2(cand.r, cand.t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
+      cnt += reproj_err2(cand.r, cand.t, cam_of<KIND>(cams, p), p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
     }
     const unsigned long long key = ((unsigned long long)cnt << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)h);
     if (key > best_key) {
@@ -826,7 +852,7 @@ __device__ void pose_task(
     bool in = false;
     if (i < k) {
       const float* p = L.pts + PS * i;
-      in = reproj_err2(R, t, cam, p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
+      in = reproj_err2(R, t, cam_of<KIND>(cams, p), p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
     }
     const unsigned long long m = __ballot(in);
     if (in) L.list[n_inl + __popcll(m & ((1ull << lane) - 1ull))] = i;
@@ -834,9 +860,9 @@ __device__ void pose_task(
   }
   __builtin_amdgcn_wave_barrier();
   PP_T(3);
-  lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 0, prm.lm_iters_l2, lane);
+  lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, prm.lm_iters_l2, lane);
   PP_T(4);
-  const float err = lm_refine<KIND>(R, t, cam, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
+  const float err = lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
   PP_T(5);
   if (lane == 0) {
     float q[4];
@@ -868,6 +894,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
     const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
+    const DevCam* __restrict__ cam_table, const int32_t* __restrict__ img_of, int n_images,
     mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
     const int32_t* obj_base_dev, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
@@ -881,7 +908,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
   const int obj_base = obj_base_dev ? *obj_base_dev : 0;
   for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     pose_task<KIND>(L, task / R_, task % R_, corr, depth, alpha, members, cl_model, cl_begin, cl_count, cam,
-                    prm, seed, seed_dev, obj_base, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
+                    cam_table, img_of, n_images, prm, seed, seed_dev, obj_base, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
                     obj_cluster, obj_valid, counts);
     __syncthreads();  // LDS is reused by the next task
   }
@@ -940,6 +967,7 @@ template <int KIND>
 static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alpha, const int32_t* members,
                              const int32_t* cl_model, const int32_t* cl_begin, const int32_t* cl_count,
                              const int32_t* n_clusters_dev, int max_clusters, const DevCam& cam,
+                             const DevCam* cam_table, const int32_t* img_of, int n_images,
                              const mh_pose_params& p, uint64_t seed, const uint64_t* seed_dev,
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
@@ -950,7 +978,8 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
   hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster))), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
-                     n_clusters_dev, cam, p, seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl,
+                     n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, seed_dev, obj_base_dev, max_objects, obj_model,
+                     obj_pose, obj_ninl,
                      obj_err, obj_cluster, obj_valid, counts, tail);
 }
 
@@ -960,17 +989,21 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
                  const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
-                 int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s) {
+                 int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s,
+                 const PoseImages& images) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
   const float4* d4 = reinterpret_cast<const float4*>(depth4);
   const int kind = depth4 ? depth_kind : 0;
-#define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, p, \
+#define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, \
+                  images.cams, images.img_of, images.n_images, p,                                       \
                   seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
                   obj_valid, counts, tail, s
-  if (kind == 1)
+  if (images.img_of && images.cams && kind == 0)
+    launch_pose_kind<3>(POSE_ARGS);
+  else if (kind == 1)
     launch_pose_kind<1>(POSE_ARGS);
   else if (kind == 2)
     launch_pose_kind<2>(POSE_ARGS);

@@ -83,7 +83,7 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
                   const DepthRules& rules = DepthRules(), int shard_stride = 0 /* words between shard blocks; 0 = 3 Q */,
                   int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */);
-void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s);
+void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s, const int32_t* img = nullptr);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);
 
@@ -95,7 +95,14 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s);
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1);
+// Frames with several images, between group and CLUSTER: m_img[i] = image of match i; m_rep redone with the
+// image in the key (FILTER's bestPoints map is keyed by (coord2D, image), FILTER_PROJECTION_CPU.hpp:89); and the
+// matches once more in (model, image, query) order -- mi_corr / mi_img, off2[n_models * n_images + 1] -- the point
+// sets CLUSTER_MEAN_SHIFT_CPU::process hands to MeanShift image by image (:189-195).
+void launch_image_split(const mh_corr* m_corr, const int32_t* m_q, const int32_t* m_model, const int32_t* model_off,
+                        int n_models, const int32_t* q_img, int n_images, const FrameCounts* counts, int32_t* m_img,
+                        int32_t* m_rep, mh_corr* mi_corr, int32_t* mi_img, int32_t* off2, hipStream_t s);
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,
                              int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                              int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s);
@@ -132,6 +139,13 @@ struct DevCam {
   float tc[3];
 };
 DevCam make_devcam(const mh_cam& cam);
+// Frames with several images: a device table of the cameras and, aligned with the correspondence array a
+// kernel works on, the image of every correspondence.  img_of == nullptr: one camera (the DevCam argument).
+struct PoseImages {
+  const DevCam* cams = nullptr;
+  const int32_t* img_of = nullptr;
+  int n_images = 1;
+};
 
 // Work of the last workgroup of a POSE launch inside a frame (ticket == nullptr: none):
 // *n_slots = min(max_objects, *obj_base_dev + n_clusters * R); optionally the number of
@@ -154,7 +168,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const uint64_t* seed_dev /* optional: XORed into seed, read on the device */,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
-                 FrameCounts* counts, const PoseTail& tail, hipStream_t s);
+                 FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages());
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
                          float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
                          hipStream_t s);
@@ -163,7 +177,10 @@ void launch_project_test(const float* pose7, const mh_corr* corr, int n, const D
 struct FilterBuffers {
   // inputs
   const mh_corr* corr;        // matches in (model, query) order
-  const int32_t* m_rep;       // first match with the same (u,v)
+  const int32_t* m_rep;       // first match with the same (u,v) [and image]
+  const int32_t* m_img;       // image of every match, nullptr = one image
+  const DevCam* cams;         // device table of the frame's cameras (m_img != nullptr)
+  int n_images;
   const int32_t* model_off;
   int n_models;
   int max_m;

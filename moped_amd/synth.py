@@ -160,6 +160,92 @@ def make_frame(db: ModelDB, n_vis: int = 2, seed: int = 0, Q: int = 3000,
                  src[perm], bad[perm])
 
 
+def camera_pose(rot_y: float = 0.0, t=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """cameraPose (qx,qy,qz,qw,tx,ty,tz) of a camera rotated by rot_y about the world's y axis at position t
+    (Image::cameraPose maps camera coordinates to world coordinates, include/moped.hpp:226-241)."""
+    return np.array([0.0, np.sin(rot_y / 2), 0.0, np.cos(rot_y / 2), t[0], t[1], t[2]], np.float32)
+
+
+def project_cam_np(pose7, xyz, K, cam):
+    """float64 projection of model points at world pose `pose7` through the camera with cameraPose `cam`."""
+    R = quat_to_R(pose7[:4])
+    pw = xyz.astype(np.float64) @ R.T + np.asarray(pose7[4:7], np.float64)
+    Rc = quat_to_R(cam[:4])
+    pc = (pw - np.asarray(cam[4:7], np.float64)) @ Rc          # TM^-1: Rc^T (p - tc)
+    u = pc[:, 0] / pc[:, 2] * float(K[0]) + float(K[2])
+    v = pc[:, 1] / pc[:, 2] * float(K[1]) + float(K[3])
+    return np.stack([u, v], axis=1), pc[:, 2]
+
+
+@dataclass
+class FrameImages:
+    desc: np.ndarray        # [Q,128]
+    uv: np.ndarray          # [Q,2]
+    image: np.ndarray       # [Q] int32 image (camera) of every feature
+    visible: np.ndarray
+    poses: np.ndarray       # [n_vis,7] planted WORLD poses
+    src_point: np.ndarray   # [Q] DB row of a planted feature, -1 = clutter
+    is_outlier: np.ndarray
+    Ks: np.ndarray          # [n_images,4]
+    cams: np.ndarray        # [n_images,7]
+
+
+def make_frame_images(db: ModelDB, cams, n_vis: int = 2, seed: int = 0, q_per_image: int = 1200,
+                      pts_per_obj: int = 120, outlier_frac: float = 0.2, pix_noise: float = 0.5, K=K_DEFAULT,
+                      base: np.ndarray | None = None) -> FrameImages:
+    """One frame seen by several cameras (FrameData::images): every planted object is rendered into every image
+    (its own random subset of the model's points), clutter per image; the features of image 0 come first, then
+    image 1, ..., each image's features shuffled among themselves (as FEAT extracts image by image)."""
+    if base is None:
+        base, _, _ = load_sift_fixture()
+    cams = np.asarray(cams, np.float32).reshape(-1, 7)
+    rng = np.random.default_rng([0x1A6E5, seed])
+    visible = rng.choice(db.n_models, size=min(n_vis, db.n_models), replace=False).astype(np.int32)
+    poses = []
+    per_image = [([], [], [], []) for _ in cams]     # desc, uv, src, outlier
+    for m in visible:
+        rows = np.nonzero(db.model_of == m)[0]
+        for _ in range(200):
+            q = random_quat(rng)
+            z = rng.uniform(0.6, 0.9)
+            u0, v0 = rng.uniform(200, IMG_W - 200), rng.uniform(160, IMG_H - 160)
+            pose = np.concatenate([q, [(u0 - K[2]) / K[0] * z, (v0 - K[3]) / K[1] * z, z]]).astype(np.float32)
+            oks = []
+            for c in cams:
+                uv_all, zc = project_cam_np(pose, db.xyz[rows], K, c)
+                oks.append((uv_all, (zc > 0.05) & (uv_all[:, 0] >= 0) & (uv_all[:, 0] < IMG_W) &
+                            (uv_all[:, 1] >= 0) & (uv_all[:, 1] < IMG_H)))
+            if all(ok.sum() >= pts_per_obj for _, ok in oks):
+                break
+        poses.append(pose)
+        for ci, (uv_all, ok) in enumerate(oks):
+            sel = rng.choice(np.nonzero(ok)[0], size=pts_per_obj, replace=False)
+            uv = uv_all[sel] + rng.uniform(-pix_noise, pix_noise, size=(pts_per_obj, 2))
+            bad = rng.random(pts_per_obj) < outlier_frac
+            uv[bad] = rng.uniform([0, 0], [IMG_W, IMG_H], size=(int(bad.sum()), 2))
+            d = db.desc[rows[sel]] + rng.normal(0, 0.01, size=(pts_per_obj, 128)).astype(np.float32)
+            per_image[ci][0].append(l2_normalize(np.maximum(d, 0).astype(np.float32)))
+            per_image[ci][1].append(uv.astype(np.float32))
+            per_image[ci][2].append(rows[sel].astype(np.int32))
+            per_image[ci][3].append(bad)
+    descs, uvs, imgs, srcs, outl = [], [], [], [], []
+    for ci in range(len(cams)):
+        n_planted = sum(len(x) for x in per_image[ci][2])
+        n_clutter = max(q_per_image - n_planted, 0)
+        pick = rng.integers(0, base.shape[0], size=n_clutter)
+        d = np.concatenate(per_image[ci][0] + [base[pick]])
+        uv = np.concatenate(per_image[ci][1] + [rng.uniform([0, 0], [IMG_W, IMG_H], size=(n_clutter, 2)).astype(np.float32)])
+        src = np.concatenate(per_image[ci][2] + [np.full(n_clutter, -1, np.int32)])
+        bad = np.concatenate(per_image[ci][3] + [np.zeros(n_clutter, bool)])
+        perm = rng.permutation(len(d))
+        descs.append(d[perm]); uvs.append(uv[perm]); srcs.append(src[perm]); outl.append(bad[perm])
+        imgs.append(np.full(len(d), ci, np.int32))
+    return FrameImages(np.ascontiguousarray(np.concatenate(descs), np.float32),
+                       np.ascontiguousarray(np.concatenate(uvs), np.float32), np.concatenate(imgs), visible,
+                       np.asarray(poses, np.float32).reshape(-1, 7), np.concatenate(srcs), np.concatenate(outl),
+                       np.tile(np.asarray(K, np.float32), (len(cams), 1)), cams)
+
+
 def frame_depth(db: ModelDB, frame: Frame, seed: int = 0, K=K_DEFAULT, fill_max: float = 0.02):
     """Per-query depth attributes for the moped3d (Kinect) configuration: the camera-frame
     point the depth map holds at each keypoint (planted inliers: the true point with

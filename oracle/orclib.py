@@ -275,6 +275,84 @@ def filter_projection(uv, xyz, model_off, obj_model, obj_pose, K, cam, min_point
     return score[:n_obj], keep[:n_obj].astype(bool), order[:k].copy(), clusters
 
 
+def _cams(Ks, cams):
+    Ks = _c(np.asarray(Ks, np.float32).reshape(-1, 4), np.float32)
+    cams = _c(np.asarray(cams, np.float32).reshape(-1, 7), np.float32)
+    return Ks, cams, Ks.shape[0]
+
+
+def ransac_images(uv, xyz, img, Ks, cams, params=POSE1, seed=None):
+    """orc_ransac with every correspondence in its own image."""
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    Ks, cams, n = _cams(Ks, cams)
+    pose = np.zeros(7, np.float32)
+    pp = PoseParams(**params)
+    L = lib()
+    L.orc_ransac_images.restype = C.c_int
+    L.orc_ransac_images.argtypes = [_f32p, _f32p, _i32p, C.c_int, _f32p, _f32p, C.c_int, C.c_void_p, _f32p]
+    ok = L.orc_ransac_images(_c(uv, np.float32).reshape(-1), _c(xyz, np.float32).reshape(-1), _c(img, np.int32),
+                             len(uv), Ks.reshape(-1), cams.reshape(-1), n, C.addressof(pp), pose)
+    return bool(ok), pose
+
+
+def project_images(pose7, xyz, img, Ks, cams):
+    """project() of every point through its own image's camera."""
+    Ks, cams, n = _cams(Ks, cams)
+    out = np.zeros((len(xyz), 2), np.float32)
+    img = np.asarray(img, np.int32)
+    for i in range(n):
+        sel = img == i
+        if sel.any():
+            out[sel] = project(pose7, np.asarray(xyz, np.float32)[sel], Ks[i], cams[i])
+    return out
+
+
+def filter_images(uv, img, xyz, model_off, obj_model, obj_pose, Ks, cams, min_points, feature_distance, min_score):
+    Ks, cams, n = _cams(Ks, cams)
+    n_obj = len(obj_model)
+    M = len(uv)
+    score = np.zeros(max(n_obj, 1), np.float32)
+    keep = np.zeros(max(n_obj, 1), np.uint8)
+    order = np.zeros(max(n_obj, 1), np.int32)
+    members = np.zeros(max(M, 1), np.int32)
+    off = np.zeros(n_obj + 2, np.int32)
+    L = lib()
+    L.orc_filter_images.restype = C.c_int
+    L.orc_filter_images.argtypes = [_f32p, _i32p, _f32p, _i32p, C.c_int, _i32p, _f32p, C.c_int, _f32p, _f32p, C.c_int,
+                                    C.c_int, C.c_float, C.c_float, _f32p, C.c_void_p, _i32p, _i32p, _i32p]
+    kept = L.orc_filter_images(_c(uv, np.float32).reshape(-1), _c(img, np.int32), _c(xyz, np.float32).reshape(-1),
+                               _c(model_off, np.int32), len(model_off) - 1, _c(obj_model, np.int32),
+                               _c(obj_pose, np.float32).reshape(-1), n_obj, Ks.reshape(-1), cams.reshape(-1), n,
+                               min_points, feature_distance, min_score, score, keep.ctypes.data, order, members, off)
+    clusters = [members[off[i]:off[i + 1]].copy() for i in range(kept)]
+    return score[:n_obj], keep[:n_obj].astype(bool), order[:kept].copy(), clusters
+
+
+def frame_rest_images(q_uv, q_img, idx1, d1, d2, model_of, db_xyz, n_models, Ks, cams, params=None, seed=None,
+                      max_obj=4096):
+    """CPU frame after the NN search for a frame with several images -> (models, poses, scores, counts[4])."""
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    fp = params or default_frame_params()
+    Ks, cams, n = _cams(Ks, cams)
+    om = np.zeros(max_obj, np.int32)
+    op = np.zeros(max_obj * 7, np.float32)
+    osc = np.zeros(max_obj, np.float32)
+    counts = np.zeros(4, np.int32)
+    q_uv = _c(q_uv, np.float32)
+    L = lib()
+    L.orc_frame_rest_images.restype = C.c_int
+    L.orc_frame_rest_images.argtypes = [_f32p, _i32p, _i32p, _f32p, _f32p, C.c_int, C.c_float, _i32p, _f32p, C.c_int,
+                                        _f32p, _f32p, C.c_int, C.c_void_p, _i32p, _f32p, _f32p, C.c_int, _i32p]
+    k = L.orc_frame_rest_images(q_uv.reshape(-1), _c(q_img, np.int32), _c(idx1, np.int32), _c(d1, np.float32),
+                                _c(d2, np.float32), q_uv.shape[0], fp.ratio, _c(model_of, np.int32),
+                                _c(db_xyz, np.float32).reshape(-1), n_models, Ks.reshape(-1), cams.reshape(-1), n,
+                                C.addressof(fp), om, op, osc, max_obj, counts)
+    k = min(k, max_obj)
+    return om[:k].copy(), op[:7 * k].reshape(k, 7).copy(), osc[:k].copy(), counts
+
+
 def default_frame_params(run_stage2=True):
     """The shipped constants of moped2/libmoped/src/config.hpp:83-120."""
     return FrameParams(0.8, 200.0, 20.0, 7, 100, PoseParams(**POSE1), 5, 4096.0, 2.0,
