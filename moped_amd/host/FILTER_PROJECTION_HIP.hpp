@@ -4,8 +4,9 @@
 //     pipeline.addAlg( "FILTER2", new FILTER_PROJECTION_HIP( 7, 4096., 3 ) );
 // Scores every object, gives each keypoint to the best-scoring object, erases
 // objects with too few points / too low a score and rewrites frameData.clusters
-// (:80-162).  Single-image frames (every shipped moped2 driver); with more images
-// the step leaves the frame untouched.
+// (:80-162).  Every match is projected through the image it came from and the ownership map is keyed by
+// (coord2D, image) (:100-141), whatever else FrameData::images holds (a moped3d frame lists its depth and
+// distance maps there too; moped3d wires this same step, moped3d/libmoped/src/config.hpp:48,50).
 #pragma once
 #include "hip_session.hpp"
 
@@ -36,9 +37,11 @@ class FILTER_PROJECTION_HIP : public MopedAlg {
   void process(FrameData& frameData) {
     vector<vector<FrameData::Match> >& matches = frameData.matches;
     if (matches.size() < models->size()) return;  // the reference's sanity check (:85-87)
-    if (frameData.images.size() != 1) return;
     const int nm = (int)models->size();
+    const HipCameraTable table(frameData);
+    if (!table.ok) return;
     vector<mh_corr> corr;
+    vector<int32_t> imageOf;
     vector<int32_t> off(nm + 1, 0);
     for (int m = 0; m < nm; ++m) {
       for (size_t k = 0; k < matches[m].size(); ++k) {
@@ -46,6 +49,7 @@ class FILTER_PROJECTION_HIP : public MopedAlg {
         c.u = matches[m][k].coord2D[0]; c.v = matches[m][k].coord2D[1];
         c.x = matches[m][k].coord3D[0]; c.y = matches[m][k].coord3D[1]; c.z = matches[m][k].coord3D[2];
         corr.push_back(c);
+        imageOf.push_back(table.local[matches[m][k].imageIdx]);
       }
       off[m + 1] = (int32_t)corr.size();
     }
@@ -65,20 +69,22 @@ class FILTER_PROJECTION_HIP : public MopedAlg {
     frameData.clusters.clear();
     frameData.clusters.resize(nm);
     if (nobj == 0) return;
-    const Image& im = *frameData.images[0];
-    mh_cam cam;
-    for (int i = 0; i < 4; ++i) cam.K[i] = im.intrinsicLinearCalibration[i];
-    for (int i = 0; i < 4; ++i) cam.cam[i] = im.cameraPose.rotation[i];
-    for (int i = 0; i < 3; ++i) cam.cam[4 + i] = im.cameraPose.translation[i];
+    if (corr.empty()) {  // no match anywhere: every object scores 0 and goes (:143-160 with empty newClusters)
+      for (int o = 0; o < nobj; ++o) {
+        (*its[o])->score = 0;
+        if (MinPoints > 0 || MinScore > 0) frameData.objects->erase(its[o]);
+        else frameData.clusters[objModel[o]].push_back(FrameData::Cluster());
+      }
+      return;
+    }
     vector<float> score(nobj);
     vector<uint8_t> keep(nobj);
     vector<int32_t> order(nobj), members(corr.size() + 1), cloff(nobj + 1);
     int32_t kept = 0;
-    mh_corr dummy;
-    if (mh_filter(HipSession::get(), corr.empty() ? &dummy : &corr[0], &off[0], nm, &objModel[0], &objPose[0], nobj,
-                  &cam, MinPoints, FeatureDistance, MinScore, &score[0], &keep[0], &order[0], &members[0],
-                  &cloff[0], &kept) != MH_OK) {
-      HipSession::warn("mh_filter");
+    if (mh_filter_images(HipSession::get(), &corr[0], &imageOf[0], &off[0], nm, &objModel[0], &objPose[0], nobj,
+                         &table.cams[0], (int)table.cams.size(), MinPoints, FeatureDistance, MinScore, &score[0],
+                         &keep[0], &order[0], &members[0], &cloff[0], &kept) != MH_OK) {
+      HipSession::warn("mh_filter_images");
       return;
     }
     for (int o = 0; o < nobj; ++o) (*its[o])->score = score[o];

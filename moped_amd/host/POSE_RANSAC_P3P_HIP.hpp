@@ -48,46 +48,47 @@ class POSE_RANSAC_P3P_HIP : public MopedAlg {
     prm.error_threshold = ErrorThreshold;
     prm.lm_iters_l2 = 10;
     prm.lm_iters_l4 = 10;
-    // a cluster lives in one image (MeanShift runs per image); one launch per image
-    for (int img = 0; img < (int)frameData.images.size(); ++img) {
+    // every cluster of the frame in ONE launch, in the reference's task order (model, cluster) (:275-303); each
+    // correspondence carries its own image (LmData::image, :228-237): CLUSTER's clusters live in one image,
+    // FILTER's (the input of POSE2) mix images
+    const HipCameraTable table(frameData);
+    if (table.ok) {
       vector<mh_corr> corr;
+      vector<int32_t> imageOf;
       vector<int32_t> off(1, 0);
       vector<int> clModel;
       for (int model = 0; model < (int)frameData.clusters.size(); ++model)
         for (int c = 0; c < (int)frameData.clusters[model].size(); ++c) {
           const FrameData::Cluster& cl = frameData.clusters[model][c];
-          if (cl.empty() || frameData.matches[model][cl.front()].imageIdx != img) continue;
+          if (cl.empty()) continue;
           for (FrameData::Cluster::const_iterator it = cl.begin(); it != cl.end(); ++it) {
             const FrameData::Match& m = frameData.matches[model][*it];
             mh_corr k;
             k.u = m.coord2D[0]; k.v = m.coord2D[1];
             k.x = m.coord3D[0]; k.y = m.coord3D[1]; k.z = m.coord3D[2];
             corr.push_back(k);
+            imageOf.push_back(table.local[m.imageIdx]);
           }
           off.push_back((int32_t)corr.size());
           clModel.push_back(model);
         }
       const int ncl = (int)clModel.size();
-      if (ncl == 0) continue;
-      const Image& im = *frameData.images[img];
-      mh_cam cam;
-      for (int i = 0; i < 4; ++i) cam.K[i] = im.intrinsicLinearCalibration[i];
-      for (int i = 0; i < 4; ++i) cam.cam[i] = im.cameraPose.rotation[i];
-      for (int i = 0; i < 3; ++i) cam.cam[4 + i] = im.cameraPose.translation[i];
-      vector<mh_pose_out> out((size_t)ncl * MaxObjectsPerCluster);
-      int32_t nout = 0;
-      if (mh_pose_ransac(ctx, &corr[0], &off[0], ncl, &cam, &prm, (uint64_t)frameCounter * 2654435761ul + _alg,
-                         &out[0], &nout) != MH_OK) {
-        HipSession::warn("mh_pose_ransac");
-        continue;
-      }
-      for (int o = 0; o < nout; ++o) {
-        SP_Object obj(new Object);
-        frameData.objects->push_back(obj);
-        obj->pose.rotation.init(out[o].pose[0], out[o].pose[1], out[o].pose[2], out[o].pose[3]);
-        obj->pose.translation.init(out[o].pose[4], out[o].pose[5], out[o].pose[6]);
-        obj->model = (*models)[clModel[out[o].cluster]];
-        obj->score = 0;
+      if (ncl > 0) {
+        vector<mh_pose_out> out((size_t)ncl * MaxObjectsPerCluster);
+        int32_t nout = 0;
+        if (mh_pose_ransac_images(ctx, &corr[0], &imageOf[0], &off[0], ncl, &table.cams[0], (int)table.cams.size(),
+                                  &prm, (uint64_t)frameCounter * 2654435761ul + _alg, &out[0], &nout) != MH_OK) {
+          HipSession::warn("mh_pose_ransac_images");
+          nout = 0;
+        }
+        for (int o = 0; o < nout; ++o) {
+          SP_Object obj(new Object);
+          frameData.objects->push_back(obj);
+          obj->pose.rotation.init(out[o].pose[0], out[o].pose[1], out[o].pose[2], out[o].pose[3]);
+          obj->pose.translation.init(out[o].pose[4], out[o].pose[5], out[o].pose[6]);
+          obj->model = (*models)[clModel[out[o].cluster]];
+          obj->score = 0;
+        }
       }
     }
     if (_stepName == "POSE") frameData.oldObjects = *frameData.objects;

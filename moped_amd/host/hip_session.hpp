@@ -6,6 +6,7 @@
 #include <moped_hip.h>
 
 #include <iostream>
+#include <vector>
 
 namespace MopedNS {
 
@@ -31,6 +32,40 @@ class HipSession {
     if (ctx_) mh_destroy(ctx_);
   }
   mh_ctx* ctx_;
+};
+
+// The cameras of a frame for the *_images entry points.  The reference projects every match through
+// *frameData.images[match.imageIdx] whatever else the image list holds (FILTER_PROJECTION_CPU.hpp:100-104,
+// POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:228-237) -- a moped3d frame carries its depth and distance maps as
+// further Images that no match points to -- so the table holds the images the matches REFER to, renumbered in
+// image order (which keeps CLUSTER's and FILTER's per-image ordering), and `local` maps imageIdx to that number.
+struct HipCameraTable {
+  std::vector<mh_cam> cams;
+  std::vector<int> local;  // imageIdx -> index into cams, -1 = no match refers to it
+  bool ok;
+
+  explicit HipCameraTable(const FrameData& frameData) : local(frameData.images.size(), -1), ok(true) {
+    for (size_t m = 0; m < frameData.matches.size() && ok; ++m)
+      for (size_t k = 0; k < frameData.matches[m].size(); ++k) {
+        const int i = frameData.matches[m][k].imageIdx;
+        if (i < 0 || i >= (int)local.size()) { ok = false; break; }
+        local[i] = 0;
+      }
+    for (size_t i = 0; i < local.size() && ok; ++i) {
+      if (local[i] < 0) continue;
+      local[i] = (int)cams.size();
+      const Image& im = *frameData.images[i];
+      mh_cam c;
+      for (int j = 0; j < 4; ++j) c.K[j] = im.intrinsicLinearCalibration[j];
+      for (int j = 0; j < 4; ++j) c.cam[j] = im.cameraPose.rotation[j];
+      for (int j = 0; j < 3; ++j) c.cam[4 + j] = im.cameraPose.translation[j];
+      cams.push_back(c);
+    }
+    if (ok && (int)cams.size() > MH_MAX_IMAGES) ok = false;
+    if (!ok)
+      std::clog << "[moped_hip] frame refers to an image outside FrameData::images or to more than " << MH_MAX_IMAGES
+                << " images: step skipped" << std::endl;
+  }
 };
 
 // Same key layout as GET_CONFIG: "<STEP>:<algIdx>:<HeaderBasename>/<var>" (src/util.hpp:62)

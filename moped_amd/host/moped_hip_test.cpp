@@ -4,12 +4,17 @@
 // scene file (models + one frame of detected features) and prints the objects.
 //
 //   moped_hip_test scene.bin [repeats]
+//   moped_hip_test --images scene.bin [repeats]   (frame with several Images, second format below)
 //   moped_hip_test --sift image.pgm      (FEAT step only: binary P5 image -> keypoints)
 //
 // Scene file (little endian, written by scripts/dump_scene.py):
 //   int32 n_models, Q ; float K[4] ; float cam[7]
 //   per model: int32 n_pts ; float xyz[n_pts][3] ; float desc[n_pts][128]
 //   float q_uv[Q][2] ; float q_desc[Q][128]
+// With --images (dump_scene.dump_images): FrameData::images holds n_images entries, cameras and -- as a moped3d
+// frame does -- maps no feature refers to; every feature names its image:
+//   int32 n_models, Q, n_images ; per image: int32 is_map ; float K[4] ; float cam[7]
+//   models as above ; float q_uv[Q][2] ; float q_desc[Q][128] ; int32 q_image[Q]
 #include <cstdio>
 #include <ctime>
 #include <iostream>
@@ -71,16 +76,32 @@ static int run_sift(const char* path) {
 
 int main(int argc, char** argv) {
   if (argc == 3 && std::string(argv[1]) == "--sift") return run_sift(argv[2]);
+  const bool multi = argc >= 3 && std::string(argv[1]) == "--images";
+  if (multi) { --argc; ++argv; }
   if (argc < 2) {
-    std::fprintf(stderr, "usage: %s scene.bin [repeats]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s [--images] scene.bin [repeats]\n", argv[0]);
     return 2;
   }
   const int repeats = argc > 2 ? std::atoi(argv[2]) : 1;
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror(argv[1]); return 2; }
-  int32_t nm = 0, Q = 0;
-  float K[4], cam[7];
-  if (!rd(f, &nm, 1) || !rd(f, &Q, 1) || !rd(f, K, 4) || !rd(f, cam, 7)) return 2;
+  int32_t nm = 0, Q = 0, n_images = 1;
+  if (!rd(f, &nm, 1) || !rd(f, &Q, 1) || (multi && !rd(f, &n_images, 1)) || n_images < 1 || n_images > 64) return 2;
+  vector<SP_Image> images;
+  for (int i = 0; i < n_images; ++i) {
+    int32_t is_map = 0;
+    float K[4], cam[7];
+    if ((multi && !rd(f, &is_map, 1)) || !rd(f, K, 4) || !rd(f, cam, 7)) return 2;
+    SP_Image image(new Image);
+    image->width = 640;
+    image->height = 480;
+    image->intrinsicLinearCalibration.init(K[0], K[1], K[2], K[3]);
+    image->intrinsicNonlinearCalibration.init(0.f, 0.f, 0.f, 0.f);
+    image->cameraPose.rotation.init(cam[0], cam[1], cam[2], cam[3]);
+    image->cameraPose.translation.init(cam[4], cam[5], cam[6]);
+    image->name = is_map ? "map" : "camera";
+    images.push_back(image);
+  }
   vector<SP_Model> models;
   for (int m = 0; m < nm; ++m) {
     int32_t n = 0;
@@ -98,7 +119,9 @@ int main(int argc, char** argv) {
     models.push_back(model);
   }
   vector<float> uv((size_t)Q * 2), qd((size_t)Q * 128);
-  if (!rd(f, &uv[0], uv.size()) || !rd(f, &qd[0], qd.size())) return 2;
+  vector<int32_t> qimg(Q, 0);
+  if (!rd(f, &uv[0], uv.size()) || !rd(f, &qd[0], qd.size()) || (multi && Q > 0 && !rd(f, &qimg[0], qimg.size())))
+    return 2;
   std::fclose(f);
 
   MopedPipeline pipeline;
@@ -112,25 +135,17 @@ int main(int argc, char** argv) {
     (*a)->modelsUpdated(models);  // as MopedPimpl::addModel does (src/moped.cpp:94-99)
   }
 
-  SP_Image image(new Image);
-  image->width = 640;
-  image->height = 480;
-  image->intrinsicLinearCalibration.init(K[0], K[1], K[2], K[3]);
-  image->intrinsicNonlinearCalibration.init(0.f, 0.f, 0.f, 0.f);
-  image->cameraPose.rotation.init(cam[0], cam[1], cam[2], cam[3]);
-  image->cameraPose.translation.init(cam[4], cam[5], cam[6]);
-
   list<SP_Object> objects;
   map<string, double> total;
   for (int rep = 0; rep < repeats; ++rep) {
     objects.clear();
     FrameData frameData;
     frameData.objects = &objects;
-    frameData.images.push_back(image);
+    frameData.images = images;
     vector<FrameData::DetectedFeature>& feats = frameData.detectedFeatures["SIFT"];
     feats.resize(Q);
     for (int i = 0; i < Q; ++i) {
-      feats[i].imageIdx = 0;
+      feats[i].imageIdx = qimg[i];
       feats[i].coord2D.init(uv[2 * i], uv[2 * i + 1]);
       feats[i].descriptor.assign(qd.begin() + (size_t)i * 128, qd.begin() + (size_t)(i + 1) * 128);
     }

@@ -24,6 +24,25 @@ def dump(path, db, frame, K=synth.K_DEFAULT, cam=synth.CAM_IDENTITY):
         f.write(frame.desc.astype("<f4").tobytes())
 
 
+def dump_images(path, db, frame, images, q_image):
+    """Frame with several Images (moped_hip_test --images): images = [(is_map, K[4], cam[7]), ...] in
+    FrameData::images order, q_image[Q] = list index of every feature's image."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", db.n_models, frame.desc.shape[0], len(images)))
+        for is_map, K, cam in images:
+            f.write(struct.pack("<i", int(is_map)))
+            f.write(np.asarray(K, "<f4").tobytes())
+            f.write(np.asarray(cam, "<f4").tobytes())
+        for m in range(db.n_models):
+            rows = np.nonzero(db.model_of == m)[0]
+            f.write(struct.pack("<i", len(rows)))
+            f.write(db.xyz[rows].astype("<f4").tobytes())
+            f.write(db.desc[rows].astype("<f4").tobytes())
+        f.write(frame.uv.astype("<f4").tobytes())
+        f.write(frame.desc.astype("<f4").tobytes())
+        f.write(np.asarray(q_image, "<i4").tobytes())
+
+
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "scene.bin"
     n_models = int(sys.argv[2]) if len(sys.argv) > 2 else 20

@@ -76,3 +76,43 @@ def test_feat_sift_plugin_through_pipeline(tmp_path):
     assert n == len(xy) and abs(n - len(gold["xy0"])) <= 2
     assert np.abs(kp[:, :2] - xy).max() < 1e-5
     assert np.abs(kp[:, 2] - (desc.astype(np.float64) * np.arange(1, 129)).sum(1)).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_step_plugins_two_cameras_among_maps(tmp_path):
+    """FrameData::images = [camera 0, depth map, distance map, camera 1] (a moped3d frame lists its maps as Images too,
+    moped3d/libmoped/src/depthfill/DEPTH_NO_FILL_CPU.hpp:88-96): CLUSTER per image, POSE / POSE2 with every
+    correspondence in its own image, FILTER / FILTER2 keyed by (coord2D, image) -- against the oracle's frame."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    db = synth.make_db(6, 1500, seed=8)
+    cams = [synth.camera_pose(0.0), synth.camera_pose(-0.12, (0.10, 0.0, 0.0))]
+    fr = synth.make_frame_images(db, cams, n_vis=2, seed=5, q_per_image=900, pts_per_obj=130)
+    junk = (1, [1.0, 1.0, 0.0, 0.0], CAM0)
+    images = [(0, fr.Ks[0], fr.cams[0]), junk, junk, (0, fr.Ks[1], fr.cams[1])]
+    scene = str(tmp_path / "scene2.bin")
+    dump_scene.dump_images(scene, db, fr, images, np.where(fr.image == 0, 0, 3))
+    out = subprocess.check_output([os.path.join(HOST, "moped_hip_test"), "--images", scene, "2"], text=True)
+    objs, counts = [], None
+    for line in out.splitlines():
+        w = line.split()
+        if w[0] == "OBJ":
+            objs.append((int(w[1].replace("model", "")), np.array([float(x) for x in w[5:9] + w[2:5]], np.float32), float(w[9])))
+        if w[0] == "MATCHES":
+            counts = (int(w[1]), int(w[3]))
+    dbn, qn = orclib.normalize(db.desc), orclib.normalize(fr.desc)
+    idx, d1, d2 = orclib.match_2nn(dbn, qn)
+    om, op, osc, oc = orclib.frame_rest_images(fr.uv, fr.image, idx, d1, d2, db.model_of, db.xyz, db.n_models, fr.Ks,
+                                               fr.cams, seed=2)
+    assert counts == (int(oc[0]), int(oc[1]))
+    assert sorted(m for m, _, _ in objs) == sorted(om.tolist()) == sorted(fr.visible.tolist())
+    for m, pose, score in objs:
+        j = list(om).index(m)
+        rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+        rows = rows[db.model_of[fr.src_point[rows]] == m]
+        xyz, uv, img = db.xyz[fr.src_point[rows]], fr.uv[rows], fr.image[rows]
+        e_g = np.sqrt(((orclib.project_images(pose, xyz, img, fr.Ks, fr.cams) - uv) ** 2).sum(1)).mean()
+        e_o = np.sqrt(((orclib.project_images(op[j], xyz, img, fr.Ks, fr.cams) - uv) ** 2).sum(1)).mean()
+        assert e_g <= e_o + 1.0 and e_g < 1.0
+        assert score > 0 and abs(score - osc[j]) <= 0.05 * osc[j]      # scored over both cameras' matches
