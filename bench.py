@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per MATCH launch and exchange with a sharded DB (default 8: a shard of ~12k rows does "
                          "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
+    ap.add_argument("--comms", type=int, default=4,
+                    help="RCCL communicators per rank for the sharded path (slot i uses communicator i %% comms)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,13 +152,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1 or args.force_exchange:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    if world > 1:
+        # torch.distributed: the barrier / max-over-ranks of the timing contract and the hand-over of rank 0's
+        # communicator id; the frames' collectives are issued by libmoped_hip.so itself (csrc/comm.hip)
+        dist.init_process_group("nccl", device_id=dev)
 
     Q = args.queries
     db = synth.make_db(args.models, 5000)
@@ -181,7 +180,7 @@ def main():
         params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
         params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
     pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q * args.batch, params=params,
-                         force_exchange=args.force_exchange)
+                         force_exchange=args.force_exchange, n_comms=args.comms)
     pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
     work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
@@ -435,7 +434,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     pipe.close()
-    if world > 1 or args.force_exchange:
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -35,6 +35,7 @@
 #ifndef MOPED_HIP_H
 #define MOPED_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -389,6 +390,56 @@ int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host
 /* Device address of the frame's packed result block {int32 n; mh_object[cap]}
  * for exchange 2 (gather of per-rank objects); *bytes = its size. */
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);
+
+/* ---- N > 1: the DB sharded over ranks, the frame's exchanges inside the library ----------------
+ *
+ * Rank r of W holds the models [r n/W, (r+1) n/W) (mh_db_upload with index_base = its first global row) and every
+ * rank sees every frame.  A sharded frame = this shard's top-2 per query, ONE all-gather of [3][Q] words per rank
+ * (exchange 1; behind them rides the result block of the context's previous frame = exchange 2, so a frame costs
+ * one collective), merge, then CLUSTER .. FILTER2 for the models the rank owns -- all on the context's stream.
+ * The objects of a sharded frame are bit-identical to the single-context frame's (tests/test_gpu_comm.py).
+ * The loop this serves: MopedPimpl::processImages, moped2/libmoped/src/moped.cpp:166-194.
+ *
+ * Transport: RCCL (ncclAllGather over xGMI), resolved at run time -- the copy already in the process, else
+ * librccl.so.1 from the loader path or /opt/rocm/lib, else $MH_RCCL_PATH -- or a host callback.
+ *   mh_comm_create      one process per GPU: rank 0 makes the id (mh_comm_unique_id), the host's launcher hands
+ *                       it to the others (MPI_Bcast, a file, torch.distributed ...), every rank calls this
+ *   mh_comm_create_all  one process that owns W devices (ncclCommInitAll): comms[r] belongs to ctxs[r]
+ *   mh_comm_create_host bring-your-own transport: fn(user, send, recv, bytes) must fill recv[W][bytes] with every
+ *                       rank's send block in rank order; it is called on the host with the stream drained
+ *                       (ranks that share a device, MPI-only hosts, test rigs)
+ * A communicator may serve several contexts of its device (frames in flight); like any NCCL communicator it wants
+ * its collectives issued in the same order on every rank. */
+#define MH_COMM_ID_BYTES 128
+#define MH_EX2_OBJECTS 62   /* objects per rank and frame that ride on the next frame's exchange */
+typedef struct mh_comm mh_comm;
+typedef int (*mh_allgather_fn)(void* user, const void* send_host, void* recv_host, size_t bytes_per_rank);
+int mh_comm_unique_id(unsigned char id[MH_COMM_ID_BYTES]);
+int mh_comm_create(mh_ctx* ctx, const unsigned char id[MH_COMM_ID_BYTES], int rank, int world, mh_comm** comm);
+int mh_comm_create_all(mh_ctx* const* ctxs, int world, mh_comm** comms);
+int mh_comm_create_host(mh_ctx* ctx, int rank, int world, mh_allgather_fn fn, void* user, mh_comm** comm);
+int mh_comm_destroy(mh_comm* comm);
+int mh_comm_info(const mh_comm* comm, int* rank, int* world, int* is_rccl);
+/* One frame / a batch of B <= MH_MAX_BATCH frames (descriptors and keypoints of the B frames one after the other:
+ * one MATCH launch and one exchange for all of them; frame f leaves its objects in result slot f). */
+int mh_frame_enqueue_sharded(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, const float* q_uv_dev, int Q,
+                             const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+int mh_frame_enqueue_sharded_batch(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, const float* q_uv_dev, int Q, int B,
+                                   const mh_cam* cam, const mh_frame_params* prm, const uint64_t* seeds);
+/* The single-process form: rank r's copy of the frame inputs on its device in q_desc_dev[r] / q_uv_dev[r]; the W
+ * collectives go out as one group. */
+int mh_frame_enqueue_sharded_all(mh_ctx* const* ctxs, mh_comm* const* comms, int world, float* const* q_desc_dev,
+                                 const float* const* q_uv_dev, int Q, int B, const mh_cam* cam,
+                                 const mh_frame_params* prm, const uint64_t* seeds);
+/* Objects of ALL ranks (rank order = model order) for the frame(s) this context ran BEFORE the current one, as
+ * they arrived with the current exchange: frame_in_batch < B.  Synchronises the stream.  *n_objects may exceed
+ * cap (the first cap are written).  A rank with more than MH_EX2_OBJECTS objects -> MH_ERR_CAPACITY (use
+ * mh_frame_gather_objects for that frame). */
+int mh_frame_previous_objects(mh_ctx* ctx, int frame_in_batch, mh_object* objects_host, int cap, int32_t* n_objects);
+/* Exchange 2 on its own for the frame in result slot `slot` (the last frame of a stream, or any frame whose
+ * objects are wanted at once): all ranks call it; all ranks get all objects. */
+int mh_frame_gather_objects(mh_ctx* ctx, mh_comm* comm, int slot, mh_object* objects_host, int cap,
+                            int32_t* n_objects);
 
 /* ---- FEAT: SIFT extraction ---------------------------------------- */
 

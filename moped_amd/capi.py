@@ -101,7 +101,13 @@ EXPORTS = [
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
     "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
     "mh_pose_ransac_images",
+    "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
+    "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
+    "mh_frame_previous_objects", "mh_frame_gather_objects",
 ]
+COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
+EX2_OBJECTS = 62         # MH_EX2_OBJECTS
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # mh_allgather_fn
 
 _lib = None
 
@@ -210,6 +216,19 @@ def load():
     L.mh_screen_margin.restype = f32
     L.mh_enable_timing.argtypes = [vp, i32]
     L.mh_timing.argtypes = [vp, C.POINTER(mh_times)]
+    L.mh_comm_unique_id.argtypes = [vp]
+    L.mh_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.mh_comm_create_all.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    L.mh_comm_create_host.argtypes = [vp, i32, i32, ALLGATHER_FN, vp, C.POINTER(vp)]
+    L.mh_comm_destroy.argtypes = [vp]
+    L.mh_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.mh_frame_enqueue_sharded.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_enqueue_sharded_batch.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(mh_cam),
+                                                 C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
+    L.mh_frame_enqueue_sharded_all.argtypes = [C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), i32, i32,
+                                               C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
+    L.mh_frame_previous_objects.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_frame_gather_objects.argtypes = [vp, vp, i32, vp, i32, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -264,6 +283,80 @@ def pack_corr(uv, xyz) -> np.ndarray:
         c["u"], c["v"] = uv[:, 0], uv[:, 1]
         c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
     return c
+
+
+def comm_unique_id() -> bytes:
+    """mh_comm_unique_id: rank 0 makes it, the launcher hands it to the other ranks."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if load().mh_comm_unique_id(buf) != MH_OK:
+        raise MhError("mh_comm_unique_id failed: RCCL not loadable?")
+    return buf.raw
+
+
+class Comm:
+    """mh_comm of one rank: RCCL (`create`), or a host transport (`create_host`: fn(send: bytes) -> bytes of all
+    ranks in rank order -- ranks that share a device, test rigs)."""
+
+    def __init__(self, handle, keep=None):
+        self.L = load()
+        self.h = handle
+        self._keep = keep   # the ctypes callback must outlive the communicator
+
+    @classmethod
+    def create(cls, ctx: "Context", unique_id: bytes, rank: int, world: int) -> "Comm":
+        h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, COMM_ID_BYTES)
+        ctx._ck(ctx.L.mh_comm_create(ctx.h, buf, rank, world, C.byref(h)), "mh_comm_create")
+        return cls(h)
+
+    @classmethod
+    def create_host(cls, ctx: "Context", rank: int, world: int, allgather) -> "Comm":
+        def _cb(_user, send, recv, nbytes):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                if len(out) != nbytes * world:
+                    return 1
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:   # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = ALLGATHER_FN(_cb)
+        h = C.c_void_p()
+        ctx._ck(ctx.L.mh_comm_create_host(ctx.h, rank, world, fn, None, C.byref(h)), "mh_comm_create_host")
+        return cls(h, keep=fn)
+
+    @classmethod
+    def create_all(cls, ctxs) -> "list[Comm]":
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        ctxs[0]._ck(ctxs[0].L.mh_comm_create_all(hs, n, out), "mh_comm_create_all")
+        return [cls(C.c_void_p(out[i])) for i in range(n)]
+
+    def info(self):
+        r, w, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.L.mh_comm_info(self.h, C.byref(r), C.byref(w), C.byref(k))
+        return r.value, w.value, bool(k.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mh_comm_destroy(self.h)
+            self.h = None
+
+
+def frame_enqueue_sharded_all(ctxs, comms, q_desc_ptrs, q_uv_ptrs, Q, B, K, cam, params, seeds):
+    """mh_frame_enqueue_sharded_all: one host thread, one context + communicator per device."""
+    n = len(ctxs)
+    c = make_cam(K, cam)
+    sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
+    rc = ctxs[0].L.mh_frame_enqueue_sharded_all((C.c_void_p * n)(*[x.h for x in ctxs]), (C.c_void_p * n)(*[x.h for x in comms]),
+                                                n, (C.c_void_p * n)(*q_desc_ptrs), (C.c_void_p * n)(*q_uv_ptrs), Q, B,
+                                                C.byref(c), C.byref(params), sd)
+    if rc != MH_OK:
+        msgs = [x.L.mh_last_error(x.h).decode() for x in ctxs]
+        raise MhError(f"mh_frame_enqueue_sharded_all -> {rc}: {msgs}")
 
 
 class Context:
@@ -649,6 +742,36 @@ class Context:
         self._ck(self.L.mh_frame_enqueue_rest_batch(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
                                                     stride_words, plane_words, slot, C.byref(c), C.byref(params), seed),
                  "mh_frame_enqueue_rest_batch")
+
+    def frame_enqueue_sharded(self, comm: Comm, q_desc_ptr, q_uv_ptr, Q, K, cam, params: mh_frame_params, seed=1,
+                              _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        self._ck(self.L.mh_frame_enqueue_sharded(self.h, comm.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q,
+                                                 C.byref(c), C.byref(params), seed), "mh_frame_enqueue_sharded")
+
+    def frame_enqueue_sharded_batch(self, comm: Comm, q_desc_ptr, q_uv_ptr, Q, B, K, cam, params: mh_frame_params,
+                                    seeds, _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
+        self._ck(self.L.mh_frame_enqueue_sharded_batch(self.h, comm.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q, B,
+                                                       C.byref(c), C.byref(params), sd),
+                 "mh_frame_enqueue_sharded_batch")
+
+    def frame_previous_objects(self, frame_in_batch=0, cap=8 * EX2_OBJECTS):
+        objs = np.zeros(cap, OBJECT_DTYPE)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_frame_previous_objects(self.h, frame_in_batch, _ptr(objs), cap, C.byref(n)),
+                 "mh_frame_previous_objects")
+        if n.value > cap:
+            return self.frame_previous_objects(frame_in_batch, n.value)
+        return objs[:n.value].copy()
+
+    def frame_gather_objects(self, comm: Comm, slot=0, cap=4096):
+        objs = np.zeros(cap, OBJECT_DTYPE)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_frame_gather_objects(self.h, comm.h, slot, _ptr(objs), cap, C.byref(n)),
+                 "mh_frame_gather_objects")
+        return objs[:min(n.value, cap)].copy()
 
     def frame_fetch_slot(self, slot, max_objects=4096):
         objs = np.zeros(max_objects, OBJECT_DTYPE)

@@ -181,6 +181,7 @@ void mh_destroy(mh_ctx* ctx) {
   mh_free_frame_state(ctx);
   mh_free_sift_state(ctx);
   free_screen_bufs(ctx);
+  mh::free_exchange(ctx);
   ctx->store.reset();   // the DB goes with its last user
   void* ptrs[] = {ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
@@ -191,8 +192,9 @@ void mh_destroy(mh_ctx* ctx) {
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->ev_made)
     for (auto& e : ctx->ev) hipEventDestroy(e);
-    for (auto& set : ctx->mev)
-      for (auto& e : set) hipEventDestroy(e);
+  for (auto& set : ctx->mev)
+    for (auto& e : set)
+      if (e) hipEventDestroy(e);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -84,6 +84,17 @@ struct mh_ctx {
   int exchange_plane = 0;             // words between the idx / d1 / d2 planes of one shard's block (0 = Q)
   int exchange_stride = 0;            // words between the shards' blocks of the gathered exchange buffer (0 = 3 Q)
 
+  // N > 1 (comm.hip): the send / receive blocks of the frame exchange, the flush buffer of the last frames
+  struct Exchange {
+    int32_t* local = nullptr;      // [3][B Q] top-2 words + B result heads
+    int32_t* gathered = nullptr;   // world of those
+    size_t cap_local = 0, cap_gather = 0, stride = 0;   // words
+    int world = 0, batch = 0, bq = 0;
+    unsigned char* flush = nullptr;
+    size_t flush_bytes = 0;
+    std::vector<int32_t> host;
+  } ex;
+
   // frames with several images (mh_frame_set_images): image of every query + the cameras; n_images == 1 = off
   const int32_t* q_img = nullptr;     // device, [Q]
   mh::DevCam* cams_dev = nullptr;     // device, [MH_MAX_IMAGES]
@@ -130,6 +141,8 @@ struct mh_ctx {
 };
 
 namespace mh {
+
+void free_exchange(mh_ctx* ctx);   // comm.hip
 
 #define MH_HIP(ctx, call)                                                         \
   do {                                                                            \

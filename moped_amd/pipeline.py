@@ -3,8 +3,9 @@ POSE2 -> FILTER2, one mh_ctx per frame in flight, optional model sharding over
 ranks with the two small exchanges of SURVEY.md 8(e).
 
 PyTorch is used for what the C ABI does not own: device buffers for the frame
-inputs, HIP streams, and torch.distributed (RCCL) for the all-gathers.  All
-computation happens inside libmoped_hip.so.
+inputs, HIP streams, and handing rank 0's communicator id to the other ranks.  All
+computation AND the exchanges (ncclAllGather on the slot's stream, csrc/comm.hip)
+happen inside libmoped_hip.so.
 """
 from __future__ import annotations
 
@@ -36,11 +37,19 @@ class ShardedDB:
 class FramePipeline:
     """`depth` frames in flight on one GPU; each has its own mh_ctx + HIP stream so
     the latency-bound CLUSTER/POSE/FILTER kernels of one frame overlap the MATCH
-    kernel of the next."""
+    kernel of the next.
+
+    With a sharded DB (world > 1, or force_exchange to run the same code on one rank) every frame goes through
+    mh_frame_enqueue_sharded[_batch]: the exchanges happen inside libmoped_hip.so, on the slot's stream, over
+    communicators this class only creates --
+      * RCCL (mh_comm_create) when torch.distributed runs on nccl or is not initialised (world 1): rank 0's id
+        travels by broadcast_object_list; `n_comms` communicators, slot i uses communicator i % n_comms;
+      * the host transport (mh_comm_create_host over the gloo group) when the group is gloo: ranks that share one
+        device (RCCL refuses that), the rehearsal of tests/test_gpu_dist.py."""
 
     def __init__(self, device: int, db: ShardedDB, depth: int = 1, max_queries: int = 4096,
                  params: capi.mh_frame_params | None = None, K=None, cam=None, group=None,
-                 force_exchange: bool = False):
+                 force_exchange: bool = False, n_comms: int = 4):
         from . import synth
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -67,27 +76,33 @@ class FramePipeline:
             self.streams.append(s)
         self.depth = depth
         self.exchange = force_exchange or self.world > 1
-        self._local = [None] * depth    # send block per slot: [3][Q] words of exchange 1 + the result block riding along
-        self._gather = [None] * depth   # receive block: W of those
-        self._ex_q = [0] * depth
+        self.comms = []
+        if self.exchange:
+            self.comms = self._make_comms(max(1, min(n_comms, depth)))
+        self._batch = [1] * depth
         self._inputs = [None] * depth   # the slot's current input tensors: its stream may still be reading them
         self._cam = capi.make_cam(self.K, self.cam)
 
-    # Exchange 2 rides on exchange 1: behind its [3][Q] top-2 words every rank sends the result block
-    # of the PREVIOUS frame of the same slot (complete by then: same stream), so one all-gather per
-    # frame carries both exchanges of SURVEY 8(e).  EX2_OBJECTS objects per rank and frame.
-    EX2_OBJECTS = 62
-    EX2_WORDS = (16 + EX2_OBJECTS * capi.OBJECT_DTYPE.itemsize) // 4
+    def _make_comms(self, n):
+        import torch.distributed as dist
+        inited = dist.is_available() and dist.is_initialized()
+        if inited and dist.get_backend(self.group) == "gloo":
+            def allgather(blob: bytes) -> bytes:
+                mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+                out = torch.empty(self.world * mine.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, mine, group=self.group)
+                return out.numpy().tobytes()
+            return [capi.Comm.create_host(self.ctxs[0], self.db.rank, self.world, allgather)]
+        comms = []
+        for _ in range(n):
+            ids = [capi.comm_unique_id() if self.db.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=self.group)
+            comms.append(capi.Comm.create(self.ctxs[0], ids[0], self.db.rank, self.world))
+        return comms
 
-    def _unpack_block(self, blk: np.ndarray) -> np.ndarray:
-        """One rank's piggy-backed result block {n, flags, pad, pad, objects...} -> object array.
-        The block carries at most EX2_OBJECTS objects: a frame with more, or one whose capacity flags
-        are set, is an error here and not a silently shortened list (gather_objects() has no limit)."""
-        n, flags = int(blk[0]), int(blk[1])
-        if n > self.EX2_OBJECTS or flags != 0:
-            raise RuntimeError(f"exchange 2: a rank reported {n} objects (block holds {self.EX2_OBJECTS}), "
-                               f"capacity flags {flags}; use gather_objects() for this frame")
-        return blk[4:].view(np.uint8)[:n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE).copy()
+    def _comm(self, slot):
+        return self.comms[slot % len(self.comms)]
 
     # ---- single frame in slot i ------------------------------------------------------
     def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
@@ -104,20 +119,9 @@ class FramePipeline:
         if not self.exchange:
             c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
             return
-        stride = 3 * Q + self.EX2_WORDS
-        if self._local[slot] is None or self._ex_q[slot] != Q:
-            s.synchronize()   # an earlier frame of this slot may still read the old blocks
-            self._local[slot] = torch.zeros(stride, dtype=torch.int32, device=self.dev)
-            self._gather[slot] = torch.zeros(self.world * stride, dtype=torch.int32, device=self.dev)
-            self._ex_q[slot] = Q
-        local, gathered = self._local[slot], self._gather[slot]
-        with torch.cuda.stream(s):
-            c.frame_result_copy_dev(local.data_ptr() + 12 * Q, self.EX2_OBJECTS)   # exchange 2 of the slot's last frame
-            c.frame_enqueue_match_local(q_desc.data_ptr(), Q, local.data_ptr())
-            # exchange 1 (+2): every shard's per-query (idx1, d1, d2) -> [W][3][Q] (+ result blocks), one all-gather
-            _all_gather_into(gathered, local, self.group)
-            c.frame_enqueue_rest_strided(q_uv.data_ptr(), Q, gathered.data_ptr(), self.world, stride, self.K,
-                                         self.cam, self.params, seed, _cam_struct=self._cam)
+        self._batch[slot] = 1
+        c.frame_enqueue_sharded(self._comm(slot), q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params,
+                                seed, _cam_struct=self._cam)
 
     # ---- batches of frames (small shards) ----------------------------------------------------
     def enqueue_batch(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, B: int, seeds):
@@ -126,101 +130,47 @@ class FramePipeline:
         after the other; their CLUSTER..FILTER2 run one after the other on the slot's stream and leave
         their objects in result slots 0..B-1.  Needs the exchange path (sharded DB or force_exchange)."""
         assert self.exchange and 1 <= B <= capi.MAX_BATCH
-        c, s = self.ctxs[slot], self.streams[slot]
+        c = self.ctxs[slot]
         self._inputs[slot] = (q_desc, q_uv)
-        BQ = q_desc.shape[0]
-        Q = BQ // B
-        tail = B * self.EX2_WORDS
-        stride = 3 * BQ + tail
-        if self._local[slot] is None or self._ex_q[slot] != -BQ:
-            s.synchronize()
-            self._local[slot] = torch.zeros(stride, dtype=torch.int32, device=self.dev)
-            self._gather[slot] = torch.zeros(self.world * stride, dtype=torch.int32, device=self.dev)
-            self._ex_q[slot] = -BQ          # negative: batch layout
-            self._ex_b = B
-        local, gathered = self._local[slot], self._gather[slot]
-        with torch.cuda.stream(s):
-            c.frame_result_copy_slots_dev(local.data_ptr() + 12 * BQ, B, self.EX2_OBJECTS)   # exchange 2 of the slot's last batch
-            c.frame_enqueue_match_local(q_desc.data_ptr(), BQ, local.data_ptr())
-            _all_gather_into(gathered, local, self.group)
-            for f in range(B):
-                c.frame_enqueue_rest_batch(q_uv.data_ptr() + 8 * f * Q, Q, gathered.data_ptr() + 4 * f * Q, self.world,
-                                           stride, BQ, f, self.K, self.cam, self.params, int(seeds[f]),
-                                           _cam_struct=self._cam)
+        self._batch[slot] = B
+        Q = q_desc.shape[0] // B
+        c.frame_enqueue_sharded_batch(self._comm(slot), q_desc.data_ptr(), q_uv.data_ptr(), Q, B, self.K, self.cam,
+                                      self.params, seeds, _cam_struct=self._cam)
 
     def fetch_batch(self, slot: int, B: int):
         return [self.ctxs[slot].frame_fetch_slot(f) for f in range(B)]
 
     def previous_objects_batch(self, slot: int):
         """Objects of the B frames of the batch enqueued in `slot` BEFORE the current one, from all ranks."""
-        self.streams[slot].synchronize()
-        BQ, B = -self._ex_q[slot], self._ex_b
-        stride = 3 * BQ + B * self.EX2_WORDS
-        host = self._gather[slot].view(self.world, stride)[:, 3 * BQ:].contiguous().cpu().numpy()
-        out = []
-        for f in range(B):
-            objs = []
-            for r in range(self.world):
-                objs.append(self._unpack_block(host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]))
-            out.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
-        return out
+        return [self.ctxs[slot].frame_previous_objects(f) for f in range(self._batch[slot])]
 
     def flush_objects_batch(self, slot: int, B: int):
-        """Exchange 2 for the LAST batch of a slot (nothing follows to carry it): one small all-gather."""
-        c, s = self.ctxs[slot], self.streams[slot]
-        with torch.cuda.stream(s):
-            mine = torch.zeros(B * self.EX2_WORDS, dtype=torch.int32, device=self.dev)
-            c.frame_result_copy_slots_dev(mine.data_ptr(), B, self.EX2_OBJECTS)
-            out = _all_gather_flat(mine, self.world, self.group).view(self.world, B * self.EX2_WORDS)
-        s.synchronize()
-        host = out.cpu().numpy()
-        res = []
-        for f in range(B):
-            objs = []
-            for r in range(self.world):
-                objs.append(self._unpack_block(host[r, f * self.EX2_WORDS:(f + 1) * self.EX2_WORDS]))
-            res.append(np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE))
-        return res
+        """Exchange 2 for the LAST batch of a slot (nothing follows to carry it)."""
+        return [self.ctxs[slot].frame_gather_objects(self._comm(slot), f) for f in range(B)]
 
     def previous_objects(self, slot: int):
         """Objects of the frame enqueued in `slot` BEFORE the current one, from all ranks, as they
         arrived with the current frame's exchange (no collective of its own).  Synchronises the slot."""
-        self.streams[slot].synchronize()
-        Q = self._ex_q[slot]
-        stride = 3 * Q + self.EX2_WORDS
-        host = self._gather[slot].view(self.world, stride)[:, 3 * Q:].contiguous().cpu().numpy()
-        objs = []
-        for r in range(self.world):
-            objs.append(self._unpack_block(host[r]))
-        return np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE)
+        return self.ctxs[slot].frame_previous_objects(0)
 
     def fetch(self, slot: int):
         """Objects of the frame in `slot` (model ids global), counts[4]."""
         return self.ctxs[slot].frame_fetch()
 
     def gather_objects(self, slot: int):
-        """Exchange 2: every rank's result block -> all ranks; returns the merged
-        object array (rank order = model order)."""
-        import torch.distributed as dist
-        c, s = self.ctxs[slot], self.streams[slot]
-        ptr, nbytes = c.frame_result_dev()
-        with torch.cuda.stream(s):
-            mine = _wrap_uint8(ptr, nbytes, self.dev)
-            out = _all_gather_flat(mine, self.world, self.group).view(self.world, nbytes)
-        s.synchronize()
-        host = out.cpu().numpy()
-        objs = []
-        for r in range(self.world):
-            n = int(host[r, :4].view(np.int32)[0])
-            blk = host[r, 16:16 + n * capi.OBJECT_DTYPE.itemsize].view(capi.OBJECT_DTYPE)
-            objs.append(blk.copy())
-        return np.concatenate(objs) if objs else np.zeros(0, capi.OBJECT_DTYPE)
+        """Exchange 2 on its own: every rank's result block -> all ranks; the merged object array
+        (rank order = model order)."""
+        return self.ctxs[slot].frame_gather_objects(self._comm(slot), 0)
 
     def synchronize(self):
         for s in self.streams:
             s.synchronize()
 
     def close(self):
+        self.synchronize()
+        for m in self.comms:
+            m.close()
+        self.comms = []
         for c in self.ctxs:
             c.close()
         self.ctxs = []
@@ -229,32 +179,14 @@ class FramePipeline:
 def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
     """Exchange 1: one fused all-gather of every rank's per-query
     local top-2.  local = [3][Q] int32 words (idx1, bits of d1, bits of d2);
-    returns [W][3][Q], the block mh_frame_enqueue_rest takes.  Device-agnostic
-    (RCCL on GPU, gloo in the CPU tests)."""
+    returns [W][3][Q], the block mh_frame_enqueue_rest takes.  The layout of the exchange on
+    torch tensors, for the world-size > 1 CPU tests (gloo); on the GPU the same all-gather is
+    issued by the library itself (csrc/comm.hip)."""
+    import torch.distributed as dist
     Q = local.shape[-1] if local.dim() == 2 else local.numel() // 3
     out = torch.empty(world * 3 * Q, dtype=local.dtype, device=local.device)
-    _all_gather_into(out, local.contiguous().view(-1), group)
+    dist.all_gather_into_tensor(out, local.contiguous().view(-1), group=group)
     return out.view(world, 3, Q)
-
-
-def _all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
-    """all_gather_into_tensor on flat buffers.  RCCL takes device tensors directly;
-    the gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal of the N > 1
-    path) is fed through host memory."""
-    import torch.distributed as dist
-    if mine.is_cuda and dist.get_backend(group) == "gloo":
-        host = mine.cpu()
-        tmp = torch.empty(out.numel(), dtype=host.dtype)
-        dist.all_gather_into_tensor(tmp, host, group=group)
-        out.copy_(tmp)
-        return
-    dist.all_gather_into_tensor(out, mine, group=group)
-
-
-def _all_gather_flat(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
-    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-    _all_gather_into(out, mine, group)
-    return out
 
 
 def owner_of_model(model: int, n_models: int, world: int) -> int:
@@ -275,7 +207,3 @@ class _DevMem:
 
 def _wrap_int32(ptr, n, dev):
     return torch.as_tensor(_DevMem(ptr, (n,), "<i4"), device=dev)
-
-
-def _wrap_uint8(ptr, n, dev):
-    return torch.as_tensor(_DevMem(ptr, (n,), "|u1"), device=dev)
