@@ -139,9 +139,9 @@ def main():
     if args.depth <= 0:
         args.depth = 16
     if args.batch <= 0:
-        args.batch = 8 if sharded else 1
-    if not sharded or args.depth_kind:
-        args.batch = 1
+        args.batch = 8 if sharded else 4
+    if args.depth_kind:
+        args.batch = 1    # per-query depth attributes belong to one frame
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
@@ -216,19 +216,19 @@ def main():
 
     active_slots = [args.depth]   # slots in use (the calibration below may settle on fewer)
 
-    def run_step_batched(step):
+    def run_step_batched(step, from_host=False):
         for g in range(groups):
             slot = (step * groups + g) % active_slots[0]
             pg = g % pool_groups
             with torch.cuda.stream(pipe.streams[slot]):
-                work_b[slot].copy_(pristine_b[pg], non_blocking=True)
+                work_b[slot].copy_(host_desc[pg] if from_host else pristine_b[pg], non_blocking=True)
             pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
 
     host_desc = None   # --h2d-steps: the same descriptors in pinned host memory
 
     def run_step(step, record=False, from_host=False):
         if B > 1:
-            return run_step_batched(step)
+            return run_step_batched(step, from_host)
         for f in range(n_frames):
             b = f % n_pool
             slot = f % args.depth
@@ -292,7 +292,8 @@ def main():
     # detections of the last step (sanity: the planted objects are found)
     if B > 1:
         last_slot = ((args.steps - 1) * groups + groups - 1) % active_slots[0]
-        det_per_frame = float(np.mean([len(o) for o in pipe.flush_objects_batch(last_slot, B)]))
+        det_per_frame = float(np.mean([len(o) for o in (pipe.flush_objects_batch(last_slot, B) if pipe.exchange else
+                                                         [r[0] for r in pipe.fetch_batch(last_slot, B)])]))
     elif world == 1 or by_frames:
         det_per_frame = float(counts_host.float().mean().item())
     else:
@@ -333,8 +334,10 @@ def main():
 
     # ---- secondary: the same frames with the descriptors in pinned HOST memory (1.5 MB over PCIe per frame, the copy
     # on the frame's own stream, overlapped with the other frames in flight).  Never `value`.
-    if rank == 0 and world == 1 and B == 1 and args.h2d_steps > 0:
+    if rank == 0 and world == 1 and args.h2d_steps > 0:
         host_desc = [torch.from_numpy(f.desc).pin_memory() for f in frames]
+        if B > 1:
+            host_desc = [torch.cat(host_desc[g * B:(g + 1) * B]).pin_memory() for g in range(pool_groups)]
         run_step(-500, from_host=True)
         sync_all()
         t0h = time.perf_counter()

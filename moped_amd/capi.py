@@ -103,7 +103,7 @@ EXPORTS = [
     "mh_pose_ransac_images",
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
-    "mh_frame_previous_objects", "mh_frame_gather_objects",
+    "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -227,6 +227,8 @@ def load():
                                                  C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
     L.mh_frame_enqueue_sharded_all.argtypes = [C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp), i32, i32,
                                                C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
+    L.mh_frame_enqueue_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
+                                         C.POINTER(C.c_uint64)]
     L.mh_frame_previous_objects.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_gather_objects.argtypes = [vp, vp, i32, vp, i32, C.POINTER(C.c_int32)]
     _lib = L
@@ -742,6 +744,12 @@ class Context:
         self._ck(self.L.mh_frame_enqueue_rest_batch(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
                                                     stride_words, plane_words, slot, C.byref(c), C.byref(params), seed),
                  "mh_frame_enqueue_rest_batch")
+
+    def frame_enqueue_batch(self, q_desc_ptr, q_uv_ptr, Q, B, K, cam, params: mh_frame_params, seeds, _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
+        self._ck(self.L.mh_frame_enqueue_batch(self.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q, B, C.byref(c),
+                                               C.byref(params), sd), "mh_frame_enqueue_batch")
 
     def frame_enqueue_sharded(self, comm: Comm, q_desc_ptr, q_uv_ptr, Q, K, cam, params: mh_frame_params, seed=1,
                               _cam_struct=None):

@@ -312,7 +312,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     rules.cauchy_scale = rs.cauchy_scale;
   }
   // MATCH tail: (shard merge,) ratio test + per-model lists; resets the frame's counters
-  launch_group(gathered, n_shards, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2, Q, prm->ratio, q_uv_dev,
+  const int q0 = gathered ? 0 : ctx->batch_q0;   // frame of a batch matched in one launch: its slice of the top-2 arrays
+  launch_group(gathered, n_shards, ctx->nn_idx + q0, ctx->nn_d1 + q0, ctx->nn_d2 + q0, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
@@ -1150,6 +1151,34 @@ int mh_frame_keypoints(mh_ctx* ctx, int32_t* n_keypoints) {
   if (!ctx || !n_keypoints || ctx->feat_last < 0) return MH_ERR_ARG;
   *n_keypoints = ctx->feat_last;
   return MH_OK;
+}
+
+int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
+                           const mh_frame_params* prm, const uint64_t* seeds) {
+  if (!ctx || Q <= 0 || B < 1 || B > MH_MAX_BATCH || !q_desc_dev || !q_uv_dev || !cam || !prm || !seeds)
+    return MH_ERR_ARG;
+  if (B > 1 && (ctx->q_depth || ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
+    ctx->err = "mh_frame_enqueue_batch: per-query frame attributes (depth, depth rules, images) belong to ONE frame";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = prepare_frame(ctx, B * Q);
+  if (rc) return rc;
+  ctx->feat_count_dev = nullptr;
+  stamp(ctx, 0);
+  launch_normalize(q_desc_dev, ctx->q_norm, B * Q, ctx->stream);
+  if ((rc = ctx_match(ctx, q_desc_dev, ctx->q_norm, B * Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
+  stamp(ctx, 1);
+  for (int f = 0; f < B && rc == MH_OK; ++f) {
+    ctx->batch_q0 = f * Q;
+    ctx->fs->slot = f;
+    if (graphs_enabled()) set_seed(ctx, seeds[f]);
+    rc = frame_rest(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, nullptr, 0, cam, prm, seeds[f]);
+  }
+  ctx->batch_q0 = 0;
+  ctx->fs->slot = 0;
+  return rc;
 }
 
 int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t* top2_dev) {

@@ -81,6 +81,7 @@ struct mh_ctx {
   int32_t* feat_count_dev = nullptr;  // frame enqueued from an image: device word with its keypoint count
   int feat_expected = 0;              // keypoints of the last fetched image frame (sizes the next MATCH launch)
   int feat_last = -1;
+  int batch_q0 = 0;                   // first query of the frame frame_rest works on (mh_frame_enqueue_batch)
   int exchange_plane = 0;             // words between the idx / d1 / d2 planes of one shard's block (0 = Q)
   int exchange_stride = 0;            // words between the shards' blocks of the gathered exchange buffer (0 = 3 Q)
 

@@ -128,12 +128,17 @@ class FramePipeline:
         """B frames through ONE MATCH launch and ONE exchange (a shard of a few thousand rows does not
         fill the chip for the 3000 queries of one frame): q_desc [B*Q,128], q_uv [B*Q,2], the frames one
         after the other; their CLUSTER..FILTER2 run one after the other on the slot's stream and leave
-        their objects in result slots 0..B-1.  Needs the exchange path (sharded DB or force_exchange)."""
-        assert self.exchange and 1 <= B <= capi.MAX_BATCH
+        their objects in result slots 0..B-1.  With a sharded DB through the exchange, otherwise
+        mh_frame_enqueue_batch."""
+        assert 1 <= B <= capi.MAX_BATCH
         c = self.ctxs[slot]
         self._inputs[slot] = (q_desc, q_uv)
         self._batch[slot] = B
         Q = q_desc.shape[0] // B
+        if not self.exchange:
+            c.frame_enqueue_batch(q_desc.data_ptr(), q_uv.data_ptr(), Q, B, self.K, self.cam, self.params, seeds,
+                                  _cam_struct=self._cam)
+            return
         c.frame_enqueue_sharded_batch(self._comm(slot), q_desc.data_ptr(), q_uv.data_ptr(), Q, B, self.K, self.cam,
                                       self.params, seeds, _cam_struct=self._cam)
 

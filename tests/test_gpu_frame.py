@@ -97,3 +97,28 @@ def test_frame_timing_api(world):
     c.enable_timing(False)
     assert t["total_ms"] > 0 and t["match_ms"] > 0
     assert abs(sum(t[k] for k in t if k != "total_ms") - t["total_ms"]) < 0.5 * t["total_ms"] + 0.5
+
+
+def test_batch_of_frames_equals_the_frames_alone(world):
+    """mh_frame_enqueue_batch: one MATCH launch sequence over the queries of B frames, CLUSTER..FILTER2 frame by
+    frame -- every frame's objects and counts are bit for bit what mh_frame_enqueue gives it alone."""
+    db, dbn, pipe, torch = world
+    dev = torch.device("cuda:0")
+    frs = [synth.make_frame(db, n_vis=n, seed=40 + i) for i, n in enumerate((2, 5, 1))]
+    alone = []
+    for i, fr in enumerate(frs):
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=70 + i)
+        alone.append(pipe.fetch(0))
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    c = pipe.ctxs[1]
+    c.reserve(3 * 3000)
+    pipe.enqueue_batch(1, qd, uv, 3, [70, 71, 72])
+    for f, (objs, counts) in enumerate(pipe.fetch_batch(1, 3)):
+        a, ac = alone[f]
+        assert np.array_equal(counts, ac) and len(objs) == len(a) >= 1
+        assert np.array_equal(objs["model"], a["model"])
+        assert np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32))
+        assert np.array_equal(objs["score"].view(np.uint32), a["score"].view(np.uint32))
+    # the batch normalised all three frames' descriptors in place, like the single frames
+    assert np.array_equal(qd[:3000].cpu().numpy().view(np.uint32), orclib.normalize(frs[0].desc).view(np.uint32))
