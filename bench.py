@@ -52,10 +52,11 @@ def parse():
                     help="with --depth-kind: the frame takes the depth map itself and runs moped3d's shipped front end on "
                          "the device (DEPTHFILTER, depth-adaptive ratio, DEPTHFILTER2, DEPTHMAP_PROP, CLUSTER_LINKAGE; "
                          "moped3d/libmoped/src/config.hpp:41-45) instead of per-query depth attributes + mean shift")
-    ap.add_argument("--parallelism", choices=("models", "frames"), default="models",
-                    help="N > 1: 'models' (default, the north-star design) shards the DB by model with one all-gather per "
-                         "batch of frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: "
-                         "SURVEY 8(e)'s alternative for DBs too small to shard)")
+    ap.add_argument("--parallelism", choices=("auto", "models", "frames"), default="auto",
+                    help="N > 1: 'models' (the north-star design) shards the DB by model with one all-gather per batch of "
+                         "frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: SURVEY "
+                         "8(e)'s alternative for DBs too small to shard); 'auto' (default) shards when every rank still "
+                         "gets >= 25 models (BASELINE configs[3]: MATCH stays a rank's dominant cost), else splits frames")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per MATCH launch and exchange with a sharded DB (default 8: a shard of ~12k rows does "
                          "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
@@ -133,6 +134,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.parallelism == "auto":
+        args.parallelism = "models" if args.models // max(world, 2) >= 25 else "frames"
     by_frames = args.parallelism == "frames" and not args.force_exchange
     sharded = (world > 1 and not by_frames) or args.force_exchange
     depth_given = args.depth > 0
@@ -311,7 +314,7 @@ def main():
         "metric": "detections/sec (frames/s) 640x480 ~3k SIFT vs N models",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if by_frames else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.models}-model DB ({db.n} descriptors), 640x480 frames, "
                                f"{Q} SIFT-like keypoints, {args.n_vis} planted objects, "

@@ -706,7 +706,9 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   auto splits_for = [&](int n_sel, int target, int s_max) {
     int S = std::max(1, target / nqb_e);
     S = std::min(std::min(S, n_sel), s_max);
-    if (S >= 8) S = S / 8 * 8;   // whole splits per XCD
+    // whole splits per XCD (a split's rows stay in one L2) unless the rounding would leave CUs without a workgroup:
+    // 24 query blocks x 8 splits fill 192 of 256 CUs, x 10 fill 240 (measured: 10% on the stage at Q = 12000)
+    if (S >= 8 && (S / 8 * 8) * 33 >= S * 32) S = S / 8 * 8;
     return std::max(S, 1);
   };
   // pass A: every `stride`-th tile, starting in the middle of the first stride
@@ -727,7 +729,9 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
                      a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
   if (ev) hipEventRecord(ev[3], s);
   // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
-  const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
+  static const int sb_pin = env_int("MH_SCREEN_SPLITS_B", 0);   // experiments
+  const int Sb = sb_pin > 0 ? std::min(std::min(sb_pin, n_tiles), SC_SLOTS_MAX / 2)
+                            : splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
   a.n_sel = n_tiles;
   a.tile_first = 0;
   a.tile_stride = 1;
