@@ -160,6 +160,76 @@ __global__ __launch_bounds__(BT_THREADS) void blur_level_kernel(const float* __r
   }
 }
 
+// The same tile blur for up to two independent pyramid levels in one launch (a job list): the levels of an octave
+// depend on each other, but octave o + 1 starts from level kScales of octave o, so levels kScales + 1, kScales + 2 of
+// octave o and levels 1, 2 of octave o + 1 are pairwise independent -- 13 launches for four octaves instead of 24.
+// A job whose source is the previous octave (`half`) reads it at every second row and column (HalfImageSize,
+// :390-408), writes those pixels out as its octave's level 0 and blurs them: the same numbers the half kernel followed
+// by the blur kernel produces.  dog = source - blurred (SubtractImage, :440-466) comes from the tile in LDS.
+struct BlurJob {
+  const float* src;
+  float* dst;
+  float* dog;
+  float* half_dst;   // level 0 of the job's octave when `half`
+  int rows, cols, src_cols, half, taps, tiles_x, tile_begin;
+};
+struct BlurJobs {
+  BlurJob j[2];
+  Taps t[2];
+  int n;
+};
+__global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
+  __shared__ float in_s[(BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW)];
+  __shared__ __attribute__((aligned(8))) float row_s[(BT_Y + 2 * BT_MAXW) * BT_X];
+  const int tid = threadIdx.x;
+  const int jn = (J.n > 1 && (int)blockIdx.x >= J.j[1].tile_begin) ? 1 : 0;
+  const BlurJob& job = J.j[jn];
+  const Taps& t = J.t[job.taps];
+  const int rows = job.rows, cols = job.cols;
+  const int tile = blockIdx.x - job.tile_begin;
+  const int w = t.n >> 1;
+  const int c0 = (tile % job.tiles_x) * BT_X, r0 = (tile / job.tiles_x) * BT_Y;
+  const int in_w = BT_X + 2 * w, in_h = BT_Y + 2 * w;
+  const int step = job.half ? 2 : 1;
+  for (int e = tid; e < in_w * in_h; e += BT_THREADS) {
+    const int yy = e / in_w, xx = e - yy * in_w;
+    int y = r0 - w + yy, x = c0 - w + xx;
+    const bool inside = y >= r0 && y < r0 + BT_Y && y < rows && x >= c0 && x < c0 + BT_X && x < cols;
+    y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
+    x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
+    const float v = job.src[(size_t)(step * y) * job.src_cols + step * x];
+    in_s[e] = v;
+    if (job.half && inside) job.half_dst[(size_t)y * cols + x] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < (in_h >> 1) * BT_X; e += BT_THREADS) {   // in_h is even
+    const int yy = 2 * (e / BT_X), x = e % BT_X;
+    const float* r0p = in_s + yy * in_w + x;
+    const float* r1p = r0p + in_w;
+    v2f a = {0.f, 0.f};
+    for (int j = 0; j < t.n; ++j) a = a + v2f{r0p[j], r1p[j]} * v2f{t.k[j], t.k[j]};
+    row_s[yy * BT_X + x] = a.x;
+    row_s[(yy + 1) * BT_X + x] = a.y;
+  }
+  __syncthreads();
+  for (int e = tid; e < BT_Y * (BT_X / 2); e += BT_THREADS) {
+    const int y = e / (BT_X / 2), x = 2 * (e % (BT_X / 2));
+    const int r = r0 + y, c = c0 + x;
+    if (r >= rows || c >= cols) continue;
+    const float* col = row_s + y * BT_X + x;
+    v2f a = {0.f, 0.f};
+    for (int j = 0; j < t.n; ++j) a = a + *reinterpret_cast<const v2f*>(col + j * BT_X) * v2f{t.k[j], t.k[j]};
+    const size_t o = (size_t)r * cols + c;
+    const float* old = in_s + (y + w) * in_w + (x + w);
+    job.dst[o] = a.x;
+    if (job.dog) job.dog[o] = __fsub_rn(old[0], a.x);
+    if (c + 1 < cols) {
+      job.dst[o + 1] = a.y;
+      if (job.dog) job.dog[o + 1] = __fsub_rn(old[1], a.y);
+    }
+  }
+}
+
 // HalfImageSize (:390-408)
 __global__ void half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -538,55 +608,46 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
 }
 
 // ---- descriptor (MakeKeypointSample / KeySample / AddSample / PlaceInIndex, :1424-1668) ---------
-// Lane L of a wavefront owns descriptor entries 2L and 2L+1 (cell L/4 of the 4x4 grid, orientation
-// bins 2(L%4) and 2(L%4)+1).  Samples are evaluated 64 at a time in raster order and then folded
-// one after the other, each lane taking its share of the sample's up to eight contributions --
-// the same products, added in the same order, as the serial code.
-// Workgroups have eight wavefronts.  With many keys each wavefront describes its own key; with few
-// (the chip would be mostly idle and the serial fold is what a key waits for) the eight wavefronts
-// share ONE key, wavefront (r, h) folding only the samples that touch cell row r and cell columns
-// 2h, 2h + 1 (about a quarter of them) on its first eight lanes: the entries are independent, so the
-// per-entry addition order is untouched.  (Four wavefronts, a cell row each: 0.86 ms per frame instead
-// of 0.83; sixteen, a cell each: 1.01 -- every wavefront evaluates all the samples.)
-constexpr int DESC_WAVES = 8;
-constexpr int DESC_SHARE_BELOW = 1536;   // keys; below this the wavefronts of a workgroup share a key
+// One 256-thread workgroup per key.  The reference adds a sample's (up to eight) contributions to the descriptor
+// entries it touches one sample after the other in raster order; the 128 entries are independent of each other, so
+// what has to be kept is the ORDER OF THE ADDITIONS PER ENTRY (a chain of only ~S/16 additions), not the walk over all
+// S samples.  The window is taken in chunks of 256 raster-ordered samples:
+//   A. four wavefronts, 64 samples each, one per lane: the sample's weight, bilinear fractions and first row / column
+//      / orientation bin (the arithmetic of KeySample / PlaceInIndex).  A sample feeds entry (cell, bin) when it
+//      touches the cell (rows nr, nr + 1, columns nc, nc + 1) AND the bin is its own or the next one -- two
+//      independent conditions, so 16 cell ballots + 8 bin ballots describe all 128 lists of the wavefront:
+//      list (cell, bin) = lanes in cmask[cell] & bmask[bin], in lane = raster order.  Their sizes (two lists per
+//      lane, a wave prefix sum) give every list its place in the wavefront's value array; every sample then writes
+//      its up to eight products -- the reference's cg (1 - of) / cg of -- at offset + rank;
+//   B. thread E < 128 owns entry E = 8 cell + bin and adds its list's values, wavefront after wavefront: the same
+//      products in the same order as the serial code, and nothing else (no entry is visited that is not added).
+// History (per 640x480 frame): every wavefront folding all samples of its key with readlanes, eight wavefronts sharing
+// a key when keys are few 0.28 ms; per-cell lists that four lanes per cell filter by bin 0.14; this 0.0x.
+constexpr int DESC_WAVES = 4;
+struct DescLds {
+  unsigned long long cmask[DESC_WAVES][16];
+  unsigned long long bmask[DESC_WAVES][8];
+  uint16_t off[DESC_WAVES][130];     // list (cell, bin) of the wavefront = val[off[8 cell + bin] .. off[8 cell + bin + 1])
+  float val[DESC_WAVES][512];
+  float d[128];
+  float scal;
+};
 __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
                                                       const int32_t* __restrict__ n_keys, int key_cap,
                                                       float* __restrict__ desc_out /* [key][128] */,
                                                       float* __restrict__ geo_out /* [key][4] col,row,scale,ori */) {
-  __shared__ float d_all[DESC_WAVES][128];
-  __shared__ float scal_all[DESC_WAVES];
-  __shared__ int any_all[DESC_WAVES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ DescLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
-  const bool share = n < DESC_SHARE_BELOW;
-  // shared key: wavefront `wave` owns cell row wave / 2, columns 2 (wave % 2) + {0, 1} on its first 8 lanes;
-  // results meet in d_all[0]
-  const int cell_r = share ? (wave >> 1) : (lane >> 4);
-  const int col_lo = 2 * (wave & 1);                       // shared key: this wavefront's two cell columns
-  const int cell_c = share ? col_lo + ((lane >> 2) & 1) : ((lane >> 2) & 3), ob0 = 2 * (lane & 3);
-  const bool owner = !share || lane < 8;
-  float* const d_s = share ? d_all[0] : d_all[wave];
-  float& scal_s = share ? scal_all[0] : scal_all[wave];
-  int& any_s = share ? any_all[0] : any_all[wave];
-  // a key's 128 values belong to one wavefront, or (shared key) to the workgroup
-  auto sync_scope = [&]() {
-    if (share) {
-      __syncthreads();
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // LDS written by one lane of a wavefront and read by another of the same wavefront
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
-  const int entry = share ? ((cell_r * 4 + cell_c) * 4 + (lane & 3)) : lane;   // this lane's pair of entries: 2 entry, 2 entry + 1
-  const int k_first = share ? blockIdx.x : blockIdx.x * DESC_WAVES + wave;
-  const int k_step = share ? gridDim.x : gridDim.x * DESC_WAVES;
-  const int n_round = share ? n : ((n + DESC_WAVES - 1) / DESC_WAVES) * DESC_WAVES;   // whole workgroups reach the barriers
-  for (int kb = k_first - (share ? 0 : wave); kb < n_round; kb += k_step) {
-    const int ki = share ? kb : kb + wave;
-    const bool live = ki < n;
-    const SiftKey k = keys[live ? ki : 0];
+  for (int ki = blockIdx.x; ki < n; ki += gridDim.x) {
+    const SiftKey k = keys[ki];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
     const float* grad = O.grad[k.index - 1];
@@ -599,110 +660,148 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
     const int win = (int)__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(frealsize, kSqrt2), 5.0f), 0.5f), 0.5f);
     const float fsr = __fmul_rn(sinang, firealsize), fcr = __fmul_rn(cosang, firealsize);
     const float fdrr = __fmul_rn(-fdrow, firealsize), fdcr = __fmul_rn(-fdcol, firealsize);
-    const int side = 2 * win + 1, total = live ? side * side : 0;
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int base = 0; base < total; base += 64) {
-      const int s = base + lane;
-      bool ok = false;
-      float mag = 0.f, rf = 0.f, cf = 0.f, of = 0.f;
-      int nr = 0, nc = 0, no = 0;
-      if (s < total) {
-        const int row = s / side - win, col = s % side - win;
-        const float fr = (float)row, fc = (float)col;
-        const float rpos = __fadd_rn(__fadd_rn(__fmul_rn(fsr, fc), __fmul_rn(fcr, fr)), fdrr);
-        const float cpos = __fadd_rn(__fsub_rn(__fmul_rn(fcr, fc), __fmul_rn(fsr, fr)), fdcr);
-        const float rx = __fadd_rn(rpos, 2.0f - 0.5f), cx = __fadd_rn(cpos, 2.0f - 0.5f);
-        const int r = rowstart + row, c = colstart + col;
-        if (rx > -0.9999f && rx < 3.9999f && cx > -0.9999f && cx < 3.9999f && r >= 0 && r < rows && c >= 0 &&
-            c < cols) {
-          ok = true;
-          const float e = expf(__fmul_rn(-0.125f, __fadd_rn(__fmul_rn(rpos, rpos), __fmul_rn(cpos, cpos))));
-          mag = __fmul_rn(grad[(size_t)r * cols + c], e);
-          float o = __fsub_rn(orim[(size_t)r * cols + c], ang);
-          while (o > 2 * kPi) o = __fsub_rn(o, 2 * kPi);
-          while (o < 0) o = __fadd_rn(o, 2 * kPi);
-          const float oribin = __fmul_rn(o, 8.0f / (2 * (float)kPi));   // PlaceInIndex
-          nr = rx < 0 ? (int)__fsub_rn(rx, 1.f) : (int)rx;
-          rf = __fsub_rn(rx, (float)nr);
-          nc = cx < 0 ? (int)__fsub_rn(cx, 1.f) : (int)cx;
-          cf = __fsub_rn(cx, (float)nc);
-          no = oribin < 0 ? (int)__fsub_rn(oribin, 1.f) : (int)oribin;
-          of = __fsub_rn(oribin, (float)no);
+    const int side = 2 * win + 1, total = side * side;
+    float acc = 0.f;
+    for (int chunk = 0; chunk < total; chunk += 64 * DESC_WAVES) {
+      // ---- A ----
+      {
+        const int s = chunk + tid;
+        bool ok = false;
+        float mag = 0.f, rf = 0.f, cf = 0.f, of = 0.f;
+        int nr = 0, nc = 0, nb = 0;
+        if (s < total) {
+          const int row = s / side - win, col = s % side - win;
+          const float fr = (float)row, fc = (float)col;
+          const float rpos = __fadd_rn(__fadd_rn(__fmul_rn(fsr, fc), __fmul_rn(fcr, fr)), fdrr);
+          const float cpos = __fadd_rn(__fsub_rn(__fmul_rn(fcr, fc), __fmul_rn(fsr, fr)), fdcr);
+          const float rx = __fadd_rn(rpos, 2.0f - 0.5f), cx = __fadd_rn(cpos, 2.0f - 0.5f);
+          const int r = rowstart + row, c = colstart + col;
+          if (rx > -0.9999f && rx < 3.9999f && cx > -0.9999f && cx < 3.9999f && r >= 0 && r < rows && c >= 0 &&
+              c < cols) {
+            ok = true;
+            const float e = expf(__fmul_rn(-0.125f, __fadd_rn(__fmul_rn(rpos, rpos), __fmul_rn(cpos, cpos))));
+            mag = __fmul_rn(grad[(size_t)r * cols + c], e);
+            float o = __fsub_rn(orim[(size_t)r * cols + c], ang);
+            while (o > 2 * kPi) o = __fsub_rn(o, 2 * kPi);
+            while (o < 0) o = __fadd_rn(o, 2 * kPi);
+            const float oribin = __fmul_rn(o, 8.0f / (2 * (float)kPi));   // PlaceInIndex
+            nr = rx < 0 ? (int)__fsub_rn(rx, 1.f) : (int)rx;
+            rf = __fsub_rn(rx, (float)nr);
+            nc = cx < 0 ? (int)__fsub_rn(cx, 1.f) : (int)cx;
+            cf = __fsub_rn(cx, (float)nc);
+            const int no = oribin < 0 ? (int)__fsub_rn(oribin, 1.f) : (int)oribin;
+            of = __fsub_rn(oribin, (float)no);
+            nb = no & 7;   // the bins wrap: orientation 2 pi falls into bin 8 = bin 0
+          }
+        }
+        // the 24 masks of this wavefront: cell c in lane c, bin b in lane 16 + b
+        unsigned long long keep = 0ull;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int r_ = c >> 2, c_ = c & 3;
+          const unsigned long long m = __ballot(ok && (nr == r_ - 1 || nr == r_) && (nc == c_ - 1 || nc == c_));
+          if (lane == c) keep = m;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const unsigned long long m = __ballot(ok && (nb == b || ((nb + 1) & 7) == b));
+          if (lane == 16 + b) keep = m;
+        }
+        if (lane < 16) L.cmask[wave][lane] = keep;
+        else if (lane < 24) L.bmask[wave][lane - 16] = keep;
+        wave_sync();
+        // sizes of lists 2 lane, 2 lane + 1 (cell lane / 4, bins 2 (lane % 4), + 1) and their places
+        {
+          const unsigned long long cm = L.cmask[wave][lane >> 2];
+          const int c0 = __popcll(cm & L.bmask[wave][2 * (lane & 3)]);
+          const int c1 = __popcll(cm & L.bmask[wave][2 * (lane & 3) + 1]);
+          int incl = c0 + c1;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+          }
+          const int excl = incl - (c0 + c1);
+          L.off[wave][2 * lane] = (uint16_t)excl;
+          L.off[wave][2 * lane + 1] = (uint16_t)(excl + c0);
+          if (lane == 63) L.off[wave][128] = (uint16_t)incl;
+        }
+        wave_sync();
+        if (ok) {
+          const float rg0 = __fmul_rn(mag, __fsub_rn(1.f, rf)), rg1 = __fmul_rn(mag, rf);   // rows nr, nr + 1
+          const float cfm = __fsub_rn(1.f, cf), ofm = __fsub_rn(1.f, of);
+          const int b1 = (nb + 1) & 7;
+          const unsigned long long bm0 = L.bmask[wave][nb] & lt, bm1 = L.bmask[wave][b1] & lt;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int r_ = nr + i;
+            if ((unsigned)r_ >= 4u) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c_ = nc + j;
+              if ((unsigned)c_ >= 4u) continue;
+              const int cell = 4 * r_ + c_;
+              const float rg = i == 0 ? rg0 : rg1;
+              const float cg = j == 0 ? __fmul_rn(rg, cfm) : __fmul_rn(rg, cf);
+              const unsigned long long cm = L.cmask[wave][cell];
+              L.val[wave][L.off[wave][8 * cell + nb] + __popcll(cm & bm0)] = __fmul_rn(cg, ofm);
+              L.val[wave][L.off[wave][8 * cell + b1] + __popcll(cm & bm1)] = __fmul_rn(cg, of);
+            }
+          }
         }
       }
-      // shared key: only the samples that reach this wavefront's cells (rows nr, nr + 1; columns nc, nc + 1)
-      unsigned long long m = __ballot(ok && (!share || ((nr == cell_r - 1 || nr == cell_r) && nc >= col_lo - 1 && nc <= col_lo + 1)));
-      while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-#define RL_F(x) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src))
-        const int snr = __builtin_amdgcn_readlane(nr, src), snc = __builtin_amdgcn_readlane(nc, src);
-        const int sno = __builtin_amdgcn_readlane(no, src);
-        const float smag = RL_F(mag), srf = RL_F(rf), scf = RL_F(cf), sof = RL_F(of);
-#undef RL_F
-        const int i = cell_r - snr, j = cell_c - snc;
-        if (owner && (unsigned)i < 2u && (unsigned)j < 2u) {
-          const float rg = i == 0 ? __fmul_rn(smag, __fsub_rn(1.f, srf)) : __fmul_rn(smag, srf);
-          const float cg = j == 0 ? __fmul_rn(rg, __fsub_rn(1.f, scf)) : __fmul_rn(rg, scf);
-          const int k0 = (ob0 - sno) & 7, k1 = (ob0 + 1 - sno) & 7;
-          if (k0 < 2) acc0 = __fadd_rn(acc0, k0 == 0 ? __fmul_rn(cg, __fsub_rn(1.f, sof)) : __fmul_rn(cg, sof));
-          if (k1 < 2) acc1 = __fadd_rn(acc1, k1 == 0 ? __fmul_rn(cg, __fsub_rn(1.f, sof)) : __fmul_rn(cg, sof));
+      __syncthreads();
+      // ---- B ----
+      if (tid < 128) {
+#pragma unroll
+        for (int w = 0; w < DESC_WAVES; ++w) {
+          const int e0 = L.off[w][tid], e1 = L.off[w][tid + 1];
+          const float* v = L.val[w];
+          for (int e = e0; e < e1; e += 4) {
+            // four at a time: the loads do not depend on the running sum (reads past the list's end stay inside val)
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = v[min(e + j, 511)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (e + j < e1) acc = __fadd_rn(acc, x[j]);
+          }
         }
       }
+      __syncthreads();   // the lists are rewritten by the next chunk
     }
-    sync_scope();
-    if (owner) {
-      d_s[2 * entry] = acc0;
-      d_s[2 * entry + 1] = acc1;
-    }
-    sync_scope();
-    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527); one
-    // wavefront works on the 128 values (its own key's, or the shared key's on wavefront 0)
-    const bool norm_wave = !share || wave == 0;
+    if (tid < 128) L.d[tid] = acc;
+    __syncthreads();
+    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527)
     for (int pass = 0; pass < 2; ++pass) {
-      if (norm_wave && lane == 0) {
+      if (tid == 0) {
         float a = 0.f;
-        for (int i = 0; i < 128; ++i) a = __fadd_rn(a, __fmul_rn(d_s[i], d_s[i]));
-        scal_s = __fdiv_rn(1.f, sqrtf(a));
+        for (int i = 0; i < 128; ++i) a = __fadd_rn(a, __fmul_rn(L.d[i], L.d[i]));
+        L.scal = __fdiv_rn(1.f, sqrtf(a));
       }
-      sync_scope();
+      __syncthreads();
       bool clamp = false;
-      if (norm_wave) {
-        const float sc = scal_s;
-        d_s[2 * lane] = __fmul_rn(d_s[2 * lane], sc);
-        d_s[2 * lane + 1] = __fmul_rn(d_s[2 * lane + 1], sc);
-        if (pass == 0) {
-          if (d_s[2 * lane] > 0.2f) {
-            d_s[2 * lane] = 0.2f;
-            clamp = true;
-          }
-          if (d_s[2 * lane + 1] > 0.2f) {
-            d_s[2 * lane + 1] = 0.2f;
-            clamp = true;
-          }
+      if (tid < 128) {
+        float v = __fmul_rn(L.d[tid], L.scal);
+        if (pass == 0 && v > 0.2f) {
+          v = 0.2f;
+          clamp = true;
         }
-        const bool any_w = __ballot(clamp) != 0ull;
-        if (lane == 0) any_s = any_w ? 1 : 0;
+        L.d[tid] = v;
       }
-      sync_scope();
-      const bool any = any_s != 0;
-      sync_scope();
+      const int any = __syncthreads_or(clamp ? 1 : 0);
       if (!any) break;
     }
-    if (live && norm_wave) {
-      float* out = desc_out + (size_t)ki * 128;
-      out[2 * lane] = d_s[2 * lane];
-      out[2 * lane + 1] = d_s[2 * lane + 1];
-      if (lane == 0) {
-        const float fscale = O.fscale;
-        float* g = geo_out + (size_t)ki * 4;
-        g[0] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
-        g[1] = __fmul_rn(fscale, frow);
-        g[2] = __fmul_rn(fscale, fSize);
-        g[3] = ang;
-      }
+    if (tid < 128) desc_out[(size_t)ki * 128 + tid] = L.d[tid];
+    if (tid == 0) {
+      const float fscale = O.fscale;
+      float* g = geo_out + (size_t)ki * 4;
+      g[0] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
+      g[1] = __fmul_rn(fscale, frow);
+      g[2] = __fmul_rn(fscale, fSize);
+      g[3] = ang;
     }
-    sync_scope();
+    __syncthreads();
   }
 }
 
@@ -844,6 +943,75 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
       o_small = o;
       break;
     }
+  bool jobs_ok = true;   // every level's kernel fits the tile kernel's halo
+  for (int i = 0; i < kScales + 2; ++i) jobs_ok = jobs_ok && (T5.t[i].n >> 1) <= BT_MAXW;
+  if (jobs_ok) {
+    // the large octaves as a dependency-ordered list of launches, two independent levels per launch where there are two
+    auto make_job = [&](int o, int i) {   // level i of octave o from level i - 1 (or, i == 1 and o > 0, from octave o - 1)
+      const SiftOctave& O = P.oct[o];
+      BlurJob b;
+      b.rows = O.rows;
+      b.cols = O.cols;
+      b.dst = O.gaus[i];
+      b.dog = O.dog[i - 1];
+      b.taps = i - 1;
+      b.tiles_x = (O.cols + BT_X - 1) / BT_X;
+      b.tile_begin = 0;
+      if (i == 1 && o > 0) {
+        b.src = P.oct[o - 1].gaus[kScales];
+        b.src_cols = P.oct[o - 1].cols;
+        b.half = 1;
+        b.half_dst = O.gaus[0];
+      } else {
+        b.src = O.gaus[i - 1];
+        b.src_cols = O.cols;
+        b.half = 0;
+        b.half_dst = nullptr;
+      }
+      return b;
+    };
+    auto tiles_of = [&](const BlurJob& b) { return b.tiles_x * ((b.rows + BT_Y - 1) / BT_Y); };
+    auto launch_jobs = [&](BlurJob a, const BlurJob* b2) {
+      BlurJobs J;
+      J.n = b2 ? 2 : 1;
+      J.j[0] = a;
+      J.t[0] = T5.t[a.taps];
+      J.j[0].taps = 0;
+      int total = tiles_of(a);
+      if (b2) {
+        J.j[1] = *b2;
+        J.t[1] = T5.t[b2->taps];
+        J.j[1].taps = 1;
+        J.j[1].tile_begin = total;
+        total += tiles_of(*b2);
+      } else {
+        J.j[1] = a;
+        J.t[1] = J.t[0];
+      }
+      hipLaunchKernelGGL(blur_jobs_kernel, dim3(total), dim3(BT_THREADS), 0, s, J);
+    };
+    for (int o = 0; o < o_small; ++o) {
+      // levels 1 (unless it went out with the previous octave's level kScales + 1), 2 .. kScales on their own
+      for (int i = (o == 0 ? 1 : 3); i <= kScales; ++i) launch_jobs(make_job(o, i), nullptr);
+      // levels kScales + 1, kScales + 2 together with levels 1, 2 of the next large octave
+      const bool next = o + 1 < o_small;
+      for (int d = 1; d <= 2; ++d) {
+        const BlurJob a = make_job(o, kScales + d);
+        if (next) {
+          const BlurJob b = make_job(o + 1, d);
+          launch_jobs(a, &b);
+        } else {
+          launch_jobs(a, nullptr);
+        }
+      }
+      if (!next && o + 1 < plan.n_octaves) {   // the first small octave's level 0
+        const SiftOctave& O = P.oct[o];
+        const SiftOctave& N = P.oct[o + 1];
+        hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
+                           N.gaus[0], N.rows, N.cols);
+      }
+    }
+  } else
   for (int o = 0; o < o_small; ++o) {
     const SiftOctave& O = P.oct[o];
     for (int i = 1; i < kScales + 3; ++i) {   // OctaveKeypoints (:410-438)
