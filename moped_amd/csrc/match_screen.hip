@@ -248,15 +248,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   const int nqb = gridDim.x / A.n_splits;
   int qblock, split;
   {
-    const int L = blockIdx.x;
-    if ((A.n_splits & 7) == 0) {
-      const int x = L & 7, j = L >> 3;
-      split = x + 8 * (j / nqb);
-      qblock = j % nqb;
-    } else {
-      split = L / nqb;
-      qblock = L % nqb;
-    }
+    // workgroup L runs on XCD L % 8: XCD x takes the x-th eighth of the (split-major) unit list, so the rows of a
+    // split -- read by all nqb query blocks -- pass through one or two of the eight L2s and not through all of them,
+    // whatever the number of splits
+    const int L = blockIdx.x, U = gridDim.x;
+    const int x = L & 7, j = L >> 3;
+    const int unit = x * (U >> 3) + min(x, U & 7) + j;
+    split = unit / nqb;
+    qblock = unit - split * nqb;
   }
   const int Qe = A.q_count ? min(A.Q, *A.q_count) : A.Q;
   if (qblock * QB >= Qe) return;   // uniform over the workgroup
