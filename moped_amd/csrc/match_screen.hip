@@ -557,6 +557,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     unsigned int* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
   __shared__ int cand_s[RS_WAVES][RS_MAXC];
+  __shared__ int ncand_s[RS_WAVES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = blockIdx.x * RS_WAVES + wave;
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     return;
   }
   const float nq = qnorm[q];
+  if (lane == 0) ncand_s[wave] = 0;
   {
     const float2 v = reinterpret_cast<const float2*>(qn + (size_t)q * DIM)[lane];
     q_s[wave][2 * lane] = v.x;
@@ -591,24 +593,17 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       } else if (j < n_slots + n_ovf) {
         rec = ovf[(size_t)q * ovf_cap + (j - n_slots)];
       }
+      // candidates in any order (the exact top-2 below breaks ties by row number): an LDS counter hands out places
       unsigned bits = rec.y & 0xFFFFu;
-      const int cnt = __popc(bits);
-      int pre = cnt;   // inclusive prefix over the lanes
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(pre, d);
-        if (lane >= d) pre += o;
-      }
-      const int total = __shfl(pre, 63);
-      int w = n_cand + pre - cnt;
       while (bits) {
         const int r = __builtin_ctz(bits);
         bits &= bits - 1;
+        const int w = atomicAdd(&ncand_s[wave], 1);
         if (w < RS_MAXC) cand_s[wave][w] = (int)rec.x + (r & 3) + 8 * (r >> 2);
-        ++w;
       }
-      n_cand += total;
     }
+    wave_lds_sync();
+    n_cand = ncand_s[wave];
     if (n_cand > RS_MAXC) brute = true;
   } else if (n_ovf > ovf_cap) {
     for (int j = lane; j < n_slots; j += 64) mine[j] = make_uint2(0u, 0u);   // the lists overflowed: empty every slot

@@ -178,9 +178,101 @@ struct BlurJobs {
   Taps t[2];
   int n;
 };
+// The tile blur with the tap count known at compile time: every thread keeps a window of the source in registers and
+// produces several neighbouring outputs from it (8 along a row for two rows at once, 4 down a column for two columns),
+// so a pixel is read from LDS once per 8 (4) outputs instead of once per output and tap -- the loop-over-taps version
+// below is bound by its 46 k LDS reads per tile.  Per output the products and sums are the ones of ConvHorizontal /
+// ConvVertical in the same (ascending tap) order.  The source tile sits in LDS with rows interleaved in pairs
+// ([row / 2][column][row % 2]): one 16-byte read gives two columns of two rows, laid out as the operands of the packed
+// multiply and add.
+template <int N>
+__device__ __forceinline__ void blur_tile_fixed(const BlurJob& job, const float* __restrict__ k, float* in_s, float* row_s,
+                                                int r0, int c0, int tid) {
+  constexpr int W = N / 2, IN_W = BT_X + 2 * W, IN_H = BT_Y + 2 * W, IN_WP = (IN_W + 3) & ~3;
+  static_assert((IN_H & 1) == 0 && IN_H * IN_WP <= (BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW), "tile buffer");
+  const int rows = job.rows, cols = job.cols;
+  const int step = job.half ? 2 : 1;
+  // staging: 16 x 16 threads over rows x columns (replicated edges; a `half` job reads every second row and column
+  // of the previous octave and writes its own pixels out as level 0)
+  for (int yy = tid >> 4; yy < IN_H; yy += 16) {
+    const int yu = r0 - W + yy;
+    const int y = yu < 0 ? 0 : (yu >= rows ? rows - 1 : yu);
+    const float* srow = job.src + (size_t)(step * y) * job.src_cols;
+    float* drow = in_s + (yy >> 1) * (2 * IN_WP) + (yy & 1);
+    for (int xx = tid & 15; xx < IN_W; xx += 16) {
+      const int xu = c0 - W + xx;
+      const int x = xu < 0 ? 0 : (xu >= cols ? cols - 1 : xu);
+      const float v = srow[step * x];
+      drow[2 * xx] = v;
+      if (job.half && yu == y && xu == x && yy >= W && yy < W + BT_Y && xx >= W && xx < W + BT_X)
+        job.half_dst[(size_t)y * cols + x] = v;
+    }
+  }
+  __syncthreads();
+  // row pass: rows 2p, 2p + 1, outputs x0 .. x0 + 7
+  if (tid < (IN_H / 2) * 8) {
+    const int p = tid >> 3, x0 = 8 * (tid & 7);
+    const float4* src = reinterpret_cast<const float4*>(in_s + p * (2 * IN_WP) + 2 * x0);
+    v2f win[N + 7];
+#pragma unroll
+    for (int i = 0; i < (N + 7) / 2; ++i) {
+      const float4 q = src[i];
+      win[2 * i] = v2f{q.x, q.y};
+      win[2 * i + 1] = v2f{q.z, q.w};
+    }
+    v2f acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const v2f kj = v2f{k[j], k[j]};
+#pragma unroll
+      for (int o = 0; o < 8; ++o) acc[o] = acc[o] + win[o + j] * kj;
+    }
+    float* d0 = row_s + (2 * p) * BT_X + x0;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      d0[o] = acc[o].x;
+      d0[BT_X + o] = acc[o].y;
+    }
+  }
+  __syncthreads();
+  // column pass: columns x, x + 1, outputs y0 .. y0 + 3
+  {
+    const int x = 2 * (tid & 31), y0 = 4 * (tid >> 5);
+    const v2f* src = reinterpret_cast<const v2f*>(row_s + y0 * BT_X + x);
+    v2f win[N + 3];
+#pragma unroll
+    for (int i = 0; i < N + 3; ++i) win[i] = src[i * (BT_X / 2)];
+    v2f acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const v2f kj = v2f{k[j], k[j]};
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] = acc[o] + win[o + j] * kj;
+    }
+    const int c = c0 + x;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int y = y0 + o, r = r0 + y;
+      if (r >= rows || c >= cols) continue;
+      const size_t at = (size_t)r * cols + c;
+      const float* old = in_s + ((y + W) >> 1) * (2 * IN_WP) + 2 * (x + W) + ((y + W) & 1);   // the source pixel (and its right neighbour: + 2)
+      job.dst[at] = acc[o].x;
+      if (job.dog) job.dog[at] = __fsub_rn(old[0], acc[o].x);
+      if (c + 1 < cols) {
+        job.dst[at + 1] = acc[o].y;
+        if (job.dog) job.dog[at + 1] = __fsub_rn(old[2], acc[o].y);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
-  __shared__ float in_s[(BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW)];
-  __shared__ __attribute__((aligned(8))) float row_s[(BT_Y + 2 * BT_MAXW) * BT_X];
+  __shared__ __attribute__((aligned(16))) float in_s[(BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW)];
+  __shared__ __attribute__((aligned(16))) float row_s[(BT_Y + 2 * BT_MAXW) * BT_X];
   const int tid = threadIdx.x;
   const int jn = (J.n > 1 && (int)blockIdx.x >= J.j[1].tile_begin) ? 1 : 0;
   const BlurJob& job = J.j[jn];
@@ -189,6 +281,15 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
   const int tile = blockIdx.x - job.tile_begin;
   const int w = t.n >> 1;
   const int c0 = (tile % job.tiles_x) * BT_X, r0 = (tile / job.tiles_x) * BT_Y;
+  // the tap counts of the shipped constants (InitSigma 1.6, 3 scales: 11, 13, 17, 21, 25) have kernels of their own
+  switch (t.n) {
+    case 11: return blur_tile_fixed<11>(job, t.k, in_s, row_s, r0, c0, tid);
+    case 13: return blur_tile_fixed<13>(job, t.k, in_s, row_s, r0, c0, tid);
+    case 17: return blur_tile_fixed<17>(job, t.k, in_s, row_s, r0, c0, tid);
+    case 21: return blur_tile_fixed<21>(job, t.k, in_s, row_s, r0, c0, tid);
+    case 25: return blur_tile_fixed<25>(job, t.k, in_s, row_s, r0, c0, tid);
+    default: break;
+  }
   const int in_w = BT_X + 2 * w, in_h = BT_Y + 2 * w;
   const int step = job.half ? 2 : 1;
   for (int e = tid; e < in_w * in_h; e += BT_THREADS) {
@@ -919,8 +1020,22 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
   hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
                      init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols);
   if (init_fused) {
-    hipLaunchKernelGGL(blur_level_kernel, dim3((O0.cols + BT_X - 1) / BT_X, (O0.rows + BT_Y - 1) / BT_Y), dim3(BT_THREADS), 0, s,
-                       (const float*)B.tmp, O0.gaus[0], O0.rows, O0.cols, t0, (const float*)nullptr, (float*)nullptr);
+    BlurJobs J;
+    J.n = 1;
+    BlurJob& b = J.j[0];
+    b.src = B.tmp;
+    b.dst = O0.gaus[0];
+    b.dog = nullptr;
+    b.half_dst = nullptr;
+    b.rows = O0.rows;
+    b.cols = b.src_cols = O0.cols;
+    b.half = 0;
+    b.taps = 0;
+    b.tiles_x = (O0.cols + BT_X - 1) / BT_X;
+    b.tile_begin = 0;
+    J.j[1] = b;
+    J.t[0] = J.t[1] = t0;
+    hipLaunchKernelGGL(blur_jobs_kernel, dim3(b.tiles_x * ((O0.rows + BT_Y - 1) / BT_Y)), dim3(BT_THREADS), 0, s, J);
   } else if (init_blur) {   // in place through the scratch image
     hipLaunchKernelGGL(blur_rows_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, O0.gaus[0], B.tmp, O0.rows, O0.cols, t0);
     hipLaunchKernelGGL(blur_cols_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, B.tmp, O0.gaus[0], O0.rows, O0.cols, t0,
