@@ -36,7 +36,14 @@ DevCam make_devcam(const mh_cam& cam) {
 
 namespace {
 
-constexpr int POSE_THREADS = 512;
+// 256 threads = one wavefront per SIMD: at 253 VGPRs a POSE workgroup then leaves half of every SIMD's register file
+// free, enough for a MATCH workgroup (2 x 128 VGPRs per SIMD) of another frame to share the compute unit; with 512
+// threads (two wavefronts per SIMD) it owned the unit for its 0.13 ms and the one-round MATCH grids queued behind it:
+// +5% frames/s at config 1 and on the per-rank load of 8 shards.  The first hypothesis stage is 256 lanes wide anyway.
+#ifndef MH_POSE_THREADS
+#define MH_POSE_THREADS 256
+#endif
+constexpr int POSE_THREADS = MH_POSE_THREADS;
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
