@@ -724,6 +724,12 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   if (ev) hipEventRecord(ev[3], s);
   // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
   static const int sb_pin = env_int("MH_SCREEN_SPLITS_B", 0);   // experiments
+  // Two workgroups per CU (they fit side by side: 2 x 66 KB LDS, 4 x 128 VGPRs per SIMD) when every one of them still
+  // sweeps >= 24 tiles: four wavefronts per SIMD hide the end-of-tile waits better (pass B alone 0.272 -> 0.261 ms at
+  // Q = 12000, N = 100k) and a grid of two rounds' worth of workgroups does not stall on the CUs that other frames'
+  // kernels hold (+5% frames/s at config 1, +3% at config 2).  With fewer tiles per workgroup the A-operand prologue
+  // costs more than that (Q = 3000: 0.445 -> 0.394 of peak), so small launches keep one workgroup per CU.
+  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= 24L * 512 ? 512 : 256;
   const int Sb = sb_pin > 0 ? std::min(std::min(sb_pin, n_tiles), SC_SLOTS_MAX / 2)
                             : splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
   a.n_sel = n_tiles;
@@ -745,7 +751,7 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
                          int32_t index_base, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
                          float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
   static const int sample = std::max(1, env_int("MH_SCREEN_SAMPLE", 8));      // pass A looks at every `sample`-th tile
-  static const int blocks_b = std::max(1, env_int("MH_SCREEN_BLOCKS", 256));  // one workgroup per CU, one round
+  static const int blocks_b = std::max(0, env_int("MH_SCREEN_BLOCKS", 0));    // workgroups of pass B; 0 = by size (launch_passes)
   static const int blocks_a = std::max(1, env_int("MH_SCREEN_BLOCKS_A", 256));
   static const int nqb_pin = env_int("MH_SCREEN_NQB", 0);
   const int q_pad = screen_q_pad(Q);
