@@ -325,11 +325,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   // wavefront's LDS buffer {destination slot, row0, bits} and written out when the workgroup is done.
   uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16));
   int* const reccnt = reinterpret_cast<int*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16) + SC_RECBUF * 16);
-  auto emit = [&](const v16f& acc, int nb, int row0) {
+  auto emit = [&](const v16f& acc, int nb, int row0, float top) {
     // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
     unsigned bits = 0;
 #pragma unroll
     for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tau[nb] - acc[r]), 31);
+    // the largest of the 16 values (it belongs to one of the flagged rows) rides along as an f16 -- its distance
+    // above the threshold, a small positive number, so the f16 costs ~1e-5 of precision and not 5e-4: pass C ranks
+    // the records by it and runs the exact arithmetic only on those that can still hold one of the two nearest rows
+    bits = (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - tau[nb])) << 16);
     const int q = q0 + nb * 32 + l32;
     if (n_rec[nb] < A.sub_cap) {
       const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb];
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (have_pend && !SC_ABL(0) && m > tau[pnb]) emit(pend, pnb, pend_row0);
+          if (have_pend && !SC_ABL(0) && m > tau[pnb]) emit(pend, pnb, pend_row0, m);
           __builtin_amdgcn_sched_barrier(0);
           pend = acc;
           pend_row0 = row0;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     float m = pend[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, pend[r]);
-    if (m > tau[NQB - 1]) emit(pend, NQB - 1, pend_row0);
+    if (m > tau[NQB - 1]) emit(pend, NQB - 1, pend_row0, m);
   }
   if (MODE == 1) {
     // the parked records to their slots
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     const float* __restrict__ qn, const float* __restrict__ qnorm, const uint8_t* __restrict__ qbad, int Q,
     const int32_t* __restrict__ q_count, const float* __restrict__ db, const float* __restrict__ dnorm, int N,
     int32_t index_base, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
-    int ovf_cap, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
+    int ovf_cap, float dmax, const float* __restrict__ tau, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
     unsigned int* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
   __shared__ int cand_s[RS_WAVES][RS_MAXC];
@@ -584,8 +588,27 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
   int n_cand = 0;
   uint2* mine = recs + (size_t)q * SC_SLOTS_MAX;
   if (!brute) {
-    for (int base = 0; base < n_slots + n_ovf; base += 64) {
-      const int j = base + lane;
+    // Every record carries the largest screen value of its rows (f16, nearest).  Two different records hold different
+    // rows, so the second largest of these values (minus the f16 rounding) is a lower bound of the DB's second largest
+    // screen value s2, and a row that belongs to the exact top-2 has a screen value >= s2 - 2 E (pass B's argument
+    // with the exact s2 in the place of pass A's sampled one): records whose largest value (plus the rounding) lies
+    // more than screen_margin below that bound cannot hold one.  Pass A's threshold comes from an eighth of the rows
+    // and lets ~25 rows per query through; ~3 survive this one and get their 512-byte row fetched.
+    constexpr int RS_ITERS = (SC_SLOTS_MAX + SCREEN_OVF_CAP + 63) / 64;
+    uint2 recv[RS_ITERS];
+    float l1 = -__builtin_inff(), l2 = -__builtin_inff();   // the lane's two largest lower bounds
+    const float tau_q = tau[q];
+    auto bounds = [tau_q](unsigned y, float& lo, float& hi) {
+      const float dv = (float)__builtin_bit_cast(_Float16, (unsigned short)(y >> 16));   // value - tau, rounded to f16
+      // nearest f16: 2^-11 dv (2^-25 below the normals), doubled; + the f32 roundings of (value - tau) and (tau + dv)
+      const float eps = fabsf(dv) * 0.001f + 1e-6f + 4e-7f * fabsf(tau_q);
+      const bool fin = fabsf(dv) < 6.0e4f && fabsf(tau_q) < 1e30f;   // inf / nan: no information
+      lo = fin ? tau_q + dv - eps : -__builtin_inff();
+      hi = fin ? tau_q + dv + eps : __builtin_inff();
+    };
+#pragma unroll
+    for (int it = 0; it < RS_ITERS; ++it) {
+      const int j = it * 64 + lane;
       uint2 rec = make_uint2(0u, 0u);
       if (j < n_slots) {
         rec = mine[j];
@@ -593,8 +616,31 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       } else if (j < n_slots + n_ovf) {
         rec = ovf[(size_t)q * ovf_cap + (j - n_slots)];
       }
-      // candidates in any order (the exact top-2 below breaks ties by row number): an LDS counter hands out places
+      recv[it] = rec;
+      if (rec.y & 0xFFFFu) {
+        float lo, hi;
+        bounds(rec.y, lo, hi);
+        l2 = fmaxf(l2, fminf(l1, lo));
+        l1 = fmaxf(l1, lo);
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o1 = __shfl_xor(l1, d), o2 = __shfl_xor(l2, d);
+      l2 = fmaxf(fmaxf(l2, o2), fminf(l1, o1));
+      l1 = fmaxf(l1, o1);
+    }
+    const float keep_from = l2 - screen_margin(nq, dmax);   // -inf with fewer than two records: everything stays
+#pragma unroll
+    for (int it = 0; it < RS_ITERS; ++it) {
+      const uint2 rec = recv[it];
       unsigned bits = rec.y & 0xFFFFu;
+      if (bits) {
+        float lo, hi;
+        bounds(rec.y, lo, hi);
+        if (hi < keep_from) bits = 0;
+      }
+      // candidates in any order (the exact top-2 below breaks ties by row number): an LDS counter hands out places
       while (bits) {
         const int r = __builtin_ctz(bits);
         bits &= bits - 1;
@@ -794,7 +840,7 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
-                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, idx1, d1, d2,
+                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, idx1, d1, d2,
                      sb.stats);
   if (sb.ev) hipEventRecord(sb.ev[5], s);
 }
