@@ -227,13 +227,11 @@ __device__ __forceinline__ int walk_block_impl(MsLds<ND>& L, int i0, int nrem, u
           if (__ballot(ch) == 0ull) break;
         }
       }
-      // indirect writes of step i: the old targets of the outward members that were not pre-empted
-      ++stamp;
-#pragma unroll
-      for (int u = 0; u < NP; ++u)
-        if (out[u] && stv[u] != 2) L.st[mpr[u]] = stamp;
-#pragma unroll
-      for (int u = 0; u < NP; ++u) fl[u] = L.st[u * 64 + lane];
+      // indirect writes of step i: the old targets of the members that were not pre-empted.  The flags of the last
+      // sweep mark exactly those positions: that sweep was made by the members with stv == 1 (all members when there
+      // was no hit; the final, unchanged state when the relaxation ran), and a flagged position that is the target of
+      // a non-outward member is itself a member and gets i below anyway -- no sweep of its own (it was two more
+      // dependent LDS round trips per row).
 #pragma unroll
       for (int u = 0; u < NP; ++u)
         if (u * 64 + lane < nrem && fl[u] == stamp) mpr[u] = i;

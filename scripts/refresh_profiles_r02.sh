@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
 # Regenerates round 2's judged artifacts under gpurun_out/profiles_r02 (copy into profiles/ afterwards).
-# usage (GPU box): bash scripts/refresh_profiles_r02.sh [part ...]   parts: bench prof traffic ranks (default: all)
+# usage (GPU box): bash scripts/refresh_profiles_r02.sh [part ...]   parts: bench prof traffic ranks sift (default: all)
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/profiles_r02
 mkdir -p $out
-parts=${*:-bench prof traffic ranks}
+parts=${*:-bench prof traffic ranks sift}
 cd $root
 has() { [[ " $parts " == *" $1 "* ]]; }
 if has bench; then
@@ -39,14 +39,15 @@ if has traffic; then
   # doubled as MI355X_MICROARCH.md prescribes for gfx950
   cd /tmp && export TMPDIR=/tmp
   echo "{" > $out/traffic_r02.json
-  for m in 20 200; do
+  for mq in "20 3000" "20 12000" "200 3000" "200 12000" "50 3000"; do
+    set -- $mq; m=$1; q=$2
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/trs_$m$c
-      timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/trs_$m$c -- python3 $root/scripts/screen_probe.py $m 3000 5 > /tmp/trs_$m$c.log 2>&1 || { tail -3 /tmp/trs_$m$c.log; exit 1; }
+      timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/trs_$m$c -- python3 $root/scripts/screen_probe.py $m $q 5 > /tmp/trs_$m$c.log 2>&1 || { tail -3 /tmp/trs_$m$c.log; exit 1; }
     done
-    python3 - $m >> $out/traffic_r02.json <<'PY'
+    python3 - $m $q >> $out/traffic_r02.json <<'PY'
 import csv, glob, sys, collections
-m = sys.argv[1]
+m, q = sys.argv[1], sys.argv[2]
 names = {"screen_b": "screen_kernel<1", "screen_a": "screen_kernel<0", "rescore": "rescore_kernel", "match": "match_mfma_kernel"}
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -58,8 +59,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             res[(k, c)] = sum(v) / len(v)
 for k in names:
     if (k, "FETCH_SIZE") in res:
-        print(f' "{k}_{m}m_3000q": {int(res[(k, "FETCH_SIZE")] * 1024 * 2)},')
-        print(f' "_raw_{k}_{m}m": "FETCH_SIZE {res[(k, "FETCH_SIZE")]:.1f} KB raw (x2 on gfx950), WRITE_SIZE {res.get((k, "WRITE_SIZE"), 0):.1f} KB per launch",')
+        print(f' "{k}_{m}m_{q}q": {int(res[(k, "FETCH_SIZE")] * 1024 * 2)},')
+        print(f' "_raw_{k}_{m}m_{q}q": "FETCH_SIZE {res[(k, "FETCH_SIZE")]:.1f} KB raw (x2 on gfx950), WRITE_SIZE {res.get((k, "WRITE_SIZE"), 0):.1f} KB per launch",')
 PY
   done
   echo ' "_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch over scripts/screen_probe.py (scripts/refresh_profiles_r02.sh traffic), KB*1024, FETCH doubled per MI355X_MICROARCH.md"' >> $out/traffic_r02.json
@@ -74,5 +75,17 @@ if has ranks; then
       echo "bench.py $a"; timeout -k 10 400 python bench.py $a --no-cpu-baseline --no-roofline 2>/dev/null | tail -1; done; } > $out/r02_per_rank_load_n8.txt 2>&1
   { for a in "--models 100 --frames-per-step 256 --steps 10" "--models 50 --frames-per-step 512" "--models 25"; do
       echo "bench.py $a --force-exchange"; timeout -k 10 500 python bench.py $a --force-exchange --no-cpu-baseline --no-roofline 2>/dev/null | tail -1; done; } > $out/r02_per_rank_load_200models.txt 2>&1
+fi
+if has sift; then
+  # FEAT and the image -> objects path on the reference's bundled frames
+  timeout -k 10 300 python tests/tools/sift_probe.py > $out/r02_sift_probe.txt 2>&1
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 16 > $out/r02_image_frame_bench.txt 2>&1
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 4 >> $out/r02_image_frame_bench.txt 2>&1
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/rp_sift
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_sift -- python3 $root/tests/tools/sift_probe.py > /tmp/rp_sift.log 2>&1
+  cp $(find /tmp/rp_sift -name "*kernel_stats.csv" | head -1) $out/r02_sift_kernel_stats.csv
+  cd $root
+  timeout -k 10 300 python tests/tools/ms_bench.py > $out/r02_meanshift_bench.txt 2>&1
 fi
 ls -la $out
