@@ -2,6 +2,10 @@
 import sys, os, ctypes as C, numpy as np, time
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], 'oracle'))
 from moped_amd import capi
+if os.environ.get('WITH_ORACLE'):
+    import orclib
+if os.environ.get('WITH_SYNTH'):
+    from moped_amd import synth
 ctx = capi.Context(0)
 L = capi.load()
 rng = np.random.default_rng(0)
