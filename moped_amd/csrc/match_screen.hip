@@ -178,7 +178,7 @@ struct ScreenArgs {
   int tiles_base, tiles_rem, n_splits;  // split s takes tiles_base selected tiles, the first tiles_rem one more
   int n_splits_a;
   float dmax;
-  int ablate;            // SC_PROF builds only: 1 = no finish(), 2 = stage only the first tile, 4 = no MFMAs
+  int ablate;            // SC_PROF builds only: 1 = no finish(), 2 = stage only the first tile, 4 = no MFMAs, 8 = no end-of-tile barrier
 };
 
 // Between the passes: a query's threshold from pass A's per-split top-2 values.  tau = +inf for queries that do not
@@ -453,8 +453,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
 #ifdef SC_PROF
     const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
 #endif
+    if (!SC_ABL(3)) {   // (experiment builds: 8 = no end-of-tile wait and barrier -- what the synchronisation costs)
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the next group have landed
     __syncthreads();   // everybody's pieces have; nobody reads this group's buffers any more
+    }
 #ifdef SC_PROF
     t_wait += __builtin_amdgcn_s_memtime() - t_w0;
 #endif
@@ -770,11 +772,11 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   if (ev) hipEventRecord(ev[3], s);
   // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
   static const int sb_pin = env_int("MH_SCREEN_SPLITS_B", 0);   // experiments
-  // Two workgroups per CU (they fit side by side: 2 x 66 KB LDS, 4 x 128 VGPRs per SIMD) when every one of them still
-  // sweeps >= 24 tiles: four wavefronts per SIMD hide the end-of-tile waits better (pass B alone 0.272 -> 0.261 ms at
-  // Q = 12000, N = 100k) and a grid of two rounds' worth of workgroups does not stall on the CUs that other frames'
-  // kernels hold (+5% frames/s at config 1, +3% at config 2).  With fewer tiles per workgroup the A-operand prologue
-  // costs more than that (Q = 3000: 0.445 -> 0.394 of peak), so small launches keep one workgroup per CU.
+  // Twice as many workgroups as CUs when every one of them still sweeps >= 24 tiles: two rounds of half-length
+  // workgroups finish more evenly than one round of ~240 (pass B alone 0.272 -> 0.261 ms at Q = 12000, N = 100k), and
+  // under load a one-round grid stalls on every CU another frame's kernel holds (+5% frames/s at config 1, +3% at
+  // config 2).  With fewer tiles per workgroup the query-operand prologue costs more than that (Q = 3000: 0.445 ->
+  // 0.394 of peak), so small launches keep one workgroup per CU.
   if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= 24L * 512 ? 512 : 256;
   const int Sb = sb_pin > 0 ? std::min(std::min(sb_pin, n_tiles), SC_SLOTS_MAX / 2)
                             : splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);

@@ -36,10 +36,11 @@ DevCam make_devcam(const mh_cam& cam) {
 
 namespace {
 
-// 256 threads = one wavefront per SIMD: at 253 VGPRs a POSE workgroup then leaves half of every SIMD's register file
-// free, enough for a MATCH workgroup (2 x 128 VGPRs per SIMD) of another frame to share the compute unit; with 512
-// threads (two wavefronts per SIMD) it owned the unit for its 0.13 ms and the one-round MATCH grids queued behind it:
-// +5% frames/s at config 1 and on the per-rank load of 8 shards.  The first hypothesis stage is 256 lanes wide anyway.
+// 256 threads = one wavefront per SIMD: at 253 VGPRs two POSE workgroups then share a compute unit, and the POSE
+// launches of the frames in flight hold half as many units as with 512 threads (two wavefronts per SIMD: the whole
+// register file of the unit for 0.13 ms).  The MATCH workgroups of other frames need a unit to themselves (236 VGPRs,
+// two wavefronts per SIMD) and queued behind them: +5% frames/s at config 1 and on the per-rank load of 8 shards.
+// The first hypothesis stage is 256 lanes wide anyway.
 #ifndef MH_POSE_THREADS
 #define MH_POSE_THREADS 256
 #endif

@@ -24,8 +24,9 @@ c.normalize_dev(q.data_ptr(), qn.data_ptr(), Q)
 c.match_set_mode(1)
 L = capi.load()
 out = (C.c_ulonglong * 8)()
-names = {0: "full", 1: "no finish()", 2: "first tile only staged", 4: "no MFMAs", 3: "no finish, no staging", 6: "no MFMA, no staging", 7: "LDS reads only"}
-for abl in (0, 1, 2, 4, 3, 6, 7):
+names = {0: "full", 1: "no finish()", 2: "first tile only staged", 4: "no MFMAs", 3: "no finish, no staging", 6: "no MFMA, no staging", 7: "LDS reads only",
+         9: "no finish, no tile barrier", 11: "no finish/staging/barrier", 13: "no finish/MFMA/barrier"}
+for abl in (0, 1, 9, 11, 4, 13, 7):
     L.mh_debug_screen_prof(out, 1, abl)
     for _ in range(3):
         c.match_local_dev(q.data_ptr(), qn.data_ptr(), Q, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
