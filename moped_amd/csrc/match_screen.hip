@@ -324,8 +324,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   // round trip too, and the tile's barrier would hand that wait to all eight wavefronts.  It is parked in the
   // wavefront's LDS buffer {destination slot, row0, bits} and written out when the workgroup is done.
   uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16));
-  int* const reccnt = reinterpret_cast<int*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16) + SC_RECBUF * 16);
-  auto emit = [&](const v16f& acc, int nb, int row0, float top) {
+  int n_parked = 0;   // records parked so far: wave-uniform (advanced by the hit lanes' count outside the divergent part)
+  auto emit = [&](const v16f& acc, int nb, int row0, float top, int pos) {
     // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
     unsigned bits = 0;
 #pragma unroll
@@ -338,16 +338,25 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     if (n_rec[nb] < A.sub_cap) {
       const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb];
       ++n_rec[nb];
-      const int pos = atomicAdd(reccnt, 1);   // LDS: the lanes with a hit get consecutive places
       if (pos < SC_RECBUF) recbuf[pos] = make_uint4(dst, (unsigned)row0, bits, 0u);
       else A.recs[dst] = make_uint2((unsigned)row0, bits);   // buffer full (a few dozen hits per wavefront are usual)
     } else {
       // the lane's sub-list is full: the query's overflow list (rare)
-      const int pos = atomicAdd(&A.ovf_cnt[q], 1);
-      if (pos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + pos] = make_uint2((unsigned)row0, bits);
+      const int opos = atomicAdd(&A.ovf_cnt[q], 1);
+      if (opos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + opos] = make_uint2((unsigned)row0, bits);
+      if (pos < SC_RECBUF) recbuf[pos] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // its place in the buffer stays empty
     }
   };
-  if (MODE == 1 && lane == 0) *reccnt = 0;   // (read by this wavefront only, after its own LDS operations in order)
+  // the hit lanes of a block get consecutive places in the wavefront's buffer: ballot + prefix count, no LDS atomic
+  // (its round trip was a quarter of the hit path)
+  auto emit_hits = [&](bool hit, const v16f& acc, int nb, int row0, float top) {
+    const unsigned long long hm = __ballot(hit);
+    if (hm == 0ull) return;
+    if (hit)
+      emit(acc, nb, row0, top,
+           n_parked + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u)));
+    n_parked += __popcll(hm);
+  };
 
   const int swz = l32 & 15;
   // A operands of a row block: row rb * 32 + l32, k-step s -> chunk 2 s + half, stored at position chunk ^ (row & 15);
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (have_pend && !SC_ABL(0) && m > tau[pnb]) emit(pend, pnb, pend_row0, m);
+          if (have_pend && !SC_ABL(0)) emit_hits(m > tau[pnb], pend, pnb, pend_row0, m);
           __builtin_amdgcn_sched_barrier(0);
           pend = acc;
           pend_row0 = row0;
@@ -466,17 +475,17 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     float m = pend[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, pend[r]);
-    if (m > tau[NQB - 1]) emit(pend, NQB - 1, pend_row0, m);
+    emit_hits(m > tau[NQB - 1], pend, NQB - 1, pend_row0, m);
   }
   if (MODE == 1) {
     // the parked records to their slots
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n = min(*reccnt, SC_RECBUF);
+    const int n = min(n_parked, SC_RECBUF);
     for (int j = lane; j < n; j += 64) {
       const uint4 e = recbuf[j];
-      A.recs[e.x] = make_uint2(e.y, e.z);
+      if (e.x != 0xFFFFFFFFu) A.recs[e.x] = make_uint2(e.y, e.z);
     }
   }
 #ifdef SC_PROF
