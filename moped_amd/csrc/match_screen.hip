@@ -312,12 +312,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
 
   // ---- what a lane does with one finished 32 x 32 block: 16 rows of one of its queries ----
   // pass A: running top-2 values
+  // (the two largest BLOCK MAXIMA, not the two largest values: 10 instructions per block instead of 32.  Two blocks
+  // are different rows, so the second largest block maximum is still some second row's value -- a lower bound of the
+  // query's second best, weaker than the exact one only when a lane's two best rows sit in the same 16-row group)
   auto fold_a = [&](const v16f& acc, int nb) {
+    float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      b2[nb] = __builtin_amdgcn_fmed3f(b1[nb], b2[nb], acc[r]);
-      b1[nb] = fmaxf(b1[nb], acc[r]);
-    }
+    for (int r = 3; r < 15; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+    m = fmaxf(m, acc[15]);
+    b2[nb] = __builtin_amdgcn_fmed3f(b1[nb], b2[nb], m);
+    b1[nb] = fmaxf(b1[nb], m);
   };
   // pass B, rare part: this lane has rows above its query's threshold -> one record.  The record does not go to
   // memory now: the s_waitcnt vmcnt(0) that ends every tile (it is there for the LDS-DMA) would wait for the store's
