@@ -278,7 +278,7 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
         st->cap_h = 0;
         int rc;
         if ((rc = realloc_dev(ctx, st->desc_h, need_h))) return rc;
-        if ((rc = realloc_dev(ctx, st->neg_h, need_h / DIM))) return rc;
+        if ((rc = realloc_dev(ctx, st->neg_h, screen_dneg_elems(N)))) return rc;
         st->cap_h = need_h;
       }
       if (!st->stats) MH_HIP(ctx, hipMalloc(&st->stats, 4 * sizeof(unsigned int)));
@@ -294,6 +294,7 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
       st->screen.dbh = st->desc_h;
       st->screen.dneg = st->neg_h;
       st->screen.dmax = std::sqrt(dd_max);
+      std::memcpy(&st->screen.spread, &h[3], 4);   // (0 for a DB of fewer than 32 rows: no whole block, never used)
       st->screen.usable = h[2] == 0 && x_max < 60000.f;   // (a NaN coordinate reads as a huge bit pattern: not < 60000)
     }
   }

@@ -24,7 +24,7 @@ struct DbStore {
   int32_t* model = nullptr;    // [padded]
   size_t cap = 0;              // rows allocated
   _Float16* desc_h = nullptr;  // f16 image for the screen (match_screen.hip)
-  float* neg_h = nullptr;      // [padded] -norm/2: the screen's accumulator seeds
+  float* neg_h = nullptr;      // [tiles][192] -norm/2 per row + row-block extrema (screen.h)
   size_t cap_h = 0;            // elements allocated
   unsigned int* stats = nullptr;
   mh::ScreenDb screen;

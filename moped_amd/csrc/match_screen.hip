@@ -57,7 +57,8 @@ constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
 constexpr int SC_RECBUF = 96;                      // records a wavefront parks in LDS before they go to memory
 constexpr int SC_GROUP = 1;                        // tiles per barrier: the wavefronts of a workgroup drift apart within a group
 constexpr int SC_NBUF = 2 * SC_GROUP;              // (a hit costs its wavefront ~300 cycles), every barrier makes seven wait for the slowest
-constexpr int SC_LDS_TILES = SC_NBUF * SC_TILE_BYTES + SC_NBUF * SC_TILE * 4;   // the tiles + their -dd/2 terms
+constexpr int SC_DD = 192;                         // floats per tile of the -dd/2 array: 128 rows, the 4 row blocks' maxima, their minima, padding
+constexpr int SC_LDS_TILES = SC_NBUF * SC_TILE_BYTES + SC_NBUF * SC_DD * 4;   // the tiles + their -dd/2 terms
 constexpr int SC_LDS_BYTES = SC_LDS_TILES + SC_WAVES * (SC_RECBUF * 16 + 16);   // + the wavefronts' record buffers and counters
 static_assert(SC_TILE == 128 && DIM == 128, "tile image and chunk swizzle assume 128 x 128");
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void db_to_half_kernel(const float* __restrict
     h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
     reinterpret_cast<half8*>(dbh)[i] = h;
     const int row = (int)(i >> 4);
-    if ((i & 15) == 0) dneg[row] = -0.5f * dnorm[row];   // the accumulators' initial values; -inf on padding rows
+    if ((i & 15) == 0) dneg[(size_t)(row >> 7) * SC_DD + (row & 127)] = -0.5f * dnorm[row];   // the rows' -dd/2; -inf on padding rows
     if (row < N) {
       // (fmaxf drops NaNs: a NaN coordinate shows in the row's norm term)
       x_max = fmaxf(x_max, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
@@ -107,6 +108,31 @@ __global__ __launch_bounds__(256) void db_to_half_kernel(const float* __restrict
     atomicMax(&stats[1], red[1]);
     if (red[2]) atomicOr(&stats[2], 1u);
   }
+}
+
+// Per 32-row block the largest and the smallest of its rows' -dd/2 (entries 128..131 and 132..135 of the tile's part of
+// the array): dot + largest >= every row's screen value >= dot + smallest.  Pass B works on the dots alone and
+// decides with the block's largest term (a superset of the rows above the threshold: for the L2-normalised rows of a
+// MOPED database the two differ in the last bit); pass C reads both to turn a record's value into bounds.
+__global__ void db_block_bounds_kernel(const float* __restrict__ dnorm, int N, int n_tiles, float* __restrict__ dneg,
+                                       unsigned int* __restrict__ stats) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;   // 32-row block
+  if (b >= n_tiles * 4) return;
+  float hi = -__builtin_inff(), lo = __builtin_inff();
+  for (int r = 0; r < 32; ++r) {
+    const int row = b * 32 + r;
+    const float v = row < N ? -0.5f * dnorm[row] : -__builtin_inff();
+    if (row < N) hi = fmaxf(hi, v);
+    lo = fminf(lo, v);
+  }
+  float* t = dneg + (size_t)(b >> 2) * SC_DD;
+  t[128 + (b & 3)] = hi;
+  t[132 + (b & 3)] = lo;
+  // the largest spread of -dd/2 inside a block of real rows (stats[3]; non-negative floats order like their bits):
+  // what a record's value can overstate its block's largest screen value by
+  if (b * 32 + 32 <= N && hi - lo >= 0.f) atomicMax(&stats[3], __float_as_uint(hi - lo));
+  if ((b & 3) == 0)
+    for (int i = 136; i < SC_DD; ++i) t[i] = 0.f;
 }
 
 // Queries of the frame: f16 rows (zero rows up to the padded count) + a flag for queries the screen
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   // w, w + 8, w + 16, w + 24.  Chunk g = 64 piece + lane of the LDS image is row g >> 4, position g & 15, and holds
   // source chunk (g & 15) ^ (row & 15); row & 15 = (4 w + (lane >> 4)) & 15 for all four pieces of a wavefront, so one
   // per-lane offset serves them and the pieces differ by 8 KB in a scalar base.  The rows' -dd/2 terms (512 B per tile)
-  // come the same way: wavefronts 0 and 1, 4 bytes per lane.
+  // and the row blocks' extrema (768 B per tile) come the same way: wavefronts 0..2, 4 bytes per lane.
   const unsigned voff = (unsigned)(wave * 1024 + (lane >> 4) * 256 + (((lane & 15) ^ ((wave * 4 + (lane >> 4)) & 15)) << 4));
   const unsigned voff_dd = (unsigned)((wave * 64 + lane) * 4);
   auto stage = [&](int sel, int buf) {
@@ -275,8 +301,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(A.dbh) + (size_t)tile * SC_TILE_BYTES;
     const unsigned l = lds_base + buf * SC_TILE_BYTES + wave * 1024;
     dma16x4(voff, tb, tb + 8192, tb + 16384, tb + 24576, l, l + 8192, l + 16384, l + 24576);
-    if (wave < 2)
-      dma4(voff_dd, A.dneg + (size_t)tile * SC_TILE, lds_base + SC_NBUF * SC_TILE_BYTES + buf * (SC_TILE * 4) + wave * 256);
+    if (wave < 3)
+      dma4(voff_dd, A.dneg + (size_t)tile * SC_DD, lds_base + SC_NBUF * SC_TILE_BYTES + buf * (SC_DD * 4) + wave * 256);
   };
 
 #ifdef SC_PROF
@@ -329,15 +355,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   // wavefront's LDS buffer {destination slot, row0, bits} and written out when the workgroup is done.
   uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16));
   int n_parked = 0;   // records parked so far: wave-uniform (advanced by the hit lanes' count outside the divergent part)
-  auto emit = [&](const v16f& acc, int nb, int row0, float top, int pos) {
-    // which of the 16: bit r = sign(tau - acc[r]) (set <=> acc[r] > tau), shifted in from r = 15 down
+  // `acc` = the block's 16 DOT PRODUCTS (pass B's accumulators start at zero), `top` their maximum, `thr` = tau - the
+  // row block's largest -dd/2: dot > thr holds for every row whose screen value dot - dd/2 exceeds tau, and for hardly
+  // any other (a superset is all pass C needs).
+  auto emit = [&](const v16f& acc, int nb, int row0, float top, float thr, int pos) {
+    // which of the 16: bit r = sign(thr - acc[r]) (set <=> acc[r] > thr), shifted in from r = 15 down
     unsigned bits = 0;
 #pragma unroll
-    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tau[nb] - acc[r]), 31);
-    // the largest of the 16 values (it belongs to one of the flagged rows) rides along as an f16 -- its distance
-    // above the threshold, a small positive number, so the f16 costs ~1e-5 of precision and not 5e-4: pass C ranks
-    // the records by it and runs the exact arithmetic only on those that can still hold one of the two nearest rows
-    bits = (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - tau[nb])) << 16);
+    for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - acc[r]), 31);
+    // the largest dot + the block's largest -dd/2 -- an upper bound of the block's largest screen value, at most the
+    // block's spread of -dd/2 above it -- rides along as an f16 of its distance above tau (a small positive number, so
+    // the f16 costs ~1e-5 and not 5e-4): pass C ranks the records by it and runs the exact arithmetic only on those
+    // that can still hold one of the two nearest rows
+    bits = (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - thr)) << 16);
     const int q = q0 + nb * 32 + l32;
     if (n_rec[nb] < A.sub_cap) {
       const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb];
@@ -353,11 +383,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   };
   // the hit lanes of a block get consecutive places in the wavefront's buffer: ballot + prefix count, no LDS atomic
   // (its round trip was a quarter of the hit path)
-  auto emit_hits = [&](bool hit, const v16f& acc, int nb, int row0, float top) {
+  auto emit_hits = [&](bool hit, const v16f& acc, int nb, int row0, float top, float thr) {
     const unsigned long long hm = __ballot(hit);
     if (hm == 0ull) return;
     if (hit)
-      emit(acc, nb, row0, top,
+      emit(acc, nb, row0, top, thr,
            n_parked + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u)));
     n_parked += __popcll(hm);
   };
@@ -369,6 +399,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     const unsigned char* rowp = T + (rb * 32 + l32) * 256;
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = *reinterpret_cast<const half8*>(rowp + (((2 * s + half) ^ swz) << 4));
+    if (MODE == 1) return;   // pass B's accumulators start at zero
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 v = *reinterpret_cast<const float4*>(ddp + rb * 32 + 8 * g + 4 * half);
@@ -384,6 +415,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
 #endif
   int side = 0;         // which half of the LDS buffers holds the current group of tiles
   v16f pend;            // pass B: the block whose MFMAs were issued last; looked at behind the next block's MFMAs
+  float pend_hi = 0.f;  // ... and the largest -dd/2 of its row block
   int pend_row0 = 0;    // (its query block is (nb + NQB - 1) % NQB when block nb is issued: a constant after unrolling --
   bool have_pend = false;   // a run-time index would put tau[] and n_rec[] into scratch memory)
   for (int grp = sel_begin; grp < sel_end; grp += SC_GROUP) {
@@ -399,7 +431,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     if (sel >= sel_end) break;
     const int buf = SC_ABL(1) ? 0 : side * SC_GROUP + j;
     const unsigned char* T = lds + buf * SC_TILE_BYTES;
-    const float* ddp = reinterpret_cast<const float*>(lds + SC_NBUF * SC_TILE_BYTES + buf * (SC_TILE * 4));
+    const float* ddp = reinterpret_cast<const float*>(lds + SC_NBUF * SC_TILE_BYTES + buf * (SC_DD * 4));
     const int row_tile = (A.tile_first + sel * A.tile_stride) * SC_TILE;
     if (MODE == 0) {
 #pragma unroll 1   // (pass A unrolled: 123 spilled registers at three query blocks)
@@ -422,16 +454,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
       // LDS and (2) the maximum over the 16 values of block b - 1 is taken, two values per MFMA -- vector instructions
       // in the shadow of the matrix pipe.  Only a lane whose maximum beats its threshold looks at single values.
       half8 a_cur[8], a_nxt[8];
-      v16f init_cur, init_nxt;
-      load_rb(T, ddp, 0, a_cur, init_cur);
+      v16f unused;
+      const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      load_rb(T, ddp, 0, a_cur, unused);
+      const float4 hi4 = *reinterpret_cast<const float4*>(ddp + 128);   // the four row blocks' largest -dd/2 (the same for all lanes)
+      const float hi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
       for (int rb = 0; rb < SC_TILE / 32; ++rb) {
-        if (rb + 1 < SC_TILE / 32) load_rb(T, ddp, rb + 1, a_nxt, init_nxt);
+        if (rb + 1 < SC_TILE / 32) load_rb(T, ddp, rb + 1, a_nxt, unused);
         const int row0 = row_tile + rb * 32 + 4 * half;
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
           const int pnb = (nb + NQB - 1) % NQB;
-          v16f acc = init_cur;
+          v16f acc = zero;
           float m = -__builtin_inff();
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
@@ -449,16 +484,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (have_pend && !SC_ABL(0)) emit_hits(m > tau[pnb], pend, pnb, pend_row0, m);
+          if (have_pend && !SC_ABL(0)) emit_hits(m > tau[pnb] - pend_hi, pend, pnb, pend_row0, m, tau[pnb] - pend_hi);
           __builtin_amdgcn_sched_barrier(0);
           pend = acc;
           pend_row0 = row0;
+          pend_hi = hi[rb];
           have_pend = true;
         }
         if (rb + 1 < SC_TILE / 32) {
 #pragma unroll
           for (int s = 0; s < 8; ++s) a_cur[s] = a_nxt[s];
-          init_cur = init_nxt;
         }
       }
     }
@@ -479,7 +514,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     float m = pend[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, pend[r]);
-    emit_hits(m > tau[NQB - 1], pend, NQB - 1, pend_row0, m);
+    emit_hits(m > tau[NQB - 1] - pend_hi, pend, NQB - 1, pend_row0, m, tau[NQB - 1] - pend_hi);
   }
   if (MODE == 1) {
     // the parked records to their slots
@@ -572,7 +607,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     const float* __restrict__ qn, const float* __restrict__ qnorm, const uint8_t* __restrict__ qbad, int Q,
     const int32_t* __restrict__ q_count, const float* __restrict__ db, const float* __restrict__ dnorm, int N,
     int32_t index_base, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
-    int ovf_cap, float dmax, const float* __restrict__ tau, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
+    int ovf_cap, float dmax, const float* __restrict__ tau, float spread, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
     unsigned int* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
   __shared__ int cand_s[RS_WAVES][RS_MAXC];
@@ -613,13 +648,18 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     uint2 recv[RS_ITERS];
     float l1 = -__builtin_inff(), l2 = -__builtin_inff();   // the lane's two largest lower bounds
     const float tau_q = tau[q];
-    auto bounds = [tau_q](unsigned y, float& lo, float& hi) {
-      const float dv = (float)__builtin_bit_cast(_Float16, (unsigned short)(y >> 16));   // value - tau, rounded to f16
-      // nearest f16: 2^-11 dv (2^-25 below the normals), doubled; + the f32 roundings of (value - tau) and (tau + dv)
-      const float eps = fabsf(dv) * 0.001f + 1e-6f + 4e-7f * fabsf(tau_q);
+    auto bounds = [tau_q, spread, N, dmax](uint2 rec, float& lo, float& hi) {
+      // the record's value: (largest dot of the block + the block's largest -dd/2) - tau, rounded to f16.  The block's
+      // largest screen value is at most that, and at least that less the spread of -dd/2 inside a block (`spread`: the
+      // largest over the DB's blocks of real rows, ~1e-7 for L2-normalised rows); a block with padding rows (their
+      // dot is 0, their -dd/2 is -inf) gives no lower bound.
+      const float dv = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec.y >> 16));
+      // nearest f16: 2^-11 dv (2^-25 below the normals), doubled; + the f32 roundings on the way
+      const float eps = fabsf(dv) * 0.001f + 1e-6f + 4e-7f * (fabsf(tau_q) + 0.5f * dmax * dmax);
       const bool fin = fabsf(dv) < 6.0e4f && fabsf(tau_q) < 1e30f;   // inf / nan: no information
-      lo = fin ? tau_q + dv - eps : -__builtin_inff();
+      const bool whole = (int)(rec.x | 31u) < N;                       // the block's 32 rows are all real rows
       hi = fin ? tau_q + dv + eps : __builtin_inff();
+      lo = fin && whole && spread < 1e30f ? tau_q + dv - spread - eps : -__builtin_inff();
     };
 #pragma unroll
     for (int it = 0; it < RS_ITERS; ++it) {
@@ -634,7 +674,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       recv[it] = rec;
       if (rec.y & 0xFFFFu) {
         float lo, hi;
-        bounds(rec.y, lo, hi);
+        bounds(rec, lo, hi);
         l2 = fmaxf(l2, fminf(l1, lo));
         l1 = fmaxf(l1, lo);
       }
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       unsigned bits = rec.y & 0xFFFFu;
       if (bits) {
         float lo, hi;
-        bounds(rec.y, lo, hi);
+        bounds(rec, lo, hi);
         if (hi < keep_from) bits = 0;
       }
       // candidates in any order (the exact top-2 below breaks ties by row number): an LDS counter hands out places
@@ -722,6 +762,7 @@ extern "C" int mh_debug_screen_prof(unsigned long long out[8], int reset, int ab
 float screen_margin_host(float qq, float dmax) { return screen_margin(qq, dmax); }
 
 size_t screen_db_half_elems(int N) { return ((size_t)N + SC_TILE - 1) / SC_TILE * SC_TILE * DIM; }
+size_t screen_dneg_elems(int N) { return ((size_t)N + SC_TILE - 1) / SC_TILE * SC_DD; }
 
 void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh, float* dneg, unsigned int* stats,
                        hipStream_t s) {
@@ -729,6 +770,8 @@ void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh
   if (n_chunks == 0) return;
   const unsigned blocks = (unsigned)std::min<size_t>((n_chunks + 255) / 256, 2048);
   hipLaunchKernelGGL(db_to_half_kernel, dim3(blocks), dim3(256), 0, s, db, dnorm, N, n_chunks, dbh, dneg, stats);
+  const int n_tiles = (int)(n_chunks * 8 / ((size_t)SC_TILE * DIM));
+  hipLaunchKernelGGL(db_block_bounds_kernel, dim3((n_tiles * 4 + 255) / 256), dim3(256), 0, s, dnorm, N, n_tiles, dneg, stats);
 }
 
 size_t screen_rec_slots() { return SC_SLOTS_MAX; }
@@ -855,7 +898,7 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
-                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, idx1, d1, d2,
+                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, sdb.spread, idx1, d1, d2,
                      sb.stats);
   if (sb.ev) hipEventRecord(sb.ev[5], s);
 }

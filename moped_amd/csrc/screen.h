@@ -9,8 +9,9 @@ namespace mh {
 // Per-database part of the screen, built at upload.
 struct ScreenDb {
   const _Float16* dbh = nullptr;   // [rows padded to 128][128] f16 image of the (normalised) descriptors
-  const float* dneg = nullptr;     // [padded rows] -dot(d,d)/2, -inf on padding rows
+  const float* dneg = nullptr;     // [tiles][192]: -dot(d,d)/2 of the tile's 128 rows (-inf on padding rows), then per 32-row block the largest and the smallest of them
   float dmax = 0.f;                // max_r |d_r| (sqrt of the largest norm term)
+  float spread = __builtin_inff(); // largest (max - min) of -dd/2 inside a 32-row block of real rows
   bool usable = false;             // every norm term finite and non-negative, every coordinate inside f16's range
 };
 
@@ -33,6 +34,7 @@ size_t screen_rec_slots();           // record slots per query
 
 float screen_margin_host(float qq, float dmax);   // tau = T - margin (the error model, for tests)
 size_t screen_db_half_elems(int N);
+size_t screen_dneg_elems(int N);   // floats of the -dd/2 array: 192 per 128-row tile (rows, row blocks' extrema)
 // f16 image + statistics {bits of max dd, bits of max |x|, non-finite flag} (stats zeroed by the caller)
 void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh, float* dneg, unsigned int* stats,
                        hipStream_t s);
