@@ -173,7 +173,7 @@ __global__ void screen_prepare_kernel(const float* __restrict__ qn, const float*
 //                  row0 + (r & 3) + 8 (r >> 2) for the set bits r.  A lane owns the sub-list (query, split, half)
 //                  -- `sub_cap` slots nobody else writes, no atomics; a sub-list that is full spills into the
 //                  query's overflow list (atomic append, rare).  bits = 0 marks an empty slot.
-constexpr int SC_SLOTS_MAX = 512;   // record slots per query: 2 halves x splits x sub_cap <= this
+constexpr int SC_SLOTS_MAX = 256;   // record slots per query: 2 halves x splits x sub_cap <= this
 
 #ifdef SC_PROF   // experiment build (make EXTRA=-DSC_PROF ...): switch parts of passes A/B off (results are wrong then)
 // and stamp a workgroup's time; scripts/screen_prof.py
