@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "context.h"
 
@@ -39,11 +40,16 @@ Rccl& rccl_state() {
   return r;
 }
 
-Rccl* rccl() {
+void rccl_load(Rccl& r);
+
+Rccl* rccl() {   // (thread safe: hosts with one thread per rank create their communicators concurrently)
   Rccl& r = rccl_state();
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
+  static std::once_flag once;
+  std::call_once(once, [&] { rccl_load(r); });
+  return r.lib ? &r : nullptr;
+}
+
+void rccl_load(Rccl& r) {
   const char* env = std::getenv("MH_RCCL_PATH");
   if (env && *env) r.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
   if (!r.lib && !(env && *env)) {
@@ -55,7 +61,7 @@ Rccl* rccl() {
   if (!r.lib) {
     const char* e = dlerror();
     r.err = std::string("RCCL not loadable: ") + (e ? e : "?");
-    return nullptr;
+    return;
   }
   bool ok = true;
   auto sym = [&](const char* name) {
@@ -71,8 +77,7 @@ Rccl* rccl() {
   r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!ok) { r.lib = nullptr; return nullptr; }
-  return &r;
+  if (!ok) r.lib = nullptr;
 }
 
 constexpr int EX2_WORDS = (16 + MH_EX2_OBJECTS * (int)sizeof(mh_object)) / 4;

@@ -453,15 +453,22 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
       // Software pipeline: while the MFMAs of block b are issued, (1) the A operands of the NEXT row block arrive from
       // LDS and (2) the maximum over the 16 values of block b - 1 is taken, two values per MFMA -- vector instructions
       // in the shadow of the matrix pipe.  Only a lane whose maximum beats its threshold looks at single values.
-      half8 a_cur[8], a_nxt[8];
+      // (three and four query blocks per wavefront: no room for the prefetched copy of the next row block's operands;
+      // the other wavefront of the SIMD covers the LDS latency at the head of a row block)
+      constexpr bool PREF = NQB <= 2;
+      half8 a_cur[8], a_nxt[PREF ? 8 : 1];
       v16f unused;
       const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      load_rb(T, ddp, 0, a_cur, unused);
+      if (PREF) load_rb(T, ddp, 0, a_cur, unused);
       const float4 hi4 = *reinterpret_cast<const float4*>(ddp + 128);   // the four row blocks' largest -dd/2 (the same for all lanes)
       const float hi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
       for (int rb = 0; rb < SC_TILE / 32; ++rb) {
-        if (rb + 1 < SC_TILE / 32) load_rb(T, ddp, rb + 1, a_nxt, unused);
+        if constexpr (PREF) {
+          if (rb + 1 < SC_TILE / 32) load_rb(T, ddp, rb + 1, a_nxt, unused);
+        } else {
+          load_rb(T, ddp, rb, a_cur, unused);
+        }
         const int row0 = row_tile + rb * 32 + 4 * half;
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
@@ -491,9 +498,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
           pend_hi = hi[rb];
           have_pend = true;
         }
-        if (rb + 1 < SC_TILE / 32) {
+        if constexpr (PREF) {
+          if (rb + 1 < SC_TILE / 32) {
 #pragma unroll
-          for (int s = 0; s < 8; ++s) a_cur[s] = a_nxt[s];
+            for (int s = 0; s < 8; ++s) a_cur[s] = a_nxt[s];
+          }
         }
       }
     }
@@ -833,7 +842,7 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   // under load a one-round grid stalls on every CU another frame's kernel holds (+5% frames/s at config 1, +3% at
   // config 2).  With fewer tiles per workgroup the query-operand prologue costs more than that (Q = 3000: 0.445 ->
   // 0.394 of peak), so small launches keep one workgroup per CU.
-  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= 24L * 512 ? 512 : 256;
+  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
   const int Sb = sb_pin > 0 ? std::min(std::min(sb_pin, n_tiles), SC_SLOTS_MAX / 2)
                             : splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
   a.n_sel = n_tiles;
@@ -888,12 +897,16 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
 #else
   a.ablate = 0;
 #endif
-  // queries per workgroup: 512, or 256 for small frames (768 = three query blocks per wavefront does not fit
-  // pass B's registers beside the prefetched A operands: selectable for experiments only)
+  // queries per workgroup: 1024 (four 32-query blocks per wavefront: every row fragment read from LDS feeds four
+  // MFMAs; 256 VGPRs, no prefetched copy of the next row block) when the launch is large enough for workgroups of
+  // >= 16 tiles -- pass B alone 8-10% faster, config 2 +9.7% frames/s --, else 512 (two blocks, row fragments
+  // prefetched), or 256 for small frames.  768 is selectable for experiments.
   int nqb_sel = qe > 640 ? 2 : 1;
-  if (nqb_pin >= 1 && nqb_pin <= 3) nqb_sel = nqb_pin;
+  if (qe >= 2048 && (long)n_tiles * ((qe + 1023) / 1024) >= 16L * 256) nqb_sel = 4;
+  if (nqb_pin >= 1 && nqb_pin <= 4) nqb_sel = nqb_pin;
   int n_slots = 0;
-  if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
+  if (nqb_sel == 4) launch_passes<4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
+  else if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   else if (nqb_sel == 2) launch_passes<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   // pass C
