@@ -54,12 +54,13 @@ constexpr int SC_THREADS = 64 * SC_WAVES;
 constexpr int SC_QPAD = 3 * 1024;                  // the query image is padded to whole workgroups of every kernel width (256, 512, 768)
 constexpr int SC_TILE = 128;                       // DB rows per LDS tile (= the DB's row padding)
 constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
-constexpr int SC_RECBUF = 96;                      // records a wavefront parks in LDS before they go to memory
+constexpr int SC_RECBUF = 112;                     // hits a wavefront parks in LDS (80 bytes each: the block's 16 values go along) before they go to memory
 constexpr int SC_GROUP = 1;                        // tiles per barrier: the wavefronts of a workgroup drift apart within a group
 constexpr int SC_NBUF = 2 * SC_GROUP;              // (a hit costs its wavefront ~300 cycles), every barrier makes seven wait for the slowest
 constexpr int SC_DD = 192;                         // floats per tile of the -dd/2 array: 128 rows, the 4 row blocks' maxima, their minima, padding
 constexpr int SC_LDS_TILES = SC_NBUF * SC_TILE_BYTES + SC_NBUF * SC_DD * 4;   // the tiles + their -dd/2 terms
-constexpr int SC_LDS_BYTES = SC_LDS_TILES + SC_WAVES * (SC_RECBUF * 16 + 16);   // + the wavefronts' record buffers and counters
+constexpr int SC_REC_BYTES = 80;                   // {slot, row0, thr, top, 16 dots}
+constexpr int SC_LDS_BYTES = SC_LDS_TILES + SC_WAVES * SC_RECBUF * SC_REC_BYTES;   // + the wavefronts' hit buffers
 static_assert(SC_TILE == 128 && DIM == 128, "tile image and chunk swizzle assume 128 x 128");
 
 // error model of the screen (see the header comment)
@@ -353,32 +354,46 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   // memory now: the s_waitcnt vmcnt(0) that ends every tile (it is there for the LDS-DMA) would wait for the store's
   // round trip too, and the tile's barrier would hand that wait to all eight wavefronts.  It is parked in the
   // wavefront's LDS buffer {destination slot, row0, bits} and written out when the workgroup is done.
-  uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * 16 + 16));
+  uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF * SC_REC_BYTES));
   int n_parked = 0;   // records parked so far: wave-uniform (advanced by the hit lanes' count outside the divergent part)
   // `acc` = the block's 16 DOT PRODUCTS (pass B's accumulators start at zero), `top` their maximum, `thr` = tau - the
   // row block's largest -dd/2: dot > thr holds for every row whose screen value dot - dd/2 exceeds tau, and for hardly
   // any other (a superset is all pass C needs).
-  auto emit = [&](const v16f& acc, int nb, int row0, float top, float thr, int pos) {
-    // which of the 16: bit r = sign(thr - acc[r]) (set <=> acc[r] > thr), shifted in from r = 15 down
+  // A record from a block's 16 dots: which of them exceed thr (bit r = sign(thr - acc[r]), shifted in from r = 15
+  // down), and the largest dot + the block's largest -dd/2 -- an upper bound of the block's largest screen value, at
+  // most the block's spread of -dd/2 above it -- as an f16 of its distance above tau (a small positive number, so the
+  // f16 costs ~1e-5 and not 5e-4): pass C ranks the records by it and runs the exact arithmetic only on those that can
+  // still hold one of the two nearest rows.
+  auto record_bits = [](const v16f& acc, float top, float thr) {
     unsigned bits = 0;
 #pragma unroll
     for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - acc[r]), 31);
-    // the largest dot + the block's largest -dd/2 -- an upper bound of the block's largest screen value, at most the
-    // block's spread of -dd/2 above it -- rides along as an f16 of its distance above tau (a small positive number, so
-    // the f16 costs ~1e-5 and not 5e-4): pass C ranks the records by it and runs the exact arithmetic only on those
-    // that can still hold one of the two nearest rows
-    bits = (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - thr)) << 16);
+    return (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - thr)) << 16);
+  };
+  // The hit path proper is as short as it can be -- a wavefront meets four or five hit blocks per tile and every
+  // cycle it spends here its MFMAs do not issue (a quarter of pass B before this): the lane takes a slot of its
+  // sub-list and parks the block's raw values in the wavefront's LDS buffer; the record is made from them when the
+  // workgroup is done, all lanes in parallel.  Only when the buffer or the sub-list is full is it made on the spot.
+  auto emit = [&](const v16f& acc, int nb, int row0, float top, float thr, int pos) {
     const int q = q0 + nb * 32 + l32;
     if (n_rec[nb] < A.sub_cap) {
       const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (2 * split + half) * A.sub_cap + n_rec[nb];
       ++n_rec[nb];
-      if (pos < SC_RECBUF) recbuf[pos] = make_uint4(dst, (unsigned)row0, bits, 0u);
-      else A.recs[dst] = make_uint2((unsigned)row0, bits);   // buffer full (a few dozen hits per wavefront are usual)
+      if (pos < SC_RECBUF) {
+        uint4* e = recbuf + 5 * pos;
+        e[0] = make_uint4(dst, (unsigned)row0, __float_as_uint(thr), __float_as_uint(top));
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          e[1 + g] = make_uint4(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]), __float_as_uint(acc[4 * g + 2]),
+                                __float_as_uint(acc[4 * g + 3]));
+      } else {
+        A.recs[dst] = make_uint2((unsigned)row0, record_bits(acc, top, thr));   // buffer full
+      }
     } else {
       // the lane's sub-list is full: the query's overflow list (rare)
       const int opos = atomicAdd(&A.ovf_cnt[q], 1);
-      if (opos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + opos] = make_uint2((unsigned)row0, bits);
-      if (pos < SC_RECBUF) recbuf[pos] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // its place in the buffer stays empty
+      if (opos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + opos] = make_uint2((unsigned)row0, record_bits(acc, top, thr));
+      if (pos < SC_RECBUF) recbuf[5 * pos] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);   // its place in the buffer stays empty
     }
   };
   // the hit lanes of a block get consecutive places in the wavefront's buffer: ballot + prefix count, no LDS atomic
@@ -478,17 +493,20 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
             if (!SC_ABL(2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[s], bq[nb][s], acc, 0, 0, 0);
-            // (nothing behind the first MFMA: the pending block's last values are still in the pipe)
-            if (have_pend && s >= 1) {
-              if (s == 1) m = fmaxf(fmaxf(pend[0], pend[1]), pend[2]);
-              else if (s < 7) m = fmaxf(fmaxf(m, pend[2 * s - 1]), pend[2 * s]);
+            // (nothing behind the first four MFMAs: the pending block's last values are still on their way out of the
+            // matrix pipe, and a vector instruction that reads them stalls the wavefront -- and the MFMAs behind it)
+            if (have_pend && s >= 4) {
+              if (s == 4) m = fmaxf(fmaxf(fmaxf(fmaxf(pend[0], pend[1]), pend[2]), pend[3]), pend[4]);
+              else if (s < 7) m = fmaxf(fmaxf(fmaxf(fmaxf(m, pend[4 * s - 15]), pend[4 * s - 14]), pend[4 * s - 13]), pend[4 * s - 12]);
               else m = fmaxf(fmaxf(fmaxf(m, pend[13]), pend[14]), pend[15]);
             }
           }
+          // pin the interleave: four MFMAs, then one MFMA and the two vector instructions of its shadow, four times
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) {   // pin the interleave: one MFMA, then the vector instructions of its shadow
+          for (int s = 4; s < 8; ++s) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
           if (have_pend && !SC_ABL(0)) emit_hits(m > tau[pnb] - pend_hi, pend, pnb, pend_row0, m, tau[pnb] - pend_hi);
@@ -532,8 +550,18 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int n = min(n_parked, SC_RECBUF);
     for (int j = lane; j < n; j += 64) {
-      const uint4 e = recbuf[j];
-      if (e.x != 0xFFFFFFFFu) A.recs[e.x] = make_uint2(e.y, e.z);
+      const uint4 e = recbuf[5 * j];
+      if (e.x == 0xFFFFFFFFu) continue;
+      v16f v;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 x = recbuf[5 * j + 1 + g];
+        v[4 * g] = __uint_as_float(x.x);
+        v[4 * g + 1] = __uint_as_float(x.y);
+        v[4 * g + 2] = __uint_as_float(x.z);
+        v[4 * g + 3] = __uint_as_float(x.w);
+      }
+      A.recs[e.x] = make_uint2(e.y, record_bits(v, __uint_as_float(e.w), __uint_as_float(e.z)));
     }
   }
 #ifdef SC_PROF
