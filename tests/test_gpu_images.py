@@ -123,3 +123,28 @@ def test_frame_with_two_cameras_matches_oracle(scene):
     _, counts1 = pipe.fetch(0)
     assert counts1[0] == counts[0] and counts1[1] != counts[1]
     pipe.close()
+
+
+def test_batches_refuse_per_query_frame_attributes(scene):
+    """The image index (like depth attributes) belongs to the queries of ONE frame: mh_frame_enqueue_batch says so
+    instead of reading it past the first frame."""
+    import torch
+    s = scene
+    db, fr = s["db"], s["fr"]
+    dev = torch.device("cuda:0")
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    Q = len(fr.uv)
+    c.reserve(2 * Q)
+    q_img = torch.from_numpy(fr.image).to(dev)
+    c.frame_set_images(q_img.data_ptr(), fr.Ks, fr.cams)
+    qd = torch.from_numpy(np.concatenate([fr.desc, fr.desc])).to(dev)
+    uv = torch.from_numpy(np.concatenate([fr.uv, fr.uv])).to(dev)
+    with pytest.raises(capi.MhError):
+        c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, fr.Ks[0], fr.cams[0], capi.default_frame_params(), [1, 2])
+    c.frame_set_images(0)
+    c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, fr.Ks[0], fr.cams[0], capi.default_frame_params(), [1, 2])
+    o0, _ = c.frame_fetch_slot(0)
+    o1, _ = c.frame_fetch_slot(1)
+    assert len(o0) == len(o1)   # the same frame twice (different seeds): the same detections
+    c.close()
