@@ -143,8 +143,8 @@ def main():
         args.depth = 16
     if args.batch <= 0:
         args.batch = 8 if sharded else 4
-    if args.depth_kind:
-        args.batch = 1    # per-query depth attributes belong to one frame
+    if args.depth_kind and (args.moped3d_frontend or sharded):
+        args.batch = 1    # a depth map belongs to one frame (per-query depth attributes batch like the queries)
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
@@ -216,6 +216,7 @@ def main():
         pristine_b = [torch.cat(pristine[g * B:(g + 1) * B]) for g in range(pool_groups)]
         uv_b = [torch.cat(uvs[g * B:(g + 1) * B]) for g in range(pool_groups)]
         work_b = [torch.empty_like(pristine_b[0]) for _ in range(args.depth)]
+        depths_b = None if depths is None else [torch.cat(depths[g * B:(g + 1) * B]) for g in range(pool_groups)]
 
     active_slots = [args.depth]   # slots in use (the calibration below may settle on fewer)
 
@@ -225,6 +226,8 @@ def main():
             pg = g % pool_groups
             with torch.cuda.stream(pipe.streams[slot]):
                 work_b[slot].copy_(host_desc[pg] if from_host else pristine_b[pg], non_blocking=True)
+            if depths_b is not None:
+                pipe.ctxs[slot].frame_set_depth(depths_b[pg].data_ptr(), args.depth_kind, 0.5)
             pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
 
     host_desc = None   # --h2d-steps: the same descriptors in pinned host memory

@@ -271,8 +271,9 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
 /* B <= MH_MAX_BATCH frames at once: their descriptors / keypoints one after the other ([B Q][128], [B Q][2]); ONE
  * MATCH launch sequence over all B Q queries (the DB passes the chip once per batch), then CLUSTER .. FILTER2 frame
  * by frame on the context's stream; frame f leaves its objects in result slot f (mh_frame_fetch_slot), the same
- * objects, bit for bit, as mh_frame_enqueue(…, seeds[f]) gives it alone.  Not with per-query frame attributes
- * (depth, depth rules, several images). */
+ * objects, bit for bit, as mh_frame_enqueue(…, seeds[f]) gives it alone.  Per-query depth attributes
+ * (mh_frame_set_depth) are then [B Q] like the queries; a depth map (mh_frame_set_depth_image), the depth rules and
+ * several images belong to one frame and are refused. */
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):

@@ -315,7 +315,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   const int q0 = gathered ? 0 : ctx->batch_q0;   // frame of a batch matched in one launch: its slice of the top-2 arrays
   launch_group(gathered, n_shards, ctx->nn_idx + q0, ctx->nn_d1 + q0, ctx->nn_d2 + q0, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
-               fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off, ctx->q_depth,
+               fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off,
+               ctx->q_depth ? ctx->q_depth + q0 : nullptr,   // (a batch's depth attributes lie frame after frame like its queries)
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
                gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0);
   stamp(ctx, 2);
@@ -1157,8 +1158,8 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
                            const mh_frame_params* prm, const uint64_t* seeds) {
   if (!ctx || Q <= 0 || B < 1 || B > MH_MAX_BATCH || !q_desc_dev || !q_uv_dev || !cam || !prm || !seeds)
     return MH_ERR_ARG;
-  if (B > 1 && (ctx->q_depth || ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
-    ctx->err = "mh_frame_enqueue_batch: per-query frame attributes (depth, depth rules, images) belong to ONE frame";
+  if (B > 1 && (ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
+    ctx->err = "mh_frame_enqueue_batch: a depth map, the depth rules and the image index belong to ONE frame";
     return MH_ERR_ARG;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));

@@ -161,6 +161,10 @@ int check_frame_args(mh_ctx* ctx, mh_comm* comm, const float* q_desc_dev, const 
     ctx->err = "mh_comm: the communicator was made for another device";
     return MH_ERR_ARG;
   }
+  if (B > 1 && (ctx->q_depth || ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
+    ctx->err = "sharded batch: depth attributes, depth maps / rules and the image index belong to ONE frame";
+    return MH_ERR_ARG;
+  }
   return MH_OK;
 }
 

@@ -101,6 +101,22 @@ def test_depth_frame_path(ctx):
             rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
             rows = rows[db.model_of[fr.src_point[rows]] == o["model"]]
             assert _mean_reproj(o["pose"], fr.uv[rows], db.xyz[fr.src_point[rows]]) < 1.5
+    # a batch of two frames (this one twice) with their depth attributes one after the other: one MATCH launch
+    # sequence, and every frame's objects bit for bit the single frame's
+    c = pipe.ctxs[0]
+    c.reserve(2 * Q)
+    kind = capi.DEPTH_BACKPROJECTION
+    c.frame_set_depth(tdepth.data_ptr(), kind, 0.5)
+    pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=10)
+    alone10, _ = pipe.fetch(0)
+    t2 = torch.cat([tdepth, tdepth])
+    c.frame_set_depth(t2.data_ptr(), kind, 0.5)
+    qd2 = torch.from_numpy(np.concatenate([fr.desc, fr.desc])).to(dev)
+    uv2 = torch.from_numpy(np.concatenate([fr.uv, fr.uv])).to(dev)
+    pipe.enqueue_batch(0, qd2, uv2, 2, [9, 10])
+    (b9, _), (b10, _) = pipe.fetch_batch(0, 2)
+    assert np.array_equal(b9["pose"].view(np.uint32), res[kind]["pose"].view(np.uint32))
+    assert np.array_equal(b10["pose"].view(np.uint32), alone10["pose"].view(np.uint32))
     pipe.ctxs[0].frame_set_depth(0, 0, 0.5)
     pipe.close()
     # the depth objective moves the pose (slightly) away from the pure 2-D optimum
