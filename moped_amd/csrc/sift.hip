@@ -444,13 +444,33 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
 }
 
 // ---- gradient / orientation (GradOriImages, :959-992) ---------------------------------------
-__global__ void grad_ori_kernel(SiftPyramid P) {
-  const int o = blockIdx.z / kScales, index = 1 + blockIdx.z % kScales;
-  if (o >= P.n_octaves) return;
+// The per-pixel kernels over all (octave, level) images run on ONE flat grid of 64 x 4 tiles: slice z = octave * kScales
+// + level - 1 owns the blocks [begin[z], begin[z + 1]) -- a 3-D grid sized for octave 0 launched six times as many
+// blocks as there are tiles (the small octaves' slices were almost all empty blocks).
+struct SiftGrid {
+  int begin[SIFT_MAX_OCTAVES * kScales + 1];
+  int tiles_x[SIFT_MAX_OCTAVES];
+  int n;   // slices
+};
+__device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index, int& bx, int& by) {
+  const int b = blockIdx.x;
+  int z = 0;
+  while (z + 1 < G.n && b >= G.begin[z + 1]) ++z;
+  o = z / kScales;
+  index = 1 + z % kScales;
+  const int t = b - G.begin[z];
+  bx = t % G.tiles_x[o];
+  by = t / G.tiles_x[o];
+  return b < G.begin[G.n];
+}
+
+__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G) {
+  int o, index, bx, by;
+  if (!sift_tile(G, o, index, bx, by)) return;
   const SiftOctave& O = P.oct[o];
   const int rows = O.rows, cols = O.cols;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y * blockDim.y + threadIdx.y;
+  const int j = bx * blockDim.x + threadIdx.x;
+  const int i = by * blockDim.y + threadIdx.y;
   if (j >= cols || i >= rows) return;
   const float* im = O.gaus[index];
   const float* p = im + (size_t)i * cols;
@@ -547,14 +567,14 @@ __device__ float fit_quadratic(float* X, const float* p0, const float* p1, const
 // FindMaxMin's scan (:925-940) + InterpKeyPoint (:1164-1206).  A surviving extremum claims
 // its FINAL pixel with atomicMin(generation key): the reference's s_MaxMinArray gives that
 // pixel to the first survivor in (scale index, row, column) order.
-__global__ void detect_kernel(SiftPyramid P, SiftCandidate* __restrict__ cand, int32_t* __restrict__ n_cand,
+__global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restrict__ cand, int32_t* __restrict__ n_cand,
                               int cap, int32_t* __restrict__ overflow) {
-  const int o = blockIdx.z / kScales, index = 1 + blockIdx.z % kScales;
-  if (o >= P.n_octaves) return;
+  int o, index, bx, by;
+  if (!sift_tile(G, o, index, bx, by)) return;
   const SiftOctave& O = P.oct[o];
   const int rows = O.rows, cols = O.cols;
-  const int c = 5 + blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = 5 + blockIdx.y * blockDim.y + threadIdx.y;
+  const int c = 5 + bx * blockDim.x + threadIdx.x;
+  const int r = 5 + by * blockDim.y + threadIdx.y;
   if (c >= cols - 5 || r >= rows - 5) return;
   const float peak_thresh = 0.04f / (float)kScales;
   const float* d1 = O.dog[index];
@@ -1150,9 +1170,17 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
   if (o_small < plan.n_octaves)
     hipLaunchKernelGGL(small_octaves_kernel, dim3(1), dim3(1024), 0, s, P, o_small, T5);
   const dim3 tb2(64, 4);
-  const dim3 g2((O0.cols + 63) / 64, (O0.rows + 3) / 4, plan.n_octaves * kScales);
-  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P);
-  hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, B.cand, B.counters + 0, B.cand_cap, B.counters + 2);
+  SiftGrid G;
+  G.n = plan.n_octaves * kScales;
+  G.begin[0] = 0;
+  for (int o = 0; o < plan.n_octaves; ++o) {
+    G.tiles_x[o] = (plan.cols[o] + 63) / 64;
+    for (int i = 0; i < kScales; ++i)
+      G.begin[o * kScales + i + 1] = G.begin[o * kScales + i] + G.tiles_x[o] * ((plan.rows[o] + 3) / 4);
+  }
+  const dim3 g2(G.begin[G.n]);
+  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G);
+  hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, G, B.cand, B.counters + 0, B.cand_cap, B.counters + 2);
   hipLaunchKernelGGL(orient_kernel, dim3(1024), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
                      (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2);
   hipLaunchKernelGGL(describe_kernel, dim3(2048), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
