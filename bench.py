@@ -143,8 +143,8 @@ def main():
         args.depth = 16
     if args.batch <= 0:
         args.batch = 8 if sharded else 4
-    if args.depth_kind and (args.moped3d_frontend or sharded):
-        args.batch = 1    # a depth map belongs to one frame (per-query depth attributes batch like the queries)
+    if args.depth_kind and sharded:
+        args.batch = 1    # (the sharded batch path carries no per-frame depth attributes)
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
@@ -228,6 +228,10 @@ def main():
                 work_b[slot].copy_(host_desc[pg] if from_host else pristine_b[pg], non_blocking=True)
             if depths_b is not None:
                 pipe.ctxs[slot].frame_set_depth(depths_b[pg].data_ptr(), args.depth_kind, 0.5)
+            if maps is not None:   # the B frames' own depth and distance maps
+                mm = maps[pg * B:(pg + 1) * B]
+                pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
+                                                            args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
             pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
 
     host_desc = None   # --h2d-steps: the same descriptors in pinned host memory

@@ -272,8 +272,8 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
  * MATCH launch sequence over all B Q queries (the DB passes the chip once per batch), then CLUSTER .. FILTER2 frame
  * by frame on the context's stream; frame f leaves its objects in result slot f (mh_frame_fetch_slot), the same
  * objects, bit for bit, as mh_frame_enqueue(…, seeds[f]) gives it alone.  Per-query depth attributes
- * (mh_frame_set_depth) are then [B Q] like the queries; a depth map (mh_frame_set_depth_image), the depth rules and
- * several images belong to one frame and are refused. */
+ * (mh_frame_set_depth) are then [B Q] like the queries; depth maps (and the depth rules that read them) come one per
+ * frame through mh_frame_set_depth_image_batch; several images per frame are refused. */
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):
@@ -298,6 +298,10 @@ int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float
  * NULL image switches depth off. */
 int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev,
                              int width, int height, int kind, float alpha, float cauchy_scale);
+/* One depth map (and distance map) per frame of the batches enqueued from now on (mh_frame_enqueue_batch with
+ * B = n_frames): pointer arrays of n_frames <= MH_MAX_BATCH device images of the same size. */
+int mh_frame_set_depth_image_batch(mh_ctx* ctx, const float* const* depth_xyzn_dev, const float* const* fill_distance_dev,
+                                   int n_frames, int width, int height, int kind, float alpha, float cauchy_scale);
 /* The same for hosts that hold the maps in host memory (the STEP plugins): copies them into
  * context-owned device buffers (4.9 MB + 1.2 MB for 640x480) and sets them. */
 int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, const float* fill_distance_host,

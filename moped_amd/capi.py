@@ -103,7 +103,7 @@ EXPORTS = [
     "mh_pose_ransac_images",
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
-    "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch",
+    "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch", "mh_frame_set_depth_image_batch",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -229,6 +229,7 @@ def load():
                                                C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
     L.mh_frame_enqueue_batch.argtypes = [vp, vp, vp, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.POINTER(C.c_uint64)]
+    L.mh_frame_set_depth_image_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, f32, f32]
     L.mh_frame_previous_objects.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_gather_objects.argtypes = [vp, vp, i32, vp, i32, C.POINTER(C.c_int32)]
     _lib = L
@@ -558,6 +559,14 @@ class Context:
         self._ck(self.L.mh_frame_set_depth_image(self.h, C.c_void_p(depth_ptr) if depth_ptr else None,
                                                  C.c_void_p(fill_ptr) if fill_ptr else None, width, height, kind,
                                                  alpha, cauchy_scale), "mh_frame_set_depth_image")
+
+    def frame_set_depth_image_batch(self, depth_ptrs, fill_ptrs, width, height, kind, alpha=0.5, cauchy_scale=0.1):
+        """One depth map (+ distance map, or None for all) per frame of the following batches."""
+        n = len(depth_ptrs)
+        d = (C.c_void_p * n)(*depth_ptrs)
+        f = (C.c_void_p * n)(*fill_ptrs) if fill_ptrs else None
+        self._ck(self.L.mh_frame_set_depth_image_batch(self.h, d, f, n, width, height, kind, alpha, cauchy_scale),
+                 "mh_frame_set_depth_image_batch")
 
     # ---- FEAT ----
     def sift(self, gray, double_size=True, cap=16384):

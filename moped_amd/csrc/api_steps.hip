@@ -706,6 +706,7 @@ int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const flo
     return MH_ERR_ARG;
   ctx->q_depth = nullptr;
   ctx->depth_img = DepthImage{};
+  ctx->batch_imgs = 0;
   if (depth_xyzn_dev) {
     ctx->depth_img.img = reinterpret_cast<const float4*>(depth_xyzn_dev);
     ctx->depth_img.fill = fill_distance_dev;
@@ -715,6 +716,22 @@ int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const flo
   }
   ctx->depth_kind = depth_xyzn_dev ? kind : MH_DEPTH_NONE;
   ctx->depth_alpha = alpha;
+  return MH_OK;
+}
+
+int mh_frame_set_depth_image_batch(mh_ctx* ctx, const float* const* depth_xyzn_dev, const float* const* fill_distance_dev,
+                                   int n_frames, int width, int height, int kind, float alpha, float cauchy_scale) {
+  if (!ctx || !depth_xyzn_dev || n_frames < 1 || n_frames > MH_MAX_BATCH) return MH_ERR_ARG;
+  for (int f = 0; f < n_frames; ++f)
+    if (!depth_xyzn_dev[f]) return MH_ERR_ARG;
+  const int rc = mh_frame_set_depth_image(ctx, depth_xyzn_dev[0], fill_distance_dev ? fill_distance_dev[0] : nullptr, width,
+                                          height, kind, alpha, cauchy_scale);
+  if (rc) return rc;
+  for (int f = 0; f < n_frames; ++f) {
+    ctx->batch_img[f] = reinterpret_cast<const float4*>(depth_xyzn_dev[f]);
+    ctx->batch_fill[f] = fill_distance_dev ? fill_distance_dev[f] : nullptr;
+  }
+  ctx->batch_imgs = n_frames;
   return MH_OK;
 }
 
@@ -1158,8 +1175,9 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
                            const mh_frame_params* prm, const uint64_t* seeds) {
   if (!ctx || Q <= 0 || B < 1 || B > MH_MAX_BATCH || !q_desc_dev || !q_uv_dev || !cam || !prm || !seeds)
     return MH_ERR_ARG;
-  if (B > 1 && (ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
-    ctx->err = "mh_frame_enqueue_batch: a depth map, the depth rules and the image index belong to ONE frame";
+  if (B > 1 && (((ctx->depth_img.img || ctx->rules.on) && ctx->batch_imgs != B) || (ctx->q_img && ctx->n_images > 1))) {
+    ctx->err = "mh_frame_enqueue_batch: a depth map belongs to ONE frame (mh_frame_set_depth_image_batch hands in one per "
+               "frame of the batch), and so does the image index";
     return MH_ERR_ARG;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
@@ -1174,6 +1192,10 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   for (int f = 0; f < B && rc == MH_OK; ++f) {
     ctx->batch_q0 = f * Q;
     ctx->fs->slot = f;
+    if (B > 1 && ctx->batch_imgs == B && ctx->depth_img.img) {   // the frame's own depth map
+      ctx->depth_img.img = ctx->batch_img[f];
+      ctx->depth_img.fill = ctx->batch_fill[f];
+    }
     if (graphs_enabled()) set_seed(ctx, seeds[f]);
     rc = frame_rest(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, nullptr, 0, cam, prm, seeds[f]);
   }

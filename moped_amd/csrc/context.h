@@ -82,6 +82,9 @@ struct mh_ctx {
   int feat_expected = 0;              // keypoints of the last fetched image frame (sizes the next MATCH launch)
   int feat_last = -1;
   int batch_q0 = 0;                   // first query of the frame frame_rest works on (mh_frame_enqueue_batch)
+  const float4* batch_img[MH_MAX_BATCH] = {};   // depth maps of the frames of a batch (mh_frame_set_depth_image_batch)
+  const float* batch_fill[MH_MAX_BATCH] = {};
+  int batch_imgs = 0;                 // how many of them are set (0: one depth map, one frame)
   int exchange_plane = 0;             // words between the idx / d1 / d2 planes of one shard's block (0 = Q)
   int exchange_stride = 0;            // words between the shards' blocks of the gathered exchange buffer (0 = 3 Q)
 

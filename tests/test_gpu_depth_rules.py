@@ -98,3 +98,45 @@ def test_depth_rules_off_is_the_plain_frame(scene):
         a = c.frame_fetch_matches()
         b = _oracle_lists(s, -1, 0.004, None)
         assert np.array_equal(a[0], b[0])
+
+
+def test_batch_with_a_depth_map_per_frame_equals_single_frames():
+    """mh_frame_set_depth_image_batch: the moped3d front end (depth rules, DEPTHMAP_PROP, linkage) on a batch of two
+    frames, each with its own depth and distance maps -- objects and counts bit for bit the single frames'."""
+    import torch
+    from moped_amd import moped3d
+    dev = torch.device("cuda:0")
+    db = synth.make_db(6, 1500, seed=2)
+    frs = [synth.make_frame(db, n_vis=2, seed=30 + i, Q=1500, pts_per_obj=130) for i in range(2)]
+    maps = []
+    for i, f in enumerate(frs):
+        img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
+        maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    Q = 1500
+    c.reserve(2 * Q)
+    table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
+    c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)
+    c.frame_set_cluster_linkage(capi.default_linkage_params())
+    prm = capi.default_frame_params()
+    alone = []
+    for i, f in enumerate(frs):
+        c.frame_set_depth_image(maps[i][0].data_ptr(), maps[i][1].data_ptr(), 640, 480, capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+        qd, uv = torch.from_numpy(f.desc).to(dev), torch.from_numpy(f.uv).to(dev)
+        c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), Q, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, 5 + i)
+        alone.append(c.frame_fetch())
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    with pytest.raises(capi.MhError):     # one depth map, two frames
+        c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, [5, 6])
+    c.frame_set_depth_image_batch([m[0].data_ptr() for m in maps], [m[1].data_ptr() for m in maps], 640, 480,
+                                  capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, [5, 6])
+    for f in range(2):
+        objs, counts = c.frame_fetch_slot(f)
+        a, ac = alone[f]
+        assert np.array_equal(counts, ac) and len(a) >= 1
+        assert np.array_equal(objs["model"], a["model"]) and np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32))
+    c.close()
