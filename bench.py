@@ -127,6 +127,12 @@ def cpu_baseline(db, frames, args):
     }
 
 
+def choose_parallelism(n_models: int, world: int) -> str:
+    """N > 1: shard the DB by model while every rank still gets >= 25 models (BASELINE configs[3]: MATCH stays the
+    dominant cost of a rank's frame), else replicate it and split the frames (no collective).  DESIGN.md 5."""
+    return "models" if n_models // max(world, 2) >= 25 else "frames"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +141,7 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     if args.parallelism == "auto":
-        args.parallelism = "models" if args.models // max(world, 2) >= 25 else "frames"
+        args.parallelism = choose_parallelism(args.models, world)
     by_frames = args.parallelism == "frames" and not args.force_exchange
     sharded = (world > 1 and not by_frames) or args.force_exchange
     depth_given = args.depth > 0

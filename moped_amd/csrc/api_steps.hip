@@ -1201,6 +1201,10 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   }
   ctx->batch_q0 = 0;
   ctx->fs->slot = 0;
+  if (B > 1 && ctx->batch_imgs == B && ctx->depth_img.img) {   // back to the first frame's map, as the setter left it
+    ctx->depth_img.img = ctx->batch_img[0];
+    ctx->depth_img.fill = ctx->batch_fill[0];
+  }
   return rc;
 }
 
