@@ -194,3 +194,16 @@ def test_db_the_screen_must_refuse(env):
         assert _same_bits(two, one)
     c.db_upload(dbn, db.model_of, db.xyz, db.n_models)
     assert c.match_stats(3000)["two_stage"]
+
+
+def test_randomised_shapes_and_value_distributions():
+    """scripts/screen_stress.py (36 of its cases here; 1200 were run when the launch policy last changed): DB sizes
+    and query counts around the policy's thresholds, unnormalised rows, near-duplicate clusters, integer-valued
+    descriptors, shards -- two-stage and exact kernels agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "screen_stress.py"), "36", "7"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "36 cases, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
