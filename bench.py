@@ -159,12 +159,22 @@ def main():
     from moped_amd import capi, synth
     from moped_amd.pipeline import FramePipeline, ShardedDB
 
+    # MH_BENCH_REHEARSE=1: the N > 1 code paths on a one-GPU box -- all ranks on cuda:0, gloo for the timing contract's
+    # barrier / max (RCCL refuses two ranks on one device); with a sharded DB the frames' exchange then runs over the
+    # library's host transport.  The numbers of such a run mean nothing; it is recorded under env_overrides.
+    rehearse = os.environ.get("MH_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    red_dev = torch.device("cpu") if rehearse else dev
     if world > 1:
         # torch.distributed: the barrier / max-over-ranks of the timing contract and the hand-over of rank 0's
         # communicator id; the frames' collectives are issued by libmoped_hip.so itself (csrc/comm.hip)
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     Q = args.queries
     db = synth.make_db(args.models, 5000)
@@ -285,7 +295,7 @@ def main():
             sync_all()
             dtc = time.perf_counter() - t0c
             if world > 1:
-                tc = torch.tensor([dtc], dtype=torch.float64, device=dev)
+                tc = torch.tensor([dtc], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tc, op=dist.ReduceOp.MAX)
                 dtc = float(tc.item())
             timing[cand] = dtc
@@ -299,7 +309,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_frames = args.steps * n_frames * (world if by_frames else 1)
