@@ -647,20 +647,39 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
     const int win = (int)__fmul_rn(__fmul_rn(fSize, 1.5f), 3.0f);
     const int side = 2 * win + 1, total = side * side;
     float h = 0.f;  // lane's bin
-    for (int base = 0; base < total; base += 64) {
-      const int s = base + lane;
+    // The window's samples 64 at a time, folded into the bins one after the other in raster order (the serial code's
+    // order per bin).  All batches' gradient / orientation values are fetched FIRST -- batch by batch every fetch was
+    // two dependent trips to L2 / HBM in front of a few hundred cycles of folding (0.048 ms per frame, most of it
+    // waiting); windows of more than OR_MAXB batches (fSize > 3.9) finish with fetches of their own.
+    constexpr int OR_MAXB = 20;
+    float gv[OR_MAXB], ov[OR_MAXB];
+#pragma unroll
+    for (int b = 0; b < OR_MAXB; ++b) {
+      gv[b] = 0.f;
+      ov[b] = 0.f;
+      const int s = b * 64 + lane;
+      if (s < total) {
+        const int r = rowstart - win + s / side, c = colstart - win + s % side;
+        if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
+          gv[b] = grad[(size_t)r * cols + c];
+          ov[b] = orim[(size_t)r * cols + c];
+        }
+      }
+    }
+    auto fold = [&](int s, float g, float ori, bool fetched) {
       int bin = -1;
       float val = 0.f;
       if (s < total) {
         const int r = rowstart - win + s / side, c = colstart - win + s % side;
         if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
-          const float g = grad[(size_t)r * cols + c];
+          if (!fetched) g = grad[(size_t)r * cols + c];
           if (g > 0) {
             const float dr = __fsub_rn((float)r, frow), dc = __fsub_rn((float)c, fcol);
             const float rad2 = __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dc, dc));
             if (__fadd_rn((float)(win * win), 0.5f) > rad2) {
               const float w = expf(__fmul_rn(rad2, fexpmult));
-              bin = (int)__fadd_rn(__fmul_rn(orim[(size_t)r * cols + c], fbinmult), fbinadd);
+              if (!fetched) ori = orim[(size_t)r * cols + c];
+              bin = (int)__fadd_rn(__fmul_rn(ori, fbinmult), fbinadd);
               if (bin > 36) bin = 0;
               if (bin == 36) bin = 35;
               val = __fmul_rn(g, w);
@@ -676,7 +695,13 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
         const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), src));
         if (lane == b) h = __fadd_rn(h, x);
       }
+    };
+#pragma unroll
+    for (int b = 0; b < OR_MAXB; ++b) {
+      if (b * 64 >= total) break;
+      fold(b * 64 + lane, gv[b], ov[b], true);
     }
+    for (int base = OR_MAXB * 64; base < total; base += 64) fold(base + lane, 0.f, 0.f, false);
     // SmoothHistogram x 6 (:1395-1408): every new bin is (previous + own) + next of the OLD values (the serial
     // loop carries the old left neighbour along and has not reached the right one yet; bin 35 closes the ring
     // with the old bin 0 and its own, shorter, constant), so the 36 lanes smooth their bins side by side.
@@ -1181,7 +1206,7 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
   const dim3 g2(G.begin[G.n]);
   hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G);
   hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, G, B.cand, B.counters + 0, B.cand_cap, B.counters + 2);
-  hipLaunchKernelGGL(orient_kernel, dim3(1024), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
+  hipLaunchKernelGGL(orient_kernel, dim3(4096), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
                      (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2);
   hipLaunchKernelGGL(describe_kernel, dim3(2048), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
                      (const int32_t*)(B.counters + 1), B.key_cap, B.desc_tmp, B.geo_tmp);
