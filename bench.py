@@ -198,8 +198,11 @@ def main():
         params.pose1.error_threshold = 8.0
         params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
         params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
+    free0, _ = torch.cuda.mem_get_info(dev)
     pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q * args.batch, params=params,
                          force_exchange=args.force_exchange, n_comms=args.comms)
+    torch.cuda.synchronize(dev)
+    hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
     pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
     uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
     work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
@@ -355,6 +358,7 @@ def main():
                    "hypotheses_per_task": round(hyp_per_task, 1), "hypotheses_per_frame": round(float(np.mean([c["hypotheses"] for c in ctr])), 1),
                    "match": ("two-stage: f16 MFMA screen + canonical f32 arithmetic on the candidates (bit-identical to the exact kernels)"
                              if ms["two_stage"] else "exact f32 kernels"),
+                   "hbm_pipeline_mb": round(hbm_pipeline_mb, 1),
                    "env_overrides": overrides},
     }
 
