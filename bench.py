@@ -193,6 +193,15 @@ def main():
     if args.no_adaptive:
         params.pose1.n_hypotheses = -abs(params.pose1.n_hypotheses)
         params.pose2.n_hypotheses = -abs(params.pose2.n_hypotheses)
+    # MH_BENCH_ABLATE (experiments; recorded under env_overrides, the line is then NOT the metric): what the steps after
+    # MATCH cost the pipeline -- lm0: no LM refine, rep1: one replica per cluster, nostage2: stop after POSE
+    for knob in os.environ.get("MH_BENCH_ABLATE", "").split(","):
+        if knob == "lm0":
+            params.pose1.lm_iters_l2 = params.pose1.lm_iters_l4 = params.pose2.lm_iters_l2 = params.pose2.lm_iters_l4 = 0
+        elif knob == "rep1":
+            params.pose1.max_objects_per_cluster = params.pose2.max_objects_per_cluster = 1
+        elif knob == "nostage2":
+            params.run_stage2 = 0
     if args.depth_kind:
         # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
         params.pose1.error_threshold = 8.0

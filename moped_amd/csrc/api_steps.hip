@@ -352,34 +352,57 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     img1.img_of = fs->mi_img;
     img2.img_of = fs->m_img;
   }
-  // POSE (+ slot count, snap[2] = objects after POSE)
+  // POSE (+ slot count, snap[2] = objects after POSE).  With the FILTER stages on, each FILTER runs in the tail of
+  // the POSE launch before it (its last workgroup: filter_dev.h) -- four launches per frame instead of six; a
+  // dependent launch costs the pipeline ~5% of its throughput whatever is in it (MH_FUSE_FILTER=0: launches of
+  // their own, the same objects).
+  static const bool fuse_filter = [] {
+    const char* e = getenv("MH_FUSE_FILTER");
+    return !(e && e[0] == '0');
+  }();
   const float* depth4 = (ctx->q_depth || ctx->depth_img.img) ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
+  FilterBuffers fb = make_fb(ctx, fs, nm);
+  if (multi) {
+    fb.m_img = fs->m_img;
+    fb.cams = ctx->cams_dev;
+    fb.n_images = ctx->n_images;
+  }
+  const bool fused = fuse_filter && prm->run_stage2 && !ctx->timing;   // (stage timing wants the steps apart)
+  const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid}, ft2{fs->tickets + 4, nullptr, result, grid};
+  FilterFuse ff1, ff2;
+  ff1.fb = ff2.fb = &fb;
+  ff1.tail = &ft1;
+  ff2.tail = &ft2;
+  ff1.n_clusters_dev = ff2.n_clusters_dev = fs->n_clusters;
+  ff1.min_points = prm->f1_min_points;
+  ff1.feature_distance = prm->f1_feature_distance;
+  ff1.min_score = prm->f1_min_score;
+  ff2.min_points = prm->f2_min_points;
+  ff2.feature_distance = prm->f2_feature_distance;
+  ff2.min_score = prm->f2_min_score;
   launch_pose(multi ? fs->mi_corr : fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model,
               fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
-              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s, img1);
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s, img1,
+              fused ? &ff1 : nullptr);
   stamp(ctx, 4);
   if (prm->run_stage2) {
-    FilterBuffers fb = make_fb(ctx, fs, nm);
-    if (multi) {
-      fb.m_img = fs->m_img;
-      fb.cams = ctx->cams_dev;
-      fb.n_images = ctx->n_images;
-    }
     // FILTER (snap[3] = objects kept)
-    launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 2, snap + 3, nullptr, grid}, s);
+    if (!fused)
+      launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
+                    fs->n_slots, fs->n_clusters, fs->counts, ft1, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
                 fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2, fused ? &ff2 : nullptr);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
-    launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
-                  fs->n_slots, fs->n_clusters, fs->counts, FilterTail{fs->tickets + 4, nullptr, result, grid}, s);
+    if (!fused)
+      launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
+                    fs->n_slots, fs->n_clusters, fs->counts, ft2, s);
     stamp(ctx, 7);
   } else {
     for (int i = 5; i <= 7; ++i) stamp(ctx, i);

@@ -20,7 +20,7 @@
 
 #include <cstdlib>
 
-#include "geom.h"
+#include "filter_dev.h"
 
 namespace mh {
 
@@ -907,7 +907,9 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     const int32_t* obj_base_dev, int max_objects,
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
     float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
-    FrameCounts* counts, PoseTail tail) {
+    FrameCounts* counts, PoseTail tail, int fuse_filter, FilterBuffers ffb, FilterTail ftail, float f_feature_distance,
+    int f_min_points, float f_min_score, int32_t* f_n_clusters_dev) {
+  static_assert(POSE_THREADS == FT, "the fused FILTER runs on the POSE workgroup's threads");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
   const int R_ = prm.max_objects_per_cluster;
@@ -938,6 +940,15 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     }
   }
   if (threadIdx.x == 0) *tail.n_slots = n_slots;
+  if (fuse_filter) {
+    // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
+    // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
+    __shared__ FilterLds FS;
+    __syncthreads();
+    filter_score(FS, ffb, cam, f_feature_distance, n_slots, 0, 1);
+    __syncthreads();
+    filter_finish(FS, ffb, f_min_points, f_min_score, n_slots, tail.n_slots, f_n_clusters_dev, counts, ftail);
+  }
 }
 
 __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_corr* __restrict__ corr,
@@ -980,7 +991,7 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
-                             const PoseTail& tail, hipStream_t s) {
+                             const PoseTail& tail, hipStream_t s, const FilterFuse* fuse) {
   static DynLds attr;   // one per KIND (this function is a template)
   attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
   const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
@@ -988,7 +999,10 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, seed_dev, obj_base_dev, max_objects, obj_model,
                      obj_pose, obj_ninl,
-                     obj_err, obj_cluster, obj_valid, counts, tail);
+                     obj_err, obj_cluster, obj_valid, counts, tail, fuse && fuse->fb && tail.ticket ? 1 : 0,
+                     fuse && fuse->fb ? *fuse->fb : FilterBuffers{}, fuse && fuse->tail ? *fuse->tail : FilterTail{},
+                     fuse ? fuse->feature_distance : 0.f, fuse ? fuse->min_points : 0, fuse ? fuse->min_score : 0.f,
+                     fuse ? fuse->n_clusters_dev : nullptr);
 }
 
 void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
@@ -998,7 +1012,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
                  int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s,
-                 const PoseImages& images) {
+                 const PoseImages& images, const FilterFuse* fuse) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
@@ -1008,7 +1022,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                   images.cams, images.img_of, images.n_images, p,                                       \
                   seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
-                  obj_valid, counts, tail, s
+                  obj_valid, counts, tail, s, fuse
   if (images.img_of && images.cams && kind == 0)
     launch_pose_kind<3>(POSE_ARGS);
   else if (kind == 1)

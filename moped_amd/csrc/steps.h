@@ -156,6 +156,17 @@ struct PoseTail {
   int32_t* snap_valid;
   int grid;   // workgroups to launch (0 = default cap); more tasks than that are looped over
 };
+struct FilterBuffers;
+struct FilterTail;
+// The FILTER step that follows a POSE launch in a frame, run by the POSE launch's last workgroup instead of a launch
+// of its own (every dependent launch of a frame costs the pipeline ~5% of its throughput, whatever is in it).
+struct FilterFuse {
+  const FilterBuffers* fb = nullptr;   // host pointers: copied into the kernel's arguments by launch_pose
+  const FilterTail* tail = nullptr;
+  float feature_distance = 0.f, min_score = 0.f;
+  int min_points = 0;
+  int32_t* n_clusters_dev = nullptr;
+};
 
 // One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
 // n_clusters_dev: device count (grid is launched for max_clusters).
@@ -168,7 +179,8 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const uint64_t* seed_dev /* optional: XORed into seed, read on the device */,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
-                 FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages());
+                 FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages(),
+                 const FilterFuse* fuse = nullptr);
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
                          float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
                          hipStream_t s);
