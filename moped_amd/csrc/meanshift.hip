@@ -52,13 +52,19 @@ constexpr int MS_WORDS = MS_CAP / 64;  // 64-bit words of one row of the closene
 template <int ND>
 struct MsLds {
   float C[ND][MS_CAP];    // canopy centre
-  float a[ND][MS_CAP];    // touchPtsAggregate
   int S[MS_CAP];          // boundPointsSize
   int ID[MS_CAP];         // canopy id (= its first point): index of head/tail
   int mp[MS_CAP];         // merges: position this one merges into (self = none)
   int head[MS_CAP];       // boundPoints as a linked list over point ids, by canopy id
   int tail[MS_CAP];
   int next[MS_CAP];       // by point
+  int nrem;
+  int merged_any;
+  int again;
+  int ntargets;
+  // ---- from here to the end of the workgroup's LDS: dead between the closeness tests of an iteration and its folds;
+  // the event matrices of the parallel merge marking live there (mark_parallel) ----
+  float a[ND][MS_CAP];    // touchPtsAggregate
   int flag[MS_CAP];       // per-step stamps
   int st[MS_CAP];         // ov relaxation state of the members of the current step (0 outside it)
   int pending[MS_CAP];    // fold phase: 1 = target with sources not folded yet, 2 = folded this round
@@ -67,11 +73,9 @@ struct MsLds {
   unsigned long long tbw[MS_WORDS];   // positions that have been merge targets in this iteration (earlier blocks)
   unsigned long long neblock[2];      // rows of the current block that have members (by block parity)
   unsigned long long slowblock[2];    // rows of the current block that need the list walk
-  int nrem;
-  int merged_any;
-  int again;
-  int ntargets;
 };
+constexpr int MS_LDS_BYTES = 160 * 1024 - 1024;   // dynamic LDS of every mean-shift kernel: the CU's 160 KB less the kernels' few static words
+static_assert(sizeof(MsLds<3>) <= MS_LDS_BYTES, "MsLds must fit the CU's LDS");
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
   const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
@@ -261,6 +265,159 @@ __device__ __noinline__ int walk_block_regs_call(MsLds<ND>& L, int i0, int nrem,
   return walk_block_impl<ND, NP>(L, i0, nrem, ne, lane, stamp);
 }
 
+// (2') Merge marking without the list walk, for point sets whose event matrices fit the LDS left of the position
+// arrays (up to 640 canopies in 2-D, 576 in 3-D; larger sets take the walk above until they have shrunk).
+//
+// The reference's loop (:122-132) is `for i: for j < i close to i: m[m[j]] = i; m[j] = i`.  Every store of step i
+// writes the value i, so "m[p] at step i" is simply the LAST STEP BEFORE i THAT WROTE p (p itself if none), and the
+// whole loop is described by its write events.  Position p is written at step i > p
+//   directly   iff p is close to i                                  D[p][i]: known up front (the closeness matrix), and
+//   indirectly iff some member q of step i (q close to i, q != p) that has not itself been redirected earlier in the
+//              step still points at p when its turn comes:           IT[p][i] = exists q: D[q][i] & !IT[q][i] & last(q, i) = p
+// with last(q, i) = the latest event of q before i in D[q] | IT[q].  (A member q that an earlier member has
+// redirected -- IT[q][i] -- reads i as its pointer, and `m[i] = i` is a no-op: that is the order dependence of the
+// step, and it is the same predicate as the indirect write.)  An event at (p, i) depends only on events at earlier
+// steps and, within step i, on events of earlier positions (last(q, i) = p implies q < p): the system is causal in
+// (i, p) order, so it has exactly one solution -- the sequential loop's -- and iterating IT <- F(IT) from IT = 0 reaches it
+// (the entries settle in causal order; 5-10 rounds on real keypoint layouts, 2 on one dense blob) and stops there
+// (F(IT) = IT).  Afterwards m[p] = the last event of p.
+//
+// A round is embarrassingly parallel from the positions' point of view: the thread that owns 64 steps of position p
+// (one word of its row) walks the events of that word in ascending order, carries `last` along and, at every direct
+// event that is not also an indirect one, reports (last, i) with one LDS atomic.  Rows are stored from their diagonal
+// word on (groups of 64 rows with W - g words each); D never changes, so a thread keeps its words of it in registers.
+constexpr int MS_PAR_UNITS = 4;   // row words a thread may own: 4096 words per matrix, 640 canopies
+template <int ND>
+__device__ __forceinline__ bool mark_parallel_fits(int nrem) {
+  const int W = (nrem + 63) >> 6;
+  const int T = 32 * W * (W + 1);   // words of one matrix: 64 rows x (W - g) words for g = 0..W-1
+  const int region = MS_LDS_BYTES - (int)offsetof(MsLds<ND>, a);
+  const int a_bytes = (int)sizeof(float) * ND * MS_CAP;
+  const int off_d = max(a_bytes, 16 * T);   // D is built from `a`: it must not lie on it; the two IT matrices may
+  return T <= MS_PAR_UNITS * MS_THREADS && off_d + 8 * T <= region;
+}
+__device__ __forceinline__ int ms_row_off(int p, int W) {   // first word (the diagonal word) of row p
+  const int g = p >> 6;
+  return 32 * g * (2 * W - g + 1) + (p & 63) * (W - g);
+}
+template <int ND>
+__device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_merge) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = (nrem + 63) >> 6;
+  const int T = 32 * W * (W + 1);
+  unsigned long long* const base = reinterpret_cast<unsigned long long*>(&L.a[0][0]);
+  unsigned long long* it_old = base;
+  unsigned long long* it_new = base + T;
+  unsigned long long* const D = base + max((int)sizeof(float) * ND * MS_CAP / 8, 2 * T);
+  // ---- D: row p = the later canopies close to p (this = the later one, other = p: :124-125) ----
+  for (int p = wave; p < nrem; p += MS_WAVES) {
+    const int g = p >> 6;
+    float ap[ND];
+#pragma unroll
+    for (int x = 0; x < ND; ++x) ap[x] = L.a[x][p];
+    unsigned long long mine = 0ull;
+    for (int w = g; w < W; ++w) {
+      const int j = w * 64 + lane;
+      bool close = false;
+      if (j > p && j < nrem) {
+        float dist = 0.f;
+#pragma unroll
+        for (int x = 0; x < ND; ++x) {
+          const float d = __fsub_rn(ap[x], L.a[x][j]);   // sqEuclDist(other): other - this
+          dist = __fadd_rn(dist, __fmul_rn(d, d));
+        }
+        close = dist < sq_merge;
+      }
+      const unsigned long long b = __ballot(close);
+      if (lane == w - g) mine = b;
+    }
+    if (lane < W - g) D[ms_row_off(p, W) + lane] = mine;
+  }
+  __syncthreads();   // `a` is dead from here on
+  for (int x = tid; x < 2 * T; x += MS_THREADS) base[x] = 0ull;
+  // ---- this thread's row words ----
+  int up[MS_PAR_UNITS], uw[MS_PAR_UNITS];
+  unsigned long long ud[MS_PAR_UNITS];
+#pragma unroll
+  for (int k = 0; k < MS_PAR_UNITS; ++k) {
+    const int x = tid + k * MS_THREADS;
+    up[k] = -1;
+    uw[k] = 0;
+    ud[k] = 0ull;
+    if (x < T) {
+      int g = 0, gb = 0;
+      while (x >= gb + 64 * (W - g)) {
+        gb += 64 * (W - g);
+        ++g;
+      }
+      const int r = x - gb, wd = W - g;
+      const int q = r / wd;
+      const int p = 64 * g + q;
+      if (p < nrem) {
+        up[k] = p;
+        uw[k] = g + (r - q * wd);
+        ud[k] = D[x];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- rounds ----
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < MS_PAR_UNITS; ++k) {
+      const int p = up[k];
+      if (p < 0) continue;
+      const int x = tid + k * MS_THREADS;
+      const unsigned long long dw = ud[k], iw = it_old[x];
+      unsigned long long ev = dw | iw;
+      if (ev == 0ull) continue;
+      const int w = uw[k], g = p >> 6;
+      int last = p;   // the latest event of p before this word
+      for (int b = 1; b <= w - g; ++b) {
+        const unsigned long long e = D[x - b] | it_old[x - b];
+        if (e) {
+          last = 64 * (w - b) + 63 - __builtin_clzll(e);
+          break;
+        }
+      }
+      do {
+        const int b = __builtin_ctzll(ev);
+        const unsigned long long bit = 1ull << b;
+        ev &= ev - 1ull;
+        if ((dw & bit) && !(iw & bit) && last != p)
+          atomicOr(&it_new[ms_row_off(last, W) + (w - (last >> 6))], bit);
+        last = 64 * w + b;
+      } while (ev);
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int x = tid; x < T; x += MS_THREADS) {
+      changed |= it_old[x] != it_new[x];
+      it_old[x] = 0ull;
+    }
+    unsigned long long* const t = it_old;
+    it_old = it_new;
+    it_new = t;
+    if (!__syncthreads_or(changed)) break;
+  }
+  // ---- m[p] = the last event of p ----
+  for (int p = tid; p < nrem; p += MS_THREADS) {
+    const int g = p >> 6, ro = ms_row_off(p, W);
+    int best = p;
+    for (int w = W - 1; w >= g; --w) {
+      const unsigned long long e = D[ro + w - g] | it_old[ro + w - g];
+      if (e) {
+        best = 64 * w + 63 - __builtin_clzll(e);
+        break;
+      }
+    }
+    L.mp[p] = best;
+  }
+  __syncthreads();
+}
+
 template <int ND>
 __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __restrict__ pts, int pts_stride, int n,
                                float radius, float merge, int min_pts, int max_iter,
@@ -377,7 +534,16 @@ __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __rest
     //       A block none of whose rows fails that test needs no walk at all: position j simply
     //       ends up pointing at the last row of the block it is close to.
     constexpr int RPW = MS_ROWS / MS_WAVES;   // rows per wavefront
-    for (int i0 = 0; i0 < nrem; i0 += MS_ROWS) {
+#ifdef MS_NO_PAR   // (experiment build: the list walk for every size)
+    const bool par_mark = false;
+#else
+    const bool par_mark = mark_parallel_fits<ND>(nrem);
+#endif
+    if (par_mark) {
+      mark_parallel<ND>(L, nrem, sq_merge);
+      MS_T(3);
+    }
+    for (int i0 = 0; i0 < nrem && !par_mark; i0 += MS_ROWS) {
       const int ps0 = i0 >> 6;                // the block's rows are the positions of word ps0
       const int par = ps0 & 1;                // the flag words alternate: they are reset a block later
       unsigned long long mine[RPW];
@@ -855,9 +1021,9 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
                              FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div) {
   static DynLds attr;
-  attr.ensure(meanshift_models_kernel, sizeof(MsLds<2>));
+  attr.ensure(meanshift_models_kernel, MS_LDS_BYTES);
   // an empty database still gets one workgroup: it publishes "0 clusters"
-  hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
+  hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), MS_LDS_BYTES, s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
                      max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket,
                      models_div > 0 ? models_div : 1);
@@ -867,13 +1033,13 @@ void launch_meanshift_single(const float* pts, int n, int dim, float radius, flo
                              int min_pts, int max_iter, int32_t* members, int32_t* cl_start,
                              int32_t* ncl, int32_t* label, int32_t* iters, hipStream_t s) {
   static DynLds attr2, attr3;
-  attr2.ensure(meanshift_single_kernel<2>, sizeof(MsLds<2>));
-  attr3.ensure(meanshift_single_kernel<3>, sizeof(MsLds<3>));
+  attr2.ensure(meanshift_single_kernel<2>, MS_LDS_BYTES);
+  attr3.ensure(meanshift_single_kernel<3>, MS_LDS_BYTES);
   if (dim == 3)
-    hipLaunchKernelGGL(meanshift_single_kernel<3>, dim3(1), dim3(MS_THREADS), sizeof(MsLds<3>), s,
+    hipLaunchKernelGGL(meanshift_single_kernel<3>, dim3(1), dim3(MS_THREADS), MS_LDS_BYTES, s,
                        pts, n, radius, merge, min_pts, max_iter, members, cl_start, ncl, label, iters);
   else
-    hipLaunchKernelGGL(meanshift_single_kernel<2>, dim3(1), dim3(MS_THREADS), sizeof(MsLds<2>), s,
+    hipLaunchKernelGGL(meanshift_single_kernel<2>, dim3(1), dim3(MS_THREADS), MS_LDS_BYTES, s,
                        pts, n, radius, merge, min_pts, max_iter, members, cl_start, ncl, label, iters);
 }
 
@@ -882,13 +1048,13 @@ void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems
                             int32_t* ncl, int32_t* label, hipStream_t s) {
   if (n_problems <= 0) return;
   static DynLds attr2, attr3;
-  attr2.ensure(meanshift_batch_kernel<2>, sizeof(MsLds<2>));
-  attr3.ensure(meanshift_batch_kernel<3>, sizeof(MsLds<3>));
+  attr2.ensure(meanshift_batch_kernel<2>, MS_LDS_BYTES);
+  attr3.ensure(meanshift_batch_kernel<3>, MS_LDS_BYTES);
   if (dim == 3)
-    hipLaunchKernelGGL(meanshift_batch_kernel<3>, dim3(n_problems), dim3(MS_THREADS), sizeof(MsLds<3>), s,
+    hipLaunchKernelGGL(meanshift_batch_kernel<3>, dim3(n_problems), dim3(MS_THREADS), MS_LDS_BYTES, s,
                        pts, off, radius, merge, min_pts, max_iter, members, cl_start, ncl, label);
   else
-    hipLaunchKernelGGL(meanshift_batch_kernel<2>, dim3(n_problems), dim3(MS_THREADS), sizeof(MsLds<2>), s,
+    hipLaunchKernelGGL(meanshift_batch_kernel<2>, dim3(n_problems), dim3(MS_THREADS), MS_LDS_BYTES, s,
                        pts, off, radius, merge, min_pts, max_iter, members, cl_start, ncl, label);
 }
 
