@@ -62,6 +62,7 @@ struct MsLds {
   int merged_any;
   int again;
   int ntargets;
+  unsigned long long pmask[MS_WORDS];   // parallel marking's folds: positions that are targets with sources not folded yet
   // ---- from here to the end of the workgroup's LDS: dead between the closeness tests of an iteration and its folds;
   // the event matrices of the parallel merge marking live there (mark_parallel) ----
   float a[ND][MS_CAP];    // touchPtsAggregate
@@ -296,12 +297,20 @@ __device__ __forceinline__ bool mark_parallel_fits(int nrem) {
   const int off_d = max(a_bytes, 16 * T);   // D is built from `a`: it must not lie on it; the two IT matrices may
   return T <= MS_PAR_UNITS * MS_THREADS && off_d + 8 * T <= region;
 }
+__device__ __forceinline__ int ms_src_off(int t) {   // first word of row t of a lower-triangular matrix (words 0 .. t >> 6)
+  const int g = t >> 6;
+  return 32 * __mul24(g, g + 1) + __mul24(t & 63, g + 1);
+}
 __device__ __forceinline__ int ms_row_off(int p, int W) {   // first word (the diagonal word) of row p
   const int g = p >> 6;
-  return 32 * g * (2 * W - g + 1) + (p & 63) * (W - g);
+  return 32 * __mul24(g, 2 * W - g + 1) + __mul24(p & 63, W - g);   // (v_mul_lo_u32 is a quarter-rate instruction)
 }
 template <int ND>
-__device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_merge) {
+__device__ __forceinline__ const unsigned long long* mark_parallel(MsLds<ND>& L, int nrem, float sq_merge
+#ifdef MS_PROF
+                                              , unsigned long long& t_prof
+#endif
+) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,7 +320,9 @@ __device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_m
   unsigned long long* it_old = base;
   unsigned long long* it_new = base + T;
   unsigned long long* const D = base + max((int)sizeof(float) * ND * MS_CAP / 8, 2 * T);
-  // ---- D: row p = the later canopies close to p (this = the later one, other = p: :124-125) ----
+  // ---- D: row p = the later canopies close to p (this = the later one, other = p: :124-125).  (Word-major with the
+  // rows as wave-uniform reads, several in flight, is no faster: the phase is bound by its instruction count with four
+  // wavefronts per SIMD, not by LDS latency.) ----
   for (int p = wave; p < nrem; p += MS_WAVES) {
     const int g = p >> 6;
     float ap[ND];
@@ -336,6 +347,7 @@ __device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_m
     if (lane < W - g) D[ms_row_off(p, W) + lane] = mine;
   }
   __syncthreads();   // `a` is dead from here on
+  MS_T(2);
   for (int x = tid; x < 2 * T; x += MS_THREADS) base[x] = 0ull;
   // ---- this thread's row words ----
   int up[MS_PAR_UNITS], uw[MS_PAR_UNITS];
@@ -363,6 +375,7 @@ __device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_m
     }
   }
   __syncthreads();
+  MS_T(7);
   // ---- rounds ----
   for (;;) {
 #pragma unroll
@@ -402,7 +415,13 @@ __device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_m
     it_new = t;
     if (!__syncthreads_or(changed)) break;
   }
-  // ---- m[p] = the last event of p ----
+  // (Leaving the step words before the first change of a round alone in the next one -- events are causal in time --
+  // was built and bought nothing: the late rounds that it shortens are cheap already.)
+  // ---- m[p] = the last event of p; SM[t] = the sources of t (row t: words 0 .. t >> 6), in the IT buffer that the last
+  // round left empty; L.pmask = the targets ----
+  unsigned long long* const SM = it_new;
+  if (tid < MS_WORDS) L.pmask[tid] = 0ull;
+  __syncthreads();
   for (int p = tid; p < nrem; p += MS_THREADS) {
     const int g = p >> 6, ro = ms_row_off(p, W);
     int best = p;
@@ -414,8 +433,89 @@ __device__ __forceinline__ void mark_parallel(MsLds<ND>& L, int nrem, float sq_m
       }
     }
     L.mp[p] = best;
+    if (best != p) {
+      atomicOr(&SM[ms_src_off(best) + g], 1ull << (p & 63));
+      atomicOr(&L.pmask[best >> 6], 1ull << (best & 63));
+    }
   }
   __syncthreads();
+  return SM;
+}
+
+// (3') the folds of (3) with the sources of a target as a bit row (mark_parallel's SM) and the unfinished targets as
+// a bit mask: a target is ready when none of its sources is an unfinished target -- two ANDs instead of a sweep over
+// the pointers of all earlier positions per target and round.
+template <int ND>
+__device__ __forceinline__ void fold_parallel(MsLds<ND>& L, const unsigned long long* SM, int nrem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = (nrem + 63) >> 6;
+  for (;;) {
+    const unsigned long long pm = lane < W ? L.pmask[lane] : 0ull;   // lane u: word u of the unfinished targets
+    if (__ballot(pm != 0ull) == 0ull) break;   // (the same in every wavefront)
+    __syncthreads();   // everybody has its snapshot
+    int k = 0;
+    for (int u = 0; u < W; ++u) {
+      unsigned long long tw = readlane64(pm, u);
+      for (; tw; tw &= tw - 1ull, ++k) {
+        if ((k & (MS_WAVES - 1)) != wave) continue;
+        const int t = u * 64 + __builtin_amdgcn_readfirstlane(__builtin_ctzll(tw));
+        const unsigned long long* row = SM + ms_src_off(t);
+        const unsigned long long sw = lane <= u ? row[lane] : 0ull;   // lane v: the sources of t among positions [64 v, 64 v + 64)
+        if (__ballot((sw & pm) != 0ull) != 0ull) continue;            // a source still waits for its own sources
+        float tC[ND];
+#pragma unroll
+        for (int x = 0; x < ND; ++x) tC[x] = L.C[x][t];
+        int tsz = L.S[t];
+        const int idt = L.ID[t];
+        int carry_tail = L.tail[idt];
+        for (int v = 0; v <= u; ++v) {
+          const unsigned long long mask = readlane64(sw, v);
+          if (mask == 0ull) continue;
+          const int pj = v * 64 + lane;
+          const bool src = (mask >> lane) & 1ull;
+          float sC[ND];
+          int ssz = 0, sh = -1, stl = -1;
+#pragma unroll
+          for (int x = 0; x < ND; ++x) sC[x] = 0.f;
+          if (src) {
+#pragma unroll
+            for (int x = 0; x < ND; ++x) sC[x] = L.C[x][pj];
+            ssz = L.S[pj];
+            const int id = L.ID[pj];
+            sh = L.head[id];
+            stl = L.tail[id];
+          }
+          const unsigned long long below = mask & ((1ull << lane) - 1ull);
+          const int prev_lane = below ? 63 - __builtin_clzll(below) : 0;
+          const int prev_tail_l = __shfl(stl, prev_lane);
+          if (src) L.next[below ? prev_tail_l : carry_tail] = sh;
+          carry_tail = __builtin_amdgcn_readlane(stl, __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask)));
+          for (unsigned long long m = mask; m; m &= m - 1ull) {
+            const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+            const int csz = __builtin_amdgcn_readlane(ssz, l);
+            const int nsz = tsz + csz;
+#pragma unroll
+            for (int x = 0; x < ND; ++x) {
+              const float cv = readlane_f(sC[x], l);
+              const float vv = __fadd_rn(__fmul_rn(tC[x], (float)tsz), __fmul_rn(cv, (float)csz));
+              tC[x] = __fdiv_rn(vv, (float)nsz);
+            }
+            tsz = nsz;
+          }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int x = 0; x < ND; ++x) L.C[x][t] = tC[x];
+          L.S[t] = tsz;
+          L.tail[idt] = carry_tail;
+          atomicAnd(&L.pmask[u], ~(1ull << (t & 63)));
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 template <int ND>
@@ -539,8 +639,13 @@ __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __rest
 #else
     const bool par_mark = mark_parallel_fits<ND>(nrem);
 #endif
+    const unsigned long long* par_sm = nullptr;
     if (par_mark) {
-      mark_parallel<ND>(L, nrem, sq_merge);
+#ifdef MS_PROF
+      par_sm = mark_parallel<ND>(L, nrem, sq_merge, t_prof);
+#else
+      par_sm = mark_parallel<ND>(L, nrem, sq_merge);
+#endif
       MS_T(3);
     }
     for (int i0 = 0; i0 < nrem && !par_mark; i0 += MS_ROWS) {
@@ -731,12 +836,20 @@ __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __rest
     // before it is folded, (b) the sources of one target are folded in list order.  Targets
     // whose sources are all complete are independent: one wavefront per target, in rounds
     // over the depth of the merge forest; very deep forests finish in list order.
-    for (int p = tid; p < nrem; p += MS_THREADS) L.pending[p] = 0;
-    if (tid == 0) {
-      L.merged_any = 0;
-      L.ntargets = 0;
-    }
-    __syncthreads();
+    if (par_mark) {
+      const unsigned long long pm = lane < MS_WORDS ? L.pmask[lane] : 0ull;
+      if (__ballot(pm != 0ull) == 0ull) {   // nothing merges: done (:96, `done` stays true)
+        ++it;
+        break;
+      }
+      fold_parallel<ND>(L, par_sm, nrem);
+    } else {
+      for (int p = tid; p < nrem; p += MS_THREADS) L.pending[p] = 0;
+      if (tid == 0) {
+        L.merged_any = 0;
+        L.ntargets = 0;
+      }
+      __syncthreads();
     for (int p = tid; p < nrem; p += MS_THREADS) {
       const int t = L.mp[p];
       if (t != p) {
@@ -787,6 +900,7 @@ __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __rest
       __syncthreads();
       if (!again) break;
     }
+    }   // (list-walk path)
     MS_T(4);
     // erase the merged canopies (:145): in-place stable compaction of the position arrays
     if (wave == 0) {

@@ -6,7 +6,7 @@ from moped_amd import capi
 ctx = capi.Context(0)
 L = capi.load()
 rng = np.random.default_rng(0)
-names = ["loop top", "(1) means", "(2a) bits", "(2b) walk", "(3) fold", "compact", "emit", "-"]
+names = ["loop top", "(1) means", "(2a) bits", "(2b) walk", "(3) fold", "compact", "emit", "(2') decode"]
 def prof(pts, label):
     out = (C.c_ulonglong * 8)()
     ctx.meanshift(pts); L.mh_debug_ms_prof(out, 1)
