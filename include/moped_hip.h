@@ -306,6 +306,28 @@ int mh_frame_set_depth_image_batch(mh_ctx* ctx, const float* const* depth_xyzn_d
  * context-owned device buffers (4.9 MB + 1.2 MB for 640x480) and sets them. */
 int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, const float* fill_distance_host,
                                   int width, int height, int kind, float alpha, float cauchy_scale);
+
+/* moped3d's DEPTHFILL step: DEPTH_FILL_EXACT_CPU::process / fillInScaled
+ * (moped3d/libmoped/src/depthfill/DEPTH_FILL_EXACT_CPU.hpp:268-349, 416-428; config.hpp:39 ships
+ * DEPTH_FILL_EXACT_CPU(8, false)).  depth_xyzn_dev [height][width][4] floats (x, y, z, norm; z < 0 = hole) is filled
+ * IN PLACE on the context's stream: every hole takes the depth the reference's FIFO wavefront over the map downscaled
+ * by scale_factor gives it (nearest-neighbour upsampling with the reference's late row advance, or bilinear != 0:
+ * its bilinear one), then x, y and norm of the filled pixels are recomputed from K = the depth map's
+ * intrinsicLinearCalibration (:249-273).  fill_distance_dev [height][width] receives the distance map the step
+ * appends to the frame ("<name>.distance": 0 on valid pixels), the one mh_frame_set_depth_image takes.
+ * scale_factor = -1 chooses the factor from the share of holes as the reference does (:283-296; one small
+ * reduction and a 4-byte read back); with a factor of 1 the reference never hands the filled depths back
+ * (:336-338) and neither does this: only the distance map is written.  *scale_used (optional) = the factor.
+ * Bit-identical to the reference's arithmetic (tests/test_gpu_depthfill.py against the oracle's restatement).
+ * Limits: the downscaled map holds at most 8192 pixels (640 x 480 from factor 8 on) -> MH_ERR_CAPACITY.
+ * Asynchronous; mh_depth_fill_status synchronises the stream and reports MH_ERR_CAPACITY if the fill's queue
+ * outgrew its 16384-entry ring in a call since the last status (no map of a real sensor comes near it). */
+int mh_depth_fill(mh_ctx* ctx, float* depth_xyzn_dev, int width, int height, int scale_factor, int bilinear,
+                  const float K[4], float* fill_distance_dev, int* scale_used);
+int mh_depth_fill_status(mh_ctx* ctx);
+/* The same on host maps (what the DEPTH_FILL_EXACT_HIP plugin calls): upload, fill, both maps back, status. */
+int mh_depth_fill_host(mh_ctx* ctx, float* depth_xyzn_host, int width, int height, int scale_factor, int bilinear,
+                       const float K[4], float* fill_distance_host, int* scale_used);
 /* moped3d's rules on which features and matches reach CLUSTER, applied on the device inside the
  * frame (they need the depth map: mh_frame_set_depth_image):
  *  - DEPTHFILTER_CPU (moped3d/libmoped/src/depthfilter/DEPTHFILTER_CPU.hpp:117-254), ToFilter = 1

@@ -93,6 +93,7 @@ EXPORTS = [
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
     "mh_frame_set_cluster_linkage", "mh_cluster_linkage", "mh_frame_set_depth_image_host",
+    "mh_depth_fill", "mh_depth_fill_status", "mh_depth_fill_host",
     "mh_frame_enqueue_rest_batch", "mh_frame_fetch_slot", "mh_frame_result_copy_slots_dev",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
@@ -162,6 +163,9 @@ def load():
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
     L.mh_frame_set_depth_image_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32]
+    L.mh_depth_fill.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.mh_depth_fill_status.argtypes = [vp]
+    L.mh_depth_fill_host.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.mh_frame_set_cluster_linkage.argtypes = [vp, C.POINTER(mh_linkage_params)]
     L.mh_cluster_linkage.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_linkage_params), vp, vp, vp]
     L.mh_frame_set_depth_rules.argtypes = [vp, C.POINTER(mh_depth_rules), vp]
@@ -559,6 +563,29 @@ class Context:
         self._ck(self.L.mh_frame_set_depth_image(self.h, C.c_void_p(depth_ptr) if depth_ptr else None,
                                                  C.c_void_p(fill_ptr) if fill_ptr else None, width, height, kind,
                                                  alpha, cauchy_scale), "mh_frame_set_depth_image")
+
+    def depth_fill_dev(self, depth_ptr, width, height, K, fill_ptr, scale=8, bilinear=False):
+        """moped3d's DEPTHFILL on a device depth map [h, w, 4], in place, + its distance map [h, w]; asynchronous.
+        -> the scale factor used."""
+        k = np.ascontiguousarray(K, np.float32)
+        used = C.c_int(0)
+        self._ck(self.L.mh_depth_fill(self.h, C.c_void_p(depth_ptr), width, height, int(scale), 1 if bilinear else 0,
+                                      _ptr(k), C.c_void_p(fill_ptr), C.byref(used)), "mh_depth_fill")
+        return used.value
+
+    def depth_fill_status(self):
+        self._ck(self.L.mh_depth_fill_status(self.h), "mh_depth_fill_status")
+
+    def depth_fill(self, depth_img, K, scale=8, bilinear=False):
+        """The same on a host map: -> (filled copy [h, w, 4], distance map [h, w], scale used)."""
+        d = np.ascontiguousarray(depth_img, np.float32).copy()
+        h, w = d.shape[:2]
+        dist = np.zeros((h, w), np.float32)
+        k = np.ascontiguousarray(K, np.float32)
+        used = C.c_int(0)
+        self._ck(self.L.mh_depth_fill_host(self.h, _ptr(d), w, h, int(scale), 1 if bilinear else 0, _ptr(k), _ptr(dist),
+                                           C.byref(used)), "mh_depth_fill_host")
+        return d, dist, used.value
 
     def frame_set_depth_image_batch(self, depth_ptrs, fill_ptrs, width, height, kind, alpha=0.5, cauchy_scale=0.1):
         """One depth map (+ distance map, or None for all) per frame of the following batches."""

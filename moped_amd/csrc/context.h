@@ -134,6 +134,7 @@ struct mh_ctx {
   float* own_fill = nullptr;
   size_t own_depth_px = 0;
   float* lk_scratch = nullptr;
+  unsigned char* df_buf = nullptr; // mh_depth_fill: [status words | downscaled depths | downscaled distances]
   size_t lk_scratch_floats = 0;
 
   bool timing = false;

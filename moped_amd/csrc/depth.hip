@@ -30,7 +30,7 @@ __device__ __forceinline__ float eucl_dist(const float* a, const float* b) {
     const float d = __fsub_rn(b[x], a[x]);
     r = __fadd_rn(r, __fmul_rn(d, d));
   }
-  return __fsqrt_rn(r);
+  return sqrtf(r);
 }
 
 // One workgroup per patch: minimum depth (:157-166, std::min semantics: NaN never wins), then

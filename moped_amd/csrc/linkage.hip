@@ -58,7 +58,7 @@ __device__ __forceinline__ void saturate(int& x, int& y, int w, int h) {
 __device__ float discontinuity(const DepthImage& D, int px, int py, int qx, int qy) {
   const float depthStart = D.img[(size_t)py * D.w + px].z, depthEnd = D.img[(size_t)qy * D.w + qx].z;
   const int xDiff = px - qx, yDiff = py - qy;
-  const float imagePlaneDist = __fsqrt_rn((float)(xDiff * xDiff + yDiff * yDiff));
+  const float imagePlaneDist = sqrtf((float)(xDiff * xDiff + yDiff * yDiff));
   const float directAngle = atan2f(__fsub_rn(depthEnd, depthStart), imagePlaneDist);
   int x0 = px, y0 = py, x1 = qx, y1 = qy, t;
   const bool steep = abs(y1 - y0) > abs(x1 - x0);
@@ -88,7 +88,7 @@ __device__ float discontinuity(const DepthImage& D, int px, int py, int qx, int 
       saturate(bx, by, D.w, D.h);
       const float depth1 = D.img[(size_t)ay * D.w + ax].z, depth2 = D.img[(size_t)by * D.w + bx].z;
       const float dx = (float)(pax - cx), dy = (float)(pay - cy);
-      const float pixDistance = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+      const float pixDistance = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
       const float pixAngle = atan2f(__fsub_rn(depth2, depth1), pixDistance);
       const float angleDiff = fabsf(__fsub_rn(directAngle, pixAngle));
       if (angleDiff > maxAngleDiff) maxAngleDiff = angleDiff;
@@ -157,7 +157,7 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
       float nn2 = __builtin_inff(), nn3 = __builtin_inff();   // Float = DBL_MAX
       for (int j = 0; j < N; ++j) {
         if (i == j) continue;
-        const float d2 = __fsqrt_rn(sq_dist(L.uv[i], L.uv[j], 2)), d3 = __fsqrt_rn(sq_dist(L.mx[i], L.mx[j], 3));
+        const float d2 = sqrtf(sq_dist(L.uv[i], L.uv[j], 2)), d3 = sqrtf(sq_dist(L.mx[i], L.mx[j], 3));
         if (nn2 > d2) nn2 = d2;
         if (nn3 > d3) nn3 = d3;
       }
@@ -224,7 +224,7 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
       first_pair(p, i, j);
       float val = 1.f;
       if (i != j) {
-        const float dm = __fsqrt_rn(sq_dist(L.mx[i], L.mx[j], 3)), dr = __fsqrt_rn(sq_dist(L.wx[i], L.wx[j], 3));
+        const float dm = sqrtf(sq_dist(L.mx[i], L.mx[j], 3)), dr = sqrtf(sq_dist(L.wx[i], L.wx[j], 3));
         const float de = __fdiv_rn(fabsf(__fsub_rn(dm, dr)), dm);
         val = expf(__fdiv_rn(__fmul_rn(__fmul_rn(-1.f, de), de), twoSigmaSq));
       }

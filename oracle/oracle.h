@@ -193,6 +193,13 @@ int orc_sift(const uint8_t* gray, int w, int h, int double_size, float* xy, floa
 int orc_sift_image(const uint8_t* gray, int w, int h, int double_size, int octave, int kind, int i,
                    float* out, int* rows, int* cols);
 
+/* moped3d's DEPTHFILL step, DEPTH_FILL_EXACT_CPU::fillInScaled
+ * (moped3d/libmoped/src/depthfill/DEPTH_FILL_EXACT_CPU.hpp:268-349; see depthfill_oracle.cpp): depth [h][w][4]
+ * (x, y, z, norm; z < 0 = hole) is filled in place, dist_out [h][w] gets the distance map the step appends to
+ * the frame.  scale = the downscale factor (-1: chosen from the share of holes, :283-296); K = the depth map's
+ * intrinsicLinearCalibration.  Returns the factor used, -1 on bad arguments. */
+int orc_depth_fill(float* depth, int w, int h, int scale, int bilinear, const float K[4], float* dist_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -850,3 +850,19 @@ def cluster_linkage(uv, model_xyz, world_xyz, depth_img, fill_img, cutoff=0.1, m
                                 K.ctypes.data if K is not None else None)
     cl = [members[off[c]:off[c + 1]].copy() for c in range(ncl)]
     return (cl, K) if want_k else cl
+
+
+def depth_fill(depth_img, K, scale=8, bilinear=False):
+    """DEPTH_FILL_EXACT_CPU (moped3d/libmoped/src/depthfill/DEPTH_FILL_EXACT_CPU.hpp:268-349; moped3d config.hpp:39
+    ships (8, false)): depth_img [h, w, 4] (z < 0 = hole) -> (filled copy, distance map [h, w], scale used)."""
+    h, w = depth_img.shape[:2]
+    out = np.ascontiguousarray(depth_img, np.float32).copy()
+    dist = np.zeros((h, w), np.float32)
+    L = lib()
+    L.orc_depth_fill.restype = C.c_int
+    L.orc_depth_fill.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
+    used = L.orc_depth_fill(out.reshape(-1), w, h, int(scale), 1 if bilinear else 0,
+                            np.ascontiguousarray(K, np.float32), dist.reshape(-1))
+    if used < 0:
+        raise ValueError("orc_depth_fill: bad arguments")
+    return out, dist, used

@@ -116,3 +116,35 @@ def test_step_plugins_two_cameras_among_maps(tmp_path):
         e_o = np.sqrt(((orclib.project_images(op[j], xyz, img, fr.Ks, fr.cams) - uv) ** 2).sum(1)).mean()
         assert e_g <= e_o + 1.0 and e_g < 1.0
         assert score > 0 and abs(score - osc[j]) <= 0.05 * osc[j]      # scored over both cameras' matches
+
+
+@pytest.mark.gpu
+def test_depthfill_plugin_through_pipeline(tmp_path):
+    """moped3d's DEPTHFILL slot: DEPTH_FILL_EXACT_HIP(8, false) as config.hpp:39 wires the CPU step, on a frame that
+    lists its camera image and its depth map; the depth map is filled in place and the "<name>.distance" map appended,
+    both bit-identical to the oracle's restatement of DEPTH_FILL_EXACT_CPU."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped3d_depthfill_test"])
+    rng = np.random.default_rng(4)
+    h, w = 480, 640
+    Kd = np.array([525.0, 525.0, 319.5, 239.5], np.float32)
+    z = rng.uniform(0.6, 3.0, size=(h, w)).astype(np.float32)
+    for _ in range(20):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(8, 60)
+        yy, xx = np.ogrid[:h, :w]
+        z[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = -1.0
+    d = np.zeros((h, w, 4), np.float32)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    d[..., 2] = z
+    d[..., 0] = (u - Kd[2]) / Kd[0] * z
+    d[..., 1] = (v - Kd[3]) / Kd[1] * z
+    d[..., 3] = np.sqrt((d[..., :3] ** 2).sum(-1))
+    src, dst = str(tmp_path / "depth_in.bin"), str(tmp_path / "depth_out.bin")
+    with open(src, "wb") as f:
+        f.write(np.array([w, h], np.int32).tobytes() + Kd.tobytes() + d.tobytes())
+    for scale, bilinear in ((8, 0), (16, 1)):
+        subprocess.check_call([os.path.join(HOST, "moped3d_depthfill_test"), src, dst, str(scale), str(bilinear)])
+        raw = np.fromfile(dst, np.float32)
+        got, got_dist = raw[:h * w * 4].reshape(h, w, 4), raw[h * w * 4:].reshape(h, w)
+        want, want_dist, _ = orclib.depth_fill(d, Kd, scale, bool(bilinear))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(got_dist.view(np.uint32), want_dist.view(np.uint32))
