@@ -39,6 +39,7 @@ struct FrameState {
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
   uint64_t* seed_dev = nullptr;  // per-frame seed in device memory: only when the launch list is replayed as a graph
   int task_grid = 32;   // workgroups for the POSE/FILTER launches: follows the task count of the last fetched frame
+  int ms_grid = 8;      // ... and of the CLUSTER launch: its cluster count + head room
   int slot = 0;            // result / snap slot the next frame_rest writes (frames of a batch share the context)
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
   // hipGraph replay of the launch list (one graph per half of the frame)
@@ -274,6 +275,11 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     return e ? atoi(e) : 0;
   }();
   const int grid = grid_env > 0 ? grid_env : fs->task_grid;
+  static const int ms_grid_env = [] {   // MH_MS_GRID: workgroups of the CLUSTER launch (0 = one per model, the old shape)
+    const char* e = getenv("MH_MS_GRID");
+    return e ? atoi(e) : -1;
+  }();
+  const int ms_grid = ms_grid_env >= 0 ? ms_grid_env : fs->ms_grid;
   const uint64_t* seed_dev = nullptr;
   if (graphs_enabled()) {   // replayed launch lists take the seed from device memory (set by the caller)
     seed_dev = fs->seed_dev;
@@ -338,12 +344,12 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     launch_meanshift_models(fs->mi_corr, fs->off2, nm * ctx->n_images, prm->ms_radius, prm->ms_merge,
                             prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                             fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
-                            fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, ctx->n_images);
+                            fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, ctx->n_images, ms_grid);
   } else
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
-                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s);
+                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, 1, ms_grid);
   stamp(ctx, 3);
   PoseImages img1, img2;   // POSE works on the (model, image, query) copy, POSE2 on FILTER's clusters over the match lists
   if (multi) {
@@ -1296,6 +1302,7 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   // clusters x 4 replicas (POSE), kept objects x 4 (POSE2), + 50 % head room, in steps of 8
   const int tasks = 4 * std::max(snap[1], snap[3]);
   fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
+  fs->ms_grid = std::min(32, std::max(4, snap[1] + 2));   // (a model with matches and no cluster still takes a turn: the workgroups loop)
   const int take = n < max_objects ? n : max_objects;
   if (take > 0 && objects_host)
     MH_HIP(ctx, hipMemcpy(objects_host, fs->result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
@@ -1349,6 +1356,7 @@ int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_
   if (counts) std::memcpy(counts, snap, sizeof snap);
   const int tasks = 4 * std::max(snap[1], snap[3]);
   fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
+  fs->ms_grid = std::min(32, std::max(4, snap[1] + 2));   // (a model with matches and no cluster still takes a turn: the workgroups loop)
   const int take = head[0] < max_objects ? head[0] : max_objects;
   if (take > 0 && objects_host)
     MH_HIP(ctx, hipMemcpy(objects_host, result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));

@@ -1035,21 +1035,46 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
   // (CLUSTER_MEAN_SHIFT_CPU.hpp:194-195) -- and the cluster table names the real model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MsLds<2>& L = *reinterpret_cast<MsLds<2>*>(smem);
-  const int m = blockIdx.x;
-  const int b = m < n_models ? model_off[m] : 0;
-  int n = m < n_models ? model_off[m + 1] - b : 0;
-  if (n <= 0 || n < min_pts) {   // fewer points than MinPts: no canopy can reach the emission threshold (:151-157)
-    if (threadIdx.x == 0 && m < n_models) ncl[m] = 0;
-  } else {
-    if (n > MS_CAP) {
-      if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
-      n = MS_CAP;
+  // A workgroup of this kernel asks for a whole compute unit (its LDS), and a workgroup that only finds an empty model
+  // still has to wait for one to drain -- behind the MATCH kernels of the other frames in flight.  So the grid is a
+  // few workgroups (about as many as the last frame had clusters), not one per model: every workgroup lists the
+  // models that have at least MinPts matches (a bit per model) and takes those whose rank is its own modulo the grid.
+  __shared__ unsigned long long busy[MS_WAVES];
+  int rank = 0;
+  for (int c0 = 0; c0 < n_models; c0 += MS_THREADS) {   // 1024 models at a time
+    {
+      const int m = c0 + threadIdx.x;
+      int n = 0;
+      if (m < n_models) {
+        n = model_off[m + 1] - model_off[m];
+        if (n <= 0 || n < min_pts) {   // fewer points than MinPts: no canopy can reach the emission threshold (:151-157)
+          n = 0;
+          if (blockIdx.x == 0) ncl[m] = 0;
+        }
+      }
+      const unsigned long long bl = __ballot(n > 0);
+      if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
     }
-    // cl_start needs n+1 slots inside a region of n: the final offset of the last
-    // cluster is implied by the region, so write starts only (see cluster table).
-    meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
-                      radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
-                      nullptr, nullptr);
+    __syncthreads();
+    for (int wd = 0; wd < MS_WAVES; ++wd) {
+      for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank) {
+        if (rank % (int)gridDim.x != (int)blockIdx.x) continue;
+        const int m = c0 + wd * 64 + __builtin_ctzll(bits);
+        const int b = model_off[m];
+        int n = model_off[m + 1] - b;
+        if (n > MS_CAP) {
+          if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
+          n = MS_CAP;
+        }
+        __syncthreads();   // the previous model's LDS is done with
+        // cl_start needs n+1 slots inside a region of n: the final offset of the last
+        // cluster is implied by the region, so write starts only (see cluster table).
+        meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
+                          radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
+                          nullptr, nullptr);
+      }
+    }
+    __syncthreads();   // (busy[] is rewritten for the next thousand)
   }
   if (!last_workgroup(ticket) || threadIdx.x != 0) return;
   int k = 0;
@@ -1133,11 +1158,12 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div) {
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div, int grid) {
   static DynLds attr;
   attr.ensure(meanshift_models_kernel, MS_LDS_BYTES);
   // an empty database still gets one workgroup: it publishes "0 clusters"
-  hipLaunchKernelGGL(meanshift_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(MS_THREADS), MS_LDS_BYTES, s,
+  const int wgs = std::max(1, grid > 0 ? std::min(grid, n_models) : n_models);
+  hipLaunchKernelGGL(meanshift_models_kernel, dim3(wgs), dim3(MS_THREADS), MS_LDS_BYTES, s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
                      max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket,
                      models_div > 0 ? models_div : 1);

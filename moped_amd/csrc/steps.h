@@ -88,14 +88,15 @@ void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q,
                    int32_t* out_idx, hipStream_t s);
 
 // ---- mean shift ----------------------------------------------------------------
-// CLUSTER of a frame: one workgroup per model; the last one to finish also writes the flat
+// CLUSTER of a frame: `grid` workgroups share the models that have matches (0 = one workgroup per model); the last one
+// to finish also writes the flat
 // cluster table in (model, emission) order, *n_clusters_out, counts->n_clusters and
 // snap[0..1] = (matches, clusters).  *ticket: zero-initialised device word (last_workgroup).
 void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1);
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1, int grid = 0);
 // Frames with several images, between group and CLUSTER: m_img[i] = image of match i; m_rep redone with the
 // image in the key (FILTER's bestPoints map is keyed by (coord2D, image), FILTER_PROJECTION_CPU.hpp:89); and the
 // matches once more in (model, image, query) order -- mi_corr / mi_img, off2[n_models * n_images + 1] -- the point
