@@ -2,6 +2,7 @@
 640x480 frames (~590 keypoints each) against the planar model of frame 0 + a synthetic N-model DB.
 usage: image_frame_bench.py [models=20] [depth=4] [frames=400]"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per frame slot (the default of 4 caps the overlap at 4 kernels)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

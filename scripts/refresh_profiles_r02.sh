@@ -79,13 +79,24 @@ fi
 if has sift; then
   # FEAT and the image -> objects path on the reference's bundled frames
   timeout -k 10 300 python tests/tools/sift_probe.py > $out/r02_sift_probe.txt 2>&1
-  timeout -k 10 300 python scripts/image_frame_bench.py 20 16 > $out/r02_image_frame_bench.txt 2>&1
-  timeout -k 10 300 python scripts/image_frame_bench.py 20 4 >> $out/r02_image_frame_bench.txt 2>&1
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 16 3000 > $out/r02_image_frame_bench.txt 2>&1
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 4 3000 >> $out/r02_image_frame_bench.txt 2>&1
+  GPU_MAX_HW_QUEUES=4 timeout -k 10 300 python scripts/image_frame_bench.py 20 16 3000 >> $out/r02_image_frame_bench.txt 2>&1   # ROCm's default queue count
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/rp_sift
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_sift -- python3 $root/tests/tools/sift_probe.py > /tmp/rp_sift.log 2>&1
   cp $(find /tmp/rp_sift -name "*kernel_stats.csv" | head -1) $out/r02_sift_kernel_stats.csv
   cd $root
   timeout -k 10 300 python tests/tools/ms_bench.py > $out/r02_meanshift_bench.txt 2>&1
+  # CLUSTER's phases (cycles of thread 0) on a -DMS_PROF build, if one lies beside the product:
+  #   make -C moped_amd/csrc EXTRA=-DMS_PROF BUILD=build_prof OUT=../libmoped_hip_prof.so
+  [ -f moped_amd/libmoped_hip_prof.so ] && MH_LIB_PATH=$root/moped_amd/libmoped_hip_prof.so timeout -k 10 300 python tests/tools/ms_prof.py > $out/r02_meanshift_phases.txt 2>&1
+  timeout -k 10 300 python scripts/depthfill_bench.py > $out/r02_depthfill_bench.txt 2>&1
+  # image -> objects kernel totals with 16 frames in flight
+  cd /tmp
+  rm -rf /tmp/rp_img
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_img -- python3 $root/scripts/image_frame_bench.py 20 16 2000 > /tmp/rp_img.log 2>&1
+  cp $(find /tmp/rp_img -name "*kernel_stats.csv" | head -1) $out/r02_image_frame_kernel_stats.csv
+  cd $root
 fi
 ls -la $out
