@@ -336,7 +336,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     launch_linkage_models(fs->m_corr, reinterpret_cast<const float*>(fs->m_depth), fs->model_off, nm, ctx->depth_img,
                           ctx->linkage, ctx->lk_scratch, ctx->lk_scratch_floats, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
-                          snap, fs->counts, fs->tickets + 0, s);
+                          snap, fs->counts, fs->tickets + 0, s, ms_grid);
   } else if (multi) {
     // MeanShift per (model, image) in image order (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195)
     launch_image_split(fs->m_corr, fs->m_q, fs->m_model, fs->model_off, nm, ctx->q_img, ctx->n_images, fs->counts,

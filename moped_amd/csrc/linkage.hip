@@ -392,33 +392,50 @@ __global__ __launch_bounds__(LK_THREADS) void linkage_models_kernel(
     int32_t* __restrict__ snap, FrameCounts* counts, unsigned int* ticket) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LkLds& L = *reinterpret_cast<LkLds*>(smem);
-  const int m = blockIdx.x;
-  const int b = m < n_models ? model_off[m] : 0;
-  int n = m < n_models ? model_off[m + 1] - b : 0;
-  if (n <= 0) {
-    if (threadIdx.x == 0 && m < n_models) ncl[m] = 0;
-  } else {
-    size_t base = 0;   // floats before this model's region: 3 n'^2 per earlier model
-    for (int mm = 0; mm < m; ++mm) {
-      size_t k = (size_t)(model_off[mm + 1] - model_off[mm]);
-      if (k > LK_CAP) k = LK_CAP;
-      base += 3 * k * k;
+  // A few workgroups share the models that have matches (as meanshift_models_kernel does: a workgroup of this kernel
+  // needs most of a compute unit's LDS, and one per model made every empty model wait for a CU to drain).
+  __shared__ unsigned long long busy[LK_THREADS / 64];
+  int rank = 0;
+  for (int c0 = 0; c0 < n_models; c0 += LK_THREADS) {
+    {
+      const int mm = c0 + threadIdx.x;
+      const int nn = mm < n_models ? model_off[mm + 1] - model_off[mm] : 0;
+      if (mm < n_models && nn <= 0 && blockIdx.x == 0) ncl[mm] = 0;
+      const unsigned long long bl = __ballot(nn > 0);
+      if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
     }
-    if (n > LK_CAP) {
-      if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
-      n = LK_CAP;
-    }
-    if (base + 3 * (size_t)n * n > scratch_floats) {
-      if (threadIdx.x == 0) {
-        atomicOr(&counts->error, ERR_MS_CAP);
-        ncl[m] = 0;
+    __syncthreads();
+    for (int wd = 0; wd < LK_THREADS / 64; ++wd) {
+      for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank) {
+        if (rank % (int)gridDim.x != (int)blockIdx.x) continue;
+        const int m = c0 + wd * 64 + __builtin_ctzll(bits);
+        const int b = model_off[m];
+        int n = model_off[m + 1] - b;
+        size_t base = 0;   // floats before this model's region: 3 n'^2 per earlier model
+        for (int mm = 0; mm < m; ++mm) {
+          size_t k = (size_t)(model_off[mm + 1] - model_off[mm]);
+          if (k > LK_CAP) k = LK_CAP;
+          base += 3 * k * k;
+        }
+        if (n > LK_CAP) {
+          if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
+          n = LK_CAP;
+        }
+        __syncthreads();   // the previous model's LDS is done with
+        if (base + 3 * (size_t)n * n > scratch_floats) {
+          if (threadIdx.x == 0) {
+            atomicOr(&counts->error, ERR_MS_CAP);
+            ncl[m] = 0;
+          }
+        } else {
+          float* A = scratch + base;
+          float* Dm = A + (size_t)n * n;
+          int32_t* mem = reinterpret_cast<int32_t*>(Dm + (size_t)n * n);
+          linkage_body(L, corr + b, depth4 + b, n, dimg, P, A, Dm, mem, members + b, b, cl_start + b + m, ncl + m, nullptr);
+        }
       }
-    } else {
-      float* A = scratch + base;
-      float* Dm = A + (size_t)n * n;
-      int32_t* mem = reinterpret_cast<int32_t*>(Dm + (size_t)n * n);
-      linkage_body(L, corr + b, depth4 + b, n, dimg, P, A, Dm, mem, members + b, b, cl_start + b + m, ncl + m, nullptr);
     }
+    __syncthreads();   // (busy[] is rewritten for the next thousand)
   }
   if (!last_workgroup(ticket) || threadIdx.x != 0) return;
   int k = 0;
@@ -482,9 +499,10 @@ void launch_linkage_models(const mh_corr* corr, const float* depth4, const int32
                            const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                            int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                            int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                           FrameCounts* counts, unsigned int* ticket, hipStream_t s) {
+                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid) {
   set_lds(linkage_models_kernel);
-  hipLaunchKernelGGL(linkage_models_kernel, dim3(n_models > 0 ? n_models : 1), dim3(LK_THREADS), sizeof(LkLds), s, corr,
+  const int wgs = std::max(1, grid > 0 ? std::min(grid, n_models) : n_models);
+  hipLaunchKernelGGL(linkage_models_kernel, dim3(wgs), dim3(LK_THREADS), sizeof(LkLds), s, corr,
                      reinterpret_cast<const float4*>(depth4), model_off, n_models, dimg, prm, scratch, scratch_floats,
                      members, cl_start, ncl, max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts,
                      ticket);

@@ -128,7 +128,7 @@ void launch_linkage_models(const mh_corr* corr, const float* depth4, const int32
                            const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                            int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                            int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                           FrameCounts* counts, unsigned int* ticket, hipStream_t s);
+                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid = 0);
 void launch_linkage_batch(const mh_corr* corr, const float* depth4, const int32_t* off, int n_problems,
                           const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                           int32_t* members, int32_t* cl_start, int32_t* ncl, int32_t* label, hipStream_t s);
