@@ -1,0 +1,134 @@
+"""Randomised frame-level parity: device-resident frames (mh_frame_enqueue, and the same frames through
+mh_frame_enqueue_batch) against the oracle pipeline over random databases, query counts, numbers of visible objects,
+points per object and outlier shares.  Exact: accepted matches, mean-shift clusters, detected model set; within the
+north-star tolerance: poses (<= 1 px of the oracle's on the planted inliers); FILTER2 scores are compared at 5% and reported.
+usage: frame_stress.py [scenes=60] [seed=0]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import orclib
+from moped_amd import capi, synth
+from moped_amd.pipeline import FramePipeline, ShardedDB
+scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
+dev = torch.device("cuda:0")
+bad = 0
+scores = 0
+spread = 0
+done = 0
+t0 = time.perf_counter()
+while done < scenes:
+    n_models, ppm = int(rng.choice([3, 6, 12, 20])), int(rng.choice([600, 1500, 3000]))
+    db_seed = int(rng.integers(1 << 30))
+    only = int(os.environ.get("FRAME_STRESS_ONLY", "-1"))   # look at one scene of the sequence (same random draws)
+    if only >= 0 and not (done <= only < done + 6):
+        for k in range(6):
+            Q = int(rng.choice([300, 900, 2000, 3000, 4000])); n_vis = int(rng.integers(0, min(n_models, 8) + 1)); rng.choice([12, 40, 150, 300])
+            rng.integers(1 << 30); rng.choice([0.0, 0.2, 0.5]); rng.integers(1, 1 << 20)
+        done += 6
+        continue
+    db = synth.make_db(n_models, ppm, seed=db_seed)
+    dbn = orclib.normalize(db.desc)
+    Qmax = 4000
+    prm = capi.default_frame_params()
+    if "FRAME_STRESS_LM" in os.environ:   # experiment: LM iteration caps of both POSE stages
+        prm.pose1.lm_iters_l2 = prm.pose1.lm_iters_l4 = prm.pose2.lm_iters_l2 = prm.pose2.lm_iters_l4 = int(os.environ["FRAME_STRESS_LM"])
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=Qmax, params=prm)
+    pipe.ctxs[1].reserve(3 * Qmax)
+    group = []
+    for k in range(6):
+        Q = int(rng.choice([300, 900, 2000, 3000, 4000]))
+        n_vis = int(rng.integers(0, min(n_models, 8) + 1))
+        pts = int(rng.choice([12, 40, 150, 300]))
+        pts = min(pts, ppm // 2, Q // max(n_vis, 1))
+        fr = synth.make_frame(db, n_vis=n_vis, seed=int(rng.integers(1 << 30)), Q=Q, pts_per_obj=pts,
+                              outlier_frac=float(rng.choice([0.0, 0.2, 0.5])))
+        seed = int(rng.integers(1, 1 << 20))
+        q_desc, q_uv = torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev)
+        pipe.enqueue(0, q_desc, q_uv, seed=seed)
+        objs, counts = pipe.fetch(0)
+        qn = orclib.normalize(fr.desc)
+        idx, d1, d2 = orclib.match_2nn(dbn, qn)
+        om, op, osc, oc = orclib.frame_rest(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed)
+        why = []
+        if counts[0] != oc[0]: why.append(f"matches {counts[0]} vs {oc[0]}")
+        if counts[1] != oc[1]: why.append(f"clusters {counts[1]} vs {oc[1]}")
+        # objects: RANSAC is randomised on both sides (the oracle keeps the reference's 5-point LM starts, the device
+        # samples P3P hypotheses) -- compared where the planted objects are unambiguous (>= 40 points), and a
+        # difference only counts when the oracle does not show the same outcome under another seed of its own
+        def objects_differ(om, op, osc):
+            w = []
+            if sorted(objs["model"].tolist()) != sorted(om.tolist()):
+                return [f"models {sorted(objs['model'].tolist())} vs {sorted(om.tolist())}"]
+            for m, p, sc in zip(om, op, osc):
+                g = objs[objs["model"] == m][0]
+                rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+                rows = rows[db.model_of[fr.src_point[rows]] == m]
+                if len(rows) < 8: continue
+                xyz, uv = db.xyz[fr.src_point[rows]], fr.uv[rows]
+                e = lambda pose: float(np.sqrt(((orclib.project(pose, xyz, K, CAM0) - uv) ** 2).sum(1)).mean())
+                if e(g["pose"]) > e(p) + 1.0: w.append(f"model {m}: pose {e(g['pose']):.2f} px vs oracle {e(p):.2f}")
+                if abs(g["score"] - sc) > 0.05 * sc + 1e-3: w.append(f"model {m}: score {g['score']:.3f} vs {sc:.3f}")
+            return w
+        if pts >= 40:
+            w = objects_differ(om, op, osc)
+            if w:
+                for alt in (1, 2, 3, 4, 5):   # the oracle's own spread
+                    om2, op2, osc2, _ = orclib.frame_rest(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed + 7919 * alt)
+                    if not objects_differ(om2, op2, osc2):
+                        print(f"note scene {done}: " + "; ".join(w) + f" -- the oracle gives the device's outcome with seed + {7919 * alt}", flush=True)
+                        w = []
+                        spread += 1
+                        break
+            if w:
+                first = objs
+                for alt in (1, 2, 3, 4, 5):   # ... and the device's
+                    pipe.enqueue(0, q_desc, q_uv, seed=seed + 104729 * alt)
+                    objs, _ = pipe.fetch(0)
+                    if not objects_differ(om, op, osc):
+                        print(f"note scene {done}: " + "; ".join(w) + f" -- the device gives the oracle's outcome with seed + {104729 * alt}", flush=True)
+                        w = []
+                        spread += 1
+                        break
+                objs = first
+            # what is left after reseeding both sides: a different model set or a pose outside the bar is a mismatch;
+            # a FILTER2 score that differs by more than 5% while the pose is inside the bar is reported and counted,
+            # not failed -- FILTER's arithmetic is bit-exact for equal poses (tests/test_gpu_steps.py), the score follows
+            # the pose, and the two RANSACs pick their inlier sets differently on purpose
+            soft = [x for x in w if ": score " in x]
+            if soft and len(soft) == len(w):
+                print(f"score scene {done}: models {n_models}x{ppm} Q={Q} n_vis={n_vis} pts={pts}: " + "; ".join(soft), flush=True)
+                scores += 1
+                w = []
+            why += w
+        group.append((fr, seed, objs, counts))
+        if only == done:
+            print("device objects:", [(int(o["model"]), round(float(o["score"]), 3)) for o in objs], "counts", counts.tolist())
+            print("oracle objects:", [(int(m), round(float(sc), 3)) for m, sc in zip(om, osc)], "counts", list(oc))
+        if why:
+            bad += 1
+            print(f"MISMATCH scene {done}: models {n_models}x{ppm} Q={Q} n_vis={n_vis} pts={pts}: " + "; ".join(why), flush=True)
+        done += 1
+    # the same frames, three at a time through one MATCH launch sequence: bit-identical objects
+    same_q = {}
+    for g in group: same_q.setdefault(len(g[0].desc), []).append(g)
+    for Q, gs in same_q.items():
+        for i in range(0, len(gs) - 1, 3):
+            part = gs[i:i + 3]
+            if len(part) < 2: continue
+            qd = torch.cat([torch.from_numpy(g[0].desc) for g in part]).to(dev)
+            uv = torch.cat([torch.from_numpy(g[0].uv) for g in part]).to(dev)
+            pipe.enqueue_batch(1, qd, uv, len(part), [g[1] for g in part])
+            for f, (objs, counts) in enumerate(pipe.fetch_batch(1, len(part))):
+                a, ac = part[f][2], part[f][3]
+                if not (np.array_equal(counts, ac) and np.array_equal(objs["model"], a["model"]) and
+                        np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32))):
+                    bad += 1
+                    print(f"MISMATCH batch of Q={Q}: frame {f} differs from the frame alone", flush=True)
+    pipe.close()
+    print(f"{done} scenes, {bad} mismatches, {time.perf_counter() - t0:.0f} s", flush=True)
+print(f"{done} scenes, {bad} mismatches ({spread} object-level differences inside the seed-to-seed spread of the oracle or of the device; "
+      f"{scores} scenes with an object whose FILTER2 score differs by more than 5% at a pose inside the 1 px bar)")
+sys.exit(1 if bad else 0)

@@ -122,3 +122,13 @@ def test_batch_of_frames_equals_the_frames_alone(world):
         assert np.array_equal(objs["score"].view(np.uint32), a["score"].view(np.uint32))
     # the batch normalised all three frames' descriptors in place, like the single frames
     assert np.array_equal(qd[:3000].cpu().numpy().view(np.uint32), orclib.normalize(frs[0].desc).view(np.uint32))
+
+
+def test_randomised_frames_against_the_oracle_pipeline():
+    """scripts/frame_stress.py, 18 scenes: random DBs, query counts, visible objects, points per object and outlier
+    shares -- matches and clusters exact, model sets equal, poses within 1 px of the oracle's, the same frames through
+    mh_frame_enqueue_batch bit-identical (600 scenes: profiles/r02_frame_stress.txt)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "frame_stress.py"), "18", "5"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
