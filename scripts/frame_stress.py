@@ -105,8 +105,33 @@ while done < scenes:
             why += w
         group.append((fr, seed, objs, counts))
         if only == done:
-            print("device objects:", [(int(o["model"]), round(float(o["score"]), 3)) for o in objs], "counts", counts.tolist())
+            print("device objects:", [(int(o["model"]), round(float(o["score"]), 3), int(o["n_points"])) for o in objs], "counts", counts.tolist())
             print("oracle objects:", [(int(m), round(float(sc), 3)) for m, sc in zip(om, osc)], "counts", list(oc))
+            dbg = int(os.environ.get("FRAME_STRESS_MODEL", "-1"))
+            if dbg >= 0:   # every accepted match of that model under the device's, the oracle's and the planted pose
+                acc = np.nonzero((idx >= 0) & (d1 < np.float32(0.8 * 0.8) * d2))[0]   # (approximate accept rule: for looking only)
+                acc = acc[db.model_of[idx[acc]] == dbg]
+                xyz, uv = db.xyz[idx[acc]], fr.uv[acc]
+                e2 = lambda pose: ((orclib.project(pose, xyz, K, CAM0) - uv) ** 2).sum(1)
+                g = objs[objs["model"] == dbg][0]["pose"]; o = op[list(om).index(dbg)]; pl = fr.poses[list(fr.visible).index(dbg)]
+                np.set_printoptions(precision=2, suppress=True, linewidth=200)
+                print("planted inlier?", (fr.src_point[acc] >= 0) & ~fr.is_outlier[acc])
+                print("device  e2:", e2(g), "pose", g)
+                print("oracle  e2:", e2(o), "pose", o)
+                print("planted e2:", e2(pl), "pose", pl)
+                # CLUSTER on its own over the model's accepted matches, then POSE on every cluster
+                cls, _ = pipe.ctxs[0].meanshift(np.ascontiguousarray(uv))
+                print("mean-shift clusters of the model's matches:", [len(c_) for c_ in cls])
+                for c_ in cls:
+                    o1 = pipe.ctxs[0].pose_ransac(capi.pack_corr(uv[c_], xyz[c_]), [0, len(c_)], K, CAM0, prm.pose1, seed=seed)
+                    print("   POSE on it:", [(int(x["n_inliers"]), round(float((1.0 / (e2(x["pose"]) + 1.0)).sum()), 2)) for x in o1])
+                # the step on its own over exactly these matches as one cluster, POSE2's parameters
+                outp = pipe.ctxs[0].pose_ransac(capi.pack_corr(uv, xyz), [0, len(uv)], K, CAM0, prm.pose2, seed=seed)
+                for o_ in outp:
+                    print("step pose_ransac: inliers", int(o_["n_inliers"]), "err", float(o_["err"]), "score-like", float((1.0 / (e2(o_["pose"]) + 1.0)).sum()), "pose", o_["pose"])
+                po = orclib.ransac(uv, xyz, K, CAM0, orclib.POSE2) if hasattr(orclib, "ransac") else None
+                if po is not None: print("oracle ransac:", po, "score-like", float((1.0 / (e2(po[1] if isinstance(po, tuple) else po) + 1.0)).sum()))
+                print("device score-like", float((1.0 / (e2(g) + 1.0)).sum()), "oracle", float((1.0 / (e2(o) + 1.0)).sum()))
         if why:
             bad += 1
             print(f"MISMATCH scene {done}: models {n_models}x{ppm} Q={Q} n_vis={n_vis} pts={pts}: " + "; ".join(why), flush=True)
