@@ -584,7 +584,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
           for (int i = 0; i < 3; ++i) t[i] = tn[i];
           // nothing left at fp32 resolution: the next steps would only be rejected.  Only a step taken at the damping
           // the iteration started with says so: one that needed rejections first is short because mu grew, not
-          // because the minimum is near (scripts/frame_stress.py: two objects in 600 frames stopped 1 degree short
+          // because the minimum is near (tests/tools/frame_stress.py: two objects in 600 frames stopped 1 degree short
           // of the optimum in a narrow valley, FILTER2 score 10-15% under the oracle's)
           converged = attempt == 0 && dF <= 1e-6f * cost;
           cost = c2;
@@ -891,7 +891,7 @@ __device__ void pose_task(
   float err = lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
   // The reference refines on the inliers of a least-squares fit of 5-6 points (:199-207); a P3P pose of three noisy
   // points is a worse judge of which points belong to the object, so the inliers are taken again under the refined pose
-  // and, if the set changed, the refine is repeated on it (once: scripts/frame_stress.py found objects whose FILTER2
+  // and, if the set changed, the refine is repeated on it (once: tests/tools/frame_stress.py found objects whose FILTER2
   // score stayed 10-15% under the oracle's because a tenth of their points never entered the refine).
   if (repass) {
     const int n0 = n_inl;

@@ -1,3 +1,5 @@
+# needs a second build without the parallel merge marking beside the product:
+#   make -C moped_amd/csrc EXTRA=-DMS_NO_PAR BUILD=build_nopar OUT=../libmoped_hip_nopar.so
 set -e
 for rep in 1 2; do
 for lib in moped_amd/libmoped_hip.so moped_amd/libmoped_hip_nopar.so; do

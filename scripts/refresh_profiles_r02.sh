@@ -91,7 +91,7 @@ if has sift; then
   # CLUSTER's phases (cycles of thread 0) on a -DMS_PROF build, if one lies beside the product:
   #   make -C moped_amd/csrc EXTRA=-DMS_PROF BUILD=build_prof OUT=../libmoped_hip_prof.so
   [ -f moped_amd/libmoped_hip_prof.so ] && MH_LIB_PATH=$root/moped_amd/libmoped_hip_prof.so timeout -k 10 300 python tests/tools/ms_prof.py > $out/r02_meanshift_phases.txt 2>&1
-  timeout -k 10 300 python scripts/depthfill_bench.py > $out/r02_depthfill_bench.txt 2>&1
+  timeout -k 10 300 python tests/tools/depthfill_bench.py > $out/r02_depthfill_bench.txt 2>&1
   # image -> objects kernel totals with 16 frames in flight
   cd /tmp
   rm -rf /tmp/rp_img

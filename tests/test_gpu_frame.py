@@ -125,10 +125,10 @@ def test_batch_of_frames_equals_the_frames_alone(world):
 
 
 def test_randomised_frames_against_the_oracle_pipeline():
-    """scripts/frame_stress.py, 18 scenes: random DBs, query counts, visible objects, points per object and outlier
+    """tests/tools/frame_stress.py, 18 scenes: random DBs, query counts, visible objects, points per object and outlier
     shares -- matches and clusters exact, model sets equal, poses within 1 px of the oracle's, the same frames through
     mh_frame_enqueue_batch bit-identical (600 scenes: profiles/r02_frame_stress.txt)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "frame_stress.py"), "18", "5"], capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "frame_stress.py"), "18", "5"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

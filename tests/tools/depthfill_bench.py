@@ -1,7 +1,7 @@
 """mh_depth_fill on a device-resident 640x480 depth map: ms per call (hole patterns of tests/test_gpu_depthfill.py)
 beside the oracle's CPU restatement.  usage: depthfill_bench.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import orclib

@@ -4,7 +4,7 @@ points per object and outlier shares.  Exact: accepted matches, mean-shift clust
 north-star tolerance: poses (<= 1 px of the oracle's on the planted inliers); FILTER2 scores are compared at 5% and reported.
 usage: frame_stress.py [scenes=60] [seed=0]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import orclib

@@ -4,7 +4,7 @@ random camera rigs (2-4 cameras), databases, visible objects, points per object.
 model sets equal, poses within 1 px of the oracle's (differences are reseeded on the oracle's side first).
 usage: frame_stress_images.py [scenes=40] [seed=0]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import orclib
