@@ -416,7 +416,12 @@ __device__ __forceinline__ const unsigned long long* mark_parallel(MsLds<ND>& L,
     if (!__syncthreads_or(changed)) break;
   }
   // (Leaving the step words before the first change of a round alone in the next one -- events are causal in time --
-  // was built and bought nothing: the late rounds that it shortens are cheap already.)
+  // was built and bought nothing: the late rounds that it shortens are cheap already.  So was one thread per
+  // (position, step) PAIR instead of per word -- a wavefront waits for the lane with the most events in its word, 9-14
+  // where the average is 3-5: pairs listed by a scan over the words' counts and kept 16 per thread in a rotating register
+  // array (sixteen unrolled bodies spill 150 registers, a run-time index puts the array into scratch).  Exact, the rounds
+  // 30% shorter at n = 500 and 586, but the list costs 35 k cycles per iteration of the mean shift and the rotation as
+  // much as the work it balances: n = 500 -8%, n = 379 +8%, n = 150 +17% on the kernel.  Dropped.)
   // ---- m[p] = the last event of p; SM[t] = the sources of t (row t: words 0 .. t >> 6), in the IT buffer that the last
   // round left empty; L.pmask = the targets ----
   unsigned long long* const SM = it_new;
