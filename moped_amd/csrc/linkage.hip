@@ -399,8 +399,11 @@ __global__ __launch_bounds__(LK_THREADS) void linkage_models_kernel(
   for (int c0 = 0; c0 < n_models; c0 += LK_THREADS) {
     {
       const int mm = c0 + threadIdx.x;
-      const int nn = mm < n_models ? model_off[mm + 1] - model_off[mm] : 0;
-      if (mm < n_models && nn <= 0 && blockIdx.x == 0) ncl[mm] = 0;
+      int nn = mm < n_models ? model_off[mm + 1] - model_off[mm] : 0;
+      if (nn <= P.min_pts) {   // a cluster is only emitted with MORE than MinPts members (CLUSTER_LINKAGE_CPU.hpp:537)
+        if (mm < n_models && blockIdx.x == 0) ncl[mm] = 0;
+        nn = 0;
+      }
       const unsigned long long bl = __ballot(nn > 0);
       if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
     }
