@@ -101,6 +101,12 @@ int mh_normalize(mh_ctx* ctx, float* desc_host, int n);
  * ratio test; d1/d2 (optional) = best / second-best squared distance. */
 int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio,
              int32_t* nn_idx, int32_t* nn_raw, float* d1, float* d2);
+/* mh_normalize + mh_match in one call, as MATCH_ANN_CPU::process does both to a frame's descriptors
+ * (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:155-165: norm() in place, then the search): q_host [Q][128] goes up
+ * raw, is normalised on the device and comes back normalised; results as mh_match.  One upload and one
+ * synchronisation instead of two of each (what MATCH_BRUTE_HIP calls). */
+int mh_normalize_match(mh_ctx* ctx, float* q_host, int Q, float ratio, int32_t* nn_idx, int32_t* nn_raw, float* d1,
+                       float* d2);
 
 /* How MATCH ran on this context since the last reset: stats[0] = candidate rows the exact stage evaluated,
  * stats[1] = queries searched by brute force inside it (candidate list overflow, or a query the f16

@@ -87,7 +87,7 @@ class mh_depth_rules(C.Structure):
 
 EXPORTS = [
     "mh_create", "mh_destroy", "mh_last_error", "mh_set_stream", "mh_synchronize", "mh_reserve",
-    "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_match_local_dev",
+    "mh_db_upload", "mh_db_size", "mh_normalize", "mh_match", "mh_normalize_match", "mh_match_local_dev",
     "mh_match_merge_dev", "mh_normalize_dev", "mh_meanshift", "mh_meanshift_batch", "mh_pose_ransac", "mh_pose_ransac_depth",
     "mh_frame_set_depth", "mh_project_test",
     "mh_filter", "mh_frame_default_params", "mh_frame_enqueue", "mh_frame_set_depth_image", "mh_frame_enqueue_match_local",
@@ -142,6 +142,7 @@ def load():
     L.mh_db_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.mh_normalize.argtypes = [vp, vp, i32]
     L.mh_match.argtypes = [vp, vp, i32, f32, vp, vp, vp, vp]
+    L.mh_normalize_match.argtypes = [vp, vp, i32, f32, vp, vp, vp, vp]
     L.mh_match_local_dev.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     L.mh_match_merge_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.mh_normalize_dev.argtypes = [vp, vp, vp, i32]
@@ -456,6 +457,18 @@ class Context:
         d2 = np.zeros(Q, np.float32)
         self._ck(self.L.mh_match(self.h, _ptr(q), Q, ratio, _ptr(acc), _ptr(raw), _ptr(d1), _ptr(d2)), "mh_match")
         return acc, raw, d1, d2
+
+    def normalize_match(self, q, ratio=0.8):
+        """mh_normalize + mh_match in one call: -> (normalised copy of q, acc, raw, d1, d2)."""
+        q = np.ascontiguousarray(q, np.float32).copy()
+        Q = q.shape[0]
+        acc = np.full(Q, -1, np.int32)
+        raw = np.full(Q, -1, np.int32)
+        d1 = np.zeros(Q, np.float32)
+        d2 = np.zeros(Q, np.float32)
+        self._ck(self.L.mh_normalize_match(self.h, _ptr(q), Q, ratio, _ptr(acc), _ptr(raw), _ptr(d1), _ptr(d2)),
+                 "mh_normalize_match")
+        return q, acc, raw, d1, d2
 
     # ---- CLUSTER ----
     def meanshift(self, pts, radius=200.0, merge=20.0, min_pts=7, max_iter=100):

@@ -380,8 +380,11 @@ int mh_match_merge_dev(mh_ctx* ctx, const int32_t* idx1_s_dev, const float* d1_s
   return MH_OK;
 }
 
-int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_idx,
-             int32_t* nn_raw, float* d1, float* d2) {
+// MATCH of host descriptors; `normalized_out` != nullptr: the rows are raw, are normalised on the device first and
+// come back normalised (what MATCH_ANN_CPU::process does to frameData's descriptors in place, :157) -- one upload
+// and one synchronisation for both.
+static int match_host(mh_ctx* ctx, const float* q_host, float* normalized_out, int Q, float ratio, int32_t* nn_idx,
+                      int32_t* nn_raw, float* d1, float* d2) {
   if (!ctx || Q < 0 || (Q > 0 && (!q_host || !nn_idx))) return MH_ERR_ARG;
   if (Q == 0) return MH_OK;
   MH_HIP(ctx, hipSetDevice(ctx->device));
@@ -391,9 +394,12 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
   if ((rc = ensure_match_scratch(ctx, Q))) return rc;
   if ((rc = ensure_pinned(ctx, (size_t)Q * 16))) return rc;
   if ((rc = ensure_scratch(ctx, (size_t)Q * 4))) return rc;
-  MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_host, (size_t)Q * DIM * sizeof(float),
-                             hipMemcpyHostToDevice, ctx->stream));
-  launch_row_norms(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
+  const size_t bytes = (size_t)Q * DIM * sizeof(float);
+  MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (normalized_out)
+    launch_normalize(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
+  else
+    launch_row_norms(ctx->q_desc, ctx->q_norm, Q, ctx->stream);
   if ((rc = ctx_match(ctx, ctx->q_desc, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
   // the reference's acceptance test on squared distances (MATCH_ANN_CPU.hpp:165)
   int32_t* d_acc = (int32_t*)ctx->scratch;
@@ -407,12 +413,23 @@ int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_i
   MH_HIP(ctx, hipMemcpyAsync(h_raw, ctx->nn_idx, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(h_d1, ctx->nn_d1, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(h_d2, ctx->nn_d2, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (normalized_out) MH_HIP(ctx, hipMemcpyAsync(normalized_out, ctx->q_desc, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::memcpy(nn_idx, h_acc, (size_t)Q * 4);
   if (nn_raw) std::memcpy(nn_raw, h_raw, (size_t)Q * 4);
   if (d1) std::memcpy(d1, h_d1, (size_t)Q * 4);
   if (d2) std::memcpy(d2, h_d2, (size_t)Q * 4);
   return MH_OK;
+}
+
+int mh_match(mh_ctx* ctx, const float* q_host, int Q, float ratio, int32_t* nn_idx,
+             int32_t* nn_raw, float* d1, float* d2) {
+  return match_host(ctx, q_host, nullptr, Q, ratio, nn_idx, nn_raw, d1, d2);
+}
+
+int mh_normalize_match(mh_ctx* ctx, float* q_host, int Q, float ratio, int32_t* nn_idx, int32_t* nn_raw, float* d1,
+                       float* d2) {
+  return match_host(ctx, q_host, q_host, Q, ratio, nn_idx, nn_raw, d1, d2);
 }
 
 float mh_screen_margin(float qq, float dmax) { return screen_margin_host(qq, dmax); }

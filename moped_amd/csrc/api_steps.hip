@@ -652,13 +652,18 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
               fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0}, s,
               images);
   MH_HIP(ctx, hipGetLastError());
-  std::vector<int32_t> valid(n_obj), ninl(n_obj), ocl(n_obj);
-  std::vector<float> pose((size_t)7 * n_obj), err(n_obj);
-  MH_HIP(ctx, hipMemcpyAsync(valid.data(), fs->obj_valid, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
-  MH_HIP(ctx, hipMemcpyAsync(ninl.data(), fs->obj_ninl, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
-  MH_HIP(ctx, hipMemcpyAsync(ocl.data(), fs->obj_cluster, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
-  MH_HIP(ctx, hipMemcpyAsync(pose.data(), fs->obj_pose, (size_t)n_obj * 28, hipMemcpyDeviceToHost, s));
-  MH_HIP(ctx, hipMemcpyAsync(err.data(), fs->obj_err, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  // the five result arrays into one pinned block (pageable destinations make every one of these copies a blocking one)
+  if (int rc_pin = ensure_pinned(ctx, (size_t)n_obj * 11 * 4)) return rc_pin;
+  int32_t* const valid = static_cast<int32_t*>(ctx->pinned);
+  int32_t* const ninl = valid + n_obj;
+  int32_t* const ocl = ninl + n_obj;
+  float* const err = reinterpret_cast<float*>(ocl + n_obj);
+  float* const pose = err + n_obj;
+  MH_HIP(ctx, hipMemcpyAsync(valid, fs->obj_valid, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(ninl, fs->obj_ninl, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(ocl, fs->obj_cluster, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(pose, fs->obj_pose, (size_t)n_obj * 28, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(err, fs->obj_err, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
   MH_HIP(ctx, hipStreamSynchronize(s));
   int k = 0;
   for (int o = 0; o < n_obj; ++o) {
@@ -1021,23 +1026,29 @@ int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
                 fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0}, s);
   MH_HIP(ctx, hipGetLastError());
-  int32_t kept = 0;
-  MH_HIP(ctx, hipMemcpyAsync(&kept, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
+  // results: everything the host needs in ONE pinned block, copied behind the kernel, one synchronisation (five
+  // blocking copies after it cost the step 0.1 ms: profiles/r02_host_step_timing.txt)
+  const size_t words = 1 + 4 * (size_t)n_obj + (size_t)std::max(M, 1);
+  if ((rc = ensure_pinned(ctx, words * 4))) return rc;
+  int32_t* const hp = static_cast<int32_t*>(ctx->pinned);
+  int32_t* const h_kept = hp;
+  float* const sc = reinterpret_cast<float*>(hp + 1);
+  int32_t* const old_of = hp + 1 + n_obj;
+  int32_t* const begin = old_of + n_obj;
+  int32_t* const count = begin + n_obj;
+  int32_t* const mem = count + n_obj;
+  MH_HIP(ctx, hipMemcpyAsync(h_kept, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(sc, fs->obj_score_raw, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(old_of, fs->obj_clsize + n_obj, (size_t)n_obj * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(begin, fs->cl_begin, (size_t)std::min(n_obj, fs->max_clusters) * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(count, fs->cl_count, (size_t)std::min(n_obj, fs->max_clusters) * 4, hipMemcpyDeviceToHost, s));
+  if (M > 0) MH_HIP(ctx, hipMemcpyAsync(mem, fs->new_members, (size_t)M * 4, hipMemcpyDeviceToHost, s));
   MH_HIP(ctx, hipStreamSynchronize(s));
-  std::vector<int32_t> old_of(std::max(kept, 1)), begin(std::max(kept, 1)), count(std::max(kept, 1));
-  std::vector<float> sc(n_obj);
-  MH_HIP(ctx, hipMemcpy(sc.data(), fs->obj_score_raw, (size_t)n_obj * 4, hipMemcpyDeviceToHost));
-  if (kept > 0) {
-    MH_HIP(ctx, hipMemcpy(old_of.data(), fs->obj_clsize + n_obj, (size_t)kept * 4, hipMemcpyDeviceToHost));
-    MH_HIP(ctx, hipMemcpy(begin.data(), fs->cl_begin, (size_t)kept * 4, hipMemcpyDeviceToHost));
-    MH_HIP(ctx, hipMemcpy(count.data(), fs->cl_count, (size_t)kept * 4, hipMemcpyDeviceToHost));
-  }
+  const int32_t kept = std::min(*h_kept, n_obj);
   if (keep) std::memset(keep, 0, n_obj);
   if (score)
     for (int o = 0; o < n_obj; ++o) score[o] = sc[o];
   int w = 0;
-  std::vector<int32_t> mem(std::max(M, 1));
-  if (M > 0) MH_HIP(ctx, hipMemcpy(mem.data(), fs->new_members, (size_t)M * 4, hipMemcpyDeviceToHost));
   for (int k = 0; k < kept; ++k) {
     const int o = old_of[k];
     if (keep) keep[o] = 1;

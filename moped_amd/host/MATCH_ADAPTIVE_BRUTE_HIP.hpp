@@ -182,13 +182,12 @@ class MATCH_ADAPTIVE_BRUTE_HIP : public MopedAlg {
     for (int i = 0; i < Q; ++i)
       for (int j = 0; j < MH_DESC_DIM; ++j) packed[(size_t)i * MH_DESC_DIM + j] = corresp[i].descriptor[j];
     mh_ctx* ctx = HipSession::get();
-    if (mh_normalize(ctx, &packed[0], Q) != MH_OK) { HipSession::warn("mh_normalize"); return; }
-    for (int i = 0; i < Q; ++i)   // the reference normalises the query descriptors in place (:453)
-      for (int j = 0; j < MH_DESC_DIM; ++j) corresp[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
     vector<int32_t> acc(Q), nn(Q);
     vector<float> d1(Q), d2(Q);
-    // ratio 2: every query with a neighbour passes; the decision is taken below per feature
-    if (mh_match(ctx, &packed[0], Q, 2.f, &acc[0], &nn[0], &d1[0], &d2[0]) != MH_OK) { HipSession::warn("mh_match"); return; }
+    // norm() + the search in one call; ratio 2: every query with a neighbour passes, the decision is taken below per feature
+    if (mh_normalize_match(ctx, &packed[0], Q, 2.f, &acc[0], &nn[0], &d1[0], &d2[0]) != MH_OK) { HipSession::warn("mh_normalize_match"); return; }
+    for (int i = 0; i < Q; ++i)   // the reference normalises the query descriptors in place (:453)
+      for (int j = 0; j < MH_DESC_DIM; ++j) corresp[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
     for (int i = 0; i < Q; ++i) {
       if (nn[i] < 0) continue;
       int x = (int)corresp[i].coord2D[0], y = (int)corresp[i].coord2D[1];

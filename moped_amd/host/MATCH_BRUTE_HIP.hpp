@@ -86,11 +86,11 @@ class MATCH_BRUTE_HIP : public MopedAlg {
     for (int i = 0; i < Q; ++i)
       for (int j = 0; j < MH_DESC_DIM; ++j) packed[(size_t)i * MH_DESC_DIM + j] = corresp[i].descriptor[j];
     mh_ctx* ctx = HipSession::get();
-    if (mh_normalize(ctx, &packed[0], Q) != MH_OK) { HipSession::warn("mh_normalize"); return; }
+    vector<int32_t> nn(Q);
+    // norm() + the search in one call: one upload, one synchronisation
+    if (mh_normalize_match(ctx, &packed[0], Q, Ratio, &nn[0], 0, 0, 0) != MH_OK) { HipSession::warn("mh_normalize_match"); return; }
     for (int i = 0; i < Q; ++i)  // the reference normalises the query descriptors in place (:157)
       for (int j = 0; j < MH_DESC_DIM; ++j) corresp[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
-    vector<int32_t> nn(Q);
-    if (mh_match(ctx, &packed[0], Q, Ratio, &nn[0], 0, 0, 0) != MH_OK) { HipSession::warn("mh_match"); return; }
     // the slot's contract (:165-176): matches[model] in ascending query order.  Two passes:
     // count per model, size each list once, then fill.
     vector<size_t> fill(models->size(), 0);

@@ -55,6 +55,21 @@ def test_match_bit_exact_vs_oracle(ctx, sift, n_models, ppm):
     _match_case(ctx, db, base)
 
 
+def test_normalize_match_equals_the_two_calls(ctx, sift):
+    """mh_normalize_match (what the MATCH plugins call): the normalised descriptors and the results of mh_normalize
+    followed by mh_match, bit for bit."""
+    base, _, _ = sift
+    db = synth.make_db(6, 2000)
+    ctx.db_upload(ctx.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    q = np.ascontiguousarray(base[:1777] * np.float32(37.5))
+    qn = ctx.normalize(q)
+    want = ctx.match(qn, 0.8)
+    got_q, *got = ctx.normalize_match(q, 0.8)
+    assert np.array_equal(got_q.view(np.uint32), qn.view(np.uint32))
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("tag,n_models,ppm", [("1k", 1, 1000), ("10k", 2, 5000), ("100k", 20, 5000)])
 def test_match_vs_reference_ann_golden(ctx, sift, tag, n_models, ppm):
     """Against the reference's own ANN kd-tree at eps=0 (tests/golden): identical
