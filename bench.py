@@ -52,6 +52,10 @@ def parse():
                     help="with --depth-kind: the frame takes the depth map itself and runs moped3d's shipped front end on "
                          "the device (DEPTHFILTER, depth-adaptive ratio, DEPTHFILTER2, DEPTHMAP_PROP, CLUSTER_LINKAGE; "
                          "moped3d/libmoped/src/config.hpp:41-45) instead of per-query depth attributes + mean shift")
+    ap.add_argument("--depthfill", action="store_true",
+                    help="with --moped3d-frontend: the sensor's depth map arrives with holes (z < 0 on ~12%% of the pixels) and "
+                         "moped3d's DEPTHFILL step (DEPTH_FILL_EXACT_CPU(8, false), config.hpp:39) runs on the device for every "
+                         "frame inside the timed region: a 4.9 MB working copy, the fill, the distance map")
     ap.add_argument("--parallelism", choices=("auto", "models", "frames"), default="auto",
                     help="N > 1: 'models' (the north-star design) shards the DB by model with one all-gather per batch of "
                          "frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: SURVEY "
@@ -222,7 +226,21 @@ def main():
         maps = []
         for i, f in enumerate(frames):
             img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
+            if args.depthfill:   # sensor-like holes (blobs + a dead border), none on a planted keypoint's pixel
+                rng_h = np.random.default_rng([0xD0F1, i])
+                hole = np.zeros((480, 640), bool)
+                yy, xx = np.ogrid[:480, :640]
+                for _ in range(18):
+                    cy, cx, r = rng_h.integers(0, 480), rng_h.integers(0, 640), rng_h.integers(6, 45)
+                    hole |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+                hole[:, :8] = True
+                rows = np.nonzero((f.src_point >= 0) & ~f.is_outlier)[0]
+                hole[np.clip(f.uv[rows, 1].astype(np.int32), 0, 479), np.clip(f.uv[rows, 0].astype(np.int32), 0, 639)] = False
+                img[hole, 2] = -1.0
             maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
+        if args.depthfill:   # per slot: the B working maps DEPTHFILL fills in place + the distance maps it writes
+            fill_work = [[(torch.empty_like(maps[0][0]), torch.empty_like(maps[0][1])) for _ in range(max(args.batch, 1))]
+                         for _ in range(args.depth)]
         table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
         for c in pipe.ctxs:
             c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
@@ -258,6 +276,13 @@ def main():
                 pipe.ctxs[slot].frame_set_depth(depths_b[pg].data_ptr(), args.depth_kind, 0.5)
             if maps is not None:   # the B frames' own depth and distance maps
                 mm = maps[pg * B:(pg + 1) * B]
+                if args.depthfill:
+                    for j, m in enumerate(mm):
+                        wd, wf = fill_work[slot][j]
+                        with torch.cuda.stream(pipe.streams[slot]):
+                            wd.copy_(m[0], non_blocking=True)
+                        pipe.ctxs[slot].depth_fill_dev(wd.data_ptr(), 640, 480, synth.K_DEFAULT, wf.data_ptr(), 8)
+                    mm = fill_work[slot][:B]
                 pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
                                                             args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
             pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
@@ -277,7 +302,13 @@ def main():
             if depths is not None:
                 pipe.ctxs[slot].frame_set_depth(depths[b].data_ptr(), args.depth_kind, 0.5)
             if maps is not None:
-                pipe.ctxs[slot].frame_set_depth_image(maps[b][0].data_ptr(), maps[b][1].data_ptr(), 640, 480,
+                mb = maps[b]
+                if args.depthfill:
+                    mb = fill_work[slot][0]
+                    with torch.cuda.stream(s):
+                        mb[0].copy_(maps[b][0], non_blocking=True)
+                    pipe.ctxs[slot].depth_fill_dev(mb[0].data_ptr(), 640, 480, synth.K_DEFAULT, mb[1].data_ptr(), 8)
+                pipe.ctxs[slot].frame_set_depth_image(mb[0].data_ptr(), mb[1].data_ptr(), 640, 480,
                                                       args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
             pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + f + 1)
             if record and f >= n_frames - n_pool and (world == 1 or by_frames):
@@ -358,7 +389,8 @@ def main():
                                f"(cluster, replica) task), MATCH->CLUSTER->POSE->FILTER->POSE2->FILTER2"
                                + ("" if not args.depth_kind else f", moped3d depth residuals kind {args.depth_kind}")
                                + ("" if not (args.depth_kind and args.moped3d_frontend) else
-                                  ", moped3d front end on the device (DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
+                                  ", moped3d front end on the device (" + ("DEPTHFILL of a map with holes, " if args.depthfill else "") +
+                                  "DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
                    "frames_per_step": n_frames, "distinct_frames": n_pool, "timed_seconds": round(dt, 3),
                    "frames_in_flight": (active_slots[0] if B > 1 else args.depth) * B, "frames_per_match_launch": B,
                    "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else

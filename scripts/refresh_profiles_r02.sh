@@ -17,6 +17,7 @@ if has bench; then
   echo "bench 200 done"
   timeout -k 10 500 python bench.py --models 50 --depth-kind 1 --frames-per-step 512 > $out/r02_bench_50models_depth.json 2>$out/bench50.err || { tail -3 $out/bench50.err; exit 1; }
   timeout -k 10 500 python bench.py --models 50 --depth-kind 1 --moped3d-frontend --frames-per-step 512 --no-cpu-baseline > $out/r02_bench_50models_moped3d_frontend.json 2>$out/bench50f.err || { tail -3 $out/bench50f.err; exit 1; }
+  timeout -k 10 500 python bench.py --models 50 --depth-kind 1 --moped3d-frontend --depthfill --frames-per-step 512 --no-cpu-baseline > $out/r02_bench_50models_moped3d_frontend_depthfill.json 2>$out/bench50d.err || { tail -3 $out/bench50d.err; exit 1; }
   echo "bench 50 done"
 fi
 if has prof; then
