@@ -216,9 +216,9 @@ extern "C" int mh_depth_fill(mh_ctx* ctx, float* depth_xyzn_dev, int width, int 
   int32_t* words = reinterpret_cast<int32_t*>(ctx->df_buf);
   float* zfill = reinterpret_cast<float*>(ctx->df_buf + 64);
   float* fdist = zfill + DF_MAX_PIX;
-  MH_HIP(ctx, hipMemsetAsync(words + 1, 0, sizeof(int32_t), s));   // (the overflow word is sticky until mh_depth_fill_status reads it)
-  int scale = scale_factor;
+  int scale = scale_factor;   // (the overflow word words[0] is sticky until mh_depth_fill_status reads it)
   if (scale == -1) {   // :283-296: the factor follows the share of holes (one small reduction + a 4-byte read)
+    MH_HIP(ctx, hipMemsetAsync(words + 1, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(depth_count_valid_kernel, dim3((n_full + 255) / 256), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(depth_xyzn_dev), n_full, words + 1);
     int32_t valid_count = 0;
