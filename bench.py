@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32-input MFMA peak
 PEAK_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA (the F16 forms take the same cycles)
+SUSTAINED_F16_TFLOPS = 1940.0   # measured: a register-only loop of v_mfma_f32_32x32x16_f16 on all 1024 SIMDs (profiles/r02_mfma_f16_rate.txt)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -486,6 +487,11 @@ def main():
                             "(mh_match_timing), 20 launch sequences after the timed region, one kernel on the chip at a time; "
                             "profiles/r02_*_depth1_kernel_stats.* is the same command under rocprofv3 with --depth 1",
                 "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
+                # `peak` is the data sheet's 2.5 PFLOP/s (2.4 GHz); a loop of nothing but this MFMA out of registers on every
+                # SIMD sustains 1 940 TFLOP/s on this part (scripts/experiments/mfma_f16_rate.hip,
+                # profiles/r02_mfma_f16_rate.txt: the clock the power budget allows under matrix load)
+                "sustained_mfma_only": {"tflops": SUSTAINED_F16_TFLOPS, "frac": round(ach_tf / SUSTAINED_F16_TFLOPS, 4),
+                                        "source": "profiles/r02_mfma_f16_rate.txt"},
                 "hbm": {"achieved": round(b_alg / (t_b * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(b_alg / (t_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
             }
