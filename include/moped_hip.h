@@ -506,6 +506,14 @@ int mh_sift_extract_dev(mh_ctx* ctx, const uint8_t* gray_dev, int width, int hei
  * (descriptors already L2-normalised like MATCH_ANN_CPU.hpp:157 leaves them). */
 int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
                            int max_keypoints, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed);
+/* B <= MH_MAX_BATCH images at once: FEAT image by image (every image's keypoints at a stride of max_keypoints rows,
+ * its count in a device word of its own), then ONE MATCH launch sequence over all of them -- an image's ~600
+ * keypoints alone leave the matrix pipes a sixth as busy per query as a batch does --, then CLUSTER..FILTER2 image
+ * after image into result slots 0 .. B-1 (mh_frame_fetch_slot).  Every image's objects are bit for bit those of
+ * mh_frame_enqueue_image(..., seeds[f]) on it alone.  One camera; not combined with depth maps or image indices. */
+int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, int n_images, int width, int height,
+                                 int double_size, int max_keypoints, const mh_cam* cam, const mh_frame_params* prm,
+                                 const uint64_t* seeds);
 int mh_frame_features_dev(mh_ctx* ctx, float** desc_dev, float** uv_dev, int32_t** n_dev);
 int mh_frame_keypoints(mh_ctx* ctx, int32_t* n_keypoints);
 

@@ -96,7 +96,7 @@ EXPORTS = [
     "mh_depth_fill", "mh_depth_fill_status", "mh_depth_fill_host",
     "mh_frame_enqueue_rest_batch", "mh_frame_fetch_slot", "mh_frame_result_copy_slots_dev",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
-    "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_features_dev", "mh_frame_keypoints",
+    "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_enqueue_image_batch", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
@@ -163,6 +163,7 @@ def load():
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
                                          C.c_uint64]
+    L.mh_frame_enqueue_image_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), vp]
     L.mh_frame_set_depth_image_host.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32]
     L.mh_depth_fill.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.mh_depth_fill_status.argtypes = [vp]
@@ -698,6 +699,17 @@ class Context:
         c = _cam_struct or make_cam(K, cam)
         self._ck(self.L.mh_frame_enqueue_image(self.h, C.c_void_p(gray_ptr), w, h, int(double_size), max_keypoints,
                                                C.byref(c), C.byref(params), seed), "mh_frame_enqueue_image")
+
+    def frame_enqueue_image_batch(self, gray_ptrs, w, h, double_size, max_keypoints, K, cam, params: mh_frame_params, seeds,
+                                  _cam_struct=None):
+        """FEAT of B device images, ONE MATCH launch sequence over all their keypoints, CLUSTER..FILTER2 image after
+        image into result slots 0..B-1 (frame_fetch_slot)."""
+        c = _cam_struct or make_cam(K, cam)
+        B = len(gray_ptrs)
+        g = (C.c_void_p * B)(*gray_ptrs)
+        sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
+        self._ck(self.L.mh_frame_enqueue_image_batch(self.h, g, B, w, h, int(double_size), max_keypoints, C.byref(c),
+                                                     C.byref(params), sd), "mh_frame_enqueue_image_batch")
 
     def frame_set_cluster_linkage(self, params: "mh_linkage_params | None"):
         """CLUSTER of the next frames: moped3d's linkage clusterer (None: mean shift again)."""

@@ -92,14 +92,15 @@ namespace mh {
 // SIFT of a device image into caller-chosen device buffers, on the context's stream;
 // *n_dev_out = the context's device word holding the keypoint count afterwards.
 int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
-              float* desc_dev, float* xy_dev, int32_t** n_dev_out) {
+              float* desc_dev, float* xy_dev, int32_t** n_dev_out, int32_t* count_word) {
   int rc = ensure_sift(ctx, width, height, double_size ? 1 : 0, cap);
   if (rc) return rc;
   SiftState* st = ctx->sift;
+  int32_t* const n_dev = count_word ? count_word : st->n_dev;   // (a batch of images keeps every image's count)
   launch_sift(gray_dev, width, height, double_size ? 1 : 0, st->plan, st->B, cap, desc_dev, xy_dev, nullptr,
-              st->n_dev, ctx->stream);
+              n_dev, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
-  *n_dev_out = st->n_dev;
+  if (n_dev_out) *n_dev_out = n_dev;
   return MH_OK;
 }
 

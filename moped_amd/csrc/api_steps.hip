@@ -178,6 +178,31 @@ FilterBuffers make_fb(const mh_ctx* ctx, const FrameState* fs, int n_models) {
 
 __global__ void set_scalar_kernel(int32_t* p, int32_t v) { *p = v; }
 
+// mh_frame_enqueue_image_batch: the B images' keypoints lie at a fixed stride of Q rows; rows past an image's count
+// become zero rows with a norm term of -1 before MATCH -- "no such query" to the two-stage search (a plain zero query is
+// its worst case: every row of a normalised DB ties, the candidate lists overflow and the query falls back to brute
+// force), a finite dummy to the exact kernels ...
+__global__ void image_batch_tail_kernel(float* __restrict__ desc, float* __restrict__ norm, const int32_t* __restrict__ counts,
+                                        int Q, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece of a row
+  if (i >= B * Q * (DIM / 4)) return;
+  const int row = i / (DIM / 4), f = row / Q, q = row - f * Q;
+  if (q < min(counts[f], Q)) return;
+  reinterpret_cast<float4*>(desc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i % (DIM / 4) == 0) norm[row] = -1.f;
+}
+// ... and "no neighbour" after it, so that no step of the frame sees them
+__global__ void image_batch_mask_kernel(int32_t* __restrict__ idx, float* __restrict__ d1, float* __restrict__ d2,
+                                        const int32_t* __restrict__ counts, int Q, int B) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B * Q) return;
+  const int f = row / Q, q = row - f * Q;
+  if (q < min(counts[f], Q)) return;
+  idx[row] = -1;
+  d1[row] = __builtin_inff();
+  d2[row] = __builtin_inff();
+}
+
 // Result block of a frame that stops after POSE (run_stage2 = 0): the valid objects in
 // list order.  Frames with the FILTER stages get it from the last FILTER launch.
 __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots,
@@ -1195,6 +1220,54 @@ int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int 
     return rc;
   stamp(ctx, 1);
   return frame_rest(ctx, ctx->q_uv, Q, nullptr, 0, cam, prm, seed);
+}
+
+int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, int B, int width, int height, int double_size,
+                                 int max_keypoints, const mh_cam* cam, const mh_frame_params* prm, const uint64_t* seeds) {
+  if (!ctx || !gray_dev || B < 1 || B > MH_MAX_BATCH || width <= 0 || height <= 0 || max_keypoints <= 0 || !cam || !prm || !seeds)
+    return MH_ERR_ARG;
+  for (int f = 0; f < B; ++f)
+    if (!gray_dev[f]) return MH_ERR_ARG;
+  if (ctx->depth_img.img || ctx->rules.on || ctx->q_depth || (ctx->q_img && ctx->n_images > 1)) {
+    ctx->err = "mh_frame_enqueue_image_batch: depth maps / rules / attributes and image indices belong to ONE frame";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  const int Q = max_keypoints;
+  int rc = prepare_frame(ctx, B * Q);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  if (!ctx->img_counts) {
+    MH_HIP(ctx, hipMalloc(&ctx->img_counts, MH_MAX_BATCH * sizeof(int32_t)));
+    MH_HIP(ctx, hipMemsetAsync(ctx->img_counts, 0, MH_MAX_BATCH * sizeof(int32_t), s));
+  }
+  // FEAT image by image into the batch's query rows (image f: rows f Q ..), every image's count in a word of its own
+  for (int f = 0; f < B; ++f) {
+    if ((rc = sift_into(ctx, gray_dev[f], width, height, double_size, Q, ctx->q_desc + (size_t)f * Q * DIM,
+                        ctx->q_uv + (size_t)f * Q * 2, nullptr, ctx->img_counts + f)))
+      return rc;
+    launch_normalize(ctx->q_desc + (size_t)f * Q * DIM, ctx->q_norm + (size_t)f * Q, Q, s, ctx->img_counts + f);
+  }
+  MH_HIP(ctx, hipGetLastError());
+  ctx->feat_count_dev = nullptr;
+  stamp(ctx, 0);
+  hipLaunchKernelGGL(image_batch_tail_kernel, dim3((B * Q * (DIM / 4) + 255) / 256), dim3(256), 0, s, ctx->q_desc, ctx->q_norm,
+                     ctx->img_counts, Q, B);
+  // ONE MATCH launch sequence over the B images' keypoints
+  if ((rc = ctx_match(ctx, ctx->q_desc, ctx->q_norm, B * Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
+  hipLaunchKernelGGL(image_batch_mask_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, s, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2,
+                     ctx->img_counts, Q, B);
+  stamp(ctx, 1);
+  for (int f = 0; f < B && rc == MH_OK; ++f) {
+    ctx->batch_q0 = f * Q;
+    ctx->fs->slot = f;
+    if (graphs_enabled()) set_seed(ctx, seeds[f]);
+    rc = frame_rest(ctx, ctx->q_uv + 2 * (size_t)f * Q, Q, nullptr, 0, cam, prm, seeds[f]);
+  }
+  ctx->batch_q0 = 0;
+  ctx->fs->slot = 0;
+  return rc;
 }
 
 int mh_frame_features_dev(mh_ctx* ctx, float** desc_dev, float** uv_dev, int32_t** n_dev) {

@@ -79,6 +79,7 @@ struct mh_ctx {
   struct FrameState* fs = nullptr;
   struct SiftState* sift = nullptr;   // pyramid + keypoint buffers of the SIFT extractor (api_sift.hip)
   int32_t* feat_count_dev = nullptr;  // frame enqueued from an image: device word with its keypoint count
+  int32_t* img_counts = nullptr;      // mh_frame_enqueue_image_batch: [MH_MAX_BATCH] keypoint counts of the batch's images (device)
   int feat_expected = 0;              // keypoints of the last fetched image frame (sizes the next MATCH launch)
   int feat_last = -1;
   int batch_q0 = 0;                   // first query of the frame frame_rest works on (mh_frame_enqueue_batch)
@@ -168,6 +169,6 @@ int ensure_match_scratch(mh_ctx* ctx, int Q);
 int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* idx1, float* d1, float* d2,
               const int32_t* q_count = nullptr, int q_expected = 0);
 int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
-              float* desc_dev, float* xy_dev, int32_t** n_dev_out);
+              float* desc_dev, float* xy_dev, int32_t** n_dev_out, int32_t* count_word = nullptr);
 
 }  // namespace mh

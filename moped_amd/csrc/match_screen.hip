@@ -159,12 +159,15 @@ __global__ void screen_prepare_kernel(const float* __restrict__ qn, const float*
 #pragma unroll
   for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
   if ((i & 15) == 0) {
-    bool bad = false;
+    int bad = 0;
     if (row < Qe) {
       const float qq = qnorm[row];
-      bad = !(qq >= 0.f) || qq == __builtin_inff() || !(m < 60000.f);
+      bad = (!(qq >= 0.f) || qq == __builtin_inff() || !(m < 60000.f)) ? 1 : 0;
+      // norm term exactly -1 = "no such query" (the rows past an image's keypoint count in a batch of images,
+      // mh_frame_enqueue_image_batch): no threshold, no records, no neighbour -- not a query the screen cannot vouch for
+      if (qq == -1.f) bad = 2;
     }
-    qbad[row] = bad ? 1 : 0;
+    qbad[row] = (uint8_t)bad;
   }
 }
 
@@ -662,6 +665,14 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     }
     return;
   }
+  if (qbad[q] == 2) {   // an absent row inside the launch (see screen_prepare_kernel)
+    if (lane == 0) {
+      idx1[q] = -1;
+      d1[q] = __builtin_inff();
+      d2[q] = __builtin_inff();
+    }
+    return;
+  }
   const float nq = qnorm[q];
   if (lane == 0) ncand_s[wave] = 0;
   {
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
   }
   // ---- records -> candidate row list in LDS; the slots read are emptied for the next frame ----
   const int n_ovf = ovf_cnt[q];
-  bool brute = n_ovf > ovf_cap || qbad[q];
+  bool brute = n_ovf > ovf_cap || qbad[q] == 1;
   int n_cand = 0;
   uint2* mine = recs + (size_t)q * SC_SLOTS_MAX;
   if (!brute) {

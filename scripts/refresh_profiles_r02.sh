@@ -82,6 +82,8 @@ if has sift; then
   timeout -k 10 300 python tests/tools/sift_probe.py > $out/r02_sift_probe.txt 2>&1
   timeout -k 10 300 python scripts/image_frame_bench.py 20 16 3000 > $out/r02_image_frame_bench.txt 2>&1
   timeout -k 10 300 python scripts/image_frame_bench.py 20 4 3000 >> $out/r02_image_frame_bench.txt 2>&1
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 16 4000 4 >> $out/r02_image_frame_bench.txt 2>&1    # four images per MATCH launch sequence
+  timeout -k 10 300 python scripts/image_frame_bench.py 20 16 4000 8 >> $out/r02_image_frame_bench.txt 2>&1
   GPU_MAX_HW_QUEUES=4 timeout -k 10 300 python scripts/image_frame_bench.py 20 16 3000 >> $out/r02_image_frame_bench.txt 2>&1   # ROCm's default queue count
   cd /tmp && export TMPDIR=/tmp
   rm -rf /tmp/rp_sift

@@ -93,3 +93,36 @@ def test_image_frame_capacity_and_empty(scene):
     c.frame_enqueue_image(g.data_ptr(), gray.shape[1], gray.shape[0], True, 256, K, CAM0, prm, seed=1)
     objs, counts = c.frame_fetch()
     assert c.frame_keypoints() == 256
+
+
+def test_batch_of_images_equals_the_images_alone(scene):
+    """mh_frame_enqueue_image_batch: FEAT image by image, ONE MATCH launch sequence over all keypoints (every image at
+    a stride of the capacity, the rows past its count zeroed before and masked after the search), CLUSTER..FILTER2 image
+    after image: every image's objects and counts bit for bit those of mh_frame_enqueue_image on it alone."""
+    c, torch, db_desc, db_xyz, model_of = scene
+    dev = torch.device("cuda:0")
+    frames = [int(x) for x in GOLD["frames"]]
+    imgs = [torch.from_numpy(GOLD[f"gray{f}"]).to(dev) for f in frames]
+    blank = torch.zeros_like(imgs[0])                      # an image without keypoints in the middle of the batch
+    h, w = GOLD["gray0"].shape
+    prm = capi.default_frame_params()
+    alone = []
+    pool = imgs + [blank]
+    for i, g in enumerate(pool):
+        c.frame_enqueue_image(g.data_ptr(), w, h, True, CAP, K, CAM0, prm, seed=40 + i)
+        alone.append(c.frame_fetch())
+    order = [0, len(pool) - 1] + list(range(1, len(pool) - 1)) + [0]   # (the blank image second, the first one again last)
+    c.reserve(len(order) * CAP)
+    batch = [pool[j] for j in order]
+    for _ in range(2):
+        c.frame_enqueue_image_batch([g.data_ptr() for g in batch], w, h, True, CAP, K, CAM0, prm, [40 + j for j in order])
+        for slot, j in enumerate(order):
+            got, got_counts = c.frame_fetch_slot(slot)
+            want, want_counts = alone[j]
+            assert np.array_equal(got_counts, want_counts)
+            assert got.tobytes() == want.tobytes()
+    assert len(alone[-1][0]) == 0 and len(alone[0][0]) >= 1
+    # single images still work on the context afterwards
+    c.frame_enqueue_image(imgs[0].data_ptr(), w, h, True, CAP, K, CAM0, prm, seed=40)
+    again, _ = c.frame_fetch()
+    assert again.tobytes() == alone[0][0].tobytes()
