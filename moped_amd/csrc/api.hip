@@ -281,11 +281,11 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
         if ((rc = realloc_dev(ctx, st->neg_h, screen_dneg_elems(N)))) return rc;
         st->cap_h = need_h;
       }
-      if (!st->stats) MH_HIP(ctx, hipMalloc(&st->stats, 4 * sizeof(unsigned int)));
-      MH_HIP(ctx, hipMemsetAsync(st->stats, 0, 4 * sizeof(unsigned int), ctx->stream));
+      if (!st->stats) MH_HIP(ctx, hipMalloc(&st->stats, 8 * sizeof(unsigned int)));
+      MH_HIP(ctx, hipMemsetAsync(st->stats, 0, 8 * sizeof(unsigned int), ctx->stream));
       launch_db_to_half(st->desc, st->norm, N, st->desc_h, st->neg_h, st->stats, ctx->stream);
       MH_HIP(ctx, hipGetLastError());
-      unsigned int h[4] = {0, 0, 0, 0};
+      unsigned int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       MH_HIP(ctx, hipMemcpyAsync(h, st->stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
       MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       float dd_max, x_max;
@@ -295,6 +295,9 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
       st->screen.dneg = st->neg_h;
       st->screen.dmax = std::sqrt(dd_max);
       std::memcpy(&st->screen.spread, &h[3], 4);   // (0 for a DB of fewer than 32 rows: no whole block, never used)
+      st->screen.zero_idx = (int32_t)h[4];
+      std::memcpy(&st->screen.zero_d1, &h[5], 4);
+      std::memcpy(&st->screen.zero_d2, &h[6], 4);
       st->screen.usable = h[2] == 0 && x_max < 60000.f;   // (a NaN coordinate reads as a huge bit pattern: not < 60000)
     }
   }

@@ -136,6 +136,55 @@ __global__ void db_block_bounds_kernel(const float* __restrict__ dnorm, int N, i
     for (int i = 136; i < SC_DD; ++i) t[i] = 0.f;
 }
 
+// The exact answer for an all-zero query: canonical distance max(0, fmaf(-2, 0, 0 + dd_r)) = dd_r, so the two smallest
+// norm terms over the real rows, the lower row on a tie (what the exact kernels' top-2 gives).  One workgroup.
+__global__ __launch_bounds__(1024) void db_zero_query_kernel(const float* __restrict__ dnorm, int N, unsigned int* __restrict__ stats) {
+  __shared__ float s1[1024], s2[1024];
+  __shared__ int si[1024];
+  float b1 = __builtin_inff(), b2 = __builtin_inff();
+  int i1 = -1;
+  for (int r = threadIdx.x; r < N; r += 1024) {   // ascending rows: a strict < keeps the lower row on ties
+    const float d = fmaxf(dnorm[r], 0.f);
+    if (d < b1 || i1 < 0) {
+      if (i1 >= 0) b2 = fminf(b2, b1);
+      b1 = d;
+      i1 = r;
+    } else {
+      b2 = fminf(b2, d);
+    }
+  }
+  s1[threadIdx.x] = b1;
+  s2[threadIdx.x] = b2;
+  si[threadIdx.x] = i1;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      const float o1 = s1[threadIdx.x + st], o2 = s2[threadIdx.x + st];
+      const int oi = si[threadIdx.x + st];
+      float a1 = s1[threadIdx.x], a2 = s2[threadIdx.x];
+      int ai = si[threadIdx.x];
+      if (oi >= 0) {
+        const bool take = ai < 0 || o1 < a1 || (o1 == a1 && oi < ai);
+        const float lose = take ? a1 : o1;
+        a2 = fminf(fminf(a2, o2), ai >= 0 ? lose : __builtin_inff());
+        if (take) {
+          a1 = o1;
+          ai = oi;
+        }
+      }
+      s1[threadIdx.x] = a1;
+      s2[threadIdx.x] = a2;
+      si[threadIdx.x] = ai;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[4] = (unsigned int)si[0];
+    stats[5] = __float_as_uint(s1[0]);
+    stats[6] = __float_as_uint(s2[0]);
+  }
+}
+
 // Queries of the frame: f16 rows (zero rows up to the padded count) + a flag for queries the screen
 // cannot vouch for (non-finite norm term, or a coordinate outside f16's range).
 __global__ void screen_prepare_kernel(const float* __restrict__ qn, const float* __restrict__ qnorm, int Q,
@@ -166,6 +215,7 @@ __global__ void screen_prepare_kernel(const float* __restrict__ qn, const float*
       // norm term exactly -1 = "no such query" (the rows past an image's keypoint count in a batch of images,
       // mh_frame_enqueue_image_batch): no threshold, no records, no neighbour -- not a query the screen cannot vouch for
       if (qq == -1.f) bad = 2;
+      else if (!bad && m == 0.f && qq == 0.f) bad = 3;   // an all-zero query: its answer is known per DB (ScreenDb::zero_*)
     }
     qbad[row] = (uint8_t)bad;
   }
@@ -648,7 +698,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     const int32_t* __restrict__ q_count, const float* __restrict__ db, const float* __restrict__ dnorm, int N,
     int32_t index_base, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
     int ovf_cap, float dmax, const float* __restrict__ tau, float spread, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
-    unsigned int* __restrict__ stats) {
+    unsigned int* __restrict__ stats, int32_t zero_idx, float zero_d1, float zero_d2) {
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
   __shared__ int cand_s[RS_WAVES][RS_MAXC];
   __shared__ int ncand_s[RS_WAVES];
@@ -670,6 +720,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       idx1[q] = -1;
       d1[q] = __builtin_inff();
       d2[q] = __builtin_inff();
+    }
+    return;
+  }
+  if (qbad[q] == 3) {   // an all-zero query: every row's distance is its norm term
+    if (lane == 0) {
+      idx1[q] = zero_idx >= 0 ? zero_idx + index_base : -1;
+      d1[q] = zero_d1;
+      d2[q] = zero_d2;
+      if (stats) stats[3 * q + 2] += 1u;   // a search, without candidates
     }
     return;
   }
@@ -820,6 +879,7 @@ void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh
   hipLaunchKernelGGL(db_to_half_kernel, dim3(blocks), dim3(256), 0, s, db, dnorm, N, n_chunks, dbh, dneg, stats);
   const int n_tiles = (int)(n_chunks * 8 / ((size_t)SC_TILE * DIM));
   hipLaunchKernelGGL(db_block_bounds_kernel, dim3((n_tiles * 4 + 255) / 256), dim3(256), 0, s, dnorm, N, n_tiles, dneg, stats);
+  hipLaunchKernelGGL(db_zero_query_kernel, dim3(1), dim3(1024), 0, s, dnorm, N, stats);
 }
 
 size_t screen_rec_slots() { return SC_SLOTS_MAX; }
@@ -951,7 +1011,7 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
                      q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, sdb.spread, idx1, d1, d2,
-                     sb.stats);
+                     sb.stats, sdb.zero_idx, sdb.zero_d1, sdb.zero_d2);
   if (sb.ev) hipEventRecord(sb.ev[5], s);
 }
 

@@ -13,6 +13,10 @@ struct ScreenDb {
   float dmax = 0.f;                // max_r |d_r| (sqrt of the largest norm term)
   float spread = __builtin_inff(); // largest (max - min) of -dd/2 inside a 32-row block of real rows
   bool usable = false;             // every norm term finite and non-negative, every coordinate inside f16's range
+  // the answer for an all-zero query (its distance to row r is the row's norm term, exactly): a zero query ties with
+  // every row of a normalised DB on the screen -- its candidate lists would overflow and it would go to brute force
+  int32_t zero_idx = -1;
+  float zero_d1 = __builtin_inff(), zero_d2 = __builtin_inff();
 };
 
 // Per-context scratch of the screen (frames of one context are stream ordered).
@@ -35,7 +39,8 @@ size_t screen_rec_slots();           // record slots per query
 float screen_margin_host(float qq, float dmax);   // tau = T - margin (the error model, for tests)
 size_t screen_db_half_elems(int N);
 size_t screen_dneg_elems(int N);   // floats of the -dd/2 array: 192 per 128-row tile (rows, row blocks' extrema)
-// f16 image + statistics {bits of max dd, bits of max |x|, non-finite flag} (stats zeroed by the caller)
+// f16 image + statistics {bits of max dd, bits of max |x|, non-finite flag, bits of the largest in-block spread,
+// row / norm term / second norm term of an all-zero query's answer} (8 words, zeroed by the caller)
 void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh, float* dneg, unsigned int* stats,
                        hipStream_t s);
 int screen_q_pad(int Q);
