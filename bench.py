@@ -350,6 +350,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         run_step(k, record=(k == args.steps - 1))
+    t_issue = time.perf_counter() - t0   # the host's share: the enqueue loop alone (behind full queues it waits for the GPU)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -393,6 +394,7 @@ def main():
                                   ", moped3d front end on the device (" + ("DEPTHFILL of a map with holes, " if args.depthfill else "") +
                                   "DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
                    "frames_per_step": n_frames, "distinct_frames": n_pool, "timed_seconds": round(dt, 3),
+                   "host_issue_seconds": round(t_issue, 3),
                    "frames_in_flight": (active_slots[0] if B > 1 else args.depth) * B, "frames_per_match_launch": B,
                    "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
                                    f"model-shard x{world}" if world > 1 else "single GPU"),
