@@ -33,6 +33,8 @@ struct LkLds {
   unsigned char inlist[LK_CAP];
   float red_v[LK_THREADS / 64];
   int red_a[LK_THREADS / 64], red_b[LK_THREADS / 64];
+  float red2_v[2][LK_THREADS / 64];   // the agglomeration's per-wavefront candidates, by iteration parity
+  int red2_a[2][LK_THREADS / 64], red2_b[2][LK_THREADS / 64];
   float sigma2, sigma3, maxv;
   float best_v;
   int best_a, best_b;
@@ -298,35 +300,33 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
           bb = ob;
         }
       }
-      __syncthreads();
+      // every wavefront's candidate, by iteration parity (the slots of the iteration before are still being read), one
+      // barrier, and every thread folds the 16 of them itself (wave-uniform reads): no single-thread section, three
+      // barriers per merge instead of five
+      const int par = iter & 1;
       if (lane == 0) {
-        L.red_v[wave] = bv;
-        L.red_a[wave] = ba;
-        L.red_b[wave] = bb;
+        L.red2_v[par][wave] = bv;
+        L.red2_a[par][wave] = ba;
+        L.red2_b[par][wave] = bb;
       }
       __syncthreads();
-      if (tid == 0) {
-        float v = -1.f;
-        int a = 0x7fffffff, b = 0x7fffffff;
-        for (int k = 0; k < LK_THREADS / 64; ++k) {
-          const float ov = L.red_v[k];
-          const int oa = L.red_a[k], ob = L.red_b[k];
-          if (ov > v || (ov == v && (oa < a || (oa == a && ob < b)))) {
-            v = ov;
-            a = oa;
-            b = ob;
-          }
+      bv = -1.f;
+      ba = 0x7fffffff;
+      bb = 0x7fffffff;
+      for (int k = 0; k < LK_THREADS / 64; ++k) {
+        const float ov = L.red2_v[par][k];
+        const int oa = L.red2_a[par][k], ob = L.red2_b[par][k];
+        if (ov > bv || (ov == bv && (oa < ba || (oa == ba && ob < bb)))) {
+          bv = ov;
+          ba = oa;
+          bb = ob;
         }
-        L.best_v = v;
-        L.best_a = a;
-        L.best_b = b;
-        if (rv_listed) L.inlist[removeValue] = 0;   // erased during this scan
       }
-      __syncthreads();
+      if (tid == 0 && rv_listed) L.inlist[removeValue] = 0;   // erased during this scan (read again only behind the barriers below)
     }
-    const float maxSimilarity = L.best_v;
+    const float maxSimilarity = bv;
     if (maxSimilarity < P.cutoff) break;
-    const int first = L.best_a, second = L.best_b;
+    const int first = ba, second = bb;
     const int S1 = L.clsize[first], S2 = L.clsize[second];
     // merge: the absorbed cluster's members are appended back to front (:493-496)
     for (int k = tid; k < S2; k += LK_THREADS) mem[(size_t)first * N + S1 + k] = mem[(size_t)second * N + (S2 - 1 - k)];
