@@ -153,7 +153,9 @@ def main():
     if args.depth <= 0:
         args.depth = 16
     if args.batch <= 0:
-        args.batch = 8 if sharded else 4
+        # eight frames per MATCH launch sequence; a batch of plain frames also shares the launches of its rest chain
+        # (one group / CLUSTER / POSE / POSE2 launch for the eight).  Frames with depth maps go frame after frame: four
+        args.batch = 8 if sharded or not (args.depth_kind or args.moped3d_frontend) else 4
     if args.depth_kind and sharded:
         args.batch = 1    # (the sharded batch path carries no per-frame depth attributes)
     if args.depth > 4:

@@ -1,6 +1,7 @@
 // C ABI: CLUSTER / POSE / FILTER entry points and the device-resident frame.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "context.h"
@@ -12,6 +13,12 @@ using namespace mh;
 // matches[model] of the reference is the slice [model_off[m], model_off[m+1]).
 struct FrameState {
   int max_m = 0, max_clusters = 0, max_objects = 0, n_models_cap = 0;
+  // The working arrays below (counts .. tickets) are carved out of ONE allocation of MH_MAX_BATCH equal arenas: the
+  // pointers name frame 0's copy, frame f of a batch that goes through the stages in one launch (FrameBatch, steps.h)
+  // has its own at + f * arena_bytes.  Results and count snapshots are slot-indexed arrays outside the arenas.
+  unsigned char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int n_arenas = 1;   // copies allocated: 1 until the first merged batch of B frames asks for B
   FrameCounts* counts = nullptr;
   int32_t* n_slots = nullptr;      // object slots in use (device scalar)
   int32_t* n_clusters = nullptr;   // rows of the current cluster table (device scalar)
@@ -60,14 +67,7 @@ int dev_alloc(mh_ctx* ctx, T*& p, size_t n) {
 
 void free_fs(FrameState* fs) {
   if (!fs) return;
-  void* ptrs[] = {fs->counts,     fs->n_slots,   fs->n_clusters, fs->acc_q,      fs->acc_model,
-                  fs->m_q,        fs->m_model,   fs->m_rep,      fs->m_corr,     fs->model_off,
-                  fs->ms_members, fs->ms_cl_start, fs->ms_ncl,   fs->cl_model,   fs->cl_begin,
-                  fs->cl_count,   fs->obj_model, fs->obj_ninl,   fs->obj_cluster, fs->obj_valid,
-                  fs->obj_npts,   fs->obj_clsize, fs->obj_pose,  fs->obj_err,    fs->obj_score,
-                  fs->best,       fs->new_members, fs->result,   fs->snap,       fs->obj_score_raw,
-                  fs->m_depth,    fs->seed_dev,    fs->tickets,    fs->m_img,      fs->mi_img,
-                  fs->off2,       fs->mi_corr};
+  void* ptrs[] = {fs->arena, fs->result, fs->snap, fs->seed_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (FrameState::Graph* g : {&fs->g_full, &fs->g_local, &fs->g_rest})
@@ -75,17 +75,29 @@ void free_fs(FrameState* fs) {
   delete fs;
 }
 
-int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_models) {
+int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_models, int n_arenas = 1) {
   FrameState* fs = ctx->fs;
   if (fs && fs->max_m >= max_m && fs->max_clusters >= max_clusters &&
-      fs->max_objects >= max_objects && fs->n_models_cap >= n_models)
+      fs->max_objects >= max_objects && fs->n_models_cap >= n_models && fs->n_arenas >= n_arenas)
     return MH_OK;
+  int task_grid = 0, ms_grid = 0;
+  unsigned char* kept_result = nullptr;
+  int32_t* kept_snap = nullptr;
   if (fs) {
+    n_arenas = std::max(n_arenas, fs->n_arenas);
+    task_grid = fs->task_grid;
+    ms_grid = fs->ms_grid;
     max_m = std::max(max_m, fs->max_m);
     max_clusters = std::max(max_clusters, fs->max_clusters);
     max_objects = std::max(max_objects, fs->max_objects);
     n_models = std::max(n_models, fs->n_models_cap);
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (max_objects == fs->max_objects) {   // the result blocks keep their size: frames not fetched yet stay fetchable
+      kept_result = fs->result;
+      kept_snap = fs->snap;
+      fs->result = nullptr;
+      fs->snap = nullptr;
+    }
     free_fs(fs);
     ctx->fs = nullptr;
   }
@@ -95,56 +107,77 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   fs->max_clusters = max_clusters;
   fs->max_objects = max_objects;
   fs->n_models_cap = n_models;
+  fs->n_arenas = n_arenas;
+  if (task_grid) {   // (what the launches had learnt about the frames' task counts)
+    fs->task_grid = task_grid;
+    fs->ms_grid = ms_grid;
+  }
   int rc = 0;
-  rc |= dev_alloc(ctx, fs->counts, 1);
-  rc |= dev_alloc(ctx, fs->n_slots, 1);
-  rc |= dev_alloc(ctx, fs->n_clusters, 1);
-  rc |= dev_alloc(ctx, fs->acc_q, max_m);
-  rc |= dev_alloc(ctx, fs->acc_model, max_m);
-  rc |= dev_alloc(ctx, fs->m_q, max_m);
-  rc |= dev_alloc(ctx, fs->m_model, max_m);
-  rc |= dev_alloc(ctx, fs->m_rep, max_m);
-  rc |= dev_alloc(ctx, fs->m_corr, max_m);
-  rc |= dev_alloc(ctx, fs->m_depth, max_m);
-  rc |= dev_alloc(ctx, fs->m_img, max_m);
-  rc |= dev_alloc(ctx, fs->mi_img, max_m);
-  rc |= dev_alloc(ctx, fs->mi_corr, max_m);
-  rc |= dev_alloc(ctx, fs->off2, (size_t)n_models + 1);
-  rc |= dev_alloc(ctx, fs->model_off, (size_t)n_models + 1);
-  rc |= dev_alloc(ctx, fs->ms_members, max_m);
-  rc |= dev_alloc(ctx, fs->ms_cl_start, (size_t)max_m + n_models + 1);
-  rc |= dev_alloc(ctx, fs->ms_ncl, (size_t)n_models + 1);
-  rc |= dev_alloc(ctx, fs->cl_model, max_clusters);
-  rc |= dev_alloc(ctx, fs->cl_begin, max_clusters);
-  rc |= dev_alloc(ctx, fs->cl_count, max_clusters);
-  rc |= dev_alloc(ctx, fs->obj_model, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_ninl, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_cluster, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_valid, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_npts, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_clsize, (size_t)2 * max_objects);
-  rc |= dev_alloc(ctx, fs->obj_pose, (size_t)7 * max_objects);
-  rc |= dev_alloc(ctx, fs->obj_err, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_score, max_objects);
-  rc |= dev_alloc(ctx, fs->obj_score_raw, max_objects);
-  rc |= dev_alloc(ctx, fs->best, max_m);
-  rc |= dev_alloc(ctx, fs->new_members, max_m);
+  // two passes over the same list: sizes first (pointers are offsets into a null arena), then the real addresses
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    size_t off = 0;
+    unsigned char* const base = fs->arena;
+    auto carve = [&](auto*& p, size_t n) {
+      typedef typename std::remove_reference<decltype(*p)>::type T;
+      p = reinterpret_cast<T*>(base + off);
+      off += ((n > 0 ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
+    };
+    carve(fs->counts, 1);
+    carve(fs->n_slots, 1);
+    carve(fs->n_clusters, 1);
+    carve(fs->tickets, 8);
+    carve(fs->acc_q, max_m);
+    carve(fs->acc_model, max_m);
+    carve(fs->m_q, max_m);
+    carve(fs->m_model, max_m);
+    carve(fs->m_rep, max_m);
+    carve(fs->m_corr, max_m);
+    carve(fs->m_depth, max_m);
+    carve(fs->m_img, max_m);
+    carve(fs->mi_img, max_m);
+    carve(fs->mi_corr, max_m);
+    carve(fs->off2, (size_t)n_models + 1);
+    carve(fs->model_off, (size_t)n_models + 1);
+    carve(fs->ms_members, max_m);
+    carve(fs->ms_cl_start, (size_t)max_m + n_models + 1);
+    carve(fs->ms_ncl, (size_t)n_models + 1);
+    carve(fs->cl_model, max_clusters);
+    carve(fs->cl_begin, max_clusters);
+    carve(fs->cl_count, max_clusters);
+    carve(fs->obj_model, max_objects);
+    carve(fs->obj_ninl, max_objects);
+    carve(fs->obj_cluster, max_objects);
+    carve(fs->obj_valid, max_objects);
+    carve(fs->obj_npts, max_objects);
+    carve(fs->obj_clsize, (size_t)2 * max_objects);
+    carve(fs->obj_pose, (size_t)7 * max_objects);
+    carve(fs->obj_err, max_objects);
+    carve(fs->obj_score, max_objects);
+    carve(fs->obj_score_raw, max_objects);
+    carve(fs->best, max_m);
+    carve(fs->new_members, max_m);
+    if (pass == 0) {
+      fs->arena_bytes = off;
+      rc |= dev_alloc(ctx, fs->arena, off * n_arenas);
+    }
+  }
   fs->result_bytes = 16 + sizeof(mh_object) * (size_t)max_objects;
-  rc |= dev_alloc(ctx, fs->result, fs->result_bytes * MH_MAX_BATCH);
-  if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes * MH_MAX_BATCH, ctx->stream));   // "0 objects" before the first frame
-  rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
+  if (kept_result) {
+    fs->result = kept_result;
+    fs->snap = kept_snap;
+  } else {
+    rc |= dev_alloc(ctx, fs->result, fs->result_bytes * MH_MAX_BATCH);
+    if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes * MH_MAX_BATCH, ctx->stream));   // "0 objects" before the first frame
+    rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
+  }
   rc |= dev_alloc(ctx, fs->seed_dev, 1);
-  rc |= dev_alloc(ctx, fs->tickets, 8);
   if (rc) {   // a half-built state must not look valid to the next call
     free_fs(fs);
     ctx->fs = nullptr;
     return MH_ERR_HIP;
   }
-  MH_HIP(ctx, hipMemsetAsync(fs->tickets, 0, 8 * sizeof(unsigned int), ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fs->best, 0, sizeof(unsigned long long) * max_m, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fs->obj_valid, 0, sizeof(int32_t) * max_objects, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fs->obj_score, 0, sizeof(float) * max_objects, ctx->stream));
-  MH_HIP(ctx, hipMemsetAsync(fs->obj_npts, 0, sizeof(int32_t) * max_objects, ctx->stream));
+  // every frame's tickets, claim table (best), obj_valid / obj_score / obj_npts start at zero
+  MH_HIP(ctx, hipMemsetAsync(fs->arena, 0, fs->arena_bytes * n_arenas, ctx->stream));
   return MH_OK;
 }
 
@@ -278,9 +311,27 @@ void stamp(mh_ctx* ctx, int i) {
 
 // CLUSTER .. FILTER2 of a device-resident frame in six launches.  gathered != nullptr:
 // exchange-1 blocks ([n_shards][3][Q]) to merge first.
+// batch_n > 1: the batch_n frames of a batch together, one launch per stage (FrameBatch, steps.h; the caller has checked
+// merged_batch_ok) -- q_uv_dev / the top-2 arrays name frame 0's, fs->slot is 0, batch_seeds the frames' seeds.
 int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered, int n_shards,
-               const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
+               const mh_cam* cam, const mh_frame_params* prm, uint64_t seed, const uint64_t* batch_seeds = nullptr,
+               int batch_n = 1) {
   FrameState* fs = ctx->fs;
+  FrameBatch fb1, fb2;
+  const FrameBatch *b1 = nullptr, *b2 = nullptr;
+  if (batch_n > 1) {
+    fb1.arena = fs->arena_bytes;
+    fb1.q = Q;
+    fb1.result_bytes = (int)fs->result_bytes;
+    fb1.n = batch_n;
+    fb2 = fb1;
+    for (int f = 0; f < batch_n; ++f) {
+      fb1.seed[f] = batch_seeds[f];
+      fb2.seed[f] = batch_seeds[f] ^ 0x5DEECE66Dull;
+    }
+    b1 = &fb1;
+    b2 = &fb2;
+  }
   hipStream_t s = ctx->stream;
   const DevCam dc = make_devcam(*cam);
   const int nm = ctx->n_models;
@@ -349,7 +400,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off,
                ctx->q_depth ? ctx->q_depth + q0 : nullptr,   // (a batch's depth attributes lie frame after frame like its queries)
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
-               gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0);
+               gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0, b1);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   const bool have_depth = ctx->q_depth || ctx->depth_img.img;
@@ -374,7 +425,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
-                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, 1, ms_grid);
+                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, 1, ms_grid, b1);
   stamp(ctx, 3);
   PoseImages img1, img2;   // POSE works on the (model, image, query) copy, POSE2 on FILTER's clusters over the match lists
   if (multi) {
@@ -415,7 +466,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
               fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
               fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s, img1,
-              fused ? &ff1 : nullptr);
+              fused ? &ff1 : nullptr, b1);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     // FILTER (snap[3] = objects kept)
@@ -428,7 +479,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                 fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2, fused ? &ff2 : nullptr);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2, fused ? &ff2 : nullptr, b2);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     if (!fused)
@@ -444,6 +495,28 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   stamp(ctx, 8);
   MH_HIP(ctx, hipGetLastError());
   return MH_OK;
+}
+
+// The frames of a batch can share their launches when nothing of the frame is per-context state: no depth
+// attributes / map / rules (one map per context), one image, the fused FILTER tails (the stand-alone FILTER and
+// result-packing kernels are per frame), no stage timing, no graph replay.  MH_MERGE_BATCH=0: frame after frame.
+bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm) {
+  static const bool on = [] {
+    const char* e = getenv("MH_MERGE_BATCH");
+    return !(e && e[0] == '0');
+  }();
+  static const bool fuse_filter = [] {
+    const char* e = getenv("MH_FUSE_FILTER");
+    return !(e && e[0] == '0');
+  }();
+  return on && fuse_filter && prm->run_stage2 && !ctx->timing && !graphs_enabled() && !ctx->q_depth && !ctx->depth_img.img &&
+         !ctx->rules.on && !ctx->linkage_on && !(ctx->q_img && ctx->n_images > 1);
+}
+
+int ensure_batch_arenas(mh_ctx* ctx, int B) {
+  FrameState* fs = ctx->fs;
+  if (fs->n_arenas >= B) return MH_OK;   // (the usual case; the first batch pays one reallocation)
+  return ensure_fs(ctx, fs->max_m, fs->max_clusters, fs->max_objects, fs->n_models_cap, B);
 }
 
 int prepare_frame(mh_ctx* ctx, int Q) {
@@ -1259,6 +1332,12 @@ int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, in
   hipLaunchKernelGGL(image_batch_mask_kernel, dim3((B * Q + 255) / 256), dim3(256), 0, s, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2,
                      ctx->img_counts, Q, B);
   stamp(ctx, 1);
+  if (B > 1 && merged_batch_ok(ctx, prm)) {
+    if ((rc = ensure_batch_arenas(ctx, B))) return rc;
+    ctx->batch_q0 = 0;
+    ctx->fs->slot = 0;
+    return frame_rest(ctx, ctx->q_uv, Q, nullptr, 0, cam, prm, seeds[0], seeds, B);
+  }
   for (int f = 0; f < B && rc == MH_OK; ++f) {
     ctx->batch_q0 = f * Q;
     ctx->fs->slot = f;
@@ -1302,6 +1381,12 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   launch_normalize(q_desc_dev, ctx->q_norm, B * Q, ctx->stream);
   if ((rc = ctx_match(ctx, q_desc_dev, ctx->q_norm, B * Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
   stamp(ctx, 1);
+  if (B > 1 && merged_batch_ok(ctx, prm)) {   // the B frames through group / CLUSTER / POSE / POSE2 in one launch each
+    if ((rc = ensure_batch_arenas(ctx, B))) return rc;
+    ctx->batch_q0 = 0;
+    ctx->fs->slot = 0;
+    return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seeds[0], seeds, B);
+  }
   for (int f = 0; f < B && rc == MH_OK; ++f) {
     ctx->batch_q0 = f * Q;
     ctx->fs->slot = f;

@@ -75,7 +75,7 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* ticket) {
   __threadfence();   // release: this workgroup's results
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int n = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned int n = gridDim.x;   // (gridDim.y = frames of a batch, each with a ticket of its own)
     const unsigned int t = atomicAdd(ticket, 1u);
     is_last_s = (t == n - 1u);
     if (t == n - 1u) atomicExch(ticket, 0u);

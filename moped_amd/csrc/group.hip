@@ -80,7 +80,16 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
-    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride) {
+    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride, FrameBatch fbx) {
+  if (blockIdx.y) {   // frame of a batch: its slice of the top-2 arrays / keypoints, its copy of the working arrays
+    const unsigned long long a = blockIdx.y * fbx.arena;
+    const size_t q0 = (size_t)blockIdx.y * fbx.q;
+    idx1 += q0; d1 += q0; d2 += q0; q_uv += 2 * q0;
+    acc_q = frame_ptr(acc_q, a); acc_model = frame_ptr(acc_model, a); m_q = frame_ptr(m_q, a);
+    m_model = frame_ptr(m_model, a); m_corr = frame_ptr(m_corr, a); m_rep = frame_ptr(m_rep, a);
+    model_off = frame_ptr(model_off, a); m_depth = frame_ptr(m_depth, a); counts = frame_ptr(counts, a);
+    n_slots = frame_ptr(n_slots, a); best = frame_ptr(best, a);
+  }
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
   __shared__ int pass_cnt[2][GROUP_THREADS / 64];
@@ -449,11 +458,12 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
-                  const DepthRules& rules, int shard_stride, int plane_stride) {
-  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
+                  const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch) {
+  hipLaunchKernelGGL(group_kernel, dim3(1, batch ? batch->n : 1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
                      m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules,
-                     shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q);
+                     shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q,
+                     batch ? *batch : FrameBatch());
 }
 
 void launch_image_split(const mh_corr* m_corr, const int32_t* m_q, const int32_t* m_model, const int32_t* model_off,

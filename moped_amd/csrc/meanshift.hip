@@ -1035,7 +1035,15 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
     float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start, int32_t* ncl,
     int max_clusters, int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
     int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out, int32_t* __restrict__ snap,
-    FrameCounts* counts, unsigned int* ticket, int models_div) {
+    FrameCounts* counts, unsigned int* ticket, int models_div, FrameBatch fbx) {
+  if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot
+    const unsigned long long a = blockIdx.y * fbx.arena;
+    corr = frame_ptr(corr, a); model_off = frame_ptr(model_off, a); members = frame_ptr(members, a);
+    cl_start = frame_ptr(cl_start, a); ncl = frame_ptr(ncl, a); cl_model = frame_ptr(cl_model, a);
+    cl_begin = frame_ptr(cl_begin, a); cl_count = frame_ptr(cl_count, a); n_clusters_out = frame_ptr(n_clusters_out, a);
+    counts = frame_ptr(counts, a); ticket = frame_ptr(ticket, a);
+    if (snap) snap += 4 * blockIdx.y;
+  }
   // models_div > 1: the "models" are (model, image) pairs in (model, image) order -- MeanShift runs per image
   // (CLUSTER_MEAN_SHIFT_CPU.hpp:194-195) -- and the cluster table names the real model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1163,15 +1171,16 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div, int grid) {
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div, int grid,
+                             const FrameBatch* batch) {
   static DynLds attr;
   attr.ensure(meanshift_models_kernel, MS_LDS_BYTES);
   // an empty database still gets one workgroup: it publishes "0 clusters"
   const int wgs = std::max(1, grid > 0 ? std::min(grid, n_models) : n_models);
-  hipLaunchKernelGGL(meanshift_models_kernel, dim3(wgs), dim3(MS_THREADS), MS_LDS_BYTES, s,
+  hipLaunchKernelGGL(meanshift_models_kernel, dim3(wgs, batch ? batch->n : 1), dim3(MS_THREADS), MS_LDS_BYTES, s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
                      max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket,
-                     models_div > 0 ? models_div : 1);
+                     models_div > 0 ? models_div : 1, batch ? *batch : FrameBatch());
 }
 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,

@@ -942,8 +942,31 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
     float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
     FrameCounts* counts, PoseTail tail, int fuse_filter, FilterBuffers ffb, FilterTail ftail, float f_feature_distance,
-    int f_min_points, float f_min_score, int32_t* f_n_clusters_dev) {
+    int f_min_points, float f_min_score, int32_t* f_n_clusters_dev, FrameBatch fbx) {
   static_assert(POSE_THREADS == FT, "the fused FILTER runs on the POSE workgroup's threads");
+  if (fbx.n > 1) seed = fbx.seed[blockIdx.y];
+  if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot and result block
+    const unsigned long long a = blockIdx.y * fbx.arena;
+    corr = frame_ptr(corr, a); depth = frame_ptr(depth, a); members = frame_ptr(members, a);
+    cl_model = frame_ptr(cl_model, a); cl_begin = frame_ptr(cl_begin, a); cl_count = frame_ptr(cl_count, a);
+    n_clusters_dev = frame_ptr(n_clusters_dev, a); obj_base_dev = frame_ptr(obj_base_dev, a);
+    obj_model = frame_ptr(obj_model, a); obj_pose = frame_ptr(obj_pose, a); obj_ninl = frame_ptr(obj_ninl, a);
+    obj_err = frame_ptr(obj_err, a); obj_cluster = frame_ptr(obj_cluster, a); obj_valid = frame_ptr(obj_valid, a);
+    counts = frame_ptr(counts, a);
+    tail.ticket = frame_ptr(tail.ticket, a); tail.n_slots = frame_ptr(tail.n_slots, a);
+    if (tail.snap_valid) tail.snap_valid += 4 * blockIdx.y;
+    ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
+    ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
+    ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
+    ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
+    ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
+    ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
+    ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
+    ftail.ticket = frame_ptr(ftail.ticket, a);
+    if (ftail.snap_kept) ftail.snap_kept += 4 * blockIdx.y;
+    ftail.result = frame_ptr(ftail.result, (unsigned long long)blockIdx.y * fbx.result_bytes);
+    f_n_clusters_dev = frame_ptr(f_n_clusters_dev, a);
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
   const int R_ = prm.max_objects_per_cluster;
@@ -1025,18 +1048,18 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
-                             const PoseTail& tail, hipStream_t s, const FilterFuse* fuse) {
+                             const PoseTail& tail, hipStream_t s, const FilterFuse* fuse, const FrameBatch* batch) {
   static DynLds attr;   // one per KIND (this function is a template)
   attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
   const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
-  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster))), dim3(POSE_THREADS),
+  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster)), batch ? batch->n : 1), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, seed_dev, obj_base_dev, max_objects, obj_model,
                      obj_pose, obj_ninl,
                      obj_err, obj_cluster, obj_valid, counts, tail, fuse && fuse->fb && tail.ticket ? 1 : 0,
                      fuse && fuse->fb ? *fuse->fb : FilterBuffers{}, fuse && fuse->tail ? *fuse->tail : FilterTail{},
                      fuse ? fuse->feature_distance : 0.f, fuse ? fuse->min_points : 0, fuse ? fuse->min_score : 0.f,
-                     fuse ? fuse->n_clusters_dev : nullptr);
+                     fuse ? fuse->n_clusters_dev : nullptr, batch ? *batch : FrameBatch());
 }
 
 void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
@@ -1046,7 +1069,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
                  int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s,
-                 const PoseImages& images, const FilterFuse* fuse) {
+                 const PoseImages& images, const FilterFuse* fuse, const FrameBatch* batch) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
@@ -1062,7 +1085,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                   images.cams, images.img_of, images.n_images, p,                                       \
                   seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
-                  obj_valid, counts, tail, s, fuse
+                  obj_valid, counts, tail, s, fuse, batch
   if (images.img_of && images.cams && kind == 0)
     launch_pose_kind<3>(POSE_ARGS);
   else if (kind == 1)

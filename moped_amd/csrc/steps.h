@@ -14,6 +14,25 @@ enum : int32_t {
   ERR_POSE_CAP = 8,      // a cluster had more than POSE_MAX_PTS points (truncated)
 };
 
+// ---- the frames of a batch in ONE launch per stage ------------------------------------
+// A dependent launch costs the pipeline about as much whatever is in it (the rest chain of a frame is four of them), so
+// the B frames of mh_frame_enqueue_batch go through group / CLUSTER / POSE / POSE2 together: blockIdx.y = frame.  The
+// frames' working arrays are copies of one arena at a fixed distance (FrameState), their top-2 arrays and keypoints lie
+// frame after frame, their result blocks too.  n = 1 (the default) is a launch for one frame: nothing moves.
+struct FrameBatch {
+  unsigned long long arena = 0;   // bytes from a frame's working arrays to the next frame's
+  int q = 0;                      // queries per frame: distance of the frames' top-2 arrays / keypoints (in elements)
+  int result_bytes = 0;           // bytes from a frame's result block to the next
+  int n = 1;                      // frames (gridDim.y)
+  unsigned long long seed[MH_MAX_BATCH] = {};   // per frame (n > 1)
+};
+#ifdef __HIPCC__
+template <typename T>
+__device__ __forceinline__ T* frame_ptr(T* p, unsigned long long bytes) {   // (optional arrays stay nullptr)
+  return p ? reinterpret_cast<T*>(reinterpret_cast<unsigned long long>(p) + bytes) : p;
+}
+#endif
+
 // ---- moped3d depth rules (depth.hip; applied inside group_kernel) --------------------
 struct DepthRules {
   // MATCH_ADAPTIVE_FLANN_CPU's ratio: per model (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh)
@@ -82,7 +101,8 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
                   const DepthRules& rules = DepthRules(), int shard_stride = 0 /* words between shard blocks; 0 = 3 Q */,
-                  int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */);
+                  int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */,
+                  const FrameBatch* batch = nullptr);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s, const int32_t* img = nullptr);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);
@@ -96,7 +116,8 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              float radius, float merge, int min_pts, int max_iter, int32_t* members,
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1, int grid = 0);
+                             FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1, int grid = 0,
+                             const FrameBatch* batch = nullptr);
 // Frames with several images, between group and CLUSTER: m_img[i] = image of match i; m_rep redone with the
 // image in the key (FILTER's bestPoints map is keyed by (coord2D, image), FILTER_PROJECTION_CPU.hpp:89); and the
 // matches once more in (model, image, query) order -- mi_corr / mi_img, off2[n_models * n_images + 1] -- the point
@@ -181,7 +202,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages(),
-                 const FilterFuse* fuse = nullptr);
+                 const FilterFuse* fuse = nullptr, const FrameBatch* batch = nullptr);
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
                          float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
                          hipStream_t s);

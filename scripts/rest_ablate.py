@@ -34,5 +34,6 @@ run("no LM", lm0)
 run("64 hypotheses", hyp64)
 run("1 replica", rep1)
 run("no FILTER/POSE2/FILTER2", nostage2)
+run("no LM + 64 hypotheses + 1 replica (same launches, little work)", lambda p: (lm0(p), hyp64(p), rep1(p)))
 run("all of these", lambda p: (lm0(p), hyp64(p), rep1(p), nostage2(p)))
 run("full again", lambda p: None)
