@@ -411,6 +411,12 @@ int mh_frame_enqueue_rest_strided(mh_ctx* ctx, const float* q_uv_dev, int Q, con
 int mh_frame_enqueue_rest_batch(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev, int n_shards,
                                 int shard_stride_words, int plane_stride_words, int slot, const mh_cam* cam,
                                 const mh_frame_params* prm, uint64_t seed);
+/* All B frames of such a batch at once -- the B calls above for f = 0..B-1 (q_uv_dev / gathered_dev name frame 0's,
+ * the others lie Q rows / Q words further on; results in slots 0..B-1), but with ONE launch per stage for the B frames
+ * where the frames allow it (no per-frame depth state): same objects, a quarter to an eighth of the dependent launches. */
+int mh_frame_enqueue_rest_frames(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev, int n_shards,
+                                 int shard_stride_words, int plane_stride_words, int B, const mh_cam* cam,
+                                 const mh_frame_params* prm, const uint64_t* seeds);
 int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_objects, int32_t* n_objects,
                         int32_t* counts);
 int mh_frame_result_copy_slots_dev(mh_ctx* ctx, void* dst_dev, int n_slots, int max_objects);

@@ -94,7 +94,7 @@ EXPORTS = [
     "mh_frame_enqueue_rest", "mh_frame_fetch", "mh_frame_result_dev", "mh_enable_timing", "mh_timing",
     "mh_frame_set_cluster_linkage", "mh_cluster_linkage", "mh_frame_set_depth_image_host",
     "mh_depth_fill", "mh_depth_fill_status", "mh_depth_fill_host",
-    "mh_frame_enqueue_rest_batch", "mh_frame_fetch_slot", "mh_frame_result_copy_slots_dev",
+    "mh_frame_enqueue_rest_batch", "mh_frame_enqueue_rest_frames", "mh_frame_fetch_slot", "mh_frame_result_copy_slots_dev",
     "mh_frame_set_depth_rules", "mh_frame_fetch_matches", "mh_frame_enqueue_rest_strided", "mh_frame_result_copy_dev",
     "mh_sift_extract", "mh_sift_extract_dev", "mh_frame_enqueue_image", "mh_frame_enqueue_image_batch", "mh_frame_features_dev", "mh_frame_keypoints",
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",

@@ -1509,6 +1509,36 @@ int mh_frame_enqueue_rest_batch(mh_ctx* ctx, const float* q_uv_dev, int Q, const
   return rc;
 }
 
+int mh_frame_enqueue_rest_frames(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev, int n_shards,
+                                 int shard_stride_words, int plane_stride_words, int B, const mh_cam* cam,
+                                 const mh_frame_params* prm, const uint64_t* seeds) {
+  if (!ctx || Q <= 0 || !q_uv_dev || !gathered_dev || n_shards <= 0 || !cam || !prm || !seeds || B < 1 || B > MH_MAX_BATCH ||
+      plane_stride_words < Q || shard_stride_words < 3 * plane_stride_words)
+    return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = prepare_frame(ctx, Q);
+  if (rc) return rc;
+  // merged: frame f merges the shards' blocks into [f Q, (f + 1) Q) of the context's top-2 arrays
+  if (B > 1 && merged_batch_ok(ctx, prm) && ctx->max_q >= B * Q) {
+    if ((rc = ensure_batch_arenas(ctx, B))) return rc;
+    ctx->exchange_stride = shard_stride_words;
+    ctx->exchange_plane = plane_stride_words;
+    ctx->batch_q0 = 0;
+    ctx->fs->slot = 0;
+    stamp(ctx, 1);
+    rc = frame_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seeds[0], seeds, B);
+    ctx->exchange_stride = 0;
+    ctx->exchange_plane = 0;
+    return rc;
+  }
+  for (int f = 0; f < B; ++f)
+    if ((rc = mh_frame_enqueue_rest_batch(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, gathered_dev + (size_t)f * Q, n_shards,
+                                          shard_stride_words, plane_stride_words, f, cam, prm, seeds[f])))
+      return rc;
+  return MH_OK;
+}
+
 int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_objects, int32_t* n_objects,
                         int32_t* counts) {
   if (!ctx || !n_objects || !ctx->fs || slot < 0 || slot >= MH_MAX_BATCH) return MH_ERR_ARG;

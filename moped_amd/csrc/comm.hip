@@ -185,11 +185,8 @@ int before_exchange(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, int Q, int B)
 
 int after_exchange(mh_ctx* ctx, mh_comm* comm, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                    const mh_frame_params* prm, const uint64_t* seeds) {
-  for (int f = 0; f < B; ++f)
-    if (int rc = mh_frame_enqueue_rest_batch(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, ctx->ex.gathered + (size_t)f * Q,
-                                             comm->world, (int)ctx->ex.stride, B * Q, f, cam, prm, seeds[f]))
-      return rc;
-  return MH_OK;
+  return mh_frame_enqueue_rest_frames(ctx, q_uv_dev, Q, ctx->ex.gathered, comm->world, (int)ctx->ex.stride, B * Q, B, cam,
+                                      prm, seeds);
 }
 
 // {n, flags, pad, pad, objects} -> objects_host; more objects than the block carries or capacity flags: an error,
