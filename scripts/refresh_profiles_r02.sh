@@ -40,7 +40,7 @@ if has traffic; then
   # doubled as MI355X_MICROARCH.md prescribes for gfx950
   cd /tmp && export TMPDIR=/tmp
   echo "{" > $out/traffic_r02.json
-  for mq in "20 3000" "20 12000" "200 3000" "200 12000" "50 3000"; do
+  for mq in "20 3000" "20 12000" "20 24000" "200 3000" "200 12000" "200 24000" "50 3000" "50 12000"; do
     set -- $mq; m=$1; q=$2
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/trs_$m$c
