@@ -6,14 +6,23 @@ FILTER2 path on MI355X, BASELINE.json's metric.
 
 A step = one batch of `--frames-per-step` synthetic 640x480 frames (~3k SIFT
 keypoints, 2 planted objects; `--frame-pool` distinct frames in turn) against an
-N-model database, inputs resident in HBM, `--depth` frames in flight per GPU.  With N > 1 (one process per GPU under
-torch.distributed.run) the model database is sharded by model over the ranks
-and every frame does the two small exchanges of SURVEY.md 8(e) over RCCL; the
-total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+N-model database, inputs resident in HBM, `--depth` frame slots in flight per GPU.
+
+N > 1 = one process per GPU.  Started under torch.distributed.run the ranks are the
+launcher's; started as plain `python bench.py --gpus N` this process starts the N
+ranks itself (a child torch.distributed.run, BEFORE anything here touches the GPU)
+and relays rank 0's line -- `n_gpus` is always the number of ranks that ran.  The
+default partition at N > 1 is BASELINE.json north_star's: the model database is
+sharded by model over the ranks and every batch of frames does the one all-gather
+of SURVEY.md 8(e) over RCCL (total work fixed: "strong" scaling).  Two secondary
+measurements ride in the same line: `replicated_frames` (DB replicated, frames
+split, no collective: SURVEY 8(e)'s alternative) and `sharded_200_models`
+(BASELINE configs[3]: the 200-model DB sharded N ways).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,9 +35,10 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32-input MFMA 
 PEAK_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA (the F16 forms take the same cycles)
 SUSTAINED_F16_TFLOPS = 1940.0   # measured: a register-only loop of v_mfma_f32_32x32x16_f16 on all 1024 SIMDs (profiles/r02_mfma_f16_rate.txt)
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
+N_CU = 256
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -58,20 +68,66 @@ def parse():
                          "moped3d's DEPTHFILL step (DEPTH_FILL_EXACT_CPU(8, false), config.hpp:39) runs on the device for every "
                          "frame inside the timed region: a 4.9 MB working copy, the fill, the distance map")
     ap.add_argument("--parallelism", choices=("auto", "models", "frames"), default="auto",
-                    help="N > 1: 'models' (the north-star design) shards the DB by model with one all-gather per batch of "
-                         "frames; 'frames' replicates the DB and gives every rank its own frames (no exchange: SURVEY "
-                         "8(e)'s alternative for DBs too small to shard); 'auto' (default) shards when every rank still "
-                         "gets >= 25 models (BASELINE configs[3]: MATCH stays a rank's dominant cost), else splits frames")
+                    help="N > 1: 'models' (the north-star design, and what 'auto' means) shards the DB by model with one "
+                         "all-gather per batch of frames; 'frames' replicates the DB and gives every rank its own frames (no "
+                         "exchange: SURVEY 8(e)'s alternative for DBs too small to shard)")
+    ap.add_argument("--assign", choices=("block", "round-robin"), default="block",
+                    help="model -> rank assignment of a sharded DB: contiguous blocks, or round-robin (SURVEY 8(e): spreads the "
+                         "visible models' POSE work over the ranks)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per MATCH launch and exchange with a sharded DB (default 8: a shard of ~12k rows does "
-                         "not fill the chip for one frame's 3000 queries; 1 = every frame on its own)")
+                    help="frames per MATCH launch and exchange (default: the library's choice for the partition; 1 = every "
+                         "frame on its own)")
     ap.add_argument("--comms", type=int, default=4,
                     help="RCCL communicators per rank for the sharded path (slot i uses communicator i %% comms)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (replicated_frames, sharded_200_models, single-frame latency, "
+                         "the C++ hosts)")
+    ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks, relay rank 0's line
+# ------------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: one rank per GPU as a child
+    `python -m torch.distributed.run`, started before this process has made any GPU call (a process that has
+    initialised the GPU must not be replaced or forked into ranks).  Returns the exit code to leave with; rank 0's
+    JSON line is the only thing written to stdout.  Fewer devices than ranks is an error (never a line that names
+    more GPUs than ran) unless MH_BENCH_REHEARSE=1 puts every rank on cuda:0 on purpose."""
+    import socket
+    import torch
+    n_dev = torch.cuda.device_count()   # counts devices without initialising the runtime
+    rehearse = os.environ.get("MH_BENCH_REHEARSE") == "1"
+    if n_dev < args.gpus and not rehearse:
+        print(f"bench.py: --gpus {args.gpus} but this host shows {n_dev} device(s); not printing a line for ranks that "
+              f"did not run", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MH_BENCH_LAUNCHED_BY="bench.py")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in child.stdout:
+        if out.startswith("{") and line is None:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        return 3
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
 
 
 def cpu_baseline(db, frames, args):
@@ -133,18 +189,303 @@ def cpu_baseline(db, frames, args):
 
 
 def choose_parallelism(n_models: int, world: int) -> str:
-    """N > 1: shard the DB by model while every rank still gets >= 25 models (BASELINE configs[3]: MATCH stays the
-    dominant cost of a rank's frame), else replicate it and split the frames (no collective).  DESIGN.md 5."""
-    return "models" if n_models // max(world, 2) >= 25 else "frames"
+    """What `--parallelism auto` runs: north_star's partition -- the model database sharded over the ranks, one
+    all-gather per batch of frames -- for every DB and every N (a small DB scales badly that way and the line says
+    so; `replicated_frames` beside it is the partition that suits such a DB).  DESIGN.md 5."""
+    return "models"
+
+
+def scaling_label(parallelism: str, world: int) -> str:
+    """The contract's `scaling` key: nothing scales at N = 1; model sharding keeps the total work fixed; frame
+    splitting keeps the per-GPU work fixed."""
+    if world <= 1:
+        return "n/a"
+    return "weak" if parallelism == "frames" else "strong"
+
+
+def default_batch(args, sharded: bool) -> int:
+    from moped_amd import capi
+    if args.batch > 0:
+        return min(args.batch, capi.MAX_BATCH)
+    if args.depth_kind and sharded:
+        return 1    # (the sharded batch path carries no per-frame depth attributes)
+    if sharded:
+        # a shard of a few thousand rows does not fill the chip for one frame's queries, and every launch of the rest
+        # chain is shared by the frames of a batch: as many as the library takes
+        return capi.MAX_BATCH if args.models // max(args.gpus, 1) < 25 else 8
+    # eight frames per MATCH launch sequence; a batch of plain frames also shares the launches of its rest chain
+    # (one group / CLUSTER / POSE / POSE2 launch for the eight).  Frames with depth maps go frame after frame: four
+    return 8 if not (args.depth_kind or args.moped3d_frontend) else 4
+
+
+class Job:
+    """One partition of one workload on this rank: the pipeline, the resident inputs, the step loop."""
+
+    def __init__(self, args, env, db, n_models_total, by_frames, sharded, batch, frames_per_step, seeds_base=0):
+        import torch
+        from moped_amd import capi, synth
+        from moped_amd.pipeline import FramePipeline, ShardedDB
+        self.args, self.env, self.db = args, env, db
+        self.by_frames, self.sharded, self.B = by_frames, sharded, batch
+        rank, world, dev = env["rank"], env["world"], env["dev"]
+        Q = args.queries
+        n_frames = max(frames_per_step, 1)
+        n_pool = max(1, min(args.frame_pool, n_frames))
+        B = batch
+        if B > 1:
+            n_pool = max(B, n_pool // B * B)
+            n_frames = max(n_pool, n_frames // n_pool * n_pool)
+        self.n_frames, self.n_pool = n_frames, n_pool
+        self.frames = [synth.make_frame(db, n_vis=args.n_vis, seed=seeds_base + s, Q=Q) for s in range(n_pool)]
+        if by_frames:   # every rank holds the whole DB and works on its own frames
+            if rank:
+                self.frames = [synth.make_frame(db, n_vis=args.n_vis, seed=seeds_base + 1000 * rank + s, Q=Q) for s in range(n_pool)]
+            self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
+        else:
+            self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world, assign=args.assign)
+        params = capi.default_frame_params()
+        if args.no_adaptive:
+            params.pose1.n_hypotheses = -abs(params.pose1.n_hypotheses)
+            params.pose2.n_hypotheses = -abs(params.pose2.n_hypotheses)
+        # MH_BENCH_ABLATE (experiments; recorded under env_overrides, the line is then NOT the metric): what the steps after
+        # MATCH cost the pipeline -- lm0: no LM refine, rep1: one replica per cluster, nostage2: stop after POSE
+        for knob in os.environ.get("MH_BENCH_ABLATE", "").split(","):
+            if knob == "lm0":
+                params.pose1.lm_iters_l2 = params.pose1.lm_iters_l4 = params.pose2.lm_iters_l2 = params.pose2.lm_iters_l4 = 0
+            elif knob == "rep1":
+                params.pose1.max_objects_per_cluster = params.pose2.max_objects_per_cluster = 1
+            elif knob == "nostage2":
+                params.run_stage2 = 0
+        if args.depth_kind:
+            # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
+            params.pose1.error_threshold = 8.0
+            params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
+            params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
+        self.params = params
+        free0, _ = torch.cuda.mem_get_info(dev)
+        self.pipe = FramePipeline(env["local_rank"], self.shard, depth=args.depth, max_queries=Q * B, params=params,
+                                  force_exchange=args.force_exchange and sharded, n_comms=args.comms)
+        torch.cuda.synchronize(dev)
+        self.hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
+        frames = self.frames
+        self.pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
+        self.uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
+        self.work = [torch.empty_like(self.pristine[0]) for _ in range(args.depth)]
+        self.depths = None
+        self.maps = None
+        if args.depth_kind and args.moped3d_frontend:
+            from moped_amd import moped3d
+            self.maps = []
+            for i, f in enumerate(frames):
+                img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
+                if args.depthfill:   # sensor-like holes (blobs + a dead border), none on a planted keypoint's pixel
+                    rng_h = np.random.default_rng([0xD0F1, i])
+                    hole = np.zeros((480, 640), bool)
+                    yy, xx = np.ogrid[:480, :640]
+                    for _ in range(18):
+                        cy, cx, r = rng_h.integers(0, 480), rng_h.integers(0, 640), rng_h.integers(6, 45)
+                        hole |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+                    hole[:, :8] = True
+                    rows = np.nonzero((f.src_point >= 0) & ~f.is_outlier)[0]
+                    hole[np.clip(f.uv[rows, 1].astype(np.int32), 0, 479), np.clip(f.uv[rows, 0].astype(np.int32), 0, 639)] = False
+                    img[hole, 2] = -1.0
+                self.maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
+            if args.depthfill:   # per slot: the B working maps DEPTHFILL fills in place + the distance maps it writes
+                self.fill_work = [[(torch.empty_like(self.maps[0][0]), torch.empty_like(self.maps[0][1])) for _ in range(max(B, 1))]
+                                  for _ in range(args.depth)]
+            table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
+            for c in self.pipe.ctxs:
+                c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
+                c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45
+        elif args.depth_kind:
+            self.depths = []
+            for i, f in enumerate(frames):
+                wpts, fill = synth.frame_depth(db, f, seed=i)
+                f32 = np.float32
+                wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
+                d = capi.pack_depth(wpts, wgt)
+                self.depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
+        self.counts_host = torch.zeros(n_pool, dtype=torch.int32).pin_memory()
+        if B > 1:
+            assert n_pool % B == 0 and n_frames % B == 0
+            self.groups = n_frames // B
+            self.pool_groups = n_pool // B
+            self.pristine_b = [torch.cat(self.pristine[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
+            self.uv_b = [torch.cat(self.uvs[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
+            self.work_b = [torch.empty_like(self.pristine_b[0]) for _ in range(args.depth)]
+            self.depths_b = None if self.depths is None else [torch.cat(self.depths[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
+        self.active_slots = args.depth   # slots in use (the calibration may settle on fewer)
+        self.host_desc = None            # h2d measurement: the same descriptors in pinned host memory
+        self.last_slots = {}             # slot -> pool group of the batch it ran last
+
+    # ---- one step -----------------------------------------------------------------------------------------
+    def _run_step_batched(self, step, from_host=False):
+        import torch
+        a, pipe, B = self.args, self.pipe, self.B
+        from moped_amd import synth
+        for g in range(self.groups):
+            slot = (step * self.groups + g) % self.active_slots
+            pg = g % self.pool_groups
+            with torch.cuda.stream(pipe.streams[slot]):
+                self.work_b[slot].copy_(self.host_desc[pg] if from_host else self.pristine_b[pg], non_blocking=True)
+            if self.depths_b is not None:
+                pipe.ctxs[slot].frame_set_depth(self.depths_b[pg].data_ptr(), a.depth_kind, 0.5)
+            if self.maps is not None:   # the B frames' own depth and distance maps
+                mm = self.maps[pg * B:(pg + 1) * B]
+                if a.depthfill:
+                    for j, m in enumerate(mm):
+                        wd, wf = self.fill_work[slot][j]
+                        with torch.cuda.stream(pipe.streams[slot]):
+                            wd.copy_(m[0], non_blocking=True)
+                        pipe.ctxs[slot].depth_fill_dev(wd.data_ptr(), 640, 480, synth.K_DEFAULT, wf.data_ptr(), 8)
+                    mm = self.fill_work[slot][:B]
+                pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
+                                                            a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
+            pipe.enqueue_batch(slot, self.work_b[slot], self.uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
+            self.last_slots[slot] = pg
+
+    def run_step(self, step, record=False, from_host=False):
+        import torch
+        if self.B > 1:
+            return self._run_step_batched(step, from_host)
+        a, pipe = self.args, self.pipe
+        from moped_amd import synth
+        world = self.env["world"]
+        for f in range(self.n_frames):
+            b = f % self.n_pool
+            slot = f % a.depth
+            s = pipe.streams[slot]
+            with torch.cuda.stream(s):
+                # fresh raw descriptors (normalise is in place): from HBM (the headline) or over PCIe from pinned memory
+                self.work[slot].copy_(self.host_desc[b] if from_host else self.pristine[b], non_blocking=True)
+            if self.depths is not None:
+                pipe.ctxs[slot].frame_set_depth(self.depths[b].data_ptr(), a.depth_kind, 0.5)
+            if self.maps is not None:
+                mb = self.maps[b]
+                if a.depthfill:
+                    mb = self.fill_work[slot][0]
+                    with torch.cuda.stream(s):
+                        mb[0].copy_(self.maps[b][0], non_blocking=True)
+                    pipe.ctxs[slot].depth_fill_dev(mb[0].data_ptr(), 640, 480, synth.K_DEFAULT, mb[1].data_ptr(), 8)
+                pipe.ctxs[slot].frame_set_depth_image(mb[0].data_ptr(), mb[1].data_ptr(), 640, 480,
+                                                      a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
+            pipe.enqueue(slot, self.work[slot], self.uvs[b], seed=1000 * step + f + 1)
+            if record and f >= self.n_frames - self.n_pool and not pipe.exchange:
+                ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
+                with torch.cuda.stream(s):
+                    from moped_amd.pipeline import _wrap_int32
+                    self.counts_host[b:b + 1].copy_(_wrap_int32(ptr, 1, self.env["dev"]), non_blocking=True)
+
+    def sync_all(self):
+        import torch
+        import torch.distributed as dist
+        self.pipe.synchronize()
+        torch.cuda.synchronize(self.env["dev"])
+        if self.env["world"] > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+        if self.env["world"] > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=self.env["red_dev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds
+
+    def calibrate_slots(self):
+        """Untimed: how many of the slots to use.  One stream per hardware queue (16) is the rule, but on some hosts a
+        process gets fewer queues' worth of concurrency and 12 slots run 10-45% faster than 16: eight
+        steps with each, all ranks together, the faster setting stays.  Only for the default slot count."""
+        timing = {}
+        for cand in (16, 12):
+            self.active_slots = cand
+            self.run_step(-100)
+            self.sync_all()
+            t0c = time.perf_counter()
+            for k in range(8):
+                self.run_step(-101 - k)
+            self.sync_all()
+            timing[cand] = self.max_over_ranks(time.perf_counter() - t0c)
+        self.active_slots = 16 if timing[16] <= timing[12] * 1.03 else 12
+
+    def timed(self, steps, warmup, from_host=False, step_base=0):
+        """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier +
+        synchronize on both sides, max over ranks.  Returns (seconds, host issue seconds)."""
+        for w in range(warmup):
+            self.run_step(step_base - 1 - w, from_host=from_host)
+        self.sync_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.run_step(step_base + k, record=(k == steps - 1), from_host=from_host)
+        t_issue = time.perf_counter() - t0   # the host's share: the enqueue loop alone (behind full queues it waits for the GPU)
+        self.sync_all()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        return dt, t_issue
+
+    def total_frames(self, steps):
+        return steps * self.n_frames * (self.env["world"] if self.by_frames else 1)
+
+    def detections_per_frame(self):
+        """Objects per frame over the last batch of EVERY slot in use (sanity: the planted objects are found).  With a
+        sharded DB the objects of all ranks (exchange 2); every rank calls this in the same order."""
+        pipe, B = self.pipe, self.B
+        if B > 1:
+            per = []
+            for slot in sorted(self.last_slots):
+                objs = pipe.flush_objects_batch(slot, B) if pipe.exchange else [r[0] for r in pipe.fetch_batch(slot, B)]
+                per += [len(o) for o in objs]
+            return float(np.mean(per)) if per else 0.0
+        if not pipe.exchange:
+            return float(self.counts_host.float().mean().item())
+        return float(len(pipe.gather_objects((self.n_frames - 1) % self.args.depth)))
+
+    def close(self):
+        self.pipe.close()
+
+
+def measure_pose(job, out_cfg):
+    """occupancy and hypotheses/s of the RANSAC kernel, next to every GPU figure.  Live: one isolated
+    batch on slot 0 with the library's stage timing (HIP events on the launching stream around every stage)."""
+    import torch
+    pipe, B, args = job.pipe, job.B, job.args
+    c, s = pipe.ctxs[0], pipe.streams[0]
+    info = c.pose_kernel_info()
+    if info is None:
+        return None
+    reps = 10
+    tot = np.zeros(2)
+    hyp = tasks = 0
+    for r in range(reps):
+        with torch.cuda.stream(s):
+            (job.work_b[0] if B > 1 else job.work[0]).copy_(job.pristine_b[0] if B > 1 else job.pristine[0], non_blocking=True)
+        c.enable_timing(True)
+        if B > 1:
+            pipe.enqueue_batch(0, job.work_b[0], job.uv_b[0], B, [7000 + r * B + f for f in range(B)])
+        else:
+            pipe.enqueue(0, job.work[0], job.uvs[0], seed=7000 + r)
+        s.synchronize()
+        t = c.timing()
+        c.enable_timing(False)
+        if r == 0:
+            continue   # first timed pass warms the event pool
+        tot += np.array([t.get("pose1_ms", 0.0), t.get("pose2_ms", 0.0)])
+        k = c.frame_counters()
+        hyp += k["hypotheses"]
+        tasks += k["pose_tasks"]
+    n = reps - 1
+    pose_ms = float(tot.sum() / n)            # both POSE launches of one batch
+    return {"pose_ms": pose_ms, "hyp": hyp / n, "tasks": tasks / n, "info": info}
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))     # nothing above or inside touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    args.gpus = world                    # n_gpus = the ranks that run, whatever --gpus said
     if args.parallelism == "auto":
         args.parallelism = choose_parallelism(args.models, world)
     by_frames = args.parallelism == "frames" and not args.force_exchange
@@ -152,19 +493,13 @@ def main():
     depth_given = args.depth > 0
     if args.depth <= 0:
         args.depth = 16
-    if args.batch <= 0:
-        # eight frames per MATCH launch sequence; a batch of plain frames also shares the launches of its rest chain
-        # (one group / CLUSTER / POSE / POSE2 launch for the eight).  Frames with depth maps go frame after frame: four
-        args.batch = 8 if sharded or not (args.depth_kind or args.moped3d_frontend) else 4
-    if args.depth_kind and sharded:
-        args.batch = 1    # (the sharded batch path carries no per-frame depth attributes)
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
     import torch
     import torch.distributed as dist
     from moped_amd import capi, synth
-    from moped_amd.pipeline import FramePipeline, ShardedDB
+    B = default_batch(args, sharded)
 
     # MH_BENCH_REHEARSE=1: the N > 1 code paths on a one-GPU box -- all ranks on cuda:0, gloo for the timing contract's
     # barrier / max (RCCL refuses two ranks on one device); with a sharded DB the frames' exchange then runs over the
@@ -182,210 +517,35 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    env = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev, "red_dev": red_dev}
 
     Q = args.queries
     db = synth.make_db(args.models, 5000)
-    n_frames = max(args.frames_per_step, 1)
-    n_pool = max(1, min(args.frame_pool, n_frames))
-    if args.batch > 1:
-        n_pool = max(args.batch, n_pool // args.batch * args.batch)
-        n_frames = max(n_pool, n_frames // n_pool * n_pool)
-    frames = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]
-    if by_frames:   # every rank holds the whole DB and works on its own frames
-        frames = [synth.make_frame(db, n_vis=args.n_vis, seed=1000 * rank + s, Q=Q) for s in range(n_pool)] if rank else frames
-        shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
-    else:
-        shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
-    params = capi.default_frame_params()
-    if args.no_adaptive:
-        params.pose1.n_hypotheses = -abs(params.pose1.n_hypotheses)
-        params.pose2.n_hypotheses = -abs(params.pose2.n_hypotheses)
-    # MH_BENCH_ABLATE (experiments; recorded under env_overrides, the line is then NOT the metric): what the steps after
-    # MATCH cost the pipeline -- lm0: no LM refine, rep1: one replica per cluster, nostage2: stop after POSE
-    for knob in os.environ.get("MH_BENCH_ABLATE", "").split(","):
-        if knob == "lm0":
-            params.pose1.lm_iters_l2 = params.pose1.lm_iters_l4 = params.pose2.lm_iters_l2 = params.pose2.lm_iters_l4 = 0
-        elif knob == "rep1":
-            params.pose1.max_objects_per_cluster = params.pose2.max_objects_per_cluster = 1
-        elif knob == "nostage2":
-            params.run_stage2 = 0
-    if args.depth_kind:
-        # moped3d's shipped constants (moped3d/libmoped/src/config.hpp:46-49)
-        params.pose1.error_threshold = 8.0
-        params.f1_min_points, params.f1_feature_distance, params.f1_min_score = 6, 4096.0, 2.0
-        params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
-    free0, _ = torch.cuda.mem_get_info(dev)
-    pipe = FramePipeline(local_rank, shard, depth=args.depth, max_queries=Q * args.batch, params=params,
-                         force_exchange=args.force_exchange, n_comms=args.comms)
-    torch.cuda.synchronize(dev)
-    hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
-    pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
-    uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
-    work = [torch.empty_like(pristine[0]) for _ in range(args.depth)]
-    depths = None
-    maps = None
-    if args.depth_kind and args.moped3d_frontend:
-        from moped_amd import moped3d
-        maps = []
-        for i, f in enumerate(frames):
-            img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
-            if args.depthfill:   # sensor-like holes (blobs + a dead border), none on a planted keypoint's pixel
-                rng_h = np.random.default_rng([0xD0F1, i])
-                hole = np.zeros((480, 640), bool)
-                yy, xx = np.ogrid[:480, :640]
-                for _ in range(18):
-                    cy, cx, r = rng_h.integers(0, 480), rng_h.integers(0, 640), rng_h.integers(6, 45)
-                    hole |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
-                hole[:, :8] = True
-                rows = np.nonzero((f.src_point >= 0) & ~f.is_outlier)[0]
-                hole[np.clip(f.uv[rows, 1].astype(np.int32), 0, 479), np.clip(f.uv[rows, 0].astype(np.int32), 0, 639)] = False
-                img[hole, 2] = -1.0
-            maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
-        if args.depthfill:   # per slot: the B working maps DEPTHFILL fills in place + the distance maps it writes
-            fill_work = [[(torch.empty_like(maps[0][0]), torch.empty_like(maps[0][1])) for _ in range(max(args.batch, 1))]
-                         for _ in range(args.depth)]
-        table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
-        for c in pipe.ctxs:
-            c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
-            c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45
-    elif args.depth_kind:
-        depths = []
-        for i, f in enumerate(frames):
-            wpts, fill = synth.frame_depth(db, f, seed=i)
-            f32 = np.float32
-            wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
-            d = capi.pack_depth(wpts, wgt)
-            depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
-    counts_host = torch.zeros(n_pool, dtype=torch.int32).pin_memory()
-    B = args.batch
-    if B > 1:
-        assert n_pool % B == 0 and n_frames % B == 0
-        groups = n_frames // B
-        pool_groups = n_pool // B
-        pristine_b = [torch.cat(pristine[g * B:(g + 1) * B]) for g in range(pool_groups)]
-        uv_b = [torch.cat(uvs[g * B:(g + 1) * B]) for g in range(pool_groups)]
-        work_b = [torch.empty_like(pristine_b[0]) for _ in range(args.depth)]
-        depths_b = None if depths is None else [torch.cat(depths[g * B:(g + 1) * B]) for g in range(pool_groups)]
-
-    active_slots = [args.depth]   # slots in use (the calibration below may settle on fewer)
-
-    def run_step_batched(step, from_host=False):
-        for g in range(groups):
-            slot = (step * groups + g) % active_slots[0]
-            pg = g % pool_groups
-            with torch.cuda.stream(pipe.streams[slot]):
-                work_b[slot].copy_(host_desc[pg] if from_host else pristine_b[pg], non_blocking=True)
-            if depths_b is not None:
-                pipe.ctxs[slot].frame_set_depth(depths_b[pg].data_ptr(), args.depth_kind, 0.5)
-            if maps is not None:   # the B frames' own depth and distance maps
-                mm = maps[pg * B:(pg + 1) * B]
-                if args.depthfill:
-                    for j, m in enumerate(mm):
-                        wd, wf = fill_work[slot][j]
-                        with torch.cuda.stream(pipe.streams[slot]):
-                            wd.copy_(m[0], non_blocking=True)
-                        pipe.ctxs[slot].depth_fill_dev(wd.data_ptr(), 640, 480, synth.K_DEFAULT, wf.data_ptr(), 8)
-                    mm = fill_work[slot][:B]
-                pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
-                                                            args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
-            pipe.enqueue_batch(slot, work_b[slot], uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
-
-    host_desc = None   # --h2d-steps: the same descriptors in pinned host memory
-
-    def run_step(step, record=False, from_host=False):
-        if B > 1:
-            return run_step_batched(step, from_host)
-        for f in range(n_frames):
-            b = f % n_pool
-            slot = f % args.depth
-            s = pipe.streams[slot]
-            with torch.cuda.stream(s):
-                # fresh raw descriptors (normalise is in place): from HBM (the headline) or over PCIe from pinned memory
-                work[slot].copy_(host_desc[b] if from_host else pristine[b], non_blocking=True)
-            if depths is not None:
-                pipe.ctxs[slot].frame_set_depth(depths[b].data_ptr(), args.depth_kind, 0.5)
-            if maps is not None:
-                mb = maps[b]
-                if args.depthfill:
-                    mb = fill_work[slot][0]
-                    with torch.cuda.stream(s):
-                        mb[0].copy_(maps[b][0], non_blocking=True)
-                    pipe.ctxs[slot].depth_fill_dev(mb[0].data_ptr(), 640, 480, synth.K_DEFAULT, mb[1].data_ptr(), 8)
-                pipe.ctxs[slot].frame_set_depth_image(mb[0].data_ptr(), mb[1].data_ptr(), 640, 480,
-                                                      args.depth_kind, 0.5, 0.1 if args.depth_kind == 1 else 25.0)
-            pipe.enqueue(slot, work[slot], uvs[b], seed=1000 * step + f + 1)
-            if record and f >= n_frames - n_pool and (world == 1 or by_frames):
-                ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
-                with torch.cuda.stream(s):
-                    from moped_amd.pipeline import _wrap_int32
-                    counts_host[b:b + 1].copy_(_wrap_int32(ptr, 1, dev), non_blocking=True)
-
-    def sync_all():
-        pipe.synchronize()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-
-    # Untimed: how many of the slots to use.  One stream per hardware queue (16) is the rule, but on some hosts a
-    # process gets fewer queues' worth of concurrency and 12 slots run 10-45% faster than 16: eight
-    # steps with each, all ranks together, the faster setting stays.  Only for the default slot count.
+    job = Job(args, env, db, args.models, by_frames, sharded, B, args.frames_per_step)
+    pipe, params = job.pipe, job.params
     if B > 1 and not depth_given and args.depth == 16:
-        timing = {}
-        for cand in (16, 12):
-            active_slots[0] = cand
-            run_step(-100)
-            sync_all()
-            t0c = time.perf_counter()
-            for k in range(8):
-                run_step(-101 - k)
-            sync_all()
-            dtc = time.perf_counter() - t0c
-            if world > 1:
-                tc = torch.tensor([dtc], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-                dtc = float(tc.item())
-            timing[cand] = dtc
-        active_slots[0] = 16 if timing[16] <= timing[12] * 1.03 else 12
-    for w in range(args.warmup):
-        run_step(-1 - w)
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        run_step(k, record=(k == args.steps - 1))
-    t_issue = time.perf_counter() - t0   # the host's share: the enqueue loop alone (behind full queues it waits for the GPU)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_frames = args.steps * n_frames * (world if by_frames else 1)
-    fps = total_frames / dt
-
-    # detections of the last step (sanity: the planted objects are found)
-    if B > 1:
-        last_slot = ((args.steps - 1) * groups + groups - 1) % active_slots[0]
-        det_per_frame = float(np.mean([len(o) for o in (pipe.flush_objects_batch(last_slot, B) if pipe.exchange else
-                                                         [r[0] for r in pipe.fetch_batch(last_slot, B)])]))
-    elif world == 1 or by_frames:
-        det_per_frame = float(counts_host.float().mean().item())
-    else:
-        objs = pipe.gather_objects((n_frames - 1) % args.depth)
-        det_per_frame = float(len(objs))
+        job.calibrate_slots()
+    dt, t_issue = job.timed(args.steps, args.warmup)
+    fps = job.total_frames(args.steps) / dt
+    det_per_frame = job.detections_per_frame()
 
     # what POSE actually evaluated (device-side counters of the last frame of every slot)
-    ctr = [c.frame_counters() for c in pipe.ctxs[:active_slots[0] if B > 1 else args.depth]]
+    ctr = [c.frame_counters() for c in pipe.ctxs[:job.active_slots if B > 1 else args.depth]]
     R_ = params.pose1.max_objects_per_cluster
     hyp_per_task = float(np.sum([c["hypotheses"] for c in ctr]) / max(1, np.sum([c["pose_tasks"] for c in ctr])))
     ms = pipe.ctxs[0].match_stats(Q * B)
     overrides = {k: v for k, v in sorted(os.environ.items()) if k.startswith("MH_") or k == "GPU_MAX_HW_QUEUES"}
+    comm_info = pipe.comm_info() if pipe.exchange else None
+    n_frames, n_pool = job.n_frames, job.n_pool
 
     out = {
         "metric": "detections/sec (frames/s) 640x480 ~3k SIFT vs N models",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak" if by_frames else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling_label(args.parallelism, world), "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "dtype_detail": "every delivered result is fp32 arithmetic (bit-identical to the exact f32 kernels and the oracle); "
+                        "the screen that decides which rows get it multiplies in f16 on the matrix pipe with a proved margin",
         "config": {"workload": f"{args.models}-model DB ({db.n} descriptors), 640x480 frames, "
                                f"{Q} SIFT-like keypoints, {args.n_vis} planted objects, "
                                f"up to {abs(params.pose1.n_hypotheses)} P3P hypotheses x {R_} replicas per cluster "
@@ -397,129 +557,235 @@ def main():
                                   "DEPTHFILTER x2, adaptive ratio, DEPTHMAP_PROP, CLUSTER_LINKAGE)"),
                    "frames_per_step": n_frames, "distinct_frames": n_pool, "timed_seconds": round(dt, 3),
                    "host_issue_seconds": round(t_issue, 3),
-                   "frames_in_flight": (active_slots[0] if B > 1 else args.depth) * B, "frames_per_match_launch": B,
+                   "frames_in_flight": (job.active_slots if B > 1 else args.depth) * B, "frames_per_match_launch": B,
                    "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
                                    f"model-shard x{world}" if world > 1 else "single GPU"),
+                   "model_assignment": (args.assign if sharded else None),
+                   "ranks_launched_by": os.environ.get("MH_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "none"),
+                   "exchange": comm_info,
                    "objects_per_frame": det_per_frame,
                    "hypotheses_per_task": round(hyp_per_task, 1), "hypotheses_per_frame": round(float(np.mean([c["hypotheses"] for c in ctr])), 1),
                    "match": ("two-stage: f16 MFMA screen + canonical f32 arithmetic on the candidates (bit-identical to the exact kernels)"
                              if ms["two_stage"] else "exact f32 kernels"),
-                   "hbm_pipeline_mb": round(hbm_pipeline_mb, 1),
+                   "hbm_pipeline_mb": round(job.hbm_pipeline_mb, 1),
                    "env_overrides": overrides},
     }
+    # sanity of the line itself: a pipeline that stops finding the planted objects must not print a clean metric
+    if det_per_frame < args.n_vis - 0.5:
+        out["suspect"] = f"only {det_per_frame:.2f} objects per frame found of {args.n_vis} planted"
 
     # ---- secondary: the same frames with the descriptors in pinned HOST memory (1.5 MB over PCIe per frame, the copy
     # on the frame's own stream, overlapped with the other frames in flight).  Never `value`.
-    if rank == 0 and world == 1 and args.h2d_steps > 0:
-        host_desc = [torch.from_numpy(f.desc).pin_memory() for f in frames]
+    if world == 1 and args.h2d_steps > 0:
+        host_desc = [torch.from_numpy(f.desc).pin_memory() for f in job.frames]
         if B > 1:
-            host_desc = [torch.cat(host_desc[g * B:(g + 1) * B]).pin_memory() for g in range(pool_groups)]
-        run_step(-500, from_host=True)
-        sync_all()
-        t0h = time.perf_counter()
-        for k in range(args.h2d_steps):
-            run_step(-501 - k, from_host=True)
-        sync_all()
-        dth = time.perf_counter() - t0h
+            host_desc = [torch.cat(host_desc[g * B:(g + 1) * B]).pin_memory() for g in range(job.pool_groups)]
+        job.host_desc = host_desc
+        dth, _ = job.timed(args.h2d_steps, 1, from_host=True, step_base=-600)
         out["h2d_inclusive"] = {"value": round(args.h2d_steps * n_frames / dth, 2), "unit": "frames/s", "steps": args.h2d_steps,
                                 "note": "descriptors start in pinned host memory: one 1.5 MB hipMemcpyAsync per frame on the frame's "
                                         "stream (keypoint coordinates resident); a reported figure, not the metric's `value`"}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the stream it is launched on ----
     if rank == 0 and not args.no_roofline:
-        c, s = pipe.ctxs[0], pipe.streams[0]
-        Qr = Q * B
-        qn = (pristine_b[0] if B > 1 else pristine[0]).clone()
-        qnorm = torch.empty(Qr, dtype=torch.float32, device=dev)
-        idx = torch.empty(Qr, dtype=torch.int32, device=dev)
-        d1 = torch.empty(Qr, dtype=torch.float32, device=dev)
-        d2 = torch.empty(Qr, dtype=torch.float32, device=dev)
-        n_local = shard.desc.shape[0]
-        flops = 2.0 * 128 * Qr * n_local                # one multiply-add per (query, row, coordinate)
-        reps = 20
-        two_stage = c.match_stats(Qr)["two_stage"]
-        c.enable_timing(True)
-        stage = np.zeros(5)
-        with torch.cuda.stream(s):
-            c.normalize_dev(qn.data_ptr(), qnorm.data_ptr(), Qr)
-            for _ in range(3):
-                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
-        s.synchronize()
-        c.match_stats(reset=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(s):   # 20 launch sequences back to back; the library records its own events around every kernel
-            e0.record(s)
-            for _ in range(reps):
-                c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
-            e1.record(s)
-        s.synchronize()
-        t_stage = e0.elapsed_time(e1)
-        if two_stage:
-            stage = np.array(list(c.match_timing().values())) * reps
-        c.enable_timing(False)
-        t_stage /= reps
-        stage /= reps
-        st = c.match_stats()
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{'screen_b' if two_stage else 'match'}_{args.models}m_{Qr}q")
-            except Exception:
-                traffic = None
-        if two_stage:
-            t_b = float(stage[3])
-            ach_tf = flops / (t_b * 1e-3) / 1e12
-            rec_bytes = 8.0 * st["candidates"] / max(st["queries"], 1) * Qr / 1.3   # ~1.3 rows per record
-            b_alg = 256.0 * n_local + 256.0 * Qr + rec_bytes      # f16 DB once + f16 queries once + candidate records
-            out["roofline"] = {
-                "kernel": "screen_kernel<1> = pass B of the two-stage MATCH: f16 x f16 -> f32 on v_mfma_f32_32x32x16_f16 over every "
-                          "(query, row) pair",
-                "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                "ms_per_launch": round(t_b, 4),
-                "algorithmic_flops": int(flops),
-                "note": "compute bound (SURVEY F10): 2*128*Q*N flops per launch against the dense F16 MFMA peak of the dtype the "
-                        "kernel multiplies in.  The match STAGE delivers exact f32 results (bit-identical to the f32 kernels and the "
-                        "oracle); its five kernels per launch, ms: "
-                        + ", ".join(f"{k} {v:.4f}" for k, v in zip(("query image", "pass A", "thresholds", "pass B", "pass C"), stage)),
-                "match_stage": {"ms_per_launch": round(t_stage, 4), "kernels_ms": [round(float(v), 4) for v in stage],
-                                "candidate_rows_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
-                                "brute_force_queries": st["brute_force_queries"],
-                                "f32_equivalent_tflops": round(flops / (t_stage * 1e-3) / 1e12, 1)},
-                "measured": "HIP events recorded by libmoped_hip.so on the launching stream around every kernel of the stage "
-                            "(mh_match_timing), 20 launch sequences after the timed region, one kernel on the chip at a time; "
-                            "profiles/r02_*_depth1_kernel_stats.* is the same command under rocprofv3 with --depth 1",
-                "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
-                # `peak` is the data sheet's 2.5 PFLOP/s (2.4 GHz); a loop of nothing but this MFMA out of registers on every
-                # SIMD sustains 1 940 TFLOP/s on this part (scripts/experiments/mfma_f16_rate.hip,
-                # profiles/r02_mfma_f16_rate.txt: the clock the power budget allows under matrix load)
-                "sustained_mfma_only": {"tflops": SUSTAINED_F16_TFLOPS, "frac": round(ach_tf / SUSTAINED_F16_TFLOPS, 4),
-                                        "source": "profiles/r02_mfma_f16_rate.txt"},
-                "hbm": {"achieved": round(b_alg / (t_b * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(b_alg / (t_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
+        out["roofline"] = roofline(job, fps, out)
+    if world > 1:
+        dist.barrier()
+
+    # ---- POSE: occupancy, hypotheses/s, share of the chip's CU time ----
+    if rank == 0 and not args.no_roofline and "roofline" in out and not (args.depth_kind or args.moped3d_frontend):
+        try:
+            pm = measure_pose(job, out["config"])
+        except Exception as e:   # a reported extra, never a reason to lose the line
+            pm = None
+            out["roofline"]["pose"] = {"error": str(e)[:200]}
+        if pm:
+            info = pm["info"]
+            frames_per_batch = B
+            cu_s_per_frame = pm["pose_ms"] * 1e-3 / frames_per_batch   # wall time of the two launches per frame, isolated
+            out["roofline"]["pose"] = {
+                "kernel": "pose_kernel<0> (POSE and POSE2 launches of one batch, isolated, HIP events by the library)",
+                "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "threads_per_workgroup": info["threads"],
+                "waves_per_simd": info["waves_per_simd"], "workgroups_per_cu": info["workgroups_per_cu"],
+                "tasks_per_batch": round(pm["tasks"], 1), "hypotheses_per_batch": round(pm["hyp"], 1),
+                "ms_per_batch_both_stages": round(pm["pose_ms"], 4),
+                "hypotheses_per_s_isolated": round(pm["hyp"] / (pm["pose_ms"] * 1e-3), 0) if pm["pose_ms"] > 0 else None,
+                "hypotheses_per_s_pipeline": round(float(np.mean([c["hypotheses"] for c in ctr])) * fps, 0),
+                "cu_time_share": info.get("cu_time_share"),
             }
-        else:
-            ach_tf = flops / (t_stage * 1e-3) / 1e12
-            b_alg = 512.0 * n_local + 512.0 * Qr + 12.0 * Qr    # DB once + queries once + (idx,d1,d2)
-            out["roofline"] = {
-                "kernel": "match_mfma_kernel / match_kernel (+ combine_splits_kernel, <1% of the time): the exact f32 search",
-                "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                "ms_per_launch": round(t_stage, 4),
-                "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s dense FP32 MFMA peak",
-                "measured": "HIP events around 20 launches on one stream after the timed region (one kernel on the chip at a time)",
-                "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),
-                "hbm": {"achieved": round(b_alg / (t_stage * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(b_alg / (t_stage * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
-            }
+    if world > 1:
+        dist.barrier()
+
+    # ---- secondary partitions / workloads in the same line (all ranks take part) ----
+    if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
+        sec_steps = max(1, args.secondary_steps)
+        if world > 1 and not by_frames:
+            job.close()
+            a2 = argparse.Namespace(**vars(args))
+            a2.parallelism = "frames"
+            j2 = Job(a2, env, db, args.models, True, False, default_batch(a2, False), args.frames_per_step)
+            dt2, _ = j2.timed(sec_steps, 1)
+            det2 = j2.detections_per_frame()
+            out["replicated_frames"] = {"value": round(j2.total_frames(sec_steps) / dt2, 2), "unit": "frames/s", "steps": sec_steps,
+                                        "parallelism": f"frame-parallel x{world} (DB replicated)", "scaling": "weak",
+                                        "objects_per_frame": det2,
+                                        "note": "SURVEY 8(e)'s alternative for a DB too small to shard: no collective, every rank "
+                                                "its own frames; a reported figure, not `value`"}
+            j2.close()
+            job = None
+        if args.models != 200:
+            if job is not None:
+                job.close()
+                job = None
+            a3 = argparse.Namespace(**vars(args))
+            a3.models, a3.parallelism = 200, "models"
+            db200 = synth.make_db(200, 5000)
+            sh3 = world > 1
+            j3 = Job(a3, env, db200, 200, False, sh3, default_batch(a3, sh3), 256)
+            dt3, _ = j3.timed(sec_steps, 1)
+            det3 = j3.detections_per_frame()
+            out["sharded_200_models"] = {"value": round(j3.total_frames(sec_steps) / dt3, 2), "unit": "frames/s", "steps": sec_steps,
+                                         "frames_per_step": j3.n_frames, "frames_per_match_launch": j3.B,
+                                         "parallelism": f"model-shard x{world}" if world > 1 else "single GPU",
+                                         "models_per_rank": 200 // world, "objects_per_frame": det3,
+                                         "note": "BASELINE configs[2] (N = 1) / configs[3] (N > 1): the 200-model DB, 1 M "
+                                                 "descriptors, sharded by model; a reported figure, not `value`"}
+            j3.close()
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out.update(host_side_figures(args))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(db, frames, args)
+        if job is None:
+            frames_cpu = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]
+        else:
+            frames_cpu = job.frames
+        out["cpu_baseline"] = cpu_baseline(db, frames_cpu, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    pipe.close()
+    if job is not None:
+        job.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_side_figures(args):
+    """Figures of the C++ hosts (no Python, no torch in the measured process): the literal drop-in -- one synchronous
+    frame through the STEP plugins (`moped_hip_test --time`) -- and the C++ streaming host that drives
+    mh_frame_enqueue_batch the way this file does (`moped_hip_bench`).  Each is a child process; absent binaries are
+    reported as such."""
+    out = {}
+    host = os.path.join(ROOT, "moped_amd", "host")
+    exe = os.path.join(host, "moped_hip_bench")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, "--models", str(args.models), "--queries", str(args.queries), "--json"],
+                               capture_output=True, text=True, timeout=300, cwd=ROOT,
+                               env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                d = json.loads(lines[-1])
+                out["cpp_host"] = d
+                if "plugin_path_fps" in d:
+                    out["plugin_path_fps"] = d["plugin_path_fps"]
+                if "single_frame_latency_ms" in d:
+                    out["single_frame_latency_ms"] = d["single_frame_latency_ms"]
+            else:
+                out["cpp_host"] = {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:
+            out["cpp_host"] = {"error": str(e)[:300]}
+    else:
+        out["cpp_host"] = {"error": "moped_amd/host/moped_hip_bench not built"}
+    return out
+
+
+def roofline(job, fps, out):
+    import torch
+    args, pipe, B = job.args, job.pipe, job.B
+    dev = job.env["dev"]
+    Q = args.queries
+    c, s = pipe.ctxs[0], pipe.streams[0]
+    Qr = Q * B
+    qn = (job.pristine_b[0] if B > 1 else job.pristine[0]).clone()
+    qnorm = torch.empty(Qr, dtype=torch.float32, device=dev)
+    idx = torch.empty(Qr, dtype=torch.int32, device=dev)
+    d1 = torch.empty(Qr, dtype=torch.float32, device=dev)
+    d2 = torch.empty(Qr, dtype=torch.float32, device=dev)
+    n_local = job.shard.desc.shape[0]
+    flops = 2.0 * 128 * Qr * n_local                # one multiply-add per (query, row, coordinate)
+    reps = 20
+    two_stage = c.match_stats(Qr)["two_stage"]
+    c.enable_timing(True)
+    stage = np.zeros(5)
+    with torch.cuda.stream(s):
+        c.normalize_dev(qn.data_ptr(), qnorm.data_ptr(), Qr)
+        for _ in range(3):
+            c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+    s.synchronize()
+    c.match_stats(reset=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s):   # 20 launch sequences back to back; the library records its own events around every kernel
+        e0.record(s)
+        for _ in range(reps):
+            c.match_local_dev(qn.data_ptr(), qnorm.data_ptr(), Qr, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+        e1.record(s)
+    s.synchronize()
+    t_stage = e0.elapsed_time(e1) / reps
+    if two_stage:
+        stage = np.array(list(c.match_timing().values()))
+    c.enable_timing(False)
+    st = c.match_stats()
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{'screen_b' if two_stage else 'match'}_{args.models}m_{Qr}q")
+        except Exception:
+            traffic = None
+    if two_stage:
+        t_b = float(stage[3])
+        ach_tf = flops / (t_b * 1e-3) / 1e12
+        rec_bytes = 8.0 * st["candidates"] / max(st["queries"], 1) * Qr / 1.3   # ~1.3 rows per record
+        b_alg = 256.0 * n_local + 256.0 * Qr + rec_bytes      # f16 DB once + f16 queries once + candidate records
+        return {
+            "kernel": "screen_kernel<1> = pass B of the two-stage MATCH: f16 x f16 -> f32 on the matrix pipe over every "
+                      "(query, row) pair",
+            "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+            "ms_per_launch": round(t_b, 4),
+            "algorithmic_flops": int(flops),
+            "note": "compute bound (SURVEY F10): 2*128*Q*N flops per launch against the dense F16 MFMA peak of the dtype the "
+                    "kernel multiplies in.  The match STAGE delivers exact f32 results (bit-identical to the f32 kernels and the "
+                    "oracle); its five kernels per launch, ms: "
+                    + ", ".join(f"{k} {v:.4f}" for k, v in zip(("query image", "pass A", "thresholds", "pass B", "pass C"), stage)),
+            "match_stage": {"ms_per_launch": round(t_stage, 4), "kernels_ms": [round(float(v), 4) for v in stage],
+                            "candidate_rows_per_query": round(st["candidates"] / max(st["queries"], 1), 2),
+                            "brute_force_queries": st["brute_force_queries"],
+                            "f32_equivalent_tflops": round(flops / (t_stage * 1e-3) / 1e12, 1)},
+            "measured": "HIP events recorded by libmoped_hip.so on the launching stream around every kernel of the stage "
+                        "(mh_match_timing), 20 launch sequences after the timed region, one kernel on the chip at a time; "
+                        "profiles/r03_*_depth1_kernel_stats.* is the same command under rocprofv3 with --depth 1",
+            "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
+            # `peak` is the data sheet's 2.5 PFLOP/s (2.4 GHz); a loop of nothing but this MFMA out of registers on every
+            # SIMD sustains 1 940 TFLOP/s on this part (scripts/experiments/mfma_f16_rate.hip,
+            # profiles/r02_mfma_f16_rate.txt: the clock the power budget allows under matrix load)
+            "sustained_mfma_only": {"tflops": SUSTAINED_F16_TFLOPS, "frac": round(ach_tf / SUSTAINED_F16_TFLOPS, 4),
+                                    "source": "profiles/r02_mfma_f16_rate.txt"},
+            "hbm": {"achieved": round(b_alg / (t_b * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(b_alg / (t_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
+        }
+    ach_tf = flops / (t_stage * 1e-3) / 1e12
+    b_alg = 512.0 * n_local + 512.0 * Qr + 12.0 * Qr    # DB once + queries once + (idx,d1,d2)
+    return {
+        "kernel": "match_mfma_kernel / match_kernel (+ combine_splits_kernel, <1% of the time): the exact f32 search",
+        "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach_tf / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+        "ms_per_launch": round(t_stage, 4),
+        "note": "compute bound (SURVEY F10): 2*128*Q*N fp32 FMA flops vs the 157.3 TFLOP/s dense FP32 MFMA peak",
+        "measured": "HIP events around 20 launches on one stream after the timed region (one kernel on the chip at a time)",
+        "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),
+        "hbm": {"achieved": round(b_alg / (t_stage * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(b_alg / (t_stage * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
+    }
 
 
 if __name__ == "__main__":

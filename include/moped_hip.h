@@ -81,6 +81,15 @@ int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects);
  * shard).  Re-upload after modelsUpdated(). */
 int mh_db_upload(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host,
                  const float* xyz_host, int N, int n_models, int32_t index_base);
+/* The same for a shard whose rows are SEVERAL runs of global rows -- a rank that owns models m, m + W, m + 2 W, ...
+ * of the flattened database (round-robin assignment: SURVEY 8(e) "interleave model -> GPU to balance POSE"; the
+ * one-tree order it must preserve is MATCH_ANN_CPU::Update's, src/match/MATCH_ANN_CPU.hpp:76-107).  The N rows are
+ * the blocks one after the other; block b holds global rows [block_global_row[b], + block_rows[b]); blocks in
+ * ascending global order, so a tie between two rows breaks the same way as in the unsharded database.  Every index
+ * the context reports is a global row.  normalize != 0: L2-normalise on the device (A1). */
+int mh_db_upload_blocks(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host, const float* xyz_host, int N,
+                        int n_models, const int32_t* block_global_row, const int32_t* block_rows, int n_blocks,
+                        int normalize);
 int mh_db_size(const mh_ctx* ctx, int* N, int* n_models);
 /* Let `dst` use the database `src` holds: same device, no copy -- one upload and one HBM copy per GPU
  * however many contexts (frames in flight) work against it.  The analogue of the ONE kd-tree every
@@ -122,6 +131,23 @@ int mh_match_set_mode(mh_ctx* ctx, int mode);
  * two nearest only if its f16 screen value exceeds T - mh_screen_margin(dot(q,q), max row norm), T =
  * any lower bound of the second largest screen value.  Exposed so that tests can check the bound. */
 float mh_screen_margin(float qq, float dmax);
+/* More of the same, for tests (none of these is on a frame's path):
+ *   mh_screen_values        the screen value of every (query, row) pair for Q queries (a multiple of 32; host, [Q][128],
+ *                           as the caller normalised them) against the first n_rows rows (a multiple of 32) of the
+ *                           uploaded DB, computed on the device by pass A's arithmetic -- f16 operands, accumulator
+ *                           seeded with -dot(d,d)/2, eight v_mfma_f32_32x32x16_f16 in ascending k -- so that the error
+ *                           model can be held against what the HARDWARE's matrix pipe accumulates, not an emulation of
+ *                           it; *dmax / *spread (optional) = the DB statistics the thresholds use.  The DB needs an
+ *                           f16 image (>= 4096 rows).
+ *   mh_screen_record_value  the 16-bit value a candidate record of pass B carries for a block whose largest dot
+ *                           product is `top` under the threshold `thr` = tau - the block's largest -dd/2
+ *   mh_screen_record_bounds what pass C concludes from it: *hi >= the largest screen value among the record's rows,
+ *                           *lo <= it (or -inf); it drops the record when hi < (second largest lo) - mh_screen_margin.
+ *                           Host arithmetic, the same inline function the kernel runs. */
+int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread);
+uint16_t mh_screen_record_value(float top, float thr);
+void mh_screen_record_bounds(uint16_t value_bits, uint32_t row0, float tau, float spread, int N, float dmax, float* lo,
+                             float* hi);
 
 /* Device-pointer forms for a model-sharded DB: local top-2 of this shard
  * (idx carries index_base; -1 when the shard is empty), then the merge of S
@@ -433,6 +459,11 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
  * sorted by (model, query) = the reference's `matches[model]` lists one after the other
  * (MATCH_ANN_CPU.hpp:165-176).  Synchronises the stream; *n_matches = their number. */
 int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches);
+/* The same for frame `slot` of the last batch (mh_frame_enqueue_batch / _rest_frames / _sharded_batch): the B frames of a
+ * batch that shared their launches keep their lists side by side; of frames that went through the steps one after the
+ * other (depth maps per frame, stage timing) only the last one's remain -> MH_ERR_ARG for the others. */
+int mh_frame_fetch_matches_slot(mh_ctx* ctx, int slot, int32_t* query_host, int32_t* model_host, int cap,
+                                int32_t* n_matches);
 /* Device address of the frame's packed result block {int32 n; mh_object[cap]}
  * for exchange 2 (gather of per-rank objects); *bytes = its size. */
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes);
@@ -563,6 +594,13 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
  * first 256 of a task's n_hypotheses when the inlier ratio they reached makes a better all-inlier sample
  * unlikely; n_hypotheses < 0 in mh_pose_params means "-n_hypotheses, all of them". */
 int mh_frame_counters(mh_ctx* ctx, int32_t out[8]);
+/* Resource use of the RANSAC kernel behind mh_pose_ransac* and the frame's POSE / POSE2 launches, as the HIP runtime
+ * reports it for this device (occupancy of the RANSAC kernel next to every GPU figure; the reference's
+ * step is POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::process, src/pose/POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:264-307):
+ * kind = MH_DEPTH_* (3 = frames with several images); out[0] VGPRs per lane, [1] LDS bytes per workgroup, [2] threads
+ * per workgroup, [3] workgroups resident per compute unit, [4] scratch bytes per lane (spills), [5] wavefronts per
+ * workgroup. */
+int mh_pose_kernel_info(mh_ctx* ctx, int kind, int32_t out[8]);
 /* GPU time of the kernels of the two-stage MATCH on this context, after mh_enable_timing(ctx, 1): the mean over
  * the launch sequences since the previous call (at most the last 32; synchronises the context's stream):
  * ms[0] query image (f16), [1] pass A (thresholds from a sample of the rows), [2] threshold merge,

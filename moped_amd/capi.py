@@ -105,6 +105,8 @@ EXPORTS = [
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
     "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch", "mh_frame_set_depth_image_batch",
+    "mh_pose_kernel_info", "mh_db_upload_blocks", "mh_frame_fetch_matches_slot",
+    "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -238,6 +240,16 @@ def load():
     L.mh_frame_set_depth_image_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, f32, f32]
     L.mh_frame_previous_objects.argtypes = [vp, i32, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_gather_objects.argtypes = [vp, vp, i32, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_pose_kernel_info.argtypes = [vp, i32, vp]
+    L.mh_frame_fetch_matches_slot.argtypes = [vp, i32, vp, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_frame_enqueue_rest_frames.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, C.POINTER(mh_cam),
+                                               C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
+    L.mh_screen_values.argtypes = [vp, vp, i32, i32, vp, C.POINTER(f32), C.POINTER(f32)]
+    L.mh_screen_record_value.argtypes = [f32, f32]
+    L.mh_screen_record_value.restype = C.c_uint16
+    L.mh_screen_record_bounds.argtypes = [C.c_uint16, C.c_uint32, f32, f32, i32, f32, C.POINTER(f32), C.POINTER(f32)]
+    L.mh_screen_record_bounds.restype = None
+    L.mh_db_upload_blocks.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32]
     _lib = L
     return L
 
@@ -292,6 +304,14 @@ def pack_corr(uv, xyz) -> np.ndarray:
         c["u"], c["v"] = uv[:, 0], uv[:, 1]
         c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
     return c
+
+
+def screen_record_bounds(value_bits, row0, tau, spread, N, dmax):
+    """mh_screen_record_bounds (host arithmetic): (lo, hi) of the largest screen value among a record's rows."""
+    lo, hi = C.c_float(0), C.c_float(0)
+    load().mh_screen_record_bounds(int(value_bits), int(row0), float(tau), float(spread), int(N), float(dmax),
+                                   C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 def comm_unique_id() -> bytes:
@@ -416,6 +436,16 @@ class Context:
         self._ck(self.L.mh_db_upload(self.h, _ptr(desc), _ptr(model_of), _ptr(xyz), desc.shape[0],
                                      n_models, index_base), "mh_db_upload")
 
+    def db_upload_blocks(self, desc, model_of, xyz, n_models, block_global_row, block_rows, normalize=False):
+        """A shard whose rows are several runs of global rows (round-robin model assignment): mh_db_upload_blocks."""
+        desc = np.ascontiguousarray(desc, np.float32)
+        model_of = np.ascontiguousarray(model_of, np.int32)
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        g = np.ascontiguousarray(block_global_row, np.int32)
+        r = np.ascontiguousarray(block_rows, np.int32)
+        self._ck(self.L.mh_db_upload_blocks(self.h, _ptr(desc), _ptr(model_of), _ptr(xyz), desc.shape[0], n_models,
+                                            _ptr(g), _ptr(r), len(g), int(normalize)), "mh_db_upload_blocks")
+
     def db_share(self, src: "Context"):
         """Use the database `src` holds (no copy; one store per GPU for all frames in flight)."""
         self._ck(self.L.mh_db_share(self.h, src.h), "mh_db_share")
@@ -427,11 +457,29 @@ class Context:
         names = ("matches", "clusters", "r2", "r3", "r4", "pose_tasks", "error", "hypotheses")
         return dict(zip(names, (int(v) for v in c)))
 
+    def pose_kernel_info(self, kind=0):
+        """mh_pose_kernel_info: registers / LDS / threads / residency of the RANSAC kernel on this device."""
+        o = np.zeros(8, np.int32)
+        self._ck(self.L.mh_pose_kernel_info(self.h, int(kind), _ptr(o)), "mh_pose_kernel_info")
+        waves = int(o[5])
+        return {"vgprs": int(o[0]), "lds_bytes": int(o[1]), "threads": int(o[2]), "workgroups_per_cu": int(o[3]),
+                "scratch_bytes": int(o[4]), "waves_per_workgroup": waves,
+                "waves_per_simd": int(o[3]) * waves / 4.0}
+
     def match_timing(self) -> dict:
         """Per-kernel GPU times (ms) of the last two-stage MATCH (after enable_timing)."""
         t = np.zeros(5, np.float32)
         self._ck(self.L.mh_match_timing(self.h, _ptr(t)), "mh_match_timing")
         return dict(zip(("prepare_ms", "pass_a_ms", "thresholds_ms", "pass_b_ms", "pass_c_ms"), (float(v) for v in t)))
+
+    def screen_values(self, qn, n_rows):
+        """mh_screen_values: [Q][n_rows] screen values as the matrix pipe computes them, + (dmax, spread) of the DB."""
+        qn = np.ascontiguousarray(qn, np.float32)
+        out = np.zeros((qn.shape[0], n_rows), np.float32)
+        dmax, spread = C.c_float(0), C.c_float(0)
+        self._ck(self.L.mh_screen_values(self.h, _ptr(qn), qn.shape[0], n_rows, _ptr(out), C.byref(dmax), C.byref(spread)),
+                 "mh_screen_values")
+        return out, dmax.value, spread.value
 
     def match_set_mode(self, mode: int):
         """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible."""
@@ -768,6 +816,23 @@ class Context:
         n = C.c_int32(0)
         self._ck(self.L.mh_frame_fetch_matches(self.h, _ptr(q), _ptr(m), cap, C.byref(n)), "mh_frame_fetch_matches")
         return q[:min(n.value, cap)].copy(), m[:min(n.value, cap)].copy()
+
+    def frame_fetch_matches_slot(self, slot, cap=1 << 16):
+        """Accepted matches of frame `slot` of the last batch: (query, model), sorted by (model, query)."""
+        q = np.zeros(cap, np.int32)
+        m = np.zeros(cap, np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_frame_fetch_matches_slot(self.h, slot, _ptr(q), _ptr(m), cap, C.byref(n)),
+                 "mh_frame_fetch_matches_slot")
+        return q[:min(n.value, cap)].copy(), m[:min(n.value, cap)].copy()
+
+    def frame_enqueue_rest_frames(self, q_uv_ptr, Q, gathered_ptr, n_shards, stride_words, plane_words, B, K, cam,
+                                  params: mh_frame_params, seeds, _cam_struct=None):
+        c = _cam_struct or make_cam(K, cam)
+        sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
+        self._ck(self.L.mh_frame_enqueue_rest_frames(self.h, C.c_void_p(q_uv_ptr), Q, C.c_void_p(gathered_ptr), n_shards,
+                                                     stride_words, plane_words, B, C.byref(c), C.byref(params), sd),
+                 "mh_frame_enqueue_rest_frames")
 
     def frame_features_dev(self):
         d, u, n = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -55,6 +55,13 @@ static void bind_store(mh_ctx* ctx) {
   ctx->N = st ? st->N : 0;
   ctx->n_models = st ? st->n_models : 0;
   ctx->index_base = st ? st->index_base : 0;
+  ctx->rmap = RowMap();
+  if (st) {
+    ctx->rmap.base = st->index_base;
+    ctx->rmap.nb = st->n_blocks;
+    ctx->rmap.glo = st->blk_glo;
+    ctx->rmap.llo = st->blk_llo;
+  }
   ctx->db_desc = st ? st->desc : nullptr;
   ctx->db_norm = st ? st->norm : nullptr;
   ctx->db_xyz = st ? st->xyz : nullptr;
@@ -116,10 +123,10 @@ int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* 
       ctx->mev_next = (ctx->mev_next + 1) % mh_ctx::MEV_SETS;
       ++ctx->mev_used;
     }
-    launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->sdb, ctx->sbuf, idx1, d1,
+    launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->sdb, ctx->sbuf, idx1, d1,
                         d2, ctx->stream, q_count, q_expected);
   } else
-    launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->index_base, ctx->match_scratch,
+    launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->match_scratch,
                  ctx->match_pack, idx1, d1, d2, ctx->stream, q_count, q_expected);
   return MH_OK;
 }
@@ -255,6 +262,7 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
   }
   st->n_models = n_models;
   st->index_base = index_base;
+  st->n_blocks = 0;   // one run of global rows starting at index_base (mh_db_upload_blocks sets the tables afterwards)
   if (N > 0) {
     MH_HIP(ctx, hipMemcpyAsync(st->desc, desc_host, (size_t)N * DIM * sizeof(float),
                                hipMemcpyHostToDevice, ctx->stream));
@@ -303,6 +311,45 @@ int mh_db_upload_raw(mh_ctx* ctx, const float* desc_host, const int32_t* model_o
   }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   st->N = N;
+  bind_store(ctx);
+  return MH_OK;
+}
+
+int mh_db_upload_blocks(mh_ctx* ctx, const float* desc_host, const int32_t* model_of_host, const float* xyz_host, int N,
+                        int n_models, const int32_t* block_global_row, const int32_t* block_rows, int n_blocks,
+                        int normalize) {
+  if (!ctx || n_blocks < 0 || (n_blocks > 0 && (!block_global_row || !block_rows))) {
+    if (ctx) ctx->err = "mh_db_upload_blocks: bad argument";
+    return MH_ERR_ARG;
+  }
+  long long rows = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    if (block_rows[b] <= 0 || block_global_row[b] < 0 ||
+        (b > 0 && (long long)block_global_row[b] < (long long)block_global_row[b - 1] + block_rows[b - 1])) {
+      ctx->err = "mh_db_upload_blocks: blocks must be non-empty runs of global rows in ascending order";
+      return MH_ERR_ARG;
+    }
+    rows += block_rows[b];
+  }
+  if (rows != N) {
+    ctx->err = "mh_db_upload_blocks: the blocks' rows do not add up to N";
+    return MH_ERR_ARG;
+  }
+  int rc = mh_db_upload_raw(ctx, desc_host, model_of_host, xyz_host, N, n_models, n_blocks > 0 ? block_global_row[0] : 0,
+                            normalize);
+  if (rc || n_blocks <= 1) return rc;
+  DbStore* st = ctx->store.get();
+  std::vector<int32_t> llo(n_blocks + 1);
+  llo[0] = 0;
+  for (int b = 0; b < n_blocks; ++b) llo[b + 1] = llo[b] + block_rows[b];
+  if (st->blk_glo) MH_HIP(ctx, hipFree(st->blk_glo));
+  if (st->blk_llo) MH_HIP(ctx, hipFree(st->blk_llo));
+  st->blk_glo = st->blk_llo = nullptr;
+  MH_HIP(ctx, hipMalloc(&st->blk_glo, sizeof(int32_t) * n_blocks));
+  MH_HIP(ctx, hipMalloc(&st->blk_llo, sizeof(int32_t) * (n_blocks + 1)));
+  MH_HIP(ctx, hipMemcpy(st->blk_glo, block_global_row, sizeof(int32_t) * n_blocks, hipMemcpyHostToDevice));
+  MH_HIP(ctx, hipMemcpy(st->blk_llo, llo.data(), sizeof(int32_t) * (n_blocks + 1), hipMemcpyHostToDevice));
+  st->n_blocks = n_blocks;
   bind_store(ctx);
   return MH_OK;
 }
@@ -435,7 +482,85 @@ int mh_normalize_match(mh_ctx* ctx, float* q_host, int Q, float ratio, int32_t* 
   return match_host(ctx, q_host, q_host, Q, ratio, nn_idx, nn_raw, d1, d2);
 }
 
+#ifdef MH_TRACE
+// experiment builds: the workgroup residency trace (common.h).  on = 1 allocates the ring and points every translation
+// unit's kernels at it; mh_trace_fetch copies up to cap records {kernel << 32 | HW_ID, block << 32 | XCC_ID, t0, t1}
+// (100 MHz ticks) and rewinds the ring.
+static unsigned long long* g_trace_dev = nullptr;
+int mh_trace_enable(int on) {
+  if (on && !g_trace_dev) {
+    if (hipMalloc(&g_trace_dev, (8 + 4 * TRACE_CAP) * sizeof(unsigned long long)) != hipSuccess) return MH_ERR_HIP;
+    hipMemset(g_trace_dev, 0, 64);
+  }
+  unsigned long long* p = on ? g_trace_dev : nullptr;
+  const int n = std::min(trace_n_binds().load(), 32);
+  for (int i = 0; i < n; ++i) trace_binds()[i](p);
+  hipDeviceSynchronize();
+  return MH_OK;
+}
+long long mh_trace_fetch(unsigned long long* out, long long cap) {
+  if (!g_trace_dev) return -1;
+  hipDeviceSynchronize();
+  unsigned long long n = 0;
+  hipMemcpy(&n, g_trace_dev, sizeof n, hipMemcpyDeviceToHost);
+  const unsigned long long have = std::min<unsigned long long>(n, TRACE_CAP);
+  const unsigned long long take = std::min<unsigned long long>(have, (unsigned long long)std::max(cap, 0ll));
+  if (take && out) hipMemcpy(out, g_trace_dev + 8, take * 32, hipMemcpyDeviceToHost);
+  hipMemset(g_trace_dev, 0, 8);
+  return (long long)n;
+}
+#endif
+
 float mh_screen_margin(float qq, float dmax) { return screen_margin_host(qq, dmax); }
+
+uint16_t mh_screen_record_value(float top, float thr) { return screen_record_value(top, thr); }
+
+void mh_screen_record_bounds(uint16_t value_bits, uint32_t row0, float tau, float spread, int N, float dmax, float* lo,
+                             float* hi) {
+  float l, h;
+  screen_record_bounds(value_bits, row0, tau, spread, N, dmax, l, h);
+  if (lo) *lo = l;
+  if (hi) *hi = h;
+}
+
+int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread) {
+  if (!ctx || !q_host || !out_host || Q <= 0 || n_rows <= 0 || (Q & 31) || (n_rows & 31)) return MH_ERR_ARG;
+  if (!ctx->sdb.dbh || n_rows > (ctx->N + 127) / 128 * 128) {
+    ctx->err = "mh_screen_values: the database has no f16 image (fewer than 4096 rows?) or fewer rows than asked for";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  const int q_pad = screen_q_pad(Q);
+  float *qd = nullptr, *qn = nullptr, *out = nullptr;
+  _Float16* qh = nullptr;
+  uint8_t* qbad = nullptr;
+  int rc = MH_OK;
+  auto done = [&]() {
+    for (void* p : {(void*)qd, (void*)qn, (void*)out, (void*)qh, (void*)qbad})
+      if (p) hipFree(p);
+  };
+  if (hipMalloc(&qd, (size_t)Q * DIM * 4) != hipSuccess || hipMalloc(&qn, (size_t)Q * 4) != hipSuccess ||
+      hipMalloc(&out, (size_t)Q * n_rows * 4) != hipSuccess || hipMalloc(&qh, (size_t)q_pad * DIM * 2) != hipSuccess ||
+      hipMalloc(&qbad, (size_t)q_pad) != hipSuccess) {
+    done();
+    ctx->err = "mh_screen_values: out of device memory";
+    return MH_ERR_HIP;
+  }
+  hipMemcpyAsync(qd, q_host, (size_t)Q * DIM * 4, hipMemcpyHostToDevice, ctx->stream);
+  launch_row_norms(qd, qn, Q, ctx->stream);
+  launch_screen_prepare(qd, qn, Q, q_pad, qh, qbad, ctx->stream);
+  launch_screen_values(qh, Q, ctx->sdb, n_rows, out, ctx->stream);
+  if (hipMemcpyAsync(out_host, out, (size_t)Q * n_rows * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    ctx->err = "mh_screen_values: device error";
+    rc = MH_ERR_HIP;
+  }
+  done();
+  if (dmax) *dmax = ctx->sdb.dmax;
+  if (spread) *spread = ctx->sdb.spread;
+  return rc;
+}
 
 int mh_match_set_mode(mh_ctx* ctx, int mode) {
   if (!ctx || mode < -1 || mode > 1) return MH_ERR_ARG;

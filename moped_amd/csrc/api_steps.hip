@@ -48,6 +48,7 @@ struct FrameState {
   int task_grid = 32;   // workgroups for the POSE/FILTER launches: follows the task count of the last fetched frame
   int ms_grid = 8;      // ... and of the CLUSTER launch: its cluster count + head room
   int slot = 0;            // result / snap slot the next frame_rest writes (frames of a batch share the context)
+  int list_first = 0, list_n = 1;   // result slots whose match lists are still in the arenas: [list_first, list_first + list_n)
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
   // hipGraph replay of the launch list (one graph per half of the frame)
   struct Graph {
@@ -343,6 +344,9 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   }
   unsigned char* const result = fs->result + (size_t)fs->slot * fs->result_bytes;
   int32_t* const snap = fs->snap + 4 * fs->slot;
+  // (mh_frame_fetch_matches_slot: a merged batch leaves every frame's lists in its own arena, a frame on its own in arena 0)
+  fs->list_first = fs->slot;
+  fs->list_n = batch_n > 1 ? batch_n : 1;
   // Every workgroup of the POSE / FILTER launches needs a free compute unit to start even if
   // it has no task, and MATCH kernels of other frames keep all of them busy: launch about as
   // many workgroups as the previous frame had tasks (MH_TASK_GRID pins the number).
@@ -396,7 +400,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   // MATCH tail: (shard merge,) ratio test + per-model lists; resets the frame's counters
   const int q0 = gathered ? 0 : ctx->batch_q0;   // frame of a batch matched in one launch: its slice of the top-2 arrays
   launch_group(gathered, n_shards, ctx->nn_idx + q0, ctx->nn_d1 + q0, ctx->nn_d2 + q0, Q, prm->ratio, q_uv_dev,
-               ctx->db_model, ctx->db_xyz, ctx->N, ctx->index_base, nm, fs->max_m, fs->acc_q,
+               ctx->db_model, ctx->db_xyz, ctx->N, ctx->rmap, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off,
                ctx->q_depth ? ctx->q_depth + q0 : nullptr,   // (a batch's depth attributes lie frame after frame like its queries)
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
@@ -1591,21 +1595,35 @@ int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects) {
   return MH_OK;
 }
 
-int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches) {
-  if (!ctx || !ctx->fs || !n_matches || cap < 0) return MH_ERR_ARG;
+int mh_frame_fetch_matches_slot(mh_ctx* ctx, int slot, int32_t* query_host, int32_t* model_host, int cap,
+                                int32_t* n_matches) {
+  if (!ctx || !ctx->fs || !n_matches || cap < 0 || slot < 0 || slot >= MH_MAX_BATCH) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   FrameState* fs = ctx->fs;
+  if (slot < fs->list_first || slot >= fs->list_first + fs->list_n) {
+    ctx->err = "mh_frame_fetch_matches_slot: the lists of that frame are gone (frames that went through the steps one "
+               "after the other share one set of working arrays: only the last one's remain)";
+    return MH_ERR_ARG;
+  }
+  const size_t a = (size_t)(slot - fs->list_first) * fs->arena_bytes;   // the frame's copy of the working arrays
   int32_t snap[4] = {0, 0, 0, 0};
-  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap + 4 * slot, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n_matches = snap[0];
   const int take = std::min(snap[0], cap);
   if (take > 0 && query_host)
-    MH_HIP(ctx, hipMemcpy(query_host, fs->m_q, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
+    MH_HIP(ctx, hipMemcpy(query_host, reinterpret_cast<const unsigned char*>(fs->m_q) + a, sizeof(int32_t) * (size_t)take,
+                          hipMemcpyDeviceToHost));
   if (take > 0 && model_host)
-    MH_HIP(ctx, hipMemcpy(model_host, fs->m_model, sizeof(int32_t) * (size_t)take, hipMemcpyDeviceToHost));
+    MH_HIP(ctx, hipMemcpy(model_host, reinterpret_cast<const unsigned char*>(fs->m_model) + a, sizeof(int32_t) * (size_t)take,
+                          hipMemcpyDeviceToHost));
   return MH_OK;
+}
+
+int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches) {
+  if (!ctx || !ctx->fs) return MH_ERR_ARG;
+  return mh_frame_fetch_matches_slot(ctx, ctx->fs->list_first + ctx->fs->list_n - 1, query_host, model_host, cap, n_matches);
 }
 
 int mh_frame_result_dev(mh_ctx* ctx, void** block_dev, int64_t* bytes) {
@@ -1623,6 +1641,12 @@ int mh_frame_counters(mh_ctx* ctx, int32_t out[8]) {
   MH_HIP(ctx, hipMemcpyAsync(out, ctx->fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MH_OK;
+}
+
+int mh_pose_kernel_info(mh_ctx* ctx, int kind, int32_t out[8]) {
+  if (!ctx || !out || kind < 0 || kind > 3) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  return pose_kernel_info(kind, out);
 }
 
 int mh_timing(mh_ctx* ctx, mh_times* out) {

@@ -32,6 +32,57 @@ struct DynLds {
   }
 };
 
+// ---- workgroup residency trace (experiment builds only: make EXTRA=-DMH_TRACE) --------------------------------
+// Which compute unit every workgroup of a frame's kernels ran on, and when: thread 0 of a workgroup stamps
+// s_memrealtime (100 MHz) at entry and exit and files {kernel id, HW_ID, XCC_ID, t0, t1} in a global ring.  From these
+// records scripts/cu_trace.py rebuilds every compute unit's timeline -- how long it held a MATCH workgroup, how long
+// only small ones (that a MATCH workgroup cannot join), how long nothing.  Nothing of this exists in the product build.
+#ifdef MH_TRACE
+enum TraceKernel : unsigned { TK_NORMALIZE = 1, TK_PREPARE, TK_PASS_A, TK_TAU, TK_PASS_B, TK_PASS_C, TK_GROUP, TK_CLUSTER, TK_POSE, TK_OTHER };
+typedef void (*TraceBindFn)(unsigned long long*);
+inline std::atomic<int>& trace_n_binds() { static std::atomic<int> n{0}; return n; }
+inline TraceBindFn* trace_binds() { static TraceBindFn fns[32]; return fns; }
+inline void trace_register(TraceBindFn f) { const int i = trace_n_binds().fetch_add(1); if (i < 32) trace_binds()[i] = f; }
+constexpr unsigned long long TRACE_CAP = 1ull << 21;   // records (32 bytes each)
+#ifdef __HIPCC__
+// one copy of the buffer pointer per translation unit (no relocatable device code): every unit registers a binder
+#define MH_TRACE_TU()                                                                                              \
+  namespace {                                                                                                      \
+  __device__ unsigned long long* g_trace_buf;                                                                      \
+  struct TraceReg_ {                                                                                               \
+    TraceReg_() {                                                                                                  \
+      mh::trace_register([](unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &p, sizeof p); }); \
+    }                                                                                                              \
+  } trace_reg_;                                                                                                    \
+  struct TraceScope {                                                                                              \
+    unsigned long long t0;                                                                                         \
+    unsigned kid;                                                                                                  \
+    __device__ __forceinline__ explicit TraceScope(unsigned k) : t0(0), kid(k) {                                   \
+      if (threadIdx.x == 0 && g_trace_buf) t0 = __builtin_amdgcn_s_memrealtime();                                  \
+    }                                                                                                              \
+    __device__ __forceinline__ ~TraceScope() {                                                                     \
+      if (threadIdx.x == 0 && g_trace_buf) {                                                                       \
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();                                            \
+        const unsigned long long i = atomicAdd(g_trace_buf, 1ull);                                                 \
+        if (i < mh::TRACE_CAP) {                                                                                   \
+          unsigned long long* r = g_trace_buf + 8 + 4 * i;                                                         \
+          r[0] = ((unsigned long long)kid << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   /* HW_REG_HW_ID */   \
+          r[1] = ((unsigned long long)blockIdx.y << 48) | ((unsigned long long)(blockIdx.x & 0xFFFF) << 32) |      \
+                 __builtin_amdgcn_s_getreg((31 << 11) | 20);                                   /* HW_REG_XCC_ID */  \
+          r[2] = t0;                                                                                               \
+          r[3] = t1;                                                                                               \
+        }                                                                                                          \
+      }                                                                                                            \
+    }                                                                                                              \
+  };                                                                                                               \
+  }
+#define MH_TRACE_SCOPE(kid) TraceScope trace_scope_(kid)
+#endif
+#else
+#define MH_TRACE_TU()
+#define MH_TRACE_SCOPE(kid) do { } while (0)
+#endif
+
 // ---- match ------------------------------------------------------------------
 // Per-query local result of one DB split / shard.
 struct Top2 {
@@ -40,6 +91,46 @@ struct Top2 {
   int32_t i1;   // row of the best (index_base applied), -1 = none
   int32_t pad;
 };
+
+// Local row <-> global row of a context's database.  A shard's rows are a concatenation of blocks, each a run of
+// consecutive global rows (a model's rows are one run: MATCH_ANN_CPU::Update flattens model after model,
+// src/match/MATCH_ANN_CPU.hpp:76-99), blocks in ascending global order -- so local order IS global order and ties
+// between rows break the same way in either numbering.  nb <= 1: one block starting at `base` (the usual
+// contiguous shard, mh_db_upload's index_base); else glo[nb] = first global row of each block, llo[nb + 1] =
+// first local row of each block (llo[nb] = N), both in device memory (mh_db_upload_blocks: a round-robin model
+// assignment).
+struct RowMap {
+  const int32_t* glo = nullptr;
+  const int32_t* llo = nullptr;
+  int nb = 0;
+  int32_t base = 0;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int32_t row_to_global(const RowMap& m, int32_t li) {
+  if (m.nb <= 1) return li + m.base;
+  int lo = 0, hi = m.nb - 1;   // largest b with llo[b] <= li
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (m.llo[mid] <= li) lo = mid; else hi = mid - 1;
+  }
+  return m.glo[lo] + (li - m.llo[lo]);
+}
+// -1: the global row belongs to another shard
+__device__ __forceinline__ int32_t row_to_local(const RowMap& m, int32_t gi, int N) {
+  if (m.nb <= 1) {
+    const int32_t li = gi - m.base;
+    return (gi >= 0 && li >= 0 && li < N) ? li : -1;
+  }
+  if (gi < m.glo[0]) return -1;
+  int lo = 0, hi = m.nb - 1;   // largest b with glo[b] <= gi
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (m.glo[mid] <= gi) lo = mid; else hi = mid - 1;
+  }
+  const int32_t off = gi - m.glo[lo];
+  return off < m.llo[lo + 1] - m.llo[lo] ? m.llo[lo] + off : -1;
+}
+#endif
 
 // A1: normalise rows in place + norm term of the normalised rows.
 // n_dev (optional): device-side row count, rows [min(n, *n_dev), n) are left alone.
@@ -52,7 +143,7 @@ size_t match_scratch_elems(int Q, int N);
 // Floats of packed-query scratch launch_match needs for Q queries.
 size_t match_pack_floats(int Q);
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                  int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
                   float* d2, hipStream_t s, const int32_t* q_count = nullptr, int q_expected = 0);
 // q_count (optional): device-side query count; queries [min(Q, *q_count), Q) get "no neighbour"
 // (idx -1) without being searched.  q_expected: host estimate of it (sizes the DB splits).

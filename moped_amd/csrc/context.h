@@ -18,6 +18,9 @@ struct DbStore {
   int device = 0;
   int N = 0, n_models = 0;
   int32_t index_base = 0;
+  int n_blocks = 0;            // > 1: the rows are n_blocks runs of global rows (mh_db_upload_blocks; RowMap, common.h)
+  int32_t* blk_glo = nullptr;  // device [n_blocks]: first global row of each block
+  int32_t* blk_llo = nullptr;  // device [n_blocks + 1]: first local row of each block, N at the end
   float* desc = nullptr;       // [rows padded to 128][128], zero padding rows
   float* norm = nullptr;       // [padded] dot(d,d), +inf on padding rows
   float* xyz = nullptr;        // [padded][3]
@@ -32,7 +35,7 @@ struct DbStore {
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     hipSetDevice(device);
-    for (void* p : {(void*)desc, (void*)norm, (void*)xyz, (void*)model, (void*)desc_h, (void*)neg_h, (void*)stats})
+    for (void* p : {(void*)desc, (void*)norm, (void*)xyz, (void*)model, (void*)desc_h, (void*)neg_h, (void*)stats, (void*)blk_glo, (void*)blk_llo})
       if (p) hipFree(p);
     if (have) hipSetDevice(cur);
   }
@@ -48,6 +51,7 @@ struct mh_ctx {
   std::shared_ptr<DbStore> store;
   int N = 0, n_models = 0;
   int32_t index_base = 0;
+  mh::RowMap rmap;               // local row <-> global row of the store (one block at index_base unless uploaded in blocks)
   float* db_desc = nullptr;      // [N][128]
   float* db_norm = nullptr;      // [N]
   float* db_xyz = nullptr;       // [N][3]

@@ -4,6 +4,8 @@
 // bookkeeping kernels between the steps of a device-resident frame.
 #include "steps.h"
 
+MH_TRACE_TU()
+
 namespace mh {
 
 namespace {
@@ -75,12 +77,13 @@ __device__ __forceinline__ void merge_top2(float& b1, float& b2, int32_t& i1, fl
 __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     const int32_t* __restrict__ gathered, int n_shards, int32_t* idx1, float* d1, float* d2,
     int Q, float ratio, const float* __restrict__ q_uv, const int32_t* __restrict__ db_model,
-    const float* __restrict__ db_xyz, int N, int32_t index_base, int n_models, int max_m,
+    const float* __restrict__ db_xyz, int N, RowMap rmap, int n_models, int max_m,
     int32_t* __restrict__ acc_q, int32_t* __restrict__ acc_model, int32_t* __restrict__ m_q,
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
     unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride, FrameBatch fbx) {
+  MH_TRACE_SCOPE(mh::TK_GROUP);
   if (blockIdx.y) {   // frame of a batch: its slice of the top-2 arrays / keypoints, its copy of the working arrays
     const unsigned long long a = blockIdx.y * fbx.arena;
     const size_t q0 = (size_t)blockIdx.y * fbx.q;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
       int model = 0;
       if (q < Q) {
         const int32_t gi = idx1[q];
-        const int32_t li = gi - index_base;
-        if (gi >= 0 && li >= 0 && li < N && !(rules.keep1 && !rules.keep1[q])) {
+        const int32_t li = gi >= 0 ? row_to_local(rmap, gi, N) : -1;
+        if (li >= 0 && !(rules.keep1 && !rules.keep1[q])) {
           model = db_model[li];
           float rq = ratio;
           bool reachable = true;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     }
     const int dst = hist[model] + rank;
     const int q = acc_q[i];
-    const int32_t li = idx1[q] - index_base;
+    const int32_t li = row_to_local(rmap, idx1[q], N);   // (an accepted match: the row is this shard's)
     m_q[dst] = q;
     m_model[dst] = model;
     mh_corr c;
@@ -455,13 +458,13 @@ void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q,
 
 void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d1, float* d2, int Q,
                   float ratio, const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
-                  int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
+                  const RowMap& rmap, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
                   const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch) {
   hipLaunchKernelGGL(group_kernel, dim3(1, batch ? batch->n : 1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
-                     Q, ratio, q_uv, db_model, db_xyz, N, index_base, n_models, max_m, acc_q, acc_model,
+                     Q, ratio, q_uv, db_model, db_xyz, N, rmap, n_models, max_m, acc_q, acc_model,
                      m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules,
                      shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q,
                      batch ? *batch : FrameBatch());

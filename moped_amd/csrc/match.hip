@@ -23,6 +23,8 @@
 
 #include "common.h"
 
+MH_TRACE_TU()
+
 namespace mh {
 
 namespace {
@@ -53,6 +55,7 @@ template <bool NORMALIZE>
 __global__ __launch_bounds__(NORM_THREADS) void normalize_kernel(float* __restrict__ desc,
                                                                 float* __restrict__ norm_out, int n,
                                                                 const int32_t* __restrict__ n_dev) {
+  MH_TRACE_SCOPE(mh::TK_NORMALIZE);
   __shared__ float tile[NORM_ROWS * NORM_STRIDE];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * NORM_ROWS;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_kernel(
 // Combine the splits of one shard: one thread per query.
 __global__ void combine_splits_kernel(const Top2* __restrict__ partial, int S, int Q,
                                       const int32_t* __restrict__ q_count, int32_t* __restrict__ idx1,
-                                      float* __restrict__ d1, float* __restrict__ d2) {
+                                      float* __restrict__ d1, float* __restrict__ d2, RowMap rmap) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Q) return;
   Best s = {__builtin_inff(), __builtin_inff(), -1};
@@ -391,7 +394,7 @@ __global__ void combine_splits_kernel(const Top2* __restrict__ partial, int S, i
     for (int j = 0; j < 8; ++j)
       if (p[j].i1 >= 0) merge(s, p[j].d1, p[j].d2, p[j].i1);
   }
-  idx1[q] = s.i1;
+  idx1[q] = s.i1 >= 0 ? row_to_global(rmap, s.i1) : -1;   // (the partials hold local rows: local order = global order)
   d1[q] = s.b1;
   d2[q] = s.b2;
 }
@@ -455,7 +458,7 @@ static int expected_queries(int Q, int q_expected) {
 int mfma_splits_for(int Q, int N);
 int mfma_max_splits(int N);
 void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
-                       int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s);
+                       Top2* scratch, int S, const int32_t* q_count, hipStream_t s);
 // Which kernel searches: the matrix-pipe one when there are enough queries to fill its 256-query
 // blocks (measured cross-over between 600 and 3000 queries), the VALU one below that.  Both give the
 // same bits.  MH_MATCH_MFMA = 0 / 1 pins the choice (A/B runs).
@@ -476,16 +479,16 @@ size_t match_scratch_elems(int Q, int N) {
 size_t match_pack_floats(int Q) { return (size_t)((Q + TQ - 1) / TQ) * TQ * (DIM + 1); }
 
 void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, int32_t index_base, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                  int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
                   float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
   if (Q <= 0) return;
   // the split count follows the number of queries expected (device-side counts: the caller's
   // estimate), the grid covers the capacity
   if (N > 0 && match_uses_mfma(expected_queries(Q, q_expected))) {
     const int Sm = mfma_splits_for(expected_queries(Q, q_expected), N);
-    launch_match_mfma(qn, qnorm, Q, db, dnorm, N, index_base, scratch, Sm, q_count, s);
+    launch_match_mfma(qn, qnorm, Q, db, dnorm, N, scratch, Sm, q_count, s);
     hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, Sm, Q, q_count, idx1, d1,
-                       d2);
+                       d2, rmap);
     return;
   }
   const int S = (N > 0) ? splits_for(expected_queries(Q, q_expected), N) : 0;
@@ -503,10 +506,10 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
     static DynLds attr;
     attr.ensure(match_kernel, lds_bytes);
     hipLaunchKernelGGL(match_kernel, dim3(qgroups * S), dim3(MATCH_THREADS), lds_bytes, s, P, Pnorm, Q,
-                       db, dnorm, N, tiles_per_split, S, index_base, scratch, q_count);
+                       db, dnorm, N, tiles_per_split, S, 0, scratch, q_count);
   }
   hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, S, Q,
-                     q_count, idx1, d1, d2);
+                     q_count, idx1, d1, d2, rmap);
 }
 
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,

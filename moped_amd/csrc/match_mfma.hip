@@ -342,14 +342,14 @@ int mfma_splits_for(int Q, int N) {
 
 // Same contract as the VALU path of launch_match (match.hip) from the normalised queries on.
 void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
-                       int32_t index_base, Top2* scratch, int S, const int32_t* q_count, hipStream_t s) {
+                       Top2* scratch, int S, const int32_t* q_count, hipStream_t s) {
   const int qblocks = (Q + MQ - 1) / MQ;
   const int n_tiles = (N + M_TILE - 1) / M_TILE;
   const size_t lds_bytes = (2 * M_TILE_FLOATS + MQ) * sizeof(float);   // two tiles + the queries' norm terms
   static DynLds attr;
   attr.ensure(match_mfma_kernel, lds_bytes);
   hipLaunchKernelGGL(match_mfma_kernel, dim3(qblocks * S), dim3(M_THREADS), lds_bytes, s, qn, qnorm, Q, db, dnorm, N,
-                     n_tiles / S, n_tiles % S, S, index_base, scratch, q_count);
+                     n_tiles / S, n_tiles % S, S, 0 /* local rows: combine_splits_kernel maps them */, scratch, q_count);
 }
 
 }  // namespace mh

@@ -40,6 +40,8 @@
 #include "common.h"
 #include "screen.h"
 
+MH_TRACE_TU()
+
 namespace mh {
 
 namespace {
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(1024) void db_zero_query_kernel(const float* __rest
 __global__ void screen_prepare_kernel(const float* __restrict__ qn, const float* __restrict__ qnorm, int Q,
                                       const int32_t* __restrict__ q_count, int q_pad, _Float16* __restrict__ qh,
                                       uint8_t* __restrict__ qbad) {
+  MH_TRACE_SCOPE(mh::TK_PREPARE);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element chunk; 16 consecutive threads = one row
   if (i >= q_pad * 16) return;
   const int row = i >> 4;
@@ -267,6 +270,7 @@ struct ScreenArgs {
 __global__ void screen_tau_kernel(const float2* __restrict__ part, int n_splits_a, int q_pad, int Q,
                                   const int32_t* __restrict__ q_count, const float* __restrict__ qnorm,
                                   const uint8_t* __restrict__ qbad, float dmax, float* __restrict__ tau) {
+  MH_TRACE_SCOPE(mh::TK_TAU);
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= q_pad) return;
   const int Qe = q_count ? min(Q, *q_count) : Q;
@@ -315,6 +319,7 @@ __device__ __forceinline__ void dma4(unsigned voff, const void* base, unsigned l
 
 template <int MODE, int NQB>
 __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs A) {
+  MH_TRACE_SCOPE(MODE == 0 ? mh::TK_PASS_A : mh::TK_PASS_B);
   constexpr int QW = 32 * NQB;            // queries per wavefront
   constexpr int QB = QW * SC_WAVES;       // queries per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     unsigned bits = 0;
 #pragma unroll
     for (int r = 15; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - acc[r]), 31);
-    return (bits & 0xFFFFu) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(top - thr)) << 16);
+    return (bits & 0xFFFFu) | ((unsigned)screen_record_value(top, thr) << 16);
   };
   // The hit path proper is as short as it can be -- a wavefront meets four or five hit blocks per tile and every
   // cycle it spends here its MFMAs do not issue (a quarter of pass B before this): the lane takes a slot of its
@@ -696,9 +701,10 @@ __device__ __forceinline__ void wave_lds_sync() {   // LDS written by some lanes
 __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     const float* __restrict__ qn, const float* __restrict__ qnorm, const uint8_t* __restrict__ qbad, int Q,
     const int32_t* __restrict__ q_count, const float* __restrict__ db, const float* __restrict__ dnorm, int N,
-    int32_t index_base, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
+    RowMap rmap, uint2* __restrict__ recs, int n_slots, int32_t* __restrict__ ovf_cnt, uint2* __restrict__ ovf,
     int ovf_cap, float dmax, const float* __restrict__ tau, float spread, int32_t* __restrict__ idx1, float* __restrict__ d1, float* __restrict__ d2,
     unsigned int* __restrict__ stats, int32_t zero_idx, float zero_d1, float zero_d2) {
+  MH_TRACE_SCOPE(mh::TK_PASS_C);
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
   __shared__ int cand_s[RS_WAVES][RS_MAXC];
   __shared__ int ncand_s[RS_WAVES];
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
   }
   if (qbad[q] == 3) {   // an all-zero query: every row's distance is its norm term
     if (lane == 0) {
-      idx1[q] = zero_idx >= 0 ? zero_idx + index_base : -1;
+      idx1[q] = zero_idx >= 0 ? row_to_global(rmap, zero_idx) : -1;
       d1[q] = zero_d1;
       d2[q] = zero_d2;
       if (stats) stats[3 * q + 2] += 1u;   // a search, without candidates
@@ -759,14 +765,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       // the record's value: (largest dot of the block + the block's largest -dd/2) - tau, rounded to f16.  The block's
       // largest screen value is at most that, and at least that less the spread of -dd/2 inside a block (`spread`: the
       // largest over the DB's blocks of real rows, ~1e-7 for L2-normalised rows); a block with padding rows (their
-      // dot is 0, their -dd/2 is -inf) gives no lower bound.
-      const float dv = (float)__builtin_bit_cast(_Float16, (unsigned short)(rec.y >> 16));
-      // nearest f16: 2^-11 dv (2^-25 below the normals), doubled; + the f32 roundings on the way
-      const float eps = fabsf(dv) * 0.001f + 1e-6f + 4e-7f * (fabsf(tau_q) + 0.5f * dmax * dmax);
-      const bool fin = fabsf(dv) < 6.0e4f && fabsf(tau_q) < 1e30f;   // inf / nan: no information
-      const bool whole = (int)(rec.x | 31u) < N;                       // the block's 32 rows are all real rows
-      hi = fin ? tau_q + dv + eps : __builtin_inff();
-      lo = fin && whole && spread < 1e30f ? tau_q + dv - spread - eps : -__builtin_inff();
+      // dot is 0, their -dd/2 is -inf) gives no lower bound.  (screen.h; checked in host arithmetic by the CPU tests)
+      screen_record_bounds((unsigned short)(rec.y >> 16), rec.x, tau_q, spread, N, dmax, lo, hi);
     };
 #pragma unroll
     for (int it = 0; it < RS_ITERS; ++it) {
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     if (oi1 >= 0) merge(best, ob1, ob2, oi1);
   }
   if (lane == 0) {
-    idx1[q] = best.i1 >= 0 ? best.i1 + index_base : -1;
+    idx1[q] = best.i1 >= 0 ? row_to_global(rmap, best.i1) : -1;
     d1[q] = best.b1;
     d2[q] = best.b2;
     if (stats) {   // per-query tallies (this wavefront is the query's only writer; launches are stream ordered): no atomics
@@ -841,6 +841,33 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       stats[3 * q + 2] += 1u;
     }
   }
+}
+
+// The screen value of every (query, row) pair of a small problem, by the arithmetic of pass A: one wavefront per
+// (32 queries, 32 rows), operands straight from the f16 images, the accumulator seeded with the rows' -dd/2, the eight
+// MFMAs of a block in ascending k.  Register r of lane (l32, half) = query l32, row (r & 3) + 8 (r >> 2) + 4 half.
+__global__ __launch_bounds__(64) void screen_values_kernel(const _Float16* __restrict__ qh, const _Float16* __restrict__ dbh,
+                                                           const float* __restrict__ dneg, int n_rows, float* __restrict__ out) {
+  const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
+  const int q0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  half8 a[8], b[8];
+  const _Float16* arow = dbh + (size_t)(r0 + l32) * DIM + 8 * half;
+  const _Float16* brow = qh + (size_t)(q0 + l32) * DIM + 8 * half;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    a[s] = *reinterpret_cast<const half8*>(arow + 16 * s);
+    b[s] = *reinterpret_cast<const half8*>(brow + 16 * s);
+  }
+  v16f acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    acc[r] = dneg[(size_t)(row >> 7) * SC_DD + (row & 127)];
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], b[s], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[(size_t)(q0 + l32) * n_rows + r0 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
 }
 
 int env_int(const char* name, int def) {
@@ -880,6 +907,15 @@ void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh
   const int n_tiles = (int)(n_chunks * 8 / ((size_t)SC_TILE * DIM));
   hipLaunchKernelGGL(db_block_bounds_kernel, dim3((n_tiles * 4 + 255) / 256), dim3(256), 0, s, dnorm, N, n_tiles, dneg, stats);
   hipLaunchKernelGGL(db_zero_query_kernel, dim3(1), dim3(1024), 0, s, dnorm, N, stats);
+}
+
+void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s) {
+  if (Q <= 0 || n_rows <= 0) return;
+  hipLaunchKernelGGL(screen_values_kernel, dim3(Q / 32, n_rows / 32), dim3(64), 0, s, qh, sdb.dbh, sdb.dneg, n_rows, out);
+}
+void launch_screen_prepare(const float* qn, const float* qnorm, int Q, int q_pad, _Float16* qh, uint8_t* qbad, hipStream_t s) {
+  hipLaunchKernelGGL(screen_prepare_kernel, dim3((q_pad * 16 + 255) / 256), dim3(256), 0, s, qn, qnorm, Q, (const int32_t*)nullptr,
+                     q_pad, qh, qbad);
 }
 
 size_t screen_rec_slots() { return SC_SLOTS_MAX; }
@@ -960,7 +996,7 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
 }  // namespace
 
 void launch_match_screen(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
-                         int32_t index_base, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
+                         const RowMap& rmap, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
                          float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
   static const int sample = std::max(1, env_int("MH_SCREEN_SAMPLE", 8));      // pass A looks at every `sample`-th tile
   static const int blocks_b = std::max(0, env_int("MH_SCREEN_BLOCKS", 0));    // workgroups of pass B; 0 = by size (launch_passes)
@@ -1010,7 +1046,7 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
-                     q_count, db, dnorm, N, index_base, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, sdb.spread, idx1, d1, d2,
+                     q_count, db, dnorm, N, rmap, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, sdb.spread, idx1, d1, d2,
                      sb.stats, sdb.zero_idx, sdb.zero_d1, sdb.zero_d2);
   if (sb.ev) hipEventRecord(sb.ev[5], s);
 }

@@ -24,6 +24,8 @@
 // One workgroup per point set (per model); all state in LDS; <= MS_CAP points.
 #include "steps.h"
 
+MH_TRACE_TU()
+
 namespace mh {
 
 namespace {
@@ -1036,6 +1038,7 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
     int max_clusters, int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
     int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out, int32_t* __restrict__ snap,
     FrameCounts* counts, unsigned int* ticket, int models_div, FrameBatch fbx) {
+  MH_TRACE_SCOPE(mh::TK_CLUSTER);
   if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot
     const unsigned long long a = blockIdx.y * fbx.arena;
     corr = frame_ptr(corr, a); model_off = frame_ptr(model_off, a); members = frame_ptr(members, a);

@@ -22,6 +22,8 @@
 
 #include "filter_dev.h"
 
+MH_TRACE_TU()
+
 namespace mh {
 
 DevCam make_devcam(const mh_cam& cam) {
@@ -45,6 +47,10 @@ namespace {
 #define MH_POSE_THREADS 256
 #endif
 constexpr int POSE_THREADS = MH_POSE_THREADS;
+// wavefronts of this kernel that must fit a SIMD together (the register cap: 512 / this)
+#ifndef MH_POSE_MIN_WAVES
+#define MH_POSE_MIN_WAVES 1
+#endif
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -931,7 +937,7 @@ __device__ void pose_task(
 // the object-slot count past this launch's slots and counts the valid objects.
 constexpr int POSE_GRID = 96;
 template <int KIND>
-__global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
+__global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
     const int32_t* __restrict__ members,
     const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
@@ -944,6 +950,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(
     FrameCounts* counts, PoseTail tail, int fuse_filter, FilterBuffers ffb, FilterTail ftail, float f_feature_distance,
     int f_min_points, float f_min_score, int32_t* f_n_clusters_dev, FrameBatch fbx) {
   static_assert(POSE_THREADS == FT, "the fused FILTER runs on the POSE workgroup's threads");
+  MH_TRACE_SCOPE(mh::TK_POSE);
   if (fbx.n > 1) seed = fbx.seed[blockIdx.y];
   if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot and result block
     const unsigned long long a = blockIdx.y * fbx.arena;
@@ -1095,6 +1102,35 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
   else
     launch_pose_kind<0>(POSE_ARGS);
 #undef POSE_ARGS
+}
+
+// Resource use of pose_kernel<KIND> as the runtime reports it (occupancy of the RANSAC kernel beside
+// every GPU figure): VGPRs per lane, LDS per workgroup, threads, resident workgroups per compute unit, spill bytes.
+template <int KIND>
+static int pose_info_kind(int32_t out[8]) {
+  static DynLds attr;
+  attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pose_kernel<KIND>)) != hipSuccess) return MH_ERR_HIP;
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pose_kernel<KIND>, POSE_THREADS, sizeof(PoseLds<KIND>)) != hipSuccess)
+    blocks = 0;
+  out[0] = fa.numRegs;
+  out[1] = (int32_t)(fa.sharedSizeBytes + sizeof(PoseLds<KIND>));
+  out[2] = POSE_THREADS;
+  out[3] = blocks;
+  out[4] = (int32_t)fa.localSizeBytes;
+  out[5] = POSE_THREADS / 64;
+  out[6] = out[7] = 0;
+  return MH_OK;
+}
+int pose_kernel_info(int kind, int32_t out[8]) {
+  switch (kind) {
+    case 1: return pose_info_kind<1>(out);
+    case 2: return pose_info_kind<2>(out);
+    case 3: return pose_info_kind<3>(out);
+    default: return pose_info_kind<0>(out);
+  }
 }
 
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,

@@ -33,10 +33,44 @@ struct ScreenBufs {
   unsigned int* stats = nullptr;   // optional [q_pad][3] per-query tallies: candidate rows, brute-force searches, searches
 };
 
+// ---- what a candidate record says about its block (pass B writes it, pass C prunes by it) -------------------------
+// Pass B works on the 16 dot products a lane holds of a 32-row block.  `top` = the largest of them, `thr` = tau(q) - the
+// block's largest -dd/2: the record carries f16(top - thr) = the block's largest screen value above tau, seen through
+// the block's largest norm term (an UPPER bound of the largest screen value of the record's rows).
+__host__ __device__ inline unsigned short screen_record_value(float top, float thr) {
+  const _Float16 h = (_Float16)(top - thr);
+  unsigned short b;
+  __builtin_memcpy(&b, &h, 2);
+  return b;
+}
+// Bounds of the largest screen value among the record's rows: hi >= it always; lo <= it when the block is 32 real
+// rows (`spread` = the DB's largest in-block spread of -dd/2; a block with padding rows gives no lower bound).  Pass C
+// drops a record whose `hi` lies below (second largest `lo` over the query's records) - screen_margin: two records hold
+// different rows, so that second largest lower bound is a lower bound of the DB's second largest screen value, and a row
+// of the exact top-2 lies at most 2E below THAT (the header of match_screen.hip).  tests/test_screen_bound_cpu.py checks
+// both inequalities in host arithmetic (mh_screen_record_bounds).
+__host__ __device__ inline void screen_record_bounds(unsigned short value_bits, unsigned row0, float tau_q, float spread, int N,
+                                                     float dmax, float& lo, float& hi) {
+  _Float16 h;
+  __builtin_memcpy(&h, &value_bits, 2);
+  const float dv = (float)h;
+  // nearest f16: 2^-11 dv (2^-25 below the normals), doubled; + the f32 roundings on the way
+  const float eps = fabsf(dv) * 0.001f + 1e-6f + 4e-7f * (fabsf(tau_q) + 0.5f * dmax * dmax);
+  const bool fin = fabsf(dv) < 6.0e4f && fabsf(tau_q) < 1e30f;   // inf / nan: no information
+  const bool whole = (int)(row0 | 31u) < N;                       // the block's 32 rows are all real rows
+  hi = fin ? tau_q + dv + eps : __builtin_inff();
+  lo = fin && whole && spread < 1e30f ? tau_q + dv - spread - eps : -__builtin_inff();
+}
+
 constexpr int SCREEN_OVF_CAP = 64;   // records in a query's overflow list before the query falls back to brute force
 size_t screen_rec_slots();           // record slots per query
 
 float screen_margin_host(float qq, float dmax);   // tau = T - margin (the error model, for tests)
+// The screen values themselves, as the matrix pipe computes them (pass A's arithmetic: f16 operands, accumulator seeded
+// with -dd/2, eight v_mfma_f32_32x32x16_f16 in ascending k): out[q][r] for q < Q, r < n_rows (both multiples of 32; qh =
+// the queries' f16 image).  For tests of the error model against the HARDWARE's accumulation (mh_screen_values).
+void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s);
+void launch_screen_prepare(const float* qn, const float* qnorm, int Q, int q_pad, _Float16* qh, uint8_t* qbad, hipStream_t s);
 size_t screen_db_half_elems(int N);
 size_t screen_dneg_elems(int N);   // floats of the -dd/2 array: 192 per 128-row tile (rows, row blocks' extrema)
 // f16 image + statistics {bits of max dd, bits of max |x|, non-finite flag, bits of the largest in-block spread,
@@ -49,7 +83,7 @@ int screen_max_splits_a();
 bool screen_wanted(int q_expected, int N, int mode = -1);
 // Same contract as launch_match (match.hip): exact (idx1, d1, d2) per query.
 void launch_match_screen(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
-                         int32_t index_base, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
+                         const RowMap& rmap, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
                          float* d2, hipStream_t s, const int32_t* q_count, int q_expected);
 
 }  // namespace mh

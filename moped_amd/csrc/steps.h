@@ -90,13 +90,13 @@ void launch_feature_density(const float* q_uv, int Q, const int32_t* q_count, in
 
 // ---- group -------------------------------------------------------------------
 // Ratio test + grouping by model in ascending query order (MATCH_ANN_CPU.hpp:165-176).
-// Rows outside [index_base, index_base+N) belong to another shard and are dropped.
+// Rows the context's row map does not hold (RowMap, common.h) belong to another shard and are dropped.
 // First launch of a frame's CLUSTER..FILTER2 part: also resets *counts and *n_slots, clears
 // best[0, n_matches) and -- when `gathered` ([n_shards][3][Q] words, exchange 1) is given --
 // first merges the shards' top-2 into idx1/d1/d2.
 void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d1, float* d2, int Q,
                   float ratio, const float* q_uv, const int32_t* db_model, const float* db_xyz, int N,
-                  int32_t index_base, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
+                  const RowMap& rmap, int n_models, int max_m, int32_t* acc_q, int32_t* acc_model,
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
@@ -203,6 +203,8 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages(),
                  const FilterFuse* fuse = nullptr, const FrameBatch* batch = nullptr);
+// pose_kernel<kind>'s registers / LDS / threads / resident workgroups per compute unit / spill bytes (mh_pose_kernel_info)
+int pose_kernel_info(int kind, int32_t out[8]);
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
                          float thr, uint8_t* inlier, float* err2, int32_t* n_inliers,
                          hipStream_t s);

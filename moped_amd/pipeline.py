@@ -21,23 +21,47 @@ import torch
 from . import capi
 
 
-class ShardedDB:
-    """This rank's slice of the model database, models assigned in contiguous
-    blocks: rank r owns models [r*n/W, (r+1)*n/W)."""
+def models_of_rank(n_models: int, rank: int, world: int, assign: str = "block"):
+    """Models rank `rank` of `world` owns: contiguous blocks [r n/W, (r+1) n/W), or round-robin (m % W == r --
+    SURVEY.md 8(e): interleaving spreads the visible models' CLUSTER / POSE work over the ranks)."""
+    if assign == "round-robin":
+        return np.arange(rank, n_models, world, dtype=np.int64)
+    if assign != "block":
+        raise ValueError(f"unknown model assignment {assign!r}")
+    return np.arange((rank * n_models) // world, ((rank + 1) * n_models) // world, dtype=np.int64)
 
-    def __init__(self, desc, xyz, model_of, n_models, rank=0, world=1):
+
+class ShardedDB:
+    """This rank's slice of the model database.  Rows of a model are contiguous in the flattened DB
+    (MATCH_ANN_CPU::Update order), so a shard is a list of runs of global rows, in ascending order: ONE run for the
+    block assignment (`row_lo` = mh_db_upload's index_base), one per maximal run of owned models for round-robin
+    (mh_db_upload_blocks).  Row and model ids stay global either way."""
+
+    def __init__(self, desc, xyz, model_of, n_models, rank=0, world=1, assign="block"):
         model_of = np.asarray(model_of, np.int32)
-        lo_m = (rank * n_models) // world
-        hi_m = ((rank + 1) * n_models) // world
-        rows = np.nonzero((model_of >= lo_m) & (model_of < hi_m))[0]
-        # rows of a model are contiguous in the flattened DB (MATCH_ANN_CPU::Update order)
+        owned = np.zeros(n_models + 1, bool)
+        owned[models_of_rank(n_models, rank, world, assign)] = True
+        mine = owned[model_of]
+        rows = np.nonzero(mine)[0]
+        # maximal runs of consecutive global rows
+        starts = rows[np.r_[True, np.diff(rows) != 1]] if len(rows) else np.zeros(0, np.int64)
+        ends = rows[np.r_[np.diff(rows) != 1, True]] + 1 if len(rows) else np.zeros(0, np.int64)
+        self.block_global_row = starts.astype(np.int32)
+        self.block_rows = (ends - starts).astype(np.int32)
+        self.rows = rows.astype(np.int32)   # global row of every local row
         self.row_lo = int(rows[0]) if len(rows) else 0
         self.row_hi = int(rows[-1]) + 1 if len(rows) else 0
-        self.desc = np.ascontiguousarray(desc[self.row_lo:self.row_hi], np.float32)
-        self.xyz = np.ascontiguousarray(xyz[self.row_lo:self.row_hi], np.float32)
-        self.model_of = np.ascontiguousarray(model_of[self.row_lo:self.row_hi])
+        self.desc = np.ascontiguousarray(desc[rows], np.float32)
+        self.xyz = np.ascontiguousarray(xyz[rows], np.float32)
+        self.model_of = np.ascontiguousarray(model_of[rows])
         self.n_models = n_models          # model ids stay global
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.assign = rank, world, assign
+
+    def upload(self, ctx: "capi.Context", normalized):
+        if len(self.block_rows) > 1:
+            ctx.db_upload_blocks(normalized, self.model_of, self.xyz, self.n_models, self.block_global_row, self.block_rows)
+        else:
+            ctx.db_upload(normalized, self.model_of, self.xyz, self.n_models, index_base=self.row_lo)
 
 
 class FramePipeline:
@@ -74,7 +98,7 @@ class FramePipeline:
             if i == 0:
                 # model descriptors are L2-normalised once, like Update() (MATCH_ANN_CPU.hpp:94)
                 normalized = c.normalize(db.desc) if db.desc.shape[0] else db.desc
-                c.db_upload(normalized, db.model_of, db.xyz, db.n_models, index_base=db.row_lo)
+                db.upload(c, normalized)
             else:
                 c.db_share(self.ctxs[0])   # one store per GPU: every frame in flight searches the same copy
             c.reserve(max_queries)
@@ -109,6 +133,14 @@ class FramePipeline:
 
     def _comm(self, slot):
         return self.comms[slot % len(self.comms)]
+
+    def comm_info(self):
+        """What carries the frames' exchange: (rank, world, transport) of this rank's communicators."""
+        if not self.comms:
+            return None
+        r, w, rccl = self.comms[0].info()
+        return {"rank": r, "world": w, "transport": "RCCL ncclAllGather" if rccl else "host callback (gloo)",
+                "communicators": len(self.comms)}
 
     # ---- single frame in slot i ------------------------------------------------------
     def enqueue(self, slot: int, q_desc: torch.Tensor, q_uv: torch.Tensor, seed: int = 1,
@@ -200,8 +232,10 @@ def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:
     return out.view(world, 3, Q)
 
 
-def owner_of_model(model: int, n_models: int, world: int) -> int:
-    """Rank that owns `model` under the contiguous block partition of ShardedDB."""
+def owner_of_model(model: int, n_models: int, world: int, assign: str = "block") -> int:
+    """Rank that owns `model` under ShardedDB's partition."""
+    if assign == "round-robin":
+        return model % world
     for r in range(world):
         if (r * n_models) // world <= model < ((r + 1) * n_models) // world:
             return r

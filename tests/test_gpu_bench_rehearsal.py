@@ -1,6 +1,8 @@
 """bench.py's N > 1 code paths rehearsed on one GPU (MH_BENCH_REHEARSE=1: both ranks on cuda:0, gloo for the timing
-contract, the library's host transport for a sharded DB's exchange): the line the driver will read comes out, names the
-partition that ran and finds the planted objects.  The numbers of such a run mean nothing."""
+contract, the library's host transport for a sharded DB's exchange): plain `python bench.py --gpus 2` -- no launcher in
+the test -- starts its two ranks itself, the line the driver will read comes out, names the partition that ran (the
+north star's model sharding by default) and the ranks the exchange saw, and finds the planted objects.  The numbers of
+such a run mean nothing."""
 import json
 import os
 import subprocess
@@ -12,26 +14,48 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra, port):
-    env = dict(os.environ, MH_BENCH_REHEARSE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline", "--h2d-steps", "0"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+def _run(extra, launcher=False, port=0):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MH_BENCH_REHEARSE"] = "1"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--no-roofline", "--h2d-steps", "0"] + extra
+    if launcher:   # the way the driver starts N > 1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # rank 0 prints ONE line
     return json.loads(lines[0])
 
 
-def test_two_ranks_small_db_split_the_frames():
-    d = _run(["--frames-per-step", "64"], 29621 + os.getpid() % 100)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("frame-parallel x2")
-    assert d["config"]["objects_per_frame"] == 2.0 and d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["config"]["env_overrides"].get("MH_BENCH_REHEARSE") == "1"
-
-
-def test_two_ranks_large_db_shard_the_models():
-    d = _run(["--models", "50", "--parallelism", "models", "--frames-per-step", "32"], 29741 + os.getpid() % 100)
+def test_plain_python_gpus_2_starts_two_ranks_and_shards_the_models():
+    d = _run(["--frames-per-step", "64", "--secondary-steps", "1"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x2"
+    assert d["config"]["ranks_launched_by"] == "bench.py"
+    ex = d["config"]["exchange"]
+    assert ex["world"] == 2 and ex["rank"] == 0        # the transport of the frames' exchange saw two ranks
+    assert d["config"]["objects_per_frame"] == 2.0 and d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
+    assert "suspect" not in d
+    assert d["config"]["env_overrides"].get("MH_BENCH_REHEARSE") == "1"
+    # the other partition and the other workload ride in the same line
+    assert d["replicated_frames"]["parallelism"].startswith("frame-parallel x2") and d["replicated_frames"]["value"] > 0
+    assert d["replicated_frames"]["objects_per_frame"] == 2.0
+    s200 = d["sharded_200_models"]
+    assert s200["parallelism"] == "model-shard x2" and s200["models_per_rank"] == 100 and s200["objects_per_frame"] == 2.0
+
+
+def test_under_the_drivers_launcher_round_robin_models():
+    d = _run(["--models", "50", "--assign", "round-robin", "--frames-per-step", "32", "--no-secondary"], launcher=True,
+             port=29741 + os.getpid() % 100)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x2"
+    assert d["config"]["model_assignment"] == "round-robin" and d["config"]["ranks_launched_by"] == "torch.distributed.run"
     assert d["config"]["objects_per_frame"] == 2.0 and d["config"]["frames_per_match_launch"] == 8
+
+
+def test_frames_partition_is_an_option():
+    d = _run(["--parallelism", "frames", "--frames-per-step", "64", "--no-secondary"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("frame-parallel x2")
+    assert d["config"]["objects_per_frame"] == 2.0

@@ -1,0 +1,184 @@
+"""Parity at the launch shape bench.py is judged on: 8 frames of 3 000 queries against the 20-model / 100 000-row DB
+through ONE MATCH launch sequence (24 000 queries: screen_kernel<1, 4> over 512 workgroups) and ONE launch per stage
+of the rest chain (blockIdx.y = frame, eight working arenas).  Reference behaviour: one frame at a time through
+MATCH_ANN_CPU::process (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:155-176) .. FILTER2; every frame of a batch must be
+bit for bit what it is alone, its accepted matches what the oracle accepts."""
+import numpy as np
+import pytest
+
+import orclib
+from moped_amd import capi, synth
+from moped_amd.pipeline import FramePipeline, ShardedDB
+
+pytestmark = pytest.mark.gpu
+K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
+B, Q = 8, 3000
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    db = synth.make_db(20, 5000)
+    dbn = orclib.normalize(db.desc)
+    frs = [synth.make_frame(db, n_vis=n, seed=200 + i, Q=Q) for i, n in enumerate((2, 2, 5, 1, 2, 3, 0, 2))]
+    yield db, dbn, frs, torch
+
+
+def _same_objects(a, b):
+    return (len(a) == len(b) and np.array_equal(a["model"], b["model"]) and
+            np.array_equal(a["pose"].view(np.uint32), b["pose"].view(np.uint32)) and
+            np.array_equal(a["score"].view(np.uint32), b["score"].view(np.uint32)) and
+            np.array_equal(a["n_points"], b["n_points"]))
+
+
+def test_eight_frames_per_launch_equal_the_frames_alone_and_the_oracles_matches(world):
+    db, dbn, frs, torch = world
+    dev = torch.device("cuda:0")
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=B * Q)
+    seeds = [900 + f for f in range(B)]
+    alone, alone_matches = [], []
+    for f, fr in enumerate(frs):
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seeds[f])
+        alone.append(pipe.fetch(0))
+        alone_matches.append(pipe.ctxs[0].frame_fetch_matches())
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    c = pipe.ctxs[1]
+    assert c.match_stats(B * Q)["two_stage"]
+    for rep in range(2):   # the second batch runs on arenas and record slots the first one used
+        qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        pipe.enqueue_batch(1, qd, uv, B, seeds)
+        got = pipe.fetch_batch(1, B)
+        for f in range(B):
+            objs, counts = got[f]
+            a, ac = alone[f]
+            assert np.array_equal(counts, ac), (rep, f, counts, ac)
+            assert _same_objects(objs, a), (rep, f)
+            mq, mm = c.frame_fetch_matches_slot(f)
+            assert np.array_equal(mq, alone_matches[f][0]) and np.array_equal(mm, alone_matches[f][1])
+    assert sum(len(a[0]) for a in alone) >= 12
+    # the accepted match lists of all eight frames against the oracle's exact search + ratio test
+    for f, fr in enumerate(frs):
+        qn = orclib.normalize(fr.desc)
+        assert np.array_equal(qd[f * Q:(f + 1) * Q].cpu().numpy().view(np.uint32), qn.view(np.uint32))   # A1 in place
+        idx, d1, d2 = orclib.match_2nn(dbn, qn)
+        acc = (idx >= 0) & ((d1 / d2) < np.float32(0.8))
+        oq = np.nonzero(acc)[0]
+        om = db.model_of[idx[oq]]
+        order = np.lexsort((oq, om))                     # (model, query): the reference's matches[model] lists in turn
+        mq, mm = c.frame_fetch_matches_slot(f)
+        assert np.array_equal(mq, oq[order]) and np.array_equal(mm, om[order]), f
+    pipe.close()
+
+
+def test_raw_match_of_24000_queries_screen_vs_exact_kernel_vs_oracle(world):
+    """screen_kernel<1, 4> at the bench's launch shape (24 query blocks x splits = 512 workgroups) against
+    match_mfma_kernel on the same 24 000 queries, bit for bit; 384 sampled queries against the oracle."""
+    db, dbn, frs, torch = world
+    dev = torch.device("cuda:0")
+    c = capi.Context(0)
+    c.db_upload(dbn, db.model_of, db.xyz, db.n_models)
+    c.reserve(B * Q)
+    qn = np.concatenate([orclib.normalize(f.desc) for f in frs])
+    tq = torch.from_numpy(qn).to(dev)
+    qnorm = torch.from_numpy(orclib.row_norms(qn)).to(dev)
+    res = {}
+    for mode in (1, 0):
+        out = [torch.empty(B * Q, dtype=t, device=dev) for t in (torch.int32, torch.float32, torch.float32)]
+        c.match_set_mode(mode)
+        c.match_stats(reset=True)
+        c.match_local_dev(tq.data_ptr(), qnorm.data_ptr(), B * Q, *[o.data_ptr() for o in out])
+        c.synchronize()
+        res[mode] = [o.cpu().numpy() for o in out]
+        if mode == 1:
+            st = c.match_stats()
+            assert st["queries"] == B * Q and st["brute_force_queries"] == 0
+            assert 1 <= st["candidates"] / st["queries"] < 200
+    c.match_set_mode(-1)
+    assert np.array_equal(res[1][0], res[0][0])
+    assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    assert np.array_equal(res[1][2].view(np.uint32), res[0][2].view(np.uint32))
+    pick = np.sort(np.random.default_rng(5).choice(B * Q, 384, replace=False))
+    oi, o1, o2 = orclib.match_2nn(dbn, qn[pick])
+    assert np.array_equal(res[1][0][pick], oi)
+    assert np.array_equal(res[1][1][pick].view(np.uint32), o1.view(np.uint32))
+    assert np.array_equal(res[1][2][pick].view(np.uint32), o2.view(np.uint32))
+    c.close()
+
+
+@pytest.mark.parametrize("assign", ["block", "round-robin"])
+def test_rest_frames_of_eight_at_eight_ranks_equal_the_single_context(world, assign):
+    """mh_frame_enqueue_rest_frames with B = 8 on each of W = 8 shard contexts (the per-rank work of bench.py --gpus 8:
+    2-3 models per rank) = the single context's eight frames, objects bit for bit."""
+    db, dbn, frs, torch = world
+    dev = torch.device("cuda:0")
+    W = 8
+    prm = capi.default_frame_params()
+    seeds = [40 + f for f in range(B)]
+    one = capi.Context(0)
+    one.db_upload(dbn, db.model_of, db.xyz, db.n_models)
+    one.reserve(B * Q)
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    one.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, B, K, CAM0, prm, seeds)
+    want = [one.frame_fetch_slot(f) for f in range(B)]
+    one.close()
+    ctxs, tops = [], []
+    for r in range(W):
+        sh = ShardedDB(dbn, db.xyz, db.model_of, db.n_models, r, W, assign=assign)
+        c = capi.Context(0)
+        sh.upload(c, sh.desc)
+        c.reserve(B * Q)
+        top = torch.empty(3 * B * Q, dtype=torch.int32, device=dev)
+        qd_r = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+        c.frame_enqueue_match_local(qd_r.data_ptr(), B * Q, top.data_ptr())   # [3][B Q] words
+        c.synchronize()
+        ctxs.append(c)
+        tops.append(top)
+    gathered = torch.cat(tops)
+    got = [[] for _ in range(B)]
+    n_matches, n_clusters = np.zeros(B, int), np.zeros(B, int)
+    for r, c in enumerate(ctxs):
+        c.frame_enqueue_rest_frames(uv.data_ptr(), Q, gathered.data_ptr(), W, 3 * B * Q, B * Q, B, K, CAM0, prm, seeds)
+        for f in range(B):
+            o, cnt = c.frame_fetch_slot(f)
+            got[f].append(o)
+            n_matches[f] += cnt[0]
+            n_clusters[f] += cnt[1]
+        c.close()
+    for f in range(B):
+        o = np.concatenate(got[f])
+        w, wc = want[f]
+        assert n_matches[f] == wc[0] and n_clusters[f] == wc[1], f
+
+        def canon(x):
+            key = [(int(t["model"]),) + tuple(t["pose"].view(np.uint32).tolist()) for t in x]
+            return x[sorted(range(len(x)), key=lambda i: key[i])]
+        assert _same_objects(canon(o), canon(w)), (assign, f)
+
+
+def test_error_model_holds_on_the_hardware_matrix_pipe():
+    """tests/test_screen_bound_cpu.py emulates the screen's f32 accumulation with one rounding per product in k order;
+    the matrix pipe adds 16 products per instruction with an internal order and width the ISA does not spell out.
+    Here the values pass A really computes (mh_screen_values: the same operands, seed and instruction sequence) are
+    held against w = f32 fmaf chain - dd/2 for that test's hardest operand sets: |w~ - w| <= margin / 2."""
+    import test_screen_bound_cpu as T
+    c = capi.Context(0)
+    for name, q, d in T._cases():
+        q = np.ascontiguousarray(q[:96], np.float32)
+        reps = -(-4096 // len(d))
+        big = np.ascontiguousarray(np.concatenate([d] * reps)[:4096], np.float32)     # an f16 image needs >= 4096 rows
+        n_rows = len(d) // 32 * 32
+        c.db_upload(big, np.zeros(len(big), np.int32), np.zeros((len(big), 3), np.float32), 1)
+        wt, dmax, spread = c.screen_values(q, n_rows)
+        dd = orclib.row_norms(big[:n_rows])
+        assert abs(dmax - float(np.sqrt(orclib.row_norms(big).max()))) <= 1e-6 * dmax
+        w = T._chain_f32(q, big[:n_rows]).astype(np.float64) - 0.5 * dd.astype(np.float64)[None, :]
+        err = np.abs(wt.astype(np.float64) - w).max(1)
+        qq = (q.astype(np.float64) ** 2).sum(1)
+        half = np.array([0.5 * T._margin(np.float32(x), dmax) for x in qq])
+        assert np.all(err <= half), (name, float((err / half).max()))
+        # and against the emulation: the hardware is not (much) worse than one rounding per product
+        emu = T._screen_f32(q, big[:n_rows], dd).astype(np.float64)
+        assert np.abs(wt - emu).max() <= 0.25 * half.min() + 1e-7, name
+    c.close()

@@ -94,3 +94,125 @@ def test_two_nearest_are_always_emitted():
         must = a[i] <= second                                # the two nearest and everything tied with them
         assert np.all(emitted[must]), i
     assert emitted_total < 0.2 * wt.size                     # and the screen still screens
+
+
+# ---- pass C's record pruning (csrc/screen.h: screen_record_value / screen_record_bounds) in host arithmetic ----------
+def _dots_f32(q, d):
+    """Pass B's accumulators: f16 operands, f32 accumulation from ZERO in k order."""
+    q16, d16 = q.astype(np.float16).astype(np.float32), d.astype(np.float16).astype(np.float32)
+    s = np.zeros((q.shape[0], d.shape[0]), np.float32)
+    for k in range(q.shape[1]):
+        s = (q16[:, k:k + 1] * d16[None, :, k] + s).astype(np.float32)
+    return s
+
+
+# rows of a 32-row block that one lane holds (match_screen.hip: register r of half h = row (r & 3) + 8 (r >> 2) + 4 h)
+_LANE_ROWS = [np.array([(r & 3) + 8 * (r >> 2) + 4 * h for r in range(16)]) for h in (0, 1)]
+
+
+def _record(dots16, neg_hi, tau):
+    """What pass B emits for a lane's 16 dots of a block: (row mask, value bits) or None."""
+    L = capi.load()
+    thr = np.float32(tau) - np.float32(neg_hi)
+    top = np.float32(dots16.max())
+    if not top > thr:
+        return None
+    mask = dots16 > thr
+    return mask, int(L.mh_screen_record_value(float(top), float(thr)))
+
+
+@pytest.mark.parametrize("kind", ["unit", "unnormalised", "tiny"])
+def test_record_bounds_bracket_the_largest_screen_value_of_the_records_rows(kind):
+    """hi >= max over the record's rows of (dot + -dd/2) >= lo: the two facts pass C's pruning rests on."""
+    base, _, _ = synth.load_sift_fixture()
+    rng = np.random.default_rng(21)
+    unit = orclib.normalize(base[rng.choice(len(base), 32 * 12 + 40)])
+    q, d = unit[:40], unit[40:]
+    if kind == "unnormalised":
+        d = (d * rng.uniform(0.5, 3.0, (len(d), 1))).astype(np.float32)
+    if kind == "tiny":
+        q = (q * np.float32(2e-3)).astype(np.float32)
+    dd = orclib.row_norms(d)
+    neg = (np.float32(-0.5) * dd).astype(np.float32)
+    dmax = float(np.sqrt(dd.max()))
+    dots = _dots_f32(q, d)
+    n_blocks = len(d) // 32
+    spread = max(float(neg[b * 32:(b + 1) * 32].max() - neg[b * 32:(b + 1) * 32].min()) for b in range(n_blocks))
+    N = len(d)
+    n_rec = 0
+    for i in range(len(q)):
+        w = dots[i].astype(np.float64) + neg.astype(np.float64)        # the rows' screen values
+        tau = float(np.sort(w)[-12])                                   # lets about a dozen rows through
+        for b in range(n_blocks):
+            hi_b = float(neg[b * 32:(b + 1) * 32].max())
+            for h in (0, 1):
+                rows = b * 32 + _LANE_ROWS[h]
+                rec = _record(dots[i, rows], hi_b, tau)
+                if rec is None:
+                    assert not np.any(w[rows] > tau + 1e-6)            # nothing above the threshold was left behind
+                    continue
+                mask, bits = rec
+                assert np.all(mask[w[rows] > tau])                     # a superset of the rows above tau
+                lo, hi = capi.screen_record_bounds(bits, b * 32 + 4 * h, tau, spread, N, dmax)
+                w_max = float(w[rows].max())
+                assert hi >= w_max, (kind, i, b, h, hi - w_max)
+                assert lo <= w_max, (kind, i, b, h, w_max - lo)
+                n_rec += 1
+    assert n_rec > 100
+
+
+def test_record_bounds_give_no_lower_bound_for_blocks_with_padding_or_without_information():
+    lo, hi = capi.screen_record_bounds(0x3C00, 96, 0.25, 1e-7, 100, 1.0)    # rows 96..127 of a 100-row DB: padding inside
+    assert lo == -np.inf and hi > 1.25 - 1e-3
+    lo, hi = capi.screen_record_bounds(0x7C00, 0, 0.25, 1e-7, 4096, 1.0)    # value +inf: no information either way
+    assert lo == -np.inf and hi == np.inf
+    lo, hi = capi.screen_record_bounds(0x3C00, 0, 0.25, np.inf, 4096, 1.0)  # a DB without a whole block: spread unknown
+    assert lo == -np.inf and np.isfinite(hi)
+    lo, hi = capi.screen_record_bounds(0x3C00, 0, 0.25, 1e-7, 4096, 1.0)
+    assert lo < 1.25 < hi and hi - lo < 5e-3
+
+
+def test_pruning_never_drops_a_row_of_the_exact_top2():
+    """Pass B + pass C's pruning replayed in host arithmetic on a DB with near-duplicates: whatever records the
+    second-largest-lower-bound rule drops, the rows of the exact 2-NN (canonical distance, ties included) stay."""
+    base, _, _ = synth.load_sift_fixture()
+    rng = np.random.default_rng(31)
+    b = orclib.normalize(base[rng.choice(len(base), 24)])
+    rows = [b[k] + 10.0 ** rng.uniform(-5, -3, (32, 1)) * rng.normal(size=(32, 128)) for k in range(24)]
+    d = orclib.normalize(np.ascontiguousarray(np.maximum(np.concatenate(rows), 0), np.float32))
+    d = d[rng.permutation(len(d))]
+    q = orclib.normalize(np.ascontiguousarray(np.concatenate([b, b + rng.normal(0, 2e-4, b.shape)]), np.float32))
+    dd, qq = orclib.row_norms(d), orclib.row_norms(q)
+    neg = (np.float32(-0.5) * dd).astype(np.float32)
+    dmax = float(np.sqrt(dd.max()))
+    N, n_blocks = len(d), len(d) // 32
+    spread = max(float(neg[k * 32:(k + 1) * 32].max() - neg[k * 32:(k + 1) * 32].min()) for k in range(n_blocks))
+    p = _chain_f32(q, d)
+    a = np.maximum((np.float32(-2) * p.astype(np.float64) + (qq[:, None] + dd[None, :]).astype(np.float64)).astype(np.float32), 0)
+    dots = _dots_f32(q, d)
+    wt = _screen_f32(q, d, dd)
+    sample = np.arange(5, N, 8)
+    dropped = kept = 0
+    for i in range(len(q)):
+        tau = float(np.float32(np.sort(wt[i, sample])[-2]) - np.float32(_margin(qq[i], dmax)))
+        recs = []
+        for k in range(n_blocks):
+            hi_b = float(neg[k * 32:(k + 1) * 32].max())
+            for h in (0, 1):
+                r = k * 32 + _LANE_ROWS[h]
+                rec = _record(dots[i, r], hi_b, tau)
+                if rec is not None:
+                    recs.append((r[rec[0]], capi.screen_record_bounds(rec[1], k * 32 + 4 * h, tau, spread, N, dmax)))
+        los = sorted((lo for _, (lo, _) in recs), reverse=True)
+        keep_from = (los[1] if len(los) > 1 else -np.inf) - _margin(qq[i], dmax)
+        survivors = set()
+        for rws, (lo, hi) in recs:
+            if hi < keep_from:
+                dropped += 1
+            else:
+                kept += 1
+                survivors.update(rws.tolist())
+        second = np.sort(a[i])[1]
+        must = np.nonzero(a[i] <= second)[0]
+        assert set(must.tolist()) <= survivors, i
+    assert dropped > 0 and kept > 0          # and the rule does prune (on a DB of near-duplicates most records must stay)
