@@ -81,6 +81,10 @@ def parse(argv=None):
                     help="RCCL communicators per rank for the sharded path (slot i uses communicator i %% comms)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="single rank, but run the N > 1 code path (match_local -> RCCL all-gather -> rest)")
+    ap.add_argument("--lane", default="",
+                    help="'streams,reserve,low_priority': the chip-filling MATCH passes of all slots on `streams` shared "
+                         "streams that leave `reserve` compute units of each XCD to the small kernels (CU mask), or (reserve "
+                         "0, low_priority 1) of the lowest stream priority; '' or 'off' = everything on the slot's own stream")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (replicated_frames, sharded_200_models, single-frame latency, "
                          "the C++ hosts)")
@@ -195,6 +199,14 @@ def choose_parallelism(n_models: int, world: int) -> str:
     return "models"
 
 
+def parse_lane(text: str):
+    """'streams,reserve,low_priority' -> tuple, '' / 'off' -> None (moped_amd.pipeline.FramePipeline(lane=...))."""
+    if not text or text == "off":
+        return None
+    v = [int(x) for x in text.split(",")]
+    return (v[0], v[1] if len(v) > 1 else 2, bool(v[2]) if len(v) > 2 else False)
+
+
 def scaling_label(parallelism: str, world: int) -> str:
     """The contract's `scaling` key: nothing scales at N = 1; model sharding keeps the total work fixed; frame
     splitting keeps the per-GPU work fixed."""
@@ -264,7 +276,8 @@ class Job:
         self.params = params
         free0, _ = torch.cuda.mem_get_info(dev)
         self.pipe = FramePipeline(env["local_rank"], self.shard, depth=args.depth, max_queries=Q * B, params=params,
-                                  force_exchange=args.force_exchange and sharded, n_comms=args.comms)
+                                  force_exchange=args.force_exchange and sharded, n_comms=args.comms, batch=B,
+                                  lane=parse_lane(args.lane))
         torch.cuda.synchronize(dev)
         self.hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
         frames = self.frames
@@ -558,6 +571,7 @@ def main():
                    "frames_per_step": n_frames, "distinct_frames": n_pool, "timed_seconds": round(dt, 3),
                    "host_issue_seconds": round(t_issue, 3),
                    "frames_in_flight": (job.active_slots if B > 1 else args.depth) * B, "frames_per_match_launch": B,
+                   "lane": args.lane or None,
                    "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
                                    f"model-shard x{world}" if world > 1 else "single GPU"),
                    "model_assignment": (args.assign if sharded else None),
@@ -652,8 +666,8 @@ def main():
                                                  "descriptors, sharded by model; a reported figure, not `value`"}
             j3.close()
 
-    if rank == 0 and world == 1 and not args.no_secondary:
-        out.update(host_side_figures(args))
+    if rank == 0 and world == 1 and not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
+        out.update(host_side_figures(args, db, [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if job is None:
             frames_cpu = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]
@@ -668,33 +682,59 @@ def main():
         dist.destroy_process_group()
 
 
-def host_side_figures(args):
-    """Figures of the C++ hosts (no Python, no torch in the measured process): the literal drop-in -- one synchronous
-    frame through the STEP plugins (`moped_hip_test --time`) -- and the C++ streaming host that drives
-    mh_frame_enqueue_batch the way this file does (`moped_hip_bench`).  Each is a child process; absent binaries are
-    reported as such."""
+def host_side_figures(args, db, frames):
+    """Figures of the C++ hosts (no Python, no torch in the measured process; each a child process on a scene file
+    written here): `moped_hip_bench` -- the streaming C++ host that drives mh_frame_enqueue_batch the way this file
+    does, descriptors from pinned host memory -- and the literal drop-in, one synchronous frame at a time through the
+    STEP plugins with host FrameData between the steps (`moped_hip_test`: the loop of
+    moped2/libmoped/src/moped.cpp:183-191).  Absent binaries are reported as such."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
     out = {}
     host = os.path.join(ROOT, "moped_amd", "host")
-    exe = os.path.join(host, "moped_hip_bench")
-    if os.path.exists(exe):
-        try:
-            r = subprocess.run([exe, "--models", str(args.models), "--queries", str(args.queries), "--json"],
-                               capture_output=True, text=True, timeout=300, cwd=ROOT,
-                               env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and lines:
-                d = json.loads(lines[-1])
-                out["cpp_host"] = d
-                if "plugin_path_fps" in d:
-                    out["plugin_path_fps"] = d["plugin_path_fps"]
-                if "single_frame_latency_ms" in d:
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(host, "moped_hip_bench")
+        if os.path.exists(exe):
+            try:
+                path = os.path.join(tmp, "frames.bin")
+                dump_scene.dump_frames(path, db, frames)
+                cmd = [exe, path, "--json", "--steps", "5", "--batch", str(default_batch(args, False))]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    d = json.loads(lines[-1])
+                    out["cpp_host"] = d
                     out["single_frame_latency_ms"] = d["single_frame_latency_ms"]
-            else:
-                out["cpp_host"] = {"error": (r.stderr or r.stdout)[-300:]}
-        except Exception as e:
-            out["cpp_host"] = {"error": str(e)[:300]}
-    else:
-        out["cpp_host"] = {"error": "moped_amd/host/moped_hip_bench not built"}
+                else:
+                    out["cpp_host"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
+                out["cpp_host"] = {"error": str(e)[:300]}
+        else:
+            out["cpp_host"] = {"error": "moped_amd/host/moped_hip_bench not built"}
+        exe = os.path.join(host, "moped_hip_test")
+        if os.path.exists(exe):
+            try:
+                path = os.path.join(tmp, "scene.bin")
+                dump_scene.dump(path, db, frames[0])
+                r = subprocess.run([exe, path, "30"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                times = {l.split()[1]: float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("TIME ")}
+                n_obj = sum(1 for l in r.stdout.splitlines() if l.startswith("OBJ "))
+                if r.returncode == 0 and times:
+                    tot = sum(times.values())
+                    out["plugin_path_fps"] = round(1.0 / tot, 1)
+                    out["plugin_path"] = {"ms_per_frame": round(1e3 * tot, 4), "objects": n_obj,
+                                          "steps_ms": {k: round(1e3 * v, 4) for k, v in times.items()},
+                                          "note": "moped_hip_test: MopedPipeline -> STEP plugins -> C ABI, ONE synchronous frame at "
+                                                  "a time, descriptors in pageable host memory, every step's inputs and outputs "
+                                                  "through host FrameData (the PCIe-inclusive figure of the literal drop-in)"}
+                else:
+                    out["plugin_path"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
+                out["plugin_path"] = {"error": str(e)[:300]}
+        else:
+            out["plugin_path"] = {"error": "moped_amd/host/moped_hip_test not built"}
     return out
 
 

@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define MH_DESC_DIM 128
-#define MH_MAX_BATCH 8   /* frames one context can carry through one MATCH launch (mh_frame_enqueue_rest_batch) */
+#define MH_MAX_BATCH 32  /* frames one context can carry through one MATCH launch (mh_frame_enqueue_batch / _sharded_batch) */
 #define MH_MAX_IMAGES 8    /* images (cameras) of one frame (mh_frame_set_images, mh_*_images) */
 #define MH_MAX_MODELS 8192   /* models a context's frames can address (sharded: the global count); more -> MH_ERR_CAPACITY */
 #define MH_OK 0
@@ -69,6 +69,12 @@ int mh_synchronize(mh_ctx* ctx);
 /* Capacities of the per-frame device buffers (defaults: 16384 queries, 16384
  * matches, 1024 clusters, 4096 objects). Call before the first frame. */
 int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects);
+/* The same for a context that will carry BATCHES: `frames` <= MH_MAX_BATCH frames of up to `queries_per_frame` queries
+ * each per mh_frame_enqueue_batch / _sharded_batch / _rest_frames call.  The MATCH buffers are sized for all
+ * frames x queries_per_frame queries of a launch, the working arrays of CLUSTER..FILTER2 once per frame for
+ * queries_per_frame matches each (mh_reserve would size every one of them for the whole launch), so that no enqueue
+ * ever has to stop the stream and reallocate. */
+int mh_reserve_batch(mh_ctx* ctx, int queries_per_frame, int frames, int max_clusters, int max_objects);
 
 /* ---- model database (A2) -------------------------------------------------- */
 
@@ -304,16 +310,20 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
  * MATCH launch sequence over all B Q queries (the DB passes the chip once per batch), then CLUSTER .. FILTER2 frame
  * by frame on the context's stream; frame f leaves its objects in result slot f (mh_frame_fetch_slot), the same
  * objects, bit for bit, as mh_frame_enqueue(…, seeds[f]) gives it alone.  Per-query depth attributes
- * (mh_frame_set_depth) are then [B Q] like the queries; depth maps (and the depth rules that read them) come one per
- * frame through mh_frame_set_depth_image_batch; several images per frame are refused. */
+ * (mh_frame_set_depth) are then [B Q] like the queries, and so is the per-query image index of frames with several
+ * images (mh_frame_set_images: q_image_dev [B Q]; one camera table for the batch); depth maps (and the depth rules that
+ * read them) come one per frame through mh_frame_set_depth_image_batch. */
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):
  * q_image_dev[Q] = image of every query of the frames enqueued from now on (device memory, read when a frame
  * runs), cams[n_images] their cameras.  CLUSTER then runs per (model, image) in image order
  * (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195), POSE / FILTER project every correspondence through its own image; the
- * `cam` argument of mh_frame_enqueue* is ignored.  n_images <= 1 or NULL: back to one image.  Not together with the
- * moped3d depth steps (single camera). */
+ * `cam` argument of mh_frame_enqueue* is ignored.  n_images <= 1 or NULL: back to one image.  With batches
+ * (mh_frame_enqueue_batch, mh_frame_enqueue_sharded_batch) q_image_dev holds [B Q] entries, frame after frame like the
+ * queries.  Not together with the moped3d depth steps: those are single-camera in the reference itself (DEPTHMAP_PROP
+ * looks every match up in the ONE depth map of the frame whatever its image,
+ * moped3d/libmoped/src/depthprop/DEPTHMAP_PROP_CPU.hpp:86-112). */
 int mh_frame_set_images(mh_ctx* ctx, const int32_t* q_image_dev, const mh_cam* cams, int n_images);
 
 /* Per-query depth attributes for the next frames (device pointer, [Q] mh_depth, in query

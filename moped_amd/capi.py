@@ -66,7 +66,7 @@ DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
 
 # every symbol include/moped_hip.h declares
-MAX_BATCH = 8   # MH_MAX_BATCH
+MAX_BATCH = 32   # MH_MAX_BATCH
 
 
 class mh_linkage_params(C.Structure):
@@ -106,7 +106,7 @@ EXPORTS = [
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
     "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch", "mh_frame_set_depth_image_batch",
     "mh_pose_kernel_info", "mh_db_upload_blocks", "mh_frame_fetch_matches_slot",
-    "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds",
+    "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -140,6 +140,11 @@ def load():
     L.mh_set_stream.argtypes = [vp, vp]
     L.mh_synchronize.argtypes = [vp]
     L.mh_reserve.argtypes = [vp, i32, i32, i32]
+    L.mh_reserve_batch.argtypes = [vp, i32, i32, i32, i32]
+    if hasattr(L, "mh_lane_create"):   # experiment builds only (csrc/api.hip)
+        L.mh_lane_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+        L.mh_lane_destroy.argtypes = [vp]
+        L.mh_set_lane.argtypes = [vp, vp]
     L.mh_db_upload.argtypes = [vp, vp, vp, vp, i32, i32, C.c_int32]
     L.mh_db_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.mh_normalize.argtypes = [vp, vp, i32]
@@ -322,6 +327,25 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+class Lane:
+    """mh_lane: streams for the chip-filling MATCH passes of all contexts of a device (CU-masked or low priority)."""
+
+    def __init__(self, device=0, n_streams=4, reserve_cus_per_xcd=2, low_priority=False):
+        self.L = load()
+        if not hasattr(self.L, "mh_lane_create"):
+            raise MhError("lanes exist only in experiment builds of the library (make EXTRA=-DMH_EXPERIMENTS; MH_LIB_PATH)")
+        h = C.c_void_p()
+        rc = self.L.mh_lane_create(device, n_streams, reserve_cus_per_xcd, int(low_priority), C.byref(h))
+        if rc != MH_OK:
+            raise MhError(f"mh_lane_create -> {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mh_lane_destroy(self.h)
+            self.h = None
+
+
 class Comm:
     """mh_comm of one rank: RCCL (`create`), or a host transport (`create_host`: fn(send: bytes) -> bytes of all
     ranks in rank order -- ranks that share a device, test rigs)."""
@@ -417,8 +441,14 @@ class Context:
     def synchronize(self):
         self._ck(self.L.mh_synchronize(self.h), "mh_synchronize")
 
+    def set_lane(self, lane: "Lane | None"):
+        self._ck(self.L.mh_set_lane(self.h, lane.h if lane is not None else None), "mh_set_lane")
+
     def reserve(self, max_queries, max_clusters=1024, max_objects=4096):
         self._ck(self.L.mh_reserve(self.h, max_queries, max_clusters, max_objects), "mh_reserve")
+
+    def reserve_batch(self, queries_per_frame, frames, max_clusters=1024, max_objects=4096):
+        self._ck(self.L.mh_reserve_batch(self.h, queries_per_frame, frames, max_clusters, max_objects), "mh_reserve_batch")
 
     def enable_timing(self, on=True):
         self._ck(self.L.mh_enable_timing(self.h, int(on)), "mh_enable_timing")

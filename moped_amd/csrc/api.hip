@@ -123,6 +123,9 @@ int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* 
       ctx->mev_next = (ctx->mev_next + 1) % mh_ctx::MEV_SETS;
       ++ctx->mev_used;
     }
+    ctx->sbuf.big = ctx->lane_stream;
+    ctx->sbuf.ev_in = ctx->lane_in;
+    ctx->sbuf.ev_out = ctx->lane_out;
     launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->sdb, ctx->sbuf, idx1, d1,
                         d2, ctx->stream, q_count, q_expected);
   } else
@@ -202,9 +205,90 @@ void mh_destroy(mh_ctx* ctx) {
   for (auto& set : ctx->mev)
     for (auto& e : set)
       if (e) hipEventDestroy(e);
+  if (ctx->lane_in) hipEventDestroy(ctx->lane_in);
+  if (ctx->lane_out) hipEventDestroy(ctx->lane_out);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
+
+#ifdef MH_EXPERIMENTS
+// ---- lanes (experiment builds only; tried in round 3 and NOT shipped) ------------------------------------------------
+// A host that keeps several frames in flight mixes two kinds of kernels on the device: passes A and B of MATCH, whose
+// workgroups each take the whole register file of a compute unit, and a dozen small, latency-bound launches per batch.
+// scripts/cu_trace.py: a fifth of the chip's unit-time holds only small workgroups, a sixth nothing.  A lane = a few
+// extra streams for the big passes, confined to a CU mask that leaves `reserve` units of each XCD to everything else
+// (mask bit i = unit i / 8 of XCD i % 8: scripts/experiments/cu_mask_probe.hip); a context with a lane hands over to
+// it before pass A and takes its stream back after pass B (two event waits per MATCH launch sequence, ~12 us each).
+// Measured (config 1, one box, bench.py --lane streams,reserve): off 12 000 frames/s; 4,1 11 940; 4,2 11 690; 4,4 11 710;
+// 2,2 10 710; 8,2 11 020 -- what the reserved units give the small kernels, the hand-offs and the lane's in-order
+// streams take back.  Lowest-priority lane streams instead of a mask HUNG the run (events between streams of different
+// priority on this runtime): that variant is refused.
+extern "C" int mh_lane_create(int device, int n_streams, int reserve_cus_per_xcd, int low_priority, mh_lane** out) {
+  if (low_priority) return MH_ERR_ARG;
+  if (!out || n_streams < 1 || n_streams > 16 || reserve_cus_per_xcd < 0 || reserve_cus_per_xcd > 16) return MH_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return MH_ERR_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MH_ERR_HIP;
+  const int n_cu = prop.multiProcessorCount;
+  mh_lane* lane = new mh_lane;
+  lane->device = device;
+  lane->reserve = reserve_cus_per_xcd;
+  lane->low_priority = low_priority;
+  // CU mask bit i = unit i / 8 of XCD i % 8 on this part (scripts/experiments/cu_mask_probe.hip): the last `reserve`
+  // units of every XCD stay out of the lane
+  std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+  const int per_xcd = n_cu / 8;
+  for (int i = 0; i < n_cu; ++i)
+    if (i / 8 < per_xcd - reserve_cus_per_xcd) mask[i / 32] |= 1u << (i % 32);
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = numerically largest = least urgent
+  for (int k = 0; k < n_streams; ++k) {
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (reserve_cus_per_xcd > 0) e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+    else if (low_priority) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo);
+    else e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      for (hipStream_t t : lane->streams) hipStreamDestroy(t);
+      delete lane;
+      return MH_ERR_HIP;
+    }
+    lane->streams.push_back(s);
+  }
+  *out = lane;
+  return MH_OK;
+}
+
+extern "C" int mh_lane_destroy(mh_lane* lane) {
+  if (!lane) return MH_OK;
+  hipSetDevice(lane->device);
+  for (hipStream_t s : lane->streams) {
+    hipStreamSynchronize(s);
+    hipStreamDestroy(s);
+  }
+  delete lane;
+  return MH_OK;
+}
+
+extern "C" int mh_set_lane(mh_ctx* ctx, mh_lane* lane) {
+  if (!ctx) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->stream) MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->lane_stream) MH_HIP(ctx, hipStreamSynchronize(ctx->lane_stream));
+  ctx->lane = nullptr;
+  ctx->lane_stream = nullptr;
+  if (!lane) return MH_OK;
+  if (lane->device != ctx->device || lane->streams.empty()) {
+    ctx->err = "mh_set_lane: the lane belongs to another device";
+    return MH_ERR_ARG;
+  }
+  if (!ctx->lane_in) MH_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
+  if (!ctx->lane_out) MH_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_out, hipEventDisableTiming));
+  ctx->lane = lane;
+  ctx->lane_stream = lane->streams[lane->next++ % lane->streams.size()];
+  return MH_OK;
+}
+#endif   // MH_EXPERIMENTS
 
 const char* mh_last_error(const mh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -524,7 +608,10 @@ void mh_screen_record_bounds(uint16_t value_bits, uint32_t row0, float tau, floa
 }
 
 int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread) {
-  if (!ctx || !q_host || !out_host || Q <= 0 || n_rows <= 0 || (Q & 31) || (n_rows & 31)) return MH_ERR_ARG;
+  if (!ctx || !q_host || !out_host || Q <= 0 || n_rows <= 0 || (Q & 31) || (n_rows & 31)) {
+    if (ctx) ctx->err = "mh_screen_values: Q and n_rows must be positive multiples of 32";
+    return MH_ERR_ARG;
+  }
   if (!ctx->sdb.dbh || n_rows > (ctx->N + 127) / 128 * 128) {
     ctx->err = "mh_screen_values: the database has no f16 image (fewer than 4096 rows?) or fewer rows than asked for";
     return MH_ERR_ARG;

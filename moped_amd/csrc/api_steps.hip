@@ -44,18 +44,11 @@ struct FrameState {
   unsigned char* result = nullptr;
   size_t result_bytes = 0;
   int32_t* snap = nullptr;  // [4] counts snapshot: matches, clusters, objects after POSE, after FILTER
-  uint64_t* seed_dev = nullptr;  // per-frame seed in device memory: only when the launch list is replayed as a graph
   int task_grid = 32;   // workgroups for the POSE/FILTER launches: follows the task count of the last fetched frame
   int ms_grid = 8;      // ... and of the CLUSTER launch: its cluster count + head room
   int slot = 0;            // result / snap slot the next frame_rest writes (frames of a batch share the context)
   int list_first = 0, list_n = 1;   // result slots whose match lists are still in the arenas: [list_first, list_first + list_n)
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
-  // hipGraph replay of the launch list (one graph per half of the frame)
-  struct Graph {
-    hipGraphExec_t exec = nullptr;
-    std::vector<unsigned char> key;
-    int uses = 0;   // identical enqueues seen so far (the first one runs eagerly)
-  } g_full, g_local, g_rest;
 };
 
 namespace {
@@ -68,11 +61,9 @@ int dev_alloc(mh_ctx* ctx, T*& p, size_t n) {
 
 void free_fs(FrameState* fs) {
   if (!fs) return;
-  void* ptrs[] = {fs->arena, fs->result, fs->snap, fs->seed_dev};
+  void* ptrs[] = {fs->arena, fs->result, fs->snap};
   for (void* p : ptrs)
     if (p) hipFree(p);
-  for (FrameState::Graph* g : {&fs->g_full, &fs->g_local, &fs->g_rest})
-    if (g->exec) hipGraphExecDestroy(g->exec);
   delete fs;
 }
 
@@ -170,8 +161,8 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
     rc |= dev_alloc(ctx, fs->result, fs->result_bytes * MH_MAX_BATCH);
     if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes * MH_MAX_BATCH, ctx->stream));   // "0 objects" before the first frame
     rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
+    if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->snap, 0, sizeof(int32_t) * 4 * MH_MAX_BATCH, ctx->stream));   // (a slot fetched before it was written reads zeros)
   }
-  rc |= dev_alloc(ctx, fs->seed_dev, 1);
   if (rc) {   // a half-built state must not look valid to the next call
     free_fs(fs);
     ctx->fs = nullptr;
@@ -260,9 +251,6 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
   reinterpret_cast<int32_t*>(result)[1] = counts->error;   // capacity flags, as the last FILTER launch reports them
 }
 
-bool graphs_enabled();
-void set_seed(mh_ctx* ctx, uint64_t seed);
-
 int ensure_linkage_scratch(mh_ctx* ctx, size_t floats) {
   if (floats <= ctx->lk_scratch_floats) return MH_OK;
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -349,22 +337,13 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   fs->list_n = batch_n > 1 ? batch_n : 1;
   // Every workgroup of the POSE / FILTER launches needs a free compute unit to start even if
   // it has no task, and MATCH kernels of other frames keep all of them busy: launch about as
-  // many workgroups as the previous frame had tasks (MH_TASK_GRID pins the number).
-  static const int grid_env = [] {
-    const char* e = getenv("MH_TASK_GRID");
-    return e ? atoi(e) : 0;
-  }();
+  // many workgroups as the previous frame had tasks (experiment builds: MH_TASK_GRID pins the number, MH_MS_GRID the
+  // CLUSTER launch's -- 0 = one workgroup per model, the old shape).
+  static const int grid_env = exp_int("MH_TASK_GRID", 0);
   const int grid = grid_env > 0 ? grid_env : fs->task_grid;
-  static const int ms_grid_env = [] {   // MH_MS_GRID: workgroups of the CLUSTER launch (0 = one per model, the old shape)
-    const char* e = getenv("MH_MS_GRID");
-    return e ? atoi(e) : -1;
-  }();
+  static const int ms_grid_env = exp_int("MH_MS_GRID", -1);
   const int ms_grid = ms_grid_env >= 0 ? ms_grid_env : fs->ms_grid;
-  const uint64_t* seed_dev = nullptr;
-  if (graphs_enabled()) {   // replayed launch lists take the seed from device memory (set by the caller)
-    seed_dev = fs->seed_dev;
-    seed = 0;
-  }
+  const uint64_t* const seed_dev = nullptr;
   const bool multi = ctx->q_img && ctx->n_images > 1 && ctx->cams_dev;
   if (multi && (ctx->q_depth || ctx->depth_img.img || ctx->linkage_on)) {
     ctx->err = "frames with several images: the moped3d depth steps are single-camera";
@@ -404,7 +383,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off,
                ctx->q_depth ? ctx->q_depth + q0 : nullptr,   // (a batch's depth attributes lie frame after frame like its queries)
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
-               gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0, b1);
+               gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0, b1,
+               fs->slot == 0 ? ctx->exchange_tags : nullptr);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   const bool have_depth = ctx->q_depth || ctx->depth_img.img;
@@ -419,7 +399,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                           snap, fs->counts, fs->tickets + 0, s, ms_grid);
   } else if (multi) {
     // MeanShift per (model, image) in image order (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195)
-    launch_image_split(fs->m_corr, fs->m_q, fs->m_model, fs->model_off, nm, ctx->q_img, ctx->n_images, fs->counts,
+    launch_image_split(fs->m_corr, fs->m_q, fs->m_model, fs->model_off, nm, ctx->q_img + (size_t)ctx->batch_f * Q, ctx->n_images, fs->counts,
                        fs->m_img, fs->m_rep, fs->mi_corr, fs->mi_img, fs->off2, s);
     launch_meanshift_models(fs->mi_corr, fs->off2, nm * ctx->n_images, prm->ms_radius, prm->ms_merge,
                             prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
@@ -442,10 +422,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   // the POSE launch before it (its last workgroup: filter_dev.h) -- four launches per frame instead of six; a
   // dependent launch costs the pipeline ~5% of its throughput whatever is in it (MH_FUSE_FILTER=0: launches of
   // their own, the same objects).
-  static const bool fuse_filter = [] {
-    const char* e = getenv("MH_FUSE_FILTER");
-    return !(e && e[0] == '0');
-  }();
+  static const bool fuse_filter = exp_int("MH_FUSE_FILTER", 1) != 0;
   const float* depth4 = (ctx->q_depth || ctx->depth_img.img) ? reinterpret_cast<const float*>(fs->m_depth) : nullptr;
   FilterBuffers fb = make_fb(ctx, fs, nm);
   if (multi) {
@@ -505,15 +482,9 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
 // attributes / map / rules (one map per context), one image, the fused FILTER tails (the stand-alone FILTER and
 // result-packing kernels are per frame), no stage timing, no graph replay.  MH_MERGE_BATCH=0: frame after frame.
 bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm) {
-  static const bool on = [] {
-    const char* e = getenv("MH_MERGE_BATCH");
-    return !(e && e[0] == '0');
-  }();
-  static const bool fuse_filter = [] {
-    const char* e = getenv("MH_FUSE_FILTER");
-    return !(e && e[0] == '0');
-  }();
-  return on && fuse_filter && prm->run_stage2 && !ctx->timing && !graphs_enabled() && !ctx->q_depth && !ctx->depth_img.img &&
+  static const bool on = exp_int("MH_MERGE_BATCH", 1) != 0;
+  static const bool fuse_filter = exp_int("MH_FUSE_FILTER", 1) != 0;
+  return on && fuse_filter && prm->run_stage2 && !ctx->timing && !ctx->q_depth && !ctx->depth_img.img &&
          !ctx->rules.on && !ctx->linkage_on && !(ctx->q_img && ctx->n_images > 1);
 }
 
@@ -523,7 +494,10 @@ int ensure_batch_arenas(mh_ctx* ctx, int B) {
   return ensure_fs(ctx, fs->max_m, fs->max_clusters, fs->max_objects, fs->n_models_cap, B);
 }
 
-int prepare_frame(mh_ctx* ctx, int Q) {
+// Buffers for a launch of Q queries = `frames` frames of q_frame queries each (0: one frame of Q): the MATCH side for
+// all of them, the working arrays of the rest chain per frame (a frame has at most as many matches as queries) with
+// `frames` copies, so that a merged batch never reallocates behind work that is already enqueued.
+int prepare_frame(mh_ctx* ctx, int Q, int q_frame = 0, int frames = 1) {
   int rc = ensure_frame_buffers(ctx, Q);
   if (rc) return rc;
   if ((rc = ensure_match_scratch(ctx, Q))) return rc;
@@ -531,7 +505,8 @@ int prepare_frame(mh_ctx* ctx, int Q) {
   const int mc = ctx->fs ? ctx->fs->max_clusters : 1024;
   const int mo = ctx->fs ? ctx->fs->max_objects : 4096;
   // (several images: CLUSTER's per-"model" tables hold one entry per (model, image) pair)
-  return ensure_fs(ctx, std::max(want_m, ctx->max_q), mc, mo, ctx->n_models * (ctx->n_images > 1 ? ctx->n_images : 1));
+  return ensure_fs(ctx, std::max(want_m, q_frame > 0 ? q_frame : Q), mc, mo,
+                   ctx->n_models * (ctx->n_images > 1 ? ctx->n_images : 1), frames);
 }
 
 }  // namespace
@@ -550,6 +525,17 @@ int mh_reserve(mh_ctx* ctx, int max_queries, int max_clusters, int max_objects) 
   int rc = ensure_frame_buffers(ctx, max_queries);
   if (rc) return rc;
   return ensure_fs(ctx, ctx->max_q, max_clusters, max_objects, ctx->n_models);
+}
+
+int mh_reserve_batch(mh_ctx* ctx, int queries_per_frame, int frames, int max_clusters, int max_objects) {
+  if (!ctx || queries_per_frame <= 0 || frames < 1 || frames > MH_MAX_BATCH || max_clusters <= 0 || max_objects <= 0)
+    return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = ensure_frame_buffers(ctx, queries_per_frame * frames);
+  if (rc) return rc;
+  if ((rc = ensure_match_scratch(ctx, queries_per_frame * frames))) return rc;
+  return ensure_fs(ctx, queries_per_frame, max_clusters, max_objects, ctx->n_models, frames);
 }
 
 void mh_frame_default_params(mh_frame_params* p) {
@@ -1165,97 +1151,7 @@ int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image
   return MH_OK;
 }
 
-}  // extern "C" (helpers below need C++ linkage)
 
-// ---- hipGraph replay of a frame's launch list --------------------------------------
-// A frame is a short list of launches with fixed grids and device-side counts, so the list
-// is identical from frame to frame as long as the pointers / sizes / constants are.
-// The first enqueue with a given key runs eagerly (it also does the one-time
-// hipFuncSetAttribute calls), the second is captured, later ones replay the graph.
-// The per-frame seed travels through device memory.
-// EXPERIMENTAL, off unless MH_GRAPH=1: on ROCm 7.2 replay cuts the host cost of a frame
-// from 95 to 23 us but does not change throughput (the GPU-side dependent-launch chain is
-// the limit, not the host), and after a few replays of the same executable graph the
-// frame counters come back corrupted (scripts/graph_debug.py) -- not shipped as default.
-namespace {
-
-bool graphs_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MH_GRAPH");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
-
-template <typename T>
-void key_add(std::vector<unsigned char>& k, const T& v) {
-  const unsigned char* p = reinterpret_cast<const unsigned char*>(&v);
-  k.insert(k.end(), p, p + sizeof(T));
-}
-
-void set_seed(mh_ctx* ctx, uint64_t seed) {
-  // two 32-bit memsets: the value rides in the command, no host buffer to keep alive
-  hipMemsetD32Async((hipDeviceptr_t)ctx->fs->seed_dev, (int)(uint32_t)seed, 1, ctx->stream);
-  hipMemsetD32Async((hipDeviceptr_t)((char*)ctx->fs->seed_dev + 4), (int)(uint32_t)(seed >> 32), 1, ctx->stream);
-}
-
-// Runs `body` (a list of stream launches) eagerly, under capture, or as a replay.
-template <typename Body>
-int run_graphed(mh_ctx* ctx, FrameState::Graph& g, const std::vector<unsigned char>& key, Body&& body) {
-  if (!graphs_enabled() || ctx->timing) return body();
-  if (g.key != key) {
-    if (g.exec) hipGraphExecDestroy(g.exec);
-    g.exec = nullptr;
-    g.key = key;
-    g.uses = 0;
-  }
-  if (g.exec) {
-    MH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
-    return MH_OK;
-  }
-  if (g.uses++ == 0) return body();  // first time: eager (one-time attribute calls happen here)
-  hipGraph_t graph = nullptr;
-  MH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  const int rc = body();
-  const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-  if (rc != MH_OK || e != hipSuccess || !graph) {
-    if (graph) hipGraphDestroy(graph);
-    ctx->err = "frame graph capture failed; running eagerly";
-    g.uses = -1000000;  // never try again for this key
-    return rc != MH_OK ? rc : body();
-  }
-  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
-  if (ei != hipSuccess) {
-    g.exec = nullptr;
-    g.uses = -1000000;
-    return body();
-  }
-  MH_HIP(ctx, hipGraphLaunch(g.exec, ctx->stream));
-  return MH_OK;
-}
-
-void key_common(mh_ctx* ctx, std::vector<unsigned char>& k, int Q, const mh_cam* cam, const mh_frame_params* prm) {
-  key_add(k, Q);
-  key_add(k, ctx->N);
-  key_add(k, ctx->n_models);
-  key_add(k, ctx->index_base);
-  key_add(k, ctx->db_desc);
-  key_add(k, ctx->q_depth);
-  key_add(k, ctx->depth_img);
-  key_add(k, ctx->depth_kind);
-  key_add(k, ctx->depth_alpha);
-  key_add(k, ctx->fs);
-  key_add(k, ctx->match_scratch);
-  key_add(k, ctx->match_pack);
-  key_add(k, ctx->stream);
-  if (cam) key_add(k, *cam);
-  if (prm) key_add(k, *prm);
-}
-
-}  // namespace
-
-extern "C" {
 
 int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q,
                      const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
@@ -1265,18 +1161,11 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   ctx->feat_count_dev = nullptr;
-  if (graphs_enabled()) set_seed(ctx, seed);
-  std::vector<unsigned char> key;
-  key_common(ctx, key, Q, cam, prm);
-  key_add(key, q_desc_dev);
-  key_add(key, q_uv_dev);
-  return run_graphed(ctx, ctx->fs->g_full, key, [&]() -> int {
-    stamp(ctx, 0);
-    launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-    if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2)) return rc_m;
-    stamp(ctx, 1);
-    return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
-  });
+  stamp(ctx, 0);
+  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+  if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2)) return rc_m;
+  stamp(ctx, 1);
+  return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
 }
 
 int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
@@ -1312,7 +1201,7 @@ int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, in
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const int Q = max_keypoints;
-  int rc = prepare_frame(ctx, B * Q);
+  int rc = prepare_frame(ctx, B * Q, Q, B > 1 && merged_batch_ok(ctx, prm) ? B : 1);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   if (!ctx->img_counts) {
@@ -1345,7 +1234,6 @@ int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, in
   for (int f = 0; f < B && rc == MH_OK; ++f) {
     ctx->batch_q0 = f * Q;
     ctx->fs->slot = f;
-    if (graphs_enabled()) set_seed(ctx, seeds[f]);
     rc = frame_rest(ctx, ctx->q_uv + 2 * (size_t)f * Q, Q, nullptr, 0, cam, prm, seeds[f]);
   }
   ctx->batch_q0 = 0;
@@ -1371,14 +1259,14 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
                            const mh_frame_params* prm, const uint64_t* seeds) {
   if (!ctx || Q <= 0 || B < 1 || B > MH_MAX_BATCH || !q_desc_dev || !q_uv_dev || !cam || !prm || !seeds)
     return MH_ERR_ARG;
-  if (B > 1 && (((ctx->depth_img.img || ctx->rules.on) && ctx->batch_imgs != B) || (ctx->q_img && ctx->n_images > 1))) {
+  if (B > 1 && (ctx->depth_img.img || ctx->rules.on) && ctx->batch_imgs != B) {
     ctx->err = "mh_frame_enqueue_batch: a depth map belongs to ONE frame (mh_frame_set_depth_image_batch hands in one per "
-               "frame of the batch), and so does the image index";
+               "frame of the batch)";
     return MH_ERR_ARG;
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, B * Q);
+  int rc = prepare_frame(ctx, B * Q, Q, B > 1 && merged_batch_ok(ctx, prm) ? B : 1);   // (the arenas before any work is enqueued)
   if (rc) return rc;
   ctx->feat_count_dev = nullptr;
   stamp(ctx, 0);
@@ -1393,15 +1281,16 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   }
   for (int f = 0; f < B && rc == MH_OK; ++f) {
     ctx->batch_q0 = f * Q;
+    ctx->batch_f = f;
     ctx->fs->slot = f;
     if (B > 1 && ctx->batch_imgs == B && ctx->depth_img.img) {   // the frame's own depth map
       ctx->depth_img.img = ctx->batch_img[f];
       ctx->depth_img.fill = ctx->batch_fill[f];
     }
-    if (graphs_enabled()) set_seed(ctx, seeds[f]);
     rc = frame_rest(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, nullptr, 0, cam, prm, seeds[f]);
   }
   ctx->batch_q0 = 0;
+  ctx->batch_f = 0;
   ctx->fs->slot = 0;
   if (B > 1 && ctx->batch_imgs == B && ctx->depth_img.img) {   // back to the first frame's map, as the setter left it
     ctx->depth_img.img = ctx->batch_img[0];
@@ -1414,21 +1303,18 @@ int mh_frame_enqueue_match_local(mh_ctx* ctx, float* q_desc_dev, int Q, int32_t*
   if (!ctx || Q <= 0 || !q_desc_dev || !top2_dev) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, Q);
+  // (the working arrays of the rest chain are sized by the calls that run it: a batch's MATCH covers B frames' queries)
+  int rc = ensure_frame_buffers(ctx, Q);
   if (rc) return rc;
+  if ((rc = ensure_match_scratch(ctx, Q))) return rc;
+  if (!ctx->fs && (rc = prepare_frame(ctx, Q))) return rc;
   float* d1 = reinterpret_cast<float*>(top2_dev + Q);
   ctx->feat_count_dev = nullptr;
-  std::vector<unsigned char> key;
-  key_common(ctx, key, Q, nullptr, nullptr);
-  key_add(key, q_desc_dev);
-  key_add(key, top2_dev);
-  return run_graphed(ctx, ctx->fs->g_local, key, [&]() -> int {
-    stamp(ctx, 0);
-    launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
-    if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, top2_dev, d1, d1 + Q)) return rc_m;
-    MH_HIP(ctx, hipGetLastError());
-    return MH_OK;
-  });
+  stamp(ctx, 0);
+  launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+  if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, top2_dev, d1, d1 + Q)) return rc_m;
+  MH_HIP(ctx, hipGetLastError());
+  return MH_OK;
 }
 
 int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered_dev,
@@ -1438,18 +1324,10 @@ int mh_frame_enqueue_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
-  if (graphs_enabled()) set_seed(ctx, seed);
-  std::vector<unsigned char> key;
-  key_common(ctx, key, Q, cam, prm);
-  key_add(key, q_uv_dev);
-  key_add(key, gathered_dev);
-  key_add(key, n_shards);
-  return run_graphed(ctx, ctx->fs->g_rest, key, [&]() -> int {
-    // shard k's block is [3][Q] words at gathered_dev + k*3*Q; the first launch merges them
-    // into the context's own top-2 arrays
-    stamp(ctx, 1);
-    return frame_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
-  });
+  // shard k's block is [3][Q] words at gathered_dev + k*3*Q; the first launch merges them
+  // into the context's own top-2 arrays
+  stamp(ctx, 1);
+  return frame_rest(ctx, q_uv_dev, Q, gathered_dev, n_shards, cam, prm, seed);
 }
 
 int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_t* n_objects,
@@ -1480,7 +1358,10 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   if (take > 0 && objects_host)
     MH_HIP(ctx, hipMemcpy(objects_host, fs->result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
   if (fc.error) {
-    ctx->err = "frame: capacity exceeded (flags " + std::to_string(fc.error) + ")";
+    ctx->err = (fc.error & ERR_EXCHANGE)
+                   ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
+                                 "their collectives in different orders (every rank must enqueue its slots in the same order)")
+                   : "frame: capacity exceeded (flags " + std::to_string(fc.error) + ")";
     return MH_ERR_CAPACITY;
   }
   return MH_OK;
@@ -1501,6 +1382,8 @@ int mh_frame_enqueue_rest_batch(mh_ctx* ctx, const float* q_uv_dev, int Q, const
                                 const mh_frame_params* prm, uint64_t seed) {
   if (!ctx || slot < 0 || slot >= MH_MAX_BATCH || plane_stride_words < Q || shard_stride_words < 3 * plane_stride_words)
     return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   int rc = prepare_frame(ctx, Q);
   if (rc) return rc;
   ctx->exchange_stride = shard_stride_words;
@@ -1521,10 +1404,11 @@ int mh_frame_enqueue_rest_frames(mh_ctx* ctx, const float* q_uv_dev, int Q, cons
     return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, Q);
+  const bool merge = B > 1 && merged_batch_ok(ctx, prm);
+  int rc = prepare_frame(ctx, merge ? B * Q : Q, Q, merge ? B : 1);
   if (rc) return rc;
   // merged: frame f merges the shards' blocks into [f Q, (f + 1) Q) of the context's top-2 arrays
-  if (B > 1 && merged_batch_ok(ctx, prm) && ctx->max_q >= B * Q) {
+  if (merge) {
     if ((rc = ensure_batch_arenas(ctx, B))) return rc;
     ctx->exchange_stride = shard_stride_words;
     ctx->exchange_plane = plane_stride_words;
@@ -1536,11 +1420,13 @@ int mh_frame_enqueue_rest_frames(mh_ctx* ctx, const float* q_uv_dev, int Q, cons
     ctx->exchange_plane = 0;
     return rc;
   }
-  for (int f = 0; f < B; ++f)
-    if ((rc = mh_frame_enqueue_rest_batch(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, gathered_dev + (size_t)f * Q, n_shards,
-                                          shard_stride_words, plane_stride_words, f, cam, prm, seeds[f])))
-      return rc;
-  return MH_OK;
+  for (int f = 0; f < B && rc == MH_OK; ++f) {
+    ctx->batch_f = f;   // (frames with several images: the frame's slice of the per-query image index)
+    rc = mh_frame_enqueue_rest_batch(ctx, q_uv_dev + 2 * (size_t)f * Q, Q, gathered_dev + (size_t)f * Q, n_shards,
+                                     shard_stride_words, plane_stride_words, f, cam, prm, seeds[f]);
+  }
+  ctx->batch_f = 0;
+  return rc;
 }
 
 int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_objects, int32_t* n_objects,
@@ -1564,7 +1450,10 @@ int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_
   if (take > 0 && objects_host)
     MH_HIP(ctx, hipMemcpy(objects_host, result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
   if (head[1]) {
-    ctx->err = "frame: capacity exceeded (flags " + std::to_string(head[1]) + ")";
+    ctx->err = (head[1] & ERR_EXCHANGE)
+                   ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
+                                 "their collectives in different orders (every rank must enqueue its slots in the same order)")
+                   : "frame: capacity exceeded (flags " + std::to_string(head[1]) + ")";
     return MH_ERR_CAPACITY;
   }
   return MH_OK;
@@ -1574,8 +1463,8 @@ int mh_frame_result_copy_slots_dev(mh_ctx* ctx, void* dst_dev, int n_slots, int 
   if (!ctx || !dst_dev || max_objects < 0 || n_slots <= 0 || n_slots > MH_MAX_BATCH) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1);
-  if (rc) return rc;
+  if (!ctx->fs)   // before the first frame: an empty result block ("0 objects")
+    if (int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1)) return rc;
   FrameState* fs = ctx->fs;
   const size_t bytes = std::min(fs->result_bytes, 16 + sizeof(mh_object) * (size_t)max_objects);
   MH_HIP(ctx, hipMemcpy2DAsync(dst_dev, bytes, fs->result, fs->result_bytes, bytes, (size_t)n_slots,
@@ -1587,8 +1476,8 @@ int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects) {
   if (!ctx || !dst_dev || max_objects < 0) return MH_ERR_ARG;
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1);
-  if (rc) return rc;
+  if (!ctx->fs)   // before the first frame: an empty result block ("0 objects")
+    if (int rc = prepare_frame(ctx, ctx->max_q > 0 ? ctx->max_q : 1)) return rc;
   FrameState* fs = ctx->fs;
   const size_t bytes = std::min(fs->result_bytes, 16 + sizeof(mh_object) * (size_t)max_objects);
   MH_HIP(ctx, hipMemcpyAsync(dst_dev, fs->result, bytes, hipMemcpyDeviceToDevice, ctx->stream));

@@ -90,6 +90,7 @@ struct mh_comm {
   mh_allgather_fn host_fn = nullptr;
   void* host_user = nullptr;
   std::vector<unsigned char> h_send, h_recv;
+  uint32_t seq = 0;   // frame exchanges issued on this communicator: stamped into every block, compared after the gather
 };
 
 #define MH_NCCL(ctx, call)                                                                       \
@@ -161,19 +162,26 @@ int check_frame_args(mh_ctx* ctx, mh_comm* comm, const float* q_desc_dev, const 
     ctx->err = "mh_comm: the communicator was made for another device";
     return MH_ERR_ARG;
   }
-  if (B > 1 && (ctx->q_depth || ctx->depth_img.img || ctx->rules.on || (ctx->q_img && ctx->n_images > 1))) {
-    ctx->err = "sharded batch: depth attributes, depth maps / rules and the image index belong to ONE frame";
+  if (B > 1 && (ctx->q_depth || ctx->depth_img.img || ctx->rules.on)) {
+    ctx->err = "sharded batch: depth attributes and depth maps / rules belong to ONE frame";
     return MH_ERR_ARG;
   }
   return MH_OK;
 }
 
 // exchange 2 of the context's previous frame(s) + this shard's top-2 into the send block
-int before_exchange(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, int Q, int B) {
+int before_exchange(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, int Q, int B, const uint64_t* seeds) {
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc = mh::use_stream(ctx)) return rc;
   if (int rc = ensure_exchange(ctx, comm->world, B * Q, B)) return rc;
   if (int rc = mh_frame_result_copy_slots_dev(ctx, ctx->ex.local + 3 * (size_t)B * Q, B, MH_EX2_OBJECTS)) return rc;
+  // the block's tag, in the two pad words of the first result head {n, flags, pad, pad}: which exchange of this
+  // communicator this is, and for which frames -- every rank's must agree after the gather (group_kernel checks)
+  int32_t* tag = ctx->ex.local + 3 * (size_t)B * Q + 2;
+  const uint32_t fold = (uint32_t)seeds[0] ^ (uint32_t)(seeds[0] >> 32) ^ ((uint32_t)B << 24) ^ (uint32_t)Q;
+  MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)tag, (int)comm->seq, 1, ctx->stream));
+  MH_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(tag + 1), (int)fold, 1, ctx->stream));
+  ++comm->seq;
   void* block = nullptr;
   int64_t bytes = 0;
   if (mh_frame_result_dev(ctx, &block, &bytes) == MH_OK && bytes < EX2_WORDS * 4) {
@@ -185,8 +193,11 @@ int before_exchange(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev, int Q, int B)
 
 int after_exchange(mh_ctx* ctx, mh_comm* comm, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                    const mh_frame_params* prm, const uint64_t* seeds) {
-  return mh_frame_enqueue_rest_frames(ctx, q_uv_dev, Q, ctx->ex.gathered, comm->world, (int)ctx->ex.stride, B * Q, B, cam,
-                                      prm, seeds);
+  ctx->exchange_tags = ctx->ex.gathered + 3 * (size_t)B * Q + 2;
+  const int rc = mh_frame_enqueue_rest_frames(ctx, q_uv_dev, Q, ctx->ex.gathered, comm->world, (int)ctx->ex.stride, B * Q, B,
+                                              cam, prm, seeds);
+  ctx->exchange_tags = nullptr;
+  return rc;
 }
 
 // {n, flags, pad, pad, objects} -> objects_host; more objects than the block carries or capacity flags: an error,
@@ -316,7 +327,7 @@ int mh_frame_enqueue_sharded_batch(mh_ctx* ctx, mh_comm* comm, float* q_desc_dev
                                    const mh_cam* cam, const mh_frame_params* prm, const uint64_t* seeds) {
   if (!seeds) return MH_ERR_ARG;
   if (int rc = check_frame_args(ctx, comm, q_desc_dev, q_uv_dev, Q, B, cam, prm)) return rc;
-  if (int rc = before_exchange(ctx, comm, q_desc_dev, Q, B)) return rc;
+  if (int rc = before_exchange(ctx, comm, q_desc_dev, Q, B, seeds)) return rc;
   if (int rc = comm_allgather(ctx, comm, ctx->ex.local, ctx->ex.gathered, ctx->ex.stride * 4)) return rc;
   return after_exchange(ctx, comm, q_uv_dev, Q, B, cam, prm, seeds);
 }
@@ -339,7 +350,7 @@ int mh_frame_enqueue_sharded_all(mh_ctx* const* ctxs, mh_comm* const* comms, int
     }
   }
   for (int r = 0; r < world; ++r)
-    if (int rc = before_exchange(ctxs[r], comms[r], q_desc_dev[r], Q, B)) return rc;
+    if (int rc = before_exchange(ctxs[r], comms[r], q_desc_dev[r], Q, B, seeds)) return rc;
   // one thread driving several ranks: the collectives of all of them go out as one group
   mh_ctx* c0 = ctxs[0];
   MH_NCCL(c0, rccl()->GroupStart());

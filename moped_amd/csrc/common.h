@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/moped_hip.h"
@@ -31,6 +32,20 @@ struct DynLds {
     word.fetch_or(bit, std::memory_order_release);
   }
 };
+
+// ---- A/B switches ------------------------------------------------------------------------------------------------
+// The product library reads NO environment variable that changes which kernels run or how (a C++ host must get the same
+// kernels as the bench).  The switches the measurement scripts flip -- launch shapes, fused / unfused steps, kernel
+// variants -- exist only in experiment builds: make EXTRA=-DMH_EXPERIMENTS BUILD=build_exp OUT=../libmoped_hip_exp.so
+// (scripts/README.md).  exp_int(name, def) is `def` in the product.
+#ifdef MH_EXPERIMENTS
+inline int exp_int(const char* name, int def) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : def;
+}
+#else
+constexpr int exp_int(const char*, int def) { return def; }
+#endif
 
 // ---- workgroup residency trace (experiment builds only: make EXTRA=-DMH_TRACE) --------------------------------
 // Which compute unit every workgroup of a frame's kernels ran on, and when: thread 0 of a workgroup stamps

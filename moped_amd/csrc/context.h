@@ -41,6 +41,16 @@ struct DbStore {
   }
 };
 
+// A lane: a few streams for the kernels whose workgroups take whole compute units (passes A and B of the two-stage
+// MATCH), either confined to a CU mask that leaves `reserve` units of every XCD to everything else, or of lower priority
+// than the contexts' own streams.  Shared by the contexts (= frames in flight) of a device (mh_lane_create).
+struct mh_lane {
+  int device = 0;
+  std::vector<hipStream_t> streams;
+  unsigned next = 0;   // round-robin hand-out to contexts
+  int reserve = 0, low_priority = 0;
+};
+
 struct mh_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -59,6 +69,9 @@ struct mh_ctx {
   mh::ScreenDb sdb;
   mh::ScreenBufs sbuf;           // the screen's per-frame scratch
   int match_mode = -1;           // mh_match_set_mode
+  struct mh_lane* lane = nullptr;   // mh_set_lane: where the chip-filling MATCH passes run (not owned)
+  hipStream_t lane_stream = nullptr;
+  hipEvent_t lane_in = nullptr, lane_out = nullptr;
 
   // ---- per-frame buffers ----
   int max_q = 0, max_clusters = 0, max_objects = 0;
@@ -87,11 +100,13 @@ struct mh_ctx {
   int feat_expected = 0;              // keypoints of the last fetched image frame (sizes the next MATCH launch)
   int feat_last = -1;
   int batch_q0 = 0;                   // first query of the frame frame_rest works on (mh_frame_enqueue_batch)
+  int batch_f = 0;                    // ... and its number in the batch: the frame's slice of per-query attributes that lie frame after frame (q_img)
   const float4* batch_img[MH_MAX_BATCH] = {};   // depth maps of the frames of a batch (mh_frame_set_depth_image_batch)
   const float* batch_fill[MH_MAX_BATCH] = {};
   int batch_imgs = 0;                 // how many of them are set (0: one depth map, one frame)
   int exchange_plane = 0;             // words between the idx / d1 / d2 planes of one shard's block (0 = Q)
   int exchange_stride = 0;            // words between the shards' blocks of the gathered exchange buffer (0 = 3 Q)
+  const int32_t* exchange_tags = nullptr;   // comm.hip: shard 0's tag words in the gathered buffer (checked by the frame's first launch)
 
   // N > 1 (comm.hip): the send / receive blocks of the frame exchange, the flush buffer of the last frames
   struct Exchange {

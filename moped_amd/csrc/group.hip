@@ -82,7 +82,8 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ m_model, mh_corr* __restrict__ m_corr, int32_t* __restrict__ m_rep,
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
-    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride, FrameBatch fbx) {
+    unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride, FrameBatch fbx,
+    const int32_t* __restrict__ tags) {
   MH_TRACE_SCOPE(mh::TK_GROUP);
   if (blockIdx.y) {   // frame of a batch: its slice of the top-2 arrays / keypoints, its copy of the working arrays
     const unsigned long long a = blockIdx.y * fbx.arena;
@@ -109,6 +110,14 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     base_s = 0;
     *counts = FrameCounts{};
     if (n_slots) *n_slots = 0;
+    // every rank stamps its block with (sequence number of the collective on its communicator, frame seed): blocks that
+    // do not agree were gathered by collectives the ranks issued in different orders -- the merge below would mix frames
+    if (tags && blockIdx.y == 0) {
+      bool same = true;
+      for (int k = 1; k < n_shards; ++k)
+        same &= tags[(size_t)k * shard_stride] == tags[0] && tags[(size_t)k * shard_stride + 1] == tags[1];
+      if (!same) counts->error = ERR_EXCHANGE;
+    }
   }
   if (gathered) {
     const float* gf = reinterpret_cast<const float*>(gathered);
@@ -462,12 +471,12 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
-                  const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch) {
+                  const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch, const int32_t* tags) {
   hipLaunchKernelGGL(group_kernel, dim3(1, batch ? batch->n : 1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, rmap, n_models, max_m, acc_q, acc_model,
                      m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules,
                      shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q,
-                     batch ? *batch : FrameBatch());
+                     batch ? *batch : FrameBatch(), gathered ? tags : nullptr);
 }
 
 void launch_image_split(const mh_corr* m_corr, const int32_t* m_q, const int32_t* m_model, const int32_t* model_off,

@@ -421,11 +421,7 @@ __global__ void merge_shards_kernel(const int32_t* __restrict__ idx1_s,
 int splits_for(int Q, int N) {
   const int qgroups = (Q + QB - 1) / QB;
   const int n_tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
-  static const int target = [] {
-    const char* e = getenv("MH_MATCH_BLOCKS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : TARGET_BLOCKS_DEFAULT;
-  }();
+  static const int target = std::max(1, exp_int("MH_MATCH_BLOCKS", TARGET_BLOCKS_DEFAULT));
   int S = (target + qgroups - 1) / qgroups;
   if (S >= 8) S = (S + 3) / 8 * 8;  // whole splits per XCD (see match_kernel); to the nearest multiple: fewer, longer workgroups win
   if (S > n_tiles) S = n_tiles;
@@ -463,11 +459,8 @@ void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* 
 // blocks (measured cross-over between 600 and 3000 queries), the VALU one below that.  Both give the
 // same bits.  MH_MATCH_MFMA = 0 / 1 pins the choice (A/B runs).
 bool match_uses_mfma(int q_expected) {
-  static const int pinned = [] {
-    const char* e = getenv("MH_MATCH_MFMA");
-    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-  }();
-  return pinned >= 0 ? pinned == 1 : q_expected >= 1536;
+  static const int pinned = exp_int("MH_MATCH_MFMA", -1);
+  return pinned >= 0 ? pinned != 0 : q_expected >= 1536;
 }
 
 size_t match_scratch_elems(int Q, int N) {

@@ -325,14 +325,8 @@ constexpr int M_TARGET_BLOCKS = 768;
 int mfma_max_splits(int N) { return std::max(1, std::min((N + M_TILE - 1) / M_TILE, M_MAX_SPLITS)); }
 int mfma_splits_for(int Q, int N) {
   const int qblocks = (Q + MQ - 1) / MQ;
-  static const int pinned = [] {
-    const char* e = getenv("MH_MATCH_SPLITS");
-    return e ? atoi(e) : 0;
-  }();
-  static const int target = [] {
-    const char* e = getenv("MH_MATCH_BLOCKS");
-    return e ? atoi(e) : 0;
-  }();
+  static const int pinned = exp_int("MH_MATCH_SPLITS", 0);
+  static const int target = exp_int("MH_MATCH_BLOCKS", 0);
   const int s_max = mfma_max_splits(N);
   if (pinned > 0) return std::min(pinned, s_max);
   int S = ((target > 0 ? target : M_TARGET_BLOCKS) + qblocks - 1) / qblocks;

@@ -51,18 +51,26 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define MH_AS1 __attribute__((address_space(1)))
 #define MH_AS3 __attribute__((address_space(3)))
 
-constexpr int SC_WAVES = 8;                        // one workgroup per CU, two wavefronts per SIMD
-constexpr int SC_THREADS = 64 * SC_WAVES;
-constexpr int SC_QPAD = 3 * 1024;                  // the query image is padded to whole workgroups of every kernel width (256, 512, 768)
+// Wavefronts per workgroup (template parameter NW of the passes): 8 = one workgroup per CU, two of ITS wavefronts per
+// SIMD; 4 = one wavefront per SIMD, so that TWO workgroups share a CU -- the two wavefronts of a SIMD then belong to
+// different workgroups (no common barrier, phases drift apart: one's LDS waits and hit paths sit under the other's MFMAs),
+// and a CU on which a small kernel of another frame holds a few wavefronts still takes one such workgroup (the 8-wavefront
+// shape needs the whole register file of the CU: scripts/cu_trace.py found 21% of all CU time spent with only small
+// workgroups resident and 16-20% with none).  Price: every tile is staged from L2 by twice as many workgroups.
+constexpr int SC_QPAD = 3 * 1024;                  // the query image is padded to whole workgroups of every kernel width
 constexpr int SC_TILE = 128;                       // DB rows per LDS tile (= the DB's row padding)
 constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
-constexpr int SC_RECBUF = 112;                     // hits a wavefront parks in LDS (80 bytes each: the block's 16 values go along) before they go to memory
+// hits a wavefront parks in LDS (80 bytes each: the block's 16 values go along) before they go to memory: 112 with eight
+// wavefronts (the whole workgroup's hits, written out at its end), 40 with four (two workgroups' LDS must fit a CU:
+// 2 x (64 KB tiles + 1.5 KB + 4 x 40 x 80 B) = 156 KB) -- written out whenever the buffer is three quarters full
+constexpr int SC_NW_LARGE = 8;   // wavefronts per workgroup of the four-query-block launches (4 or 8; MH_SCREEN_NW in experiment builds)
+__host__ __device__ constexpr int sc_recbuf(int nw) { return nw >= 8 ? 112 : 40; }
 constexpr int SC_GROUP = 1;                        // tiles per barrier: the wavefronts of a workgroup drift apart within a group
 constexpr int SC_NBUF = 2 * SC_GROUP;              // (a hit costs its wavefront ~300 cycles), every barrier makes seven wait for the slowest
 constexpr int SC_DD = 192;                         // floats per tile of the -dd/2 array: 128 rows, the 4 row blocks' maxima, their minima, padding
 constexpr int SC_LDS_TILES = SC_NBUF * SC_TILE_BYTES + SC_NBUF * SC_DD * 4;   // the tiles + their -dd/2 terms
 constexpr int SC_REC_BYTES = 80;                   // {slot, row0, thr, top, 16 dots}
-constexpr int SC_LDS_BYTES = SC_LDS_TILES + SC_WAVES * SC_RECBUF * SC_REC_BYTES;   // + the wavefronts' hit buffers
+__host__ __device__ constexpr int sc_lds_bytes(int nw) { return SC_LDS_TILES + nw * sc_recbuf(nw) * SC_REC_BYTES; }   // + the wavefronts' hit buffers
 static_assert(SC_TILE == 128 && DIM == 128, "tile image and chunk swizzle assume 128 x 128");
 
 // error model of the screen (see the header comment)
@@ -317,9 +325,11 @@ __device__ __forceinline__ void dma4(unsigned voff, const void* base, unsigned l
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
-template <int MODE, int NQB>
-__global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs A) {
+template <int MODE, int NQB, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void screen_kernel(const ScreenArgs A) {
   MH_TRACE_SCOPE(MODE == 0 ? mh::TK_PASS_A : mh::TK_PASS_B);
+  constexpr int SC_WAVES = NW;
+  constexpr int SC_RECBUF = sc_recbuf(NW);
   constexpr int QW = 32 * NQB;            // queries per wavefront
   constexpr int QB = QW * SC_WAVES;       // queries per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -349,17 +359,22 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
   const int sel_end = min(sel_begin + A.tiles_base + (split < A.tiles_rem ? 1 : 0), A.n_sel);
 
   // ---- staging: one tile = 32 pieces of 1 KB (64 lanes x 16 B, lane-linear in LDS); wavefront w brings pieces
-  // w, w + 8, w + 16, w + 24.  Chunk g = 64 piece + lane of the LDS image is row g >> 4, position g & 15, and holds
-  // source chunk (g & 15) ^ (row & 15); row & 15 = (4 w + (lane >> 4)) & 15 for all four pieces of a wavefront, so one
-  // per-lane offset serves them and the pieces differ by 8 KB in a scalar base.  The rows' -dd/2 terms (512 B per tile)
-  // and the row blocks' extrema (768 B per tile) come the same way: wavefronts 0..2, 4 bytes per lane.
+  // w, w + NW, w + 2 NW, ... (four of them with eight wavefronts, eight with four).  Chunk g = 64 piece + lane of the LDS
+  // image is row g >> 4, position g & 15, and holds source chunk (g & 15) ^ (row & 15); row & 15 = (4 w + (lane >> 4)) & 15
+  // for all pieces of a wavefront (they lie 4 NW rows apart: a multiple of 16), so one per-lane offset serves them and the
+  // pieces differ by NW KB in a scalar base.  The rows' -dd/2 terms (512 B per tile) and the row blocks' extrema (768 B
+  // per tile) come the same way: wavefronts 0..2, 4 bytes per lane.
   const unsigned voff = (unsigned)(wave * 1024 + (lane >> 4) * 256 + (((lane & 15) ^ ((wave * 4 + (lane >> 4)) & 15)) << 4));
   const unsigned voff_dd = (unsigned)((wave * 64 + lane) * 4);
   auto stage = [&](int sel, int buf) {
     const int tile = A.tile_first + sel * A.tile_stride;
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(A.dbh) + (size_t)tile * SC_TILE_BYTES;
     const unsigned l = lds_base + buf * SC_TILE_BYTES + wave * 1024;
-    dma16x4(voff, tb, tb + 8192, tb + 16384, tb + 24576, l, l + 8192, l + 16384, l + 24576);
+    constexpr int STEP = NW * 1024;   // bytes between a wavefront's pieces (the same in the source tile and in LDS)
+#pragma unroll
+    for (int g = 0; g < 32 / NW; g += 4)
+      dma16x4(voff, tb + g * STEP, tb + (g + 1) * STEP, tb + (g + 2) * STEP, tb + (g + 3) * STEP, l + g * STEP, l + (g + 1) * STEP,
+              l + (g + 2) * STEP, l + (g + 3) * STEP);
     if (wave < 3)
       dma4(voff_dd, A.dneg + (size_t)tile * SC_DD, lds_base + SC_NBUF * SC_TILE_BYTES + buf * (SC_DD * 4) + wave * 256);
   };
@@ -463,6 +478,30 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
       emit(acc, nb, row0, top, thr,
            n_parked + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u)));
     n_parked += __popcll(hm);
+  };
+
+  // the parked records to their slots (all lanes in parallel); the buffer is empty afterwards
+  auto flush_parked = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = min(n_parked, SC_RECBUF);
+    for (int j = lane; j < n; j += 64) {
+      const uint4 e = recbuf[5 * j];
+      if (e.x == 0xFFFFFFFFu) continue;
+      v16f v;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 x = recbuf[5 * j + 1 + g];
+        v[4 * g] = __uint_as_float(x.x);
+        v[4 * g + 1] = __uint_as_float(x.y);
+        v[4 * g + 2] = __uint_as_float(x.z);
+        v[4 * g + 3] = __uint_as_float(x.w);
+      }
+      A.recs[e.x] = make_uint2(e.y, record_bits(v, __uint_as_float(e.w), __uint_as_float(e.z)));
+    }
+    __builtin_amdgcn_wave_barrier();   // (everybody has read its entries before the next hit overwrites them)
+    n_parked = 0;
   };
 
   const int swz = l32 & 15;
@@ -586,10 +625,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
 #ifdef SC_PROF
     const unsigned long long t_w0 = __builtin_amdgcn_s_memtime();
 #endif
+    // a small buffer (four-wavefront workgroups) is written out when three quarters full -- behind the tile's wait for the
+    // next tile's pieces, so that the stores' round trip is not in it
+    const bool flush_now = MODE == 1 && NW < 8 && n_parked > SC_RECBUF * 3 / 4;
     if (!SC_ABL(3)) {   // (experiment builds: 8 = no end-of-tile wait and barrier -- what the synchronisation costs)
     if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the next group have landed
     __syncthreads();   // everybody's pieces have; nobody reads this group's buffers any more
     }
+    if (flush_now) flush_parked();
 #ifdef SC_PROF
     t_wait += __builtin_amdgcn_s_memtime() - t_w0;
 #endif
@@ -601,27 +644,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void screen_kernel(const ScreenArgs 
     for (int r = 1; r < 16; ++r) m = fmaxf(m, pend[r]);
     emit_hits(m > tau[NQB - 1] - pend_hi, pend, NQB - 1, pend_row0, m, tau[NQB - 1] - pend_hi);
   }
-  if (MODE == 1) {
-    // the parked records to their slots
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n = min(n_parked, SC_RECBUF);
-    for (int j = lane; j < n; j += 64) {
-      const uint4 e = recbuf[5 * j];
-      if (e.x == 0xFFFFFFFFu) continue;
-      v16f v;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const uint4 x = recbuf[5 * j + 1 + g];
-        v[4 * g] = __uint_as_float(x.x);
-        v[4 * g + 1] = __uint_as_float(x.y);
-        v[4 * g + 2] = __uint_as_float(x.z);
-        v[4 * g + 3] = __uint_as_float(x.w);
-      }
-      A.recs[e.x] = make_uint2(e.y, record_bits(v, __uint_as_float(e.w), __uint_as_float(e.z)));
-    }
-  }
+  if (MODE == 1) flush_parked();
 #ifdef SC_PROF
   if (MODE == 1 && tid == 0) {
     atomicAdd(&g_sc_prof[0], __builtin_amdgcn_s_memtime() - t_start);       // shader cycles of the workgroup
@@ -677,10 +700,13 @@ constexpr int RS_WAVES = 4;          // queries per workgroup
 constexpr int RS_MAXC = 1024;        // candidate rows a query may have before it is searched by brute force
 
 __device__ __forceinline__ float exact_dist(const float* __restrict__ q_lds, const float* __restrict__ row, float nq, float dn) {
+  // 64 bytes x 2 in flight per step: 48 VGPRs, ten wavefronts per SIMD.  (Round 3: the whole 512-byte row in flight before
+  // the chain -- one round trip per row instead of four -- takes 160 VGPRs, three wavefronts per SIMD, and pass C went
+  // from 0.047 to 0.071 ms per 24 000 queries: it lives on the number of queries in flight, not on one query's latency.)
   float s = 0.f;
   const float4* r4 = reinterpret_cast<const float4*>(row);
 #pragma unroll 2
-  for (int c = 0; c < DIM / 16; ++c) {   // 64 bytes x 4 in flight per step
+  for (int c = 0; c < DIM / 16; ++c) {
     const float4 x0 = r4[4 * c], x1 = r4[4 * c + 1], x2 = r4[4 * c + 2], x3 = r4[4 * c + 3];
     const float4 y0 = *reinterpret_cast<const float4*>(q_lds + 16 * c), y1 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 4);
     const float4 y2 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 8), y3 = *reinterpret_cast<const float4*>(q_lds + 16 * c + 12);
@@ -870,10 +896,6 @@ __global__ __launch_bounds__(64) void screen_values_kernel(const _Float16* __res
   for (int r = 0; r < 16; ++r) out[(size_t)(q0 + l32) * n_rows + r0 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
 }
 
-int env_int(const char* name, int def) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : def;
-}
 
 }  // namespace
 
@@ -927,7 +949,7 @@ int screen_max_splits_a() { return 64; }
 // enough rows for pass A's sample to mean something.  MH_MATCH_SCREEN = 0 / 1 pins the choice for the process
 // (A/B runs; bench.py records it), mh_match_set_mode for a context.
 bool screen_wanted(int q_expected, int N, int mode) {
-  static const int pinned = env_int("MH_MATCH_SCREEN", -1);
+  static const int pinned = exp_int("MH_MATCH_SCREEN", -1);
   if (mode < 0) mode = pinned;
   if (mode == 0 || N < 4096) return false;
   if (mode == 1) return true;
@@ -936,13 +958,17 @@ bool screen_wanted(int q_expected, int N, int mode) {
 
 namespace {
 
-template <int NQB>
+template <int NQB, int NW>
 void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blocks_a, int blocks_b, int* n_slots_out,
-                   hipEvent_t* ev, hipStream_t s) {
-  constexpr int QB = 32 * NQB * SC_WAVES;
+                   hipEvent_t* ev, hipStream_t s, int cu_avail) {
+  constexpr int QB = 32 * NQB * NW;
+  constexpr int SC_THREADS = 64 * NW, SC_LDS_BYTES = sc_lds_bytes(NW);
   static DynLds attr0, attr1;
-  attr0.ensure(screen_kernel<0, NQB>, SC_LDS_BYTES);
-  attr1.ensure(screen_kernel<1, NQB>, SC_LDS_BYTES);
+  attr0.ensure(screen_kernel<0, NQB, NW>, SC_LDS_BYTES);
+  attr1.ensure(screen_kernel<1, NQB, NW>, SC_LDS_BYTES);
+  // (the workgroup targets below are in units of eight wavefronts: a four-wavefront grid has twice the workgroups)
+  blocks_a *= 8 / NW;
+  (void)cu_avail;
   const int nqb = (Q + QB - 1) / QB;        // the grid covers the capacity ...
   const int nqb_e = (qe + QB - 1) / QB;     // ... the splits are sized for the queries expected
   auto splits_for = [&](int n_sel, int target, int s_max) {
@@ -965,19 +991,20 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   a.tiles_base = n_sel_a / Sa;
   a.tiles_rem = n_sel_a % Sa;
   a.n_splits_a = Sa;
-  hipLaunchKernelGGL((screen_kernel<0, NQB>), dim3(nqb * Sa), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((screen_kernel<0, NQB, NW>), dim3(nqb * Sa), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
   if (ev) hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(screen_tau_kernel, dim3((a.q_pad + 255) / 256), dim3(256), 0, s, a.part, Sa, a.q_pad, a.Q, a.q_count,
                      a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
   if (ev) hipEventRecord(ev[3], s);
   // pass B: all tiles; a query's record slots are shared out over 2 x Sb lane-private sub-lists
-  static const int sb_pin = env_int("MH_SCREEN_SPLITS_B", 0);   // experiments
+  static const int sb_pin = exp_int("MH_SCREEN_SPLITS_B", 0);   // experiments
   // Twice as many workgroups as CUs when every one of them still sweeps >= 24 tiles: two rounds of half-length
   // workgroups finish more evenly than one round of ~240 (pass B alone 0.272 -> 0.261 ms at Q = 12000, N = 100k), and
   // under load a one-round grid stalls on every CU another frame's kernel holds (+5% frames/s at config 1, +3% at
   // config 2).  With fewer tiles per workgroup the query-operand prologue costs more than that (Q = 3000: 0.445 ->
   // 0.394 of peak), so small launches keep one workgroup per CU.
-  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
+  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e * NW / 8 >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
+  blocks_b *= 8 / NW;
   const int Sb = sb_pin > 0 ? std::min(std::min(sb_pin, n_tiles), SC_SLOTS_MAX / 2)
                             : splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 2);
   a.n_sel = n_tiles;
@@ -988,7 +1015,7 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   a.tiles_rem = n_tiles % Sb;
   // (few splits = long sub-streams: a lane sees many of its query's candidates, its sub-list must hold them)
   a.sub_cap = std::max(1, std::min(48, SC_SLOTS_MAX / (2 * Sb)));
-  hipLaunchKernelGGL((screen_kernel<1, NQB>), dim3(nqb * Sb), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((screen_kernel<1, NQB, NW>), dim3(nqb * Sb), dim3(SC_THREADS), SC_LDS_BYTES, s, a);
   if (ev) hipEventRecord(ev[4], s);
   *n_slots_out = 2 * Sb * a.sub_cap;
 }
@@ -998,10 +1025,10 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
 void launch_match_screen(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
                          const RowMap& rmap, const ScreenDb& sdb, const ScreenBufs& sb, int32_t* idx1, float* d1,
                          float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
-  static const int sample = std::max(1, env_int("MH_SCREEN_SAMPLE", 8));      // pass A looks at every `sample`-th tile
-  static const int blocks_b = std::max(0, env_int("MH_SCREEN_BLOCKS", 0));    // workgroups of pass B; 0 = by size (launch_passes)
-  static const int blocks_a = std::max(1, env_int("MH_SCREEN_BLOCKS_A", 256));
-  static const int nqb_pin = env_int("MH_SCREEN_NQB", 0);
+  static const int sample = std::max(1, exp_int("MH_SCREEN_SAMPLE", 8));      // pass A looks at every `sample`-th tile
+  static const int blocks_b = std::max(0, exp_int("MH_SCREEN_BLOCKS", 0));    // workgroups of pass B; 0 = by size (launch_passes)
+  static const int blocks_a = std::max(1, exp_int("MH_SCREEN_BLOCKS_A", 256));
+  static const int nqb_pin = exp_int("MH_SCREEN_NQB", 0);
   const int q_pad = screen_q_pad(Q);
   const int qe = (q_expected > 0 && q_expected < Q) ? std::max(q_expected, std::min(Q, 256)) : Q;
   const int n_tiles = (N + SC_TILE - 1) / SC_TILE;
@@ -1009,7 +1036,14 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   if (sb.ev) hipEventRecord(sb.ev[0], s);
   hipLaunchKernelGGL(screen_prepare_kernel, dim3((q_pad * 16 + 255) / 256), dim3(256), 0, s, qn, qnorm, Q, q_count, q_pad,
                      sb.qh, sb.qbad);
-  if (sb.ev) hipEventRecord(sb.ev[1], s);
+  // the lane: everything from pass A to pass B on its stream, handed over by events
+  hipStream_t sbig = s;
+  if (sb.big && sb.ev_in && sb.ev_out) {
+    hipEventRecord(sb.ev_in, s);
+    hipStreamWaitEvent(sb.big, sb.ev_in, 0);
+    sbig = sb.big;
+  }
+  if (sb.ev) hipEventRecord(sb.ev[1], sbig);
   ScreenArgs a;
   a.qh = sb.qh;
   a.dbh = sdb.dbh;
@@ -1040,10 +1074,19 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   if (qe >= 2048 && (long)n_tiles * ((qe + 1023) / 1024) >= 16L * 256) nqb_sel = 4;
   if (nqb_pin >= 1 && nqb_pin <= 4) nqb_sel = nqb_pin;
   int n_slots = 0;
-  if (nqb_sel == 4) launch_passes<4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
-  else if (nqb_sel == 3) launch_passes<3>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
-  else if (nqb_sel == 2) launch_passes<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
-  else launch_passes<1>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, s);
+  // wavefronts per workgroup: four (two workgroups share a CU) for the large launches, see the top of the file
+  static const int nw_pin = exp_int("MH_SCREEN_NW", 0);
+  const int nw_sel = nw_pin == 4 || nw_pin == 8 ? nw_pin : (nqb_sel == 4 ? SC_NW_LARGE : 8);
+  if (nqb_sel == 4 && nw_sel == 4) launch_passes<4, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  else if (nqb_sel == 4) launch_passes<4, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  else if (nqb_sel == 3) launch_passes<3, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  else if (nqb_sel == 2 && nw_sel == 4) launch_passes<2, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  else if (nqb_sel == 2) launch_passes<2, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  else launch_passes<1, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  if (sbig != s) {
+    hipEventRecord(sb.ev_out, sbig);
+    hipStreamWaitEvent(s, sb.ev_out, 0);
+  }
   // pass C
   hipLaunchKernelGGL(rescore_kernel, dim3((Q + RS_WAVES - 1) / RS_WAVES), dim3(64 * RS_WAVES), 0, s, qn, qnorm, sb.qbad, Q,
                      q_count, db, dnorm, N, rmap, sb.recs, n_slots, sb.ovf_cnt, sb.ovf, sb.ovf_cap, sdb.dmax, (const float*)sb.tau, sdb.spread, idx1, d1, d2,

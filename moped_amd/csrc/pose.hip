@@ -47,9 +47,12 @@ namespace {
 #define MH_POSE_THREADS 256
 #endif
 constexpr int POSE_THREADS = MH_POSE_THREADS;
-// wavefronts of this kernel that must fit a SIMD together (the register cap: 512 / this)
+// Wavefronts of this kernel that must fit a SIMD together = the register cap (512 / this).  Round 3: the kernel had grown
+// to 260 registers (256 + 4 AGPRs) -- ONE wavefront per SIMD, one POSE workgroup per compute unit, where the 256-thread
+// shape above was chosen so that two share a unit (mh_pose_kernel_info reports what the runtime sees).  Capped at 256
+// (no spills): config 1 10 870 -> 12 020 frames/s, objects unchanged.
 #ifndef MH_POSE_MIN_WAVES
-#define MH_POSE_MIN_WAVES 1
+#define MH_POSE_MIN_WAVES 2
 #endif
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
@@ -1080,10 +1083,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
-  static const bool repass = [] {
-    const char* e = getenv("MH_POSE_REPASS");
-    return !(e && e[0] == '0');
-  }();
+  static const bool repass = exp_int("MH_POSE_REPASS", 1) != 0;
   if (p.lm_iters_l2 < 0) p.lm_iters_l2 = 0;
   if (!repass) p.lm_iters_l2 = p.lm_iters_l2 > 0 ? -p.lm_iters_l2 : -1;
   const float4* d4 = reinterpret_cast<const float4*>(depth4);

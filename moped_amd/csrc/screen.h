@@ -30,6 +30,11 @@ struct ScreenBufs {
   uint2* ovf = nullptr;            // [q_pad][ovf_cap]
   int ovf_cap = 0, q_pad = 0;
   hipEvent_t* ev = nullptr;        // optional [6]: recorded around prepare / pass A / thresholds / pass B / pass C (mh_match_timing)
+  // optional lane (mh_lane_create): passes A and B -- the kernels whose workgroups need whole compute units -- run on
+  // `big` (a stream confined to a CU mask, or of lower priority) between two event hand-offs; the small kernels stay on
+  // the context's stream
+  hipStream_t big = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
   unsigned int* stats = nullptr;   // optional [q_pad][3] per-query tallies: candidate rows, brute-force searches, searches
 };
 

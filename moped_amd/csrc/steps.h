@@ -12,6 +12,7 @@ enum : int32_t {
   ERR_CLUSTER_CAP = 2,   // more clusters than reserved
   ERR_OBJECT_CAP = 4,    // more objects than reserved
   ERR_POSE_CAP = 8,      // a cluster had more than POSE_MAX_PTS points (truncated)
+  ERR_EXCHANGE = 16,     // the ranks' blocks of a frame exchange carry different tags: collectives issued in different orders
 };
 
 // ---- the frames of a batch in ONE launch per stage ------------------------------------
@@ -102,7 +103,9 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
                   const DepthRules& rules = DepthRules(), int shard_stride = 0 /* words between shard blocks; 0 = 3 Q */,
                   int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */,
-                  const FrameBatch* batch = nullptr);
+                  const FrameBatch* batch = nullptr,
+                  const int32_t* tags = nullptr /* optional: shard k's two tag words at tags + k * shard_stride (comm.hip); all
+                                                   shards must carry the same, else counts->error |= ERR_EXCHANGE */);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s, const int32_t* img = nullptr);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);

@@ -1,0 +1,197 @@
+// moped_hip_bench -- the frame loop of MopedPimpl::processImages (moped2/libmoped/src/moped.cpp:166-194) for a C++ host
+// that keeps frames in flight: no Python, no torch, nothing but libmoped_hip.so's C ABI and the HIP runtime's memory /
+// stream calls.  `slots` contexts share ONE copy of the model database (mh_db_share), each carries batches of `batch`
+// frames through mh_frame_enqueue_batch on its own stream; the frames' descriptors start in PINNED HOST memory (one
+// hipMemcpyAsync per batch on the slot's stream) or, for the resident figure, in device memory; objects come back
+// through mh_frame_fetch_slot.  Also: the latency of ONE frame alone (copy + mh_frame_enqueue + mh_frame_fetch).
+//
+//   moped_hip_bench frames.bin [--slots 16] [--batch 8] [--steps 10] [--frames-per-step 1024] [--json]
+//
+// frames.bin (little endian, scripts/dump_scene.py dump_frames):
+//   int32 n_models, Q, n_frames ; float K[4] ; float cam[7]
+//   per model: int32 n_pts ; float xyz[n_pts][3] ; float desc[n_pts][128]
+//   per frame: float q_uv[Q][2] ; float q_desc[Q][128]
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "moped_hip.h"
+
+using std::vector;
+
+#define CK_HIP(x)                                                                         \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      std::fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_));                      \
+      return 4;                                                                           \
+    }                                                                                     \
+  } while (0)
+#define CK_MH(ctx, x)                                                                     \
+  do {                                                                                    \
+    int rc_ = (x);                                                                        \
+    if (rc_ != MH_OK) {                                                                   \
+      std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, (ctx) ? mh_last_error(ctx) : "?");  \
+      return 4;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+template <typename T>
+static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv) {
+  // one hardware queue per slot: the HIP runtime reads this when it creates its queues
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  if (argc < 2) {
+    std::fprintf(stderr, "usage: %s frames.bin [--slots N] [--batch B] [--steps K] [--frames-per-step F] [--json]\n", argv[0]);
+    return 2;
+  }
+  int slots = 16, B = 8, steps = 10, frames_per_step = 1024;
+  bool json = false;
+  for (int i = 2; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--slots" && i + 1 < argc) slots = std::atoi(argv[++i]);
+    else if (a == "--batch" && i + 1 < argc) B = std::atoi(argv[++i]);
+    else if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
+    else if (a == "--frames-per-step" && i + 1 < argc) frames_per_step = std::atoi(argv[++i]);
+    else if (a == "--json") json = true;
+  }
+  if (slots < 1 || slots > 64 || B < 1 || B > MH_MAX_BATCH || steps < 1) return 2;
+
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) { std::perror(argv[1]); return 2; }
+  int32_t nm = 0, Q = 0, n_frames = 0;
+  mh_cam cam;
+  if (!rd(f, &nm, 1) || !rd(f, &Q, 1) || !rd(f, &n_frames, 1) || !rd(f, cam.K, 4) || !rd(f, cam.cam, 7)) return 2;
+  vector<float> desc, xyz;
+  vector<int32_t> model_of;
+  for (int m = 0; m < nm; ++m) {
+    int32_t n = 0;
+    if (!rd(f, &n, 1)) return 2;
+    const size_t r0 = model_of.size();
+    xyz.resize((r0 + n) * 3);
+    desc.resize((r0 + n) * 128);
+    if (!rd(f, &xyz[r0 * 3], (size_t)n * 3) || !rd(f, &desc[r0 * 128], (size_t)n * 128)) return 2;
+    model_of.insert(model_of.end(), n, m);
+  }
+  const int N = (int)model_of.size();
+  n_frames = n_frames / B * B;
+  if (n_frames < B) { std::fprintf(stderr, "the file holds fewer frames than one batch\n"); return 2; }
+  // the frames: keypoints to the device once, descriptors to pinned host memory (batch after batch)
+  float *h_desc = 0, *h_uv = 0;
+  const size_t fd = (size_t)Q * 128, fu = (size_t)Q * 2;
+  CK_HIP(hipHostMalloc(&h_desc, fd * n_frames * 4, hipHostMallocDefault));
+  h_uv = (float*)std::malloc(fu * n_frames * 4);
+  for (int i = 0; i < n_frames; ++i)
+    if (!rd(f, h_uv + fu * i, fu) || !rd(f, h_desc + fd * i, fd)) return 2;
+  std::fclose(f);
+
+  // contexts: one database for all (MATCH_ANN_CPU::Update once, src/match/MATCH_ANN_CPU.hpp:72-109)
+  vector<mh_ctx*> ctx(slots, (mh_ctx*)0);
+  vector<hipStream_t> stream(slots, (hipStream_t)0);
+  if (mh_create(0, &ctx[0]) != MH_OK) { std::fprintf(stderr, "no gfx950 device\n"); return 3; }
+  for (int s = 0; s < slots; ++s) {
+    if (s && mh_create(0, &ctx[s]) != MH_OK) return 3;
+    CK_HIP(hipStreamCreateWithFlags(&stream[s], hipStreamNonBlocking));
+    CK_MH(ctx[s], mh_set_stream(ctx[s], stream[s]));
+    if (s == 0) CK_MH(ctx[0], mh_db_upload_raw(ctx[0], &desc[0], &model_of[0], &xyz[0], N, nm, 0, 1));
+    else CK_MH(ctx[s], mh_db_share(ctx[s], ctx[0]));
+    CK_MH(ctx[s], mh_reserve_batch(ctx[s], Q, B, 1024, 4096));
+  }
+  const int pool_groups = n_frames / B;
+  float* d_uv = 0;          // [n_frames][Q][2], resident
+  float* d_pristine = 0;    // [n_frames][Q][128], resident copy for the "inputs in HBM" figure
+  CK_HIP(hipMalloc(&d_uv, fu * n_frames * 4));
+  CK_HIP(hipMalloc(&d_pristine, fd * n_frames * 4));
+  CK_HIP(hipMemcpy(d_uv, h_uv, fu * n_frames * 4, hipMemcpyHostToDevice));
+  CK_HIP(hipMemcpy(d_pristine, h_desc, fd * n_frames * 4, hipMemcpyHostToDevice));
+  vector<float*> work(slots, (float*)0);
+  for (int s = 0; s < slots; ++s) CK_HIP(hipMalloc(&work[s], fd * B * 4));
+  mh_frame_params prm;
+  mh_frame_default_params(&prm);
+
+  const int groups = std::max(pool_groups, frames_per_step / B);
+  vector<uint64_t> seeds(B);
+  vector<int> last_pg(slots, -1);
+  // one step = `groups` batches, round-robin over the slots; from_host: the descriptors cross PCIe inside the loop
+  auto run_step = [&](int step, bool from_host) -> int {
+    for (int g = 0; g < groups; ++g) {
+      const int s = (step * groups + g) % slots, pg = g % pool_groups;
+      const float* src = (from_host ? h_desc : d_pristine) + fd * B * pg;
+      CK_HIP(hipMemcpyAsync(work[s], src, fd * B * 4, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream[s]));
+      for (int k = 0; k < B; ++k) seeds[k] = 1000ull * (uint64_t)(step + 7) + (uint64_t)g * B + k + 1;
+      CK_MH(ctx[s], mh_frame_enqueue_batch(ctx[s], work[s], d_uv + fu * B * pg, Q, B, &cam, &prm, &seeds[0]));
+      last_pg[s] = pg;
+    }
+    return 0;
+  };
+  auto sync_all = [&]() -> int {
+    for (int s = 0; s < slots; ++s) CK_HIP(hipStreamSynchronize(stream[s]));
+    return 0;
+  };
+  double fps[2] = {0, 0};
+  for (int mode = 0; mode < 2; ++mode) {   // 0: inputs resident in HBM, 1: descriptors from pinned host memory
+    for (int w = 0; w < 3; ++w)
+      if (int rc = run_step(-1 - w, mode == 1)) return rc;
+    if (int rc = sync_all()) return rc;
+    const double t0 = now_s();
+    for (int k = 0; k < steps; ++k)
+      if (int rc = run_step(k, mode == 1)) return rc;
+    if (int rc = sync_all()) return rc;
+    fps[mode] = (double)steps * groups * B / (now_s() - t0);
+  }
+  // objects of every slot's last batch
+  long objects = 0, frames_counted = 0;
+  vector<mh_object> objs(4096);
+  for (int s = 0; s < slots; ++s) {
+    if (last_pg[s] < 0) continue;
+    for (int k = 0; k < B; ++k) {
+      int32_t n = 0, counts[4];
+      CK_MH(ctx[s], mh_frame_fetch_slot(ctx[s], k, &objs[0], (int)objs.size(), &n, counts));
+      objects += n;
+      ++frames_counted;
+    }
+  }
+  // one frame alone: pinned host descriptors -> objects on the host
+  vector<double> lat;
+  for (int i = 0; i < 60; ++i) {
+    const int fi = i % n_frames;
+    const double t0 = now_s();
+    CK_HIP(hipMemcpyAsync(work[0], h_desc + fd * fi, fd * 4, hipMemcpyHostToDevice, stream[0]));
+    CK_MH(ctx[0], mh_frame_enqueue(ctx[0], work[0], d_uv + fu * fi, Q, &cam, &prm, 77 + i));
+    int32_t n = 0, counts[4];
+    CK_MH(ctx[0], mh_frame_fetch(ctx[0], &objs[0], (int)objs.size(), &n, counts));
+    if (i >= 10) lat.push_back(now_s() - t0);
+  }
+  std::sort(lat.begin(), lat.end());
+  const double lat_ms = 1e3 * lat[lat.size() / 2];
+  const double opf = frames_counted ? (double)objects / frames_counted : 0.0;
+  if (json)
+    std::printf("{\"host\": \"moped_hip_bench (C++, C ABI only)\", \"slots\": %d, \"frames_per_batch\": %d, \"steps\": %d, "
+                "\"frames_per_step\": %d, \"fps_resident\": %.2f, \"fps_pinned_host\": %.2f, \"single_frame_latency_ms\": %.4f, "
+                "\"objects_per_frame\": %.3f, \"models\": %d, \"rows\": %d, \"queries\": %d}\n",
+                slots, B, steps, groups * B, fps[0], fps[1], lat_ms, opf, nm, N, Q);
+  else
+    std::printf("slots %d x %d frames: %.0f frames/s (inputs in HBM), %.0f frames/s (descriptors from pinned host memory); one "
+                "frame alone %.3f ms; %.2f objects per frame\n", slots, B, fps[0], fps[1], lat_ms, opf);
+  for (int s = 0; s < slots; ++s) {
+    hipFree(work[s]);
+    mh_destroy(ctx[s]);
+    hipStreamDestroy(stream[s]);
+  }
+  hipFree(d_uv);
+  hipFree(d_pristine);
+  hipHostFree(h_desc);
+  std::free(h_uv);
+  return 0;
+}

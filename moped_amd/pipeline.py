@@ -79,7 +79,7 @@ class FramePipeline:
 
     def __init__(self, device: int, db: ShardedDB, depth: int = 1, max_queries: int = 4096,
                  params: capi.mh_frame_params | None = None, K=None, cam=None, group=None,
-                 force_exchange: bool = False, n_comms: int = 4):
+                 force_exchange: bool = False, n_comms: int = 4, batch: int = 1, lane: "tuple | None" = None):
         from . import synth
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -101,10 +101,19 @@ class FramePipeline:
                 db.upload(c, normalized)
             else:
                 c.db_share(self.ctxs[0])   # one store per GPU: every frame in flight searches the same copy
-            c.reserve(max_queries)
+            if batch > 1:   # frames travel in batches: per-frame working arrays, `batch` copies (mh_reserve_batch)
+                c.reserve_batch(-(-max_queries // batch), batch)
+            else:
+                c.reserve(max_queries)
             self.ctxs.append(c)
             self.streams.append(s)
         self.depth = depth
+        # lane = (n_streams, reserve_cus_per_xcd, low_priority): the contexts' chip-filling MATCH passes on shared streams
+        self.lane = None
+        if lane:
+            self.lane = capi.Lane(device, *lane)
+            for c in self.ctxs:
+                c.set_lane(self.lane)
         self.exchange = force_exchange or self.world > 1
         self.comms = []
         if self.exchange:
@@ -217,6 +226,9 @@ class FramePipeline:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+        if self.lane is not None:
+            self.lane.close()
+            self.lane = None
 
 
 def exchange_top2(local: torch.Tensor, world: int, group=None) -> torch.Tensor:

@@ -70,6 +70,8 @@ L.mh_trace_enable(0)
 print(f"{models} models, {B} frames per batch, {depth} slots, {batches} batches ({mode}): {batches * B / dt:.0f} frames/s traced, "
       f"{fps_untraced:.0f} untraced; {n} workgroup records")
 r = buf[:min(n, buf.shape[0])]
+if os.environ.get("CU_TRACE_SAVE"):
+    np.save(os.environ["CU_TRACE_SAVE"], r)
 kid = (r[:, 0] >> np.uint64(32)).astype(np.int64)
 hw = (r[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 xcc = (r[:, 1] & np.uint64(0xF)).astype(np.int64)

@@ -24,6 +24,24 @@ def dump(path, db, frame, K=synth.K_DEFAULT, cam=synth.CAM_IDENTITY):
         f.write(frame.desc.astype("<f4").tobytes())
 
 
+def dump_frames(path, db, frames, K=synth.K_DEFAULT, cam=synth.CAM_IDENTITY):
+    """Models + several frames of the same query count (moped_hip_bench: the streaming C++ host)."""
+    Q = frames[0].desc.shape[0]
+    assert all(f.desc.shape[0] == Q for f in frames)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", db.n_models, Q, len(frames)))
+        f.write(np.asarray(K, "<f4").tobytes())
+        f.write(np.asarray(cam, "<f4").tobytes())
+        for m in range(db.n_models):
+            rows = np.nonzero(db.model_of == m)[0]
+            f.write(struct.pack("<i", len(rows)))
+            f.write(db.xyz[rows].astype("<f4").tobytes())
+            f.write(db.desc[rows].astype("<f4").tobytes())
+        for fr in frames:
+            f.write(fr.uv.astype("<f4").tobytes())
+            f.write(fr.desc.astype("<f4").tobytes())
+
+
 def dump_images(path, db, frame, images, q_image):
     """Frame with several Images (moped_hip_test --images): images = [(is_map, K[4], cam[7]), ...] in
     FrameData::images order, q_image[Q] = list index of every feature's image."""

@@ -128,3 +128,82 @@ def test_comm_argument_errors(scene):
     with pytest.raises(capi.MhError):
         c.frame_previous_objects(0)                     # no sharded frame yet
     c.close()
+
+
+def _two_ranks_as_threads(db, fr, seeds_by_rank, batch=1):
+    """Two shard contexts on this one device, one Python thread each, over the host transport; -> per rank either the
+    gathered objects or the MhError the fetch raised."""
+    import threading
+    import torch
+    from moped_amd.pipeline import ShardedDB
+    dev = torch.device("cuda:0")
+    world = 2
+    board, cv = {"n": 0, "round": 0, "blocks": [None] * world}, threading.Condition()
+
+    def allgather_for(rank):
+        def fn(blob):
+            with cv:
+                my_round = board["round"]
+                board["blocks"][rank] = blob
+                board["n"] += 1
+                if board["n"] == world:
+                    board["out"] = b"".join(board["blocks"])
+                    board["n"] = 0
+                    board["round"] += 1
+                    cv.notify_all()
+                else:
+                    cv.wait_for(lambda: board["round"] != my_round, timeout=60)
+                return board["out"]
+        return fn
+
+    out = [None] * world
+
+    def run(rank):
+        try:
+            c = capi.Context(0)
+            sh = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world)
+            sh.upload(c, c.normalize(sh.desc))
+            c.reserve_batch(Q, batch)
+            comm = capi.Comm.create_host(c, rank, world, allgather_for(rank))
+            qd = torch.from_numpy(np.concatenate([fr.desc] * batch)).to(dev)
+            uv = torch.from_numpy(np.concatenate([fr.uv] * batch)).to(dev)
+            prm = capi.default_frame_params()
+            c.frame_enqueue_sharded_batch(comm, qd.data_ptr(), uv.data_ptr(), Q, batch, synth.K_DEFAULT, synth.CAM_IDENTITY, prm,
+                                          seeds_by_rank[rank])
+            try:
+                c.frame_fetch_slot(0)
+                out[rank] = c.frame_gather_objects(comm, 0)
+            except capi.MhError as e:
+                out[rank] = e
+                try:
+                    c.frame_gather_objects(comm, 0)    # (the other rank may be waiting in its gather)
+                except capi.MhError:
+                    pass
+            comm.close()
+            c.close()
+        except Exception as e:   # pragma: no cover - reported by the assertion below
+            out[rank] = e
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    return out
+
+
+def test_python_two_ranks_as_threads(scene, single):
+    db, fr, _ = scene
+    out = _two_ranks_as_threads(db, fr, [[7], [7]])
+    assert all(isinstance(o, np.ndarray) for o in out), out
+    assert _same(out[0], single[0]) and _same(out[1], single[0])
+
+
+def test_ranks_that_disagree_on_the_frame_fail_loudly(scene):
+    """Every block of a frame exchange carries (sequence number on its communicator, frame seed): ranks whose
+    collectives pair up differently -- here: rank 1 believes it is exchanging another frame -- get an error at fetch,
+    not a silently mixed frame (several communicators in flight are only correct if every rank issues its
+    collectives in the same order)."""
+    db, fr, _ = scene
+    out = _two_ranks_as_threads(db, fr, [[7], [8]])
+    assert all(isinstance(o, capi.MhError) for o in out), out
+    assert "different orders" in str(out[0])

@@ -125,9 +125,53 @@ def test_frame_with_two_cameras_matches_oracle(scene):
     pipe.close()
 
 
-def test_batches_refuse_per_query_frame_attributes(scene):
-    """The image index (like depth attributes) belongs to the queries of ONE frame: mh_frame_enqueue_batch says so
-    instead of reading it past the first frame."""
+def test_batch_of_two_camera_frames_equals_the_frames_alone(scene):
+    """Frames with several images through mh_frame_enqueue_batch (round 3): the per-query image index lies frame
+    after frame like the queries; per-image clustering and per-match cameras apply to every frame of the batch
+    (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195, POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:213-237) -- every frame's objects
+    are bit for bit what mh_frame_enqueue gives it alone."""
+    import torch
+    s = scene
+    db, fr = s["db"], s["fr"]
+    dev = torch.device("cuda:0")
+    Q = len(fr.uv)
+    # a second and third frame: the same rig, the image index of half of image 1's keypoints flipped / all on image 0
+    rng = np.random.default_rng(4)
+    img2 = fr.image.copy()
+    flip = np.nonzero(fr.image == 1)[0]
+    img2[rng.choice(flip, len(flip) // 2, replace=False)] = 0
+    imgs = [fr.image, img2, np.zeros_like(fr.image)]
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    c.reserve(3 * Q)
+    prm = capi.default_frame_params()
+    alone = []
+    for f, im in enumerate(imgs):
+        q_img = torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+        c.frame_set_images(q_img.data_ptr(), fr.Ks, fr.cams)
+        qd, uv = torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev)
+        c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), Q, fr.Ks[0], fr.cams[0], prm, 30 + f)
+        alone.append(c.frame_fetch())
+    assert alone[0][1][1] != alone[2][1][1]          # the image index matters: other clusters with one image
+    q_img = torch.from_numpy(np.concatenate(imgs)).to(dev)
+    c.frame_set_images(q_img.data_ptr(), fr.Ks, fr.cams)
+    qd = torch.from_numpy(np.concatenate([fr.desc] * 3)).to(dev)
+    uv = torch.from_numpy(np.concatenate([fr.uv] * 3)).to(dev)
+    c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 3, fr.Ks[0], fr.cams[0], prm, [30, 31, 32])
+    for f in range(3):
+        o, cnt = c.frame_fetch_slot(f)
+        a, ac = alone[f]
+        assert np.array_equal(cnt, ac), (f, cnt, ac)
+        assert len(o) == len(a) >= 1 and np.array_equal(o["model"], a["model"])
+        assert np.array_equal(o["pose"].view(np.uint32), a["pose"].view(np.uint32))
+        assert np.array_equal(o["score"].view(np.uint32), a["score"].view(np.uint32))
+    c.frame_set_images(0)
+    c.close()
+
+
+def test_batches_take_the_image_index_frame_after_frame_and_still_refuse_one_depth_map(scene):
+    """A depth map belongs to ONE frame: mh_frame_enqueue_batch says so (mh_frame_set_depth_image_batch hands in one
+    per frame) instead of applying the first frame's map to all."""
     import torch
     s = scene
     db, fr = s["db"], s["fr"]
@@ -136,13 +180,13 @@ def test_batches_refuse_per_query_frame_attributes(scene):
     c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
     Q = len(fr.uv)
     c.reserve(2 * Q)
-    q_img = torch.from_numpy(fr.image).to(dev)
-    c.frame_set_images(q_img.data_ptr(), fr.Ks, fr.cams)
     qd = torch.from_numpy(np.concatenate([fr.desc, fr.desc])).to(dev)
     uv = torch.from_numpy(np.concatenate([fr.uv, fr.uv])).to(dev)
+    depth = torch.zeros(480 * 640 * 4, dtype=torch.float32, device=dev)
+    c.frame_set_depth_image(depth.data_ptr(), 0, 640, 480, 1)
     with pytest.raises(capi.MhError):
         c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, fr.Ks[0], fr.cams[0], capi.default_frame_params(), [1, 2])
-    c.frame_set_images(0)
+    c.frame_set_depth_image(0, 0, 640, 480, 0)
     c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, 2, fr.Ks[0], fr.cams[0], capi.default_frame_params(), [1, 2])
     o0, _ = c.frame_fetch_slot(0)
     o1, _ = c.frame_fetch_slot(1)
