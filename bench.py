@@ -448,6 +448,8 @@ class Job:
             for slot in sorted(self.last_slots):
                 objs = pipe.flush_objects_batch(slot, B) if pipe.exchange else [r[0] for r in pipe.fetch_batch(slot, B)]
                 per += [len(o) for o in objs]
+            self.detections_detail = {"frames": len(per), "min": int(min(per)) if per else 0, "max": int(max(per)) if per else 0,
+                                      "histogram": np.bincount(per, minlength=3).tolist() if per else []}
             return float(np.mean(per)) if per else 0.0
         if not pipe.exchange:
             return float(self.counts_host.float().mean().item())
@@ -642,7 +644,7 @@ def main():
             det2 = j2.detections_per_frame()
             out["replicated_frames"] = {"value": round(j2.total_frames(sec_steps) / dt2, 2), "unit": "frames/s", "steps": sec_steps,
                                         "parallelism": f"frame-parallel x{world} (DB replicated)", "scaling": "weak",
-                                        "objects_per_frame": det2,
+                                        "objects_per_frame": det2, "objects_detail": getattr(j2, "detections_detail", None),
                                         "note": "SURVEY 8(e)'s alternative for a DB too small to shard: no collective, every rank "
                                                 "its own frames; a reported figure, not `value`"}
             j2.close()

@@ -141,7 +141,7 @@ float mh_screen_margin(float qq, float dmax);
  *   mh_screen_values        the screen value of every (query, row) pair for Q queries (a multiple of 32; host, [Q][128],
  *                           as the caller normalised them) against the first n_rows rows (a multiple of 32) of the
  *                           uploaded DB, computed on the device by pass A's arithmetic -- f16 operands, accumulator
- *                           seeded with -dot(d,d)/2, eight v_mfma_f32_32x32x16_f16 in ascending k -- so that the error
+ *                           seeded with -dot(d,d)/2, the block's f16 MFMAs in ascending k (either shape) -- so that the error
  *                           model can be held against what the HARDWARE's matrix pipe accumulates, not an emulation of
  *                           it; *dmax / *spread (optional) = the DB statistics the thresholds use.  The DB needs an
  *                           f16 image (>= 4096 rows).
@@ -150,7 +150,8 @@ float mh_screen_margin(float qq, float dmax);
  *   mh_screen_record_bounds what pass C concludes from it: *hi >= the largest screen value among the record's rows,
  *                           *lo <= it (or -inf); it drops the record when hi < (second largest lo) - mh_screen_margin.
  *                           Host arithmetic, the same inline function the kernel runs. */
-int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread);
+int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread,
+                     int shape /* 0 = the MFMA shape the large launches use, 1 = 32x32x16, 2 = 16x16x32 */);
 uint16_t mh_screen_record_value(float top, float thr);
 void mh_screen_record_bounds(uint16_t value_bits, uint32_t row0, float tau, float spread, int N, float dmax, float* lo,
                              float* hi);

@@ -249,7 +249,7 @@ def load():
     L.mh_frame_fetch_matches_slot.argtypes = [vp, i32, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_enqueue_rest_frames.argtypes = [vp, vp, i32, vp, i32, i32, i32, i32, C.POINTER(mh_cam),
                                                C.POINTER(mh_frame_params), C.POINTER(C.c_uint64)]
-    L.mh_screen_values.argtypes = [vp, vp, i32, i32, vp, C.POINTER(f32), C.POINTER(f32)]
+    L.mh_screen_values.argtypes = [vp, vp, i32, i32, vp, C.POINTER(f32), C.POINTER(f32), i32]
     L.mh_screen_record_value.argtypes = [f32, f32]
     L.mh_screen_record_value.restype = C.c_uint16
     L.mh_screen_record_bounds.argtypes = [C.c_uint16, C.c_uint32, f32, f32, i32, f32, C.POINTER(f32), C.POINTER(f32)]
@@ -502,13 +502,14 @@ class Context:
         self._ck(self.L.mh_match_timing(self.h, _ptr(t)), "mh_match_timing")
         return dict(zip(("prepare_ms", "pass_a_ms", "thresholds_ms", "pass_b_ms", "pass_c_ms"), (float(v) for v in t)))
 
-    def screen_values(self, qn, n_rows):
-        """mh_screen_values: [Q][n_rows] screen values as the matrix pipe computes them, + (dmax, spread) of the DB."""
+    def screen_values(self, qn, n_rows, shape=0):
+        """mh_screen_values: [Q][n_rows] screen values as the matrix pipe computes them, + (dmax, spread) of the DB.
+        shape: 0 = the MFMA shape the large launches use, 1 = 32x32x16, 2 = 16x16x32."""
         qn = np.ascontiguousarray(qn, np.float32)
         out = np.zeros((qn.shape[0], n_rows), np.float32)
         dmax, spread = C.c_float(0), C.c_float(0)
-        self._ck(self.L.mh_screen_values(self.h, _ptr(qn), qn.shape[0], n_rows, _ptr(out), C.byref(dmax), C.byref(spread)),
-                 "mh_screen_values")
+        self._ck(self.L.mh_screen_values(self.h, _ptr(qn), qn.shape[0], n_rows, _ptr(out), C.byref(dmax), C.byref(spread),
+                                         int(shape)), "mh_screen_values")
         return out, dmax.value, spread.value
 
     def match_set_mode(self, mode: int):

@@ -607,7 +607,8 @@ void mh_screen_record_bounds(uint16_t value_bits, uint32_t row0, float tau, floa
   if (hi) *hi = h;
 }
 
-int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread) {
+int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float* out_host, float* dmax, float* spread,
+                     int shape) {
   if (!ctx || !q_host || !out_host || Q <= 0 || n_rows <= 0 || (Q & 31) || (n_rows & 31)) {
     if (ctx) ctx->err = "mh_screen_values: Q and n_rows must be positive multiples of 32";
     return MH_ERR_ARG;
@@ -637,7 +638,7 @@ int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float*
   hipMemcpyAsync(qd, q_host, (size_t)Q * DIM * 4, hipMemcpyHostToDevice, ctx->stream);
   launch_row_norms(qd, qn, Q, ctx->stream);
   launch_screen_prepare(qd, qn, Q, q_pad, qh, qbad, ctx->stream);
-  launch_screen_values(qh, Q, ctx->sdb, n_rows, out, ctx->stream);
+  launch_screen_values(qh, Q, ctx->sdb, n_rows, out, ctx->stream, shape);
   if (hipMemcpyAsync(out_host, out, (size_t)Q * n_rows * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
     ctx->err = "mh_screen_values: device error";

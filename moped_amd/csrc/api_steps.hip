@@ -22,6 +22,10 @@ struct FrameState {
   FrameCounts* counts = nullptr;
   int32_t* n_slots = nullptr;      // object slots in use (device scalar)
   int32_t* n_clusters = nullptr;   // rows of the current cluster table (device scalar)
+  // ... and of the table FILTER rewrites for POSE2: a word of its own -- a POSE launch's workgroups read every frame's
+  // cluster count as they walk the batch, and the frame's closing workgroup (fused FILTER) may have rewritten the table
+  // by the time a workgroup without a task in that frame comes by
+  int32_t* n_clusters2 = nullptr;
   // group
   int32_t *acc_q = nullptr, *acc_model = nullptr, *m_q = nullptr, *m_model = nullptr, *m_rep = nullptr;
   mh_corr* m_corr = nullptr;
@@ -48,6 +52,14 @@ struct FrameState {
   int ms_grid = 8;      // ... and of the CLUSTER launch: its cluster count + head room
   int slot = 0;            // result / snap slot the next frame_rest writes (frames of a batch share the context)
   int list_first = 0, list_n = 1;   // result slots whose match lists are still in the arenas: [list_first, list_first + list_n)
+  // What the last launches found, written by the kernels' tails into host-visible (pinned, mapped) words and read -- without
+  // any synchronisation: a guess is all it is -- when the next launches are sized: [0][f] (cluster, replica) tasks of POSE
+  // in frame f of the batch, [1][f] of POSE2, [2][f] models that CLUSTER had to cluster.
+  int32_t* fb = nullptr;
+  // the fused FILTER / FILTER2 steps' arguments on the device + what the host last stored there (FilterFuse, steps.h)
+  FilterFuseArgs* fuse_dev = nullptr;   // [2]
+  FilterFuseArgs fuse_shadow[2];
+  bool fuse_valid[2] = {false, false};
   unsigned int* tickets = nullptr;  // [8] last_workgroup() words: 0 CLUSTER, 1 POSE, 2 FILTER, 3 POSE2, 4 FILTER2
 };
 
@@ -61,9 +73,10 @@ int dev_alloc(mh_ctx* ctx, T*& p, size_t n) {
 
 void free_fs(FrameState* fs) {
   if (!fs) return;
-  void* ptrs[] = {fs->arena, fs->result, fs->snap};
+  void* ptrs[] = {fs->arena, fs->result, fs->snap, fs->fuse_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (fs->fb) hipHostFree(fs->fb);
   delete fs;
 }
 
@@ -117,6 +130,7 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
     carve(fs->counts, 1);
     carve(fs->n_slots, 1);
     carve(fs->n_clusters, 1);
+    carve(fs->n_clusters2, 1);
     carve(fs->tickets, 8);
     carve(fs->acc_q, max_m);
     carve(fs->acc_model, max_m);
@@ -162,6 +176,11 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
     if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->result, 0, fs->result_bytes * MH_MAX_BATCH, ctx->stream));   // "0 objects" before the first frame
     rc |= dev_alloc(ctx, fs->snap, 4 * MH_MAX_BATCH);
     if (!rc) MH_HIP(ctx, hipMemsetAsync(fs->snap, 0, sizeof(int32_t) * 4 * MH_MAX_BATCH, ctx->stream));   // (a slot fetched before it was written reads zeros)
+  }
+  rc |= dev_alloc(ctx, fs->fuse_dev, 2);
+  if (!rc) {
+    if (hipHostMalloc(&fs->fb, 3 * MH_MAX_BATCH * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
+    else std::memset(fs->fb, 0xFF, 3 * MH_MAX_BATCH * sizeof(int32_t));   // -1 = nothing known yet
   }
   if (rc) {   // a half-built state must not look valid to the next call
     free_fs(fs);
@@ -340,10 +359,37 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   // many workgroups as the previous frame had tasks (experiment builds: MH_TASK_GRID pins the number, MH_MS_GRID the
   // CLUSTER launch's -- 0 = one workgroup per model, the old shape).
   static const int grid_env = exp_int("MH_TASK_GRID", 0);
-  const int grid = grid_env > 0 ? grid_env : fs->task_grid;
+  // POSE / POSE2: one row of workgroups for all frames of the launch, about as many as the launches before found tasks
+  // (+ 25%); nothing known yet: the per-frame guess (the last fetched frame's task count) times the frames
+  auto pose_grid = [&](const int32_t* found) {
+    if (grid_env > 0) return grid_env;
+    long sum = 0;
+    bool known = true;
+    for (int f = 0; f < batch_n; ++f) {
+      known &= found[f] >= 0;
+      sum += found[f] >= 0 ? found[f] : 0;
+    }
+    if (!known) sum = (long)fs->task_grid * batch_n / 2;
+    return (int)std::min<long>(160, std::max<long>(8, sum + sum / 4 + 2));
+  };
+  const int grid = pose_grid(fs->fb), grid2 = pose_grid(fs->fb + MH_MAX_BATCH);
   static const int ms_grid_env = exp_int("MH_MS_GRID", -1);
-  const int ms_grid = ms_grid_env >= 0 ? ms_grid_env : fs->ms_grid;
-  const uint64_t* const seed_dev = nullptr;
+  // CLUSTER: one row of workgroups for all frames of the launch, as many as the launches before found models to cluster
+  // (+ 1 per 8); nothing known yet: the per-frame guess times the frames.  Every one of them takes a whole compute unit.
+  int ms_grid = fs->ms_grid;
+  {
+    const int32_t* found = fs->fb + 2 * MH_MAX_BATCH;
+    long sum = 0;
+    bool known = true;
+    for (int f = 0; f < batch_n; ++f) {
+      known &= found[f] >= 0;
+      sum += found[f] >= 0 ? found[f] : 0;
+    }
+    if (!known) sum = (long)std::max(2, fs->ms_grid / 2) * batch_n;
+    ms_grid = (int)std::min<long>(48, std::max<long>(batch_n > 1 ? 4 : 2, sum + sum / 8 + 1));
+    if (batch_n == 1) ms_grid = std::max(ms_grid, std::min(fs->ms_grid, 8));
+  }
+  if (ms_grid_env >= 0) ms_grid = ms_grid_env;
   const bool multi = ctx->q_img && ctx->n_images > 1 && ctx->cams_dev;
   if (multi && (ctx->q_depth || ctx->depth_img.img || ctx->linkage_on)) {
     ctx->err = "frames with several images: the moped3d depth steps are single-camera";
@@ -409,7 +455,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   launch_meanshift_models(fs->m_corr, fs->model_off, nm, prm->ms_radius, prm->ms_merge,
                           prm->ms_min_pts, prm->ms_max_iter, fs->ms_members, fs->ms_cl_start,
                           fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
-                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, 1, ms_grid, b1);
+                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, 1, ms_grid, b1, fs->fb + 2 * MH_MAX_BATCH);
   stamp(ctx, 3);
   PoseImages img1, img2;   // POSE works on the (model, image, query) copy, POSE2 on FILTER's clusters over the match lists
   if (multi) {
@@ -436,7 +482,14 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   ff1.fb = ff2.fb = &fb;
   ff1.tail = &ft1;
   ff2.tail = &ft2;
-  ff1.n_clusters_dev = ff2.n_clusters_dev = fs->n_clusters;
+  ff1.n_clusters_dev = fs->n_clusters2;   // FILTER writes POSE2's cluster count, FILTER2 the frame's final one
+  ff2.n_clusters_dev = fs->n_clusters;
+  ff1.dev = fs->fuse_dev;
+  ff1.shadow = &fs->fuse_shadow[0];
+  ff1.shadow_valid = &fs->fuse_valid[0];
+  ff2.dev = fs->fuse_dev + 1;
+  ff2.shadow = &fs->fuse_shadow[1];
+  ff2.shadow_valid = &fs->fuse_valid[1];
   ff1.min_points = prm->f1_min_points;
   ff1.feature_distance = prm->f1_feature_distance;
   ff1.min_score = prm->f1_min_score;
@@ -444,23 +497,23 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   ff2.feature_distance = prm->f2_feature_distance;
   ff2.min_score = prm->f2_min_score;
   launch_pose(multi ? fs->mi_corr : fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model,
-              fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, seed_dev, fs->n_slots,
+              fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
-              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid}, s, img1,
+              fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid, fs->fb}, s, img1,
               fused ? &ff1 : nullptr, b1);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     // FILTER (snap[3] = objects kept)
     if (!fused)
       launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
-                    fs->n_slots, fs->n_clusters, fs->counts, ft1, s);
+                    fs->n_slots, fs->n_clusters2, fs->counts, ft1, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
-                fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose2,
-                seed ^ 0x5DEECE66Dull, seed_dev, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+                fs->cl_begin, fs->cl_count, fs->n_clusters2, fs->max_clusters, dc, prm->pose2,
+                seed ^ 0x5DEECE66Dull, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid}, s, img2, fused ? &ff2 : nullptr, b2);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid2, fs->fb + MH_MAX_BATCH}, s, img2, fused ? &ff2 : nullptr, b2);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     if (!fused)
@@ -736,8 +789,8 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, fs->n_slots, 0);
   const DevCam dc = make_devcam(*cam);
   launch_pose(fs->m_corr, depth_host ? reinterpret_cast<const float*>(fs->m_depth) : nullptr, kind, alpha,
-              fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, nullptr, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
-              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0}, s,
+              fs->ms_members, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters, n_clusters, dc, *prm, seed, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
+              fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts, PoseTail{nullptr, nullptr, nullptr, 0, nullptr}, s,
               images);
   MH_HIP(ctx, hipGetLastError());
   // the five result arrays into one pinned block (pageable destinations make every one of these copies a blocking one)

@@ -191,6 +191,24 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* ticket) {
   if (last) __threadfence();   // acquire: everybody else's results
   return last;
 }
+// The same for launches whose workgroups share the work of SEVERAL frames (a batch through one launch per stage): a
+// frame's ticket counts finished work items instead of workgroups.  `add` items of the frame's `total` are done: true
+// in exactly one workgroup, the one whose call completes the count (every global write the others made before theirs is
+// visible to it); workgroups without an item in the frame never call.  All threads of the workgroup call it.
+__device__ __forceinline__ bool frame_work_done(unsigned int* ticket, unsigned int add, unsigned int total) {
+  __shared__ int is_last_w;
+  __threadfence();   // release: this workgroup's results
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, add);
+    is_last_w = (t + add == total);
+    if (t + add == total) atomicExch(ticket, 0u);
+  }
+  __syncthreads();
+  const bool last = is_last_w != 0;
+  if (last) __threadfence();   // acquire: everybody else's results
+  return last;
+}
 #endif
 
 // Depth map of the frame as moped3d holds it (moped3d/moped3d.cpp:279-333): 4 floats per pixel

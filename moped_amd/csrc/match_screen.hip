@@ -63,6 +63,7 @@ constexpr int SC_TILE_BYTES = SC_TILE * DIM * 2;   // 32 KB of f16
 // hits a wavefront parks in LDS (80 bytes each: the block's 16 values go along) before they go to memory: 112 with eight
 // wavefronts (the whole workgroup's hits, written out at its end), 40 with four (two workgroups' LDS must fit a CU:
 // 2 x (64 KB tiles + 1.5 KB + 4 x 40 x 80 B) = 156 KB) -- written out whenever the buffer is three quarters full
+constexpr bool SC_SHAPE16_LARGE = true;   // the four-query-block launches run on v_mfma_f32_16x16x32_f16 (screen16_kernel)
 constexpr int SC_NW_LARGE = 8;   // wavefronts per workgroup of the four-query-block launches (4 or 8; MH_SCREEN_NW in experiment builds)
 __host__ __device__ constexpr int sc_recbuf(int nw) { return nw >= 8 ? 112 : 40; }
 constexpr int SC_GROUP = 1;                        // tiles per barrier: the wavefronts of a workgroup drift apart within a group
@@ -670,6 +671,299 @@ __global__ __launch_bounds__(64 * NW, 2) void screen_kernel(const ScreenArgs A) 
   }
 }
 
+// ---- passes A and B on v_mfma_f32_16x16x32_f16 ------------------------------------------------------------------
+// The same passes with the other f16 MFMA shape.  On random operands out of registers, two wavefronts per SIMD, every
+// CU busy, the 16x16x32 instruction sustains 1 842 TFLOP/s on this part and the 32x32x16 one 1 625 (the power budget's
+// clock, not the issue rate: scripts/experiments/mfma_shapes_rate.hip, profiles/r03_mfma_shapes_rate.txt) -- pass B on
+// 32x32x16 ran at 83% of what that instruction can deliver at all.
+// A 32-query x 32-row block is 2 x 2 tiles of 16 x 16 and four k-steps of 32: 16 MFMAs of 16 cycles (the other shape: 8
+// of 32).  Operands (cdna_hip_programming.md 3): lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k][col l & 15];
+// result register r of a tile: col = l & 15, row = 4 (l >> 4) + r.  Rows (A) = DB rows, columns (B) = queries, so a
+// lane holds, of a block, TWO queries (l & 15 of either 16-query tile) x EIGHT rows (16 ti + 4 (l >> 4) + r): the four
+// "quarters" l >> 4 of a wavefront see different rows of the same queries.  What follows from that:
+//   - per-query state (thresholds, running maxima, record counts) is [query block][2] per lane;
+//   - a record covers the 8 rows a lane holds of one query in a block: row0 = block + 4 quarter, bit 4 ti + r = row
+//     row0 + r + 16 ti; bit 31 of the record's row word marks the layout for pass C (the 32x32x16 records: bit r = row
+//     row0 + (r & 3) + 8 (r >> 2), 16 rows, all 16 mask bits in use);
+//   - a query's record slots are shared out over 4 x splits lane-private sub-lists (quarters) instead of 2 x splits;
+//   - pass A folds the lane's 8 rows of a block into ONE maximum per query (two blocks are still different rows).
+// Staging, swizzle (chunk ^ (row & 15): a 16-lane group reads 16 rows at one chunk index -- all 64 banks once), the
+// XCD-aware unit map, the parked records and the exactness argument are those of screen_kernel.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr unsigned SC_REC_LAYOUT16 = 0x80000000u;   // in a record's row word: the rows of the 16x16x32 passes
+constexpr int SC_REC16_BYTES = 48;                  // {slot, row0, thr, top, 8 dots}
+constexpr int SC_RECBUF16 = 8 * 1024 / SC_REC16_BYTES;   // 170 parked hits per wavefront in 8 KB
+constexpr int SC_LDS16_TAU = SC_LDS_TILES + 8 * SC_RECBUF16 * SC_REC16_BYTES;   // the wavefronts' thresholds: 8 x 128 floats
+constexpr int SC_LDS16_BYTES = SC_LDS16_TAU + 8 * 128 * 4;
+
+template <int MODE, int NQB>
+__global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
+  MH_TRACE_SCOPE(MODE == 0 ? mh::TK_PASS_A : mh::TK_PASS_B);
+  constexpr int NW = 8;
+  constexpr int QW = 32 * NQB;            // queries per wavefront
+  constexpr int QB = QW * NW;             // queries per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quarter = lane >> 4, l16 = lane & 15;
+  const unsigned lds_base = (unsigned)(uintptr_t)(MH_AS3 unsigned char*)lds;
+  const int nqb = gridDim.x / A.n_splits;
+  int qblock, split;
+  {
+    const int L = blockIdx.x, U = gridDim.x;
+    const int x = L & 7, j = L >> 3;
+    const int unit = x * (U >> 3) + min(x, U & 7) + j;
+    split = unit / nqb;
+    qblock = unit - split * nqb;
+  }
+  const int Qe = A.q_count ? min(A.Q, *A.q_count) : A.Q;
+  if (qblock * QB >= Qe) return;   // uniform over the workgroup
+  const int q0 = qblock * QB + wave * QW;
+  const int sel_begin = split * A.tiles_base + min(split, A.tiles_rem);
+  const int sel_end = min(sel_begin + A.tiles_base + (split < A.tiles_rem ? 1 : 0), A.n_sel);
+
+  const unsigned voff = (unsigned)(wave * 1024 + (lane >> 4) * 256 + (((lane & 15) ^ ((wave * 4 + (lane >> 4)) & 15)) << 4));
+  const unsigned voff_dd = (unsigned)((wave * 64 + lane) * 4);
+  auto stage = [&](int sel, int buf) {
+    const int tile = A.tile_first + sel * A.tile_stride;
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(A.dbh) + (size_t)tile * SC_TILE_BYTES;
+    const unsigned l = lds_base + buf * SC_TILE_BYTES + wave * 1024;
+    dma16x4(voff, tb, tb + 8192, tb + 16384, tb + 24576, l, l + 8192, l + 16384, l + 24576);
+    if (wave < 3)
+      dma4(voff_dd, A.dneg + (size_t)tile * SC_DD, lds_base + SC_NBUF * SC_TILE_BYTES + buf * (SC_DD * 4) + wave * 256);
+  };
+  if (sel_begin < sel_end) stage(sel_begin, 0);
+  // ---- B operands: the lane's query of either 16-query tile of each block, k = 32 s + 8 quarter .. + 7 ----
+  half8 bq[NQB][2][4];
+#pragma unroll
+  for (int nb = 0; nb < NQB; ++nb)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const _Float16* row = A.qh + (size_t)(q0 + nb * 32 + 16 * tj + l16) * DIM + 8 * quarter;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bq[nb][tj][s] = *reinterpret_cast<const half8*>(row + 32 * s);
+    }
+  // per-query state of the lane's 2 NQB queries.  Pass B is at the register limit (128 for the queries' operands, 32 + 16
+  // + 16 for a row block's fragments, the accumulators and the pending block): the thresholds wait in LDS (two ds_read_b32
+  // per block, in the MFMAs' shadow) and the sub-lists' record counts are bytes of NQB / 2 registers.
+  float b1[NQB][2], b2[NQB][2];
+  unsigned n_rec[(NQB + 1) / 2] = {};   // [nb >> 1]: byte 2 (nb & 1) + tj
+  float* const tau_lds = reinterpret_cast<float*>(lds + SC_LDS16_TAU) + wave * 128;
+#pragma unroll
+  for (int nb = 0; nb < NQB; ++nb)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      b1[nb][tj] = -__builtin_inff();
+      b2[nb][tj] = -__builtin_inff();
+    }
+  if (MODE == 1)
+    for (int i = lane; i < QW; i += 64) tau_lds[i] = A.tau[q0 + i];
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  uint4* const recbuf = reinterpret_cast<uint4*>(lds + SC_LDS_TILES + wave * (SC_RECBUF16 * SC_REC16_BYTES));
+  int n_parked = 0;
+  // a record from the lane's 8 dots of one query: bit 4 ti + r = sign(thr - dot)
+  auto record_bits8 = [](const v4f& d0, const v4f& d1, float top, float thr) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - d1[r]), 31);
+#pragma unroll
+    for (int r = 3; r >= 0; --r) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(thr - d0[r]), 31);
+    return (bits & 0xFFu) | ((unsigned)screen_record_value(top, thr) << 16);
+  };
+  auto emit = [&](const v4f& d0, const v4f& d1, unsigned& nrec_word, int shift, int q, int row0, float top, float thr, int pos) {
+    const int nrec = (int)((nrec_word >> shift) & 0xFFu);
+    if (nrec < A.sub_cap) {   // (sub_cap <= 48: the byte cannot wrap)
+      const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (4 * split + quarter) * A.sub_cap + nrec;
+      nrec_word += 1u << shift;
+      if (pos < SC_RECBUF16) {
+        uint4* e = recbuf + 3 * pos;
+        e[0] = make_uint4(dst, (unsigned)row0, __float_as_uint(thr), __float_as_uint(top));
+        e[1] = make_uint4(__float_as_uint(d0[0]), __float_as_uint(d0[1]), __float_as_uint(d0[2]), __float_as_uint(d0[3]));
+        e[2] = make_uint4(__float_as_uint(d1[0]), __float_as_uint(d1[1]), __float_as_uint(d1[2]), __float_as_uint(d1[3]));
+      } else {
+        A.recs[dst] = make_uint2((unsigned)row0 | SC_REC_LAYOUT16, record_bits8(d0, d1, top, thr));   // buffer full
+      }
+    } else {
+      const int opos = atomicAdd(&A.ovf_cnt[q], 1);
+      if (opos < A.ovf_cap) A.ovf[(size_t)q * A.ovf_cap + opos] = make_uint2((unsigned)row0 | SC_REC_LAYOUT16, record_bits8(d0, d1, top, thr));
+      if (pos < SC_RECBUF16) recbuf[3 * pos] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    }
+  };
+  // the pending block: acc[ti][tj]; query tj of the lane = tiles (0, tj) and (1, tj)
+  auto emit_block = [&](bool hit0, bool hit1, const v4f (&p)[2][2], int nb, int row0, float m0, float m1, float thr0, float thr1) {
+    const unsigned long long h0 = __ballot(hit0), h1 = __ballot(hit1);
+    if ((h0 | h1) == 0ull) return;
+    if (hit0)
+      emit(p[0][0], p[1][0], n_rec[nb >> 1], 16 * (nb & 1), q0 + nb * 32 + l16, row0, m0, thr0,
+           n_parked + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(h0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)h0, 0u)));
+    n_parked += __popcll(h0);
+    if (hit1)
+      emit(p[0][1], p[1][1], n_rec[nb >> 1], 16 * (nb & 1) + 8, q0 + nb * 32 + 16 + l16, row0, m1, thr1,
+           n_parked + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(h1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)h1, 0u)));
+    n_parked += __popcll(h1);
+  };
+  auto flush_parked = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = min(n_parked, SC_RECBUF16);
+    for (int j = lane; j < n; j += 64) {
+      const uint4 e = recbuf[3 * j];
+      if (e.x == 0xFFFFFFFFu) continue;
+      const uint4 x0 = recbuf[3 * j + 1], x1 = recbuf[3 * j + 2];
+      const v4f d0 = {__uint_as_float(x0.x), __uint_as_float(x0.y), __uint_as_float(x0.z), __uint_as_float(x0.w)};
+      const v4f d1 = {__uint_as_float(x1.x), __uint_as_float(x1.y), __uint_as_float(x1.z), __uint_as_float(x1.w)};
+      A.recs[e.x] = make_uint2(e.y | SC_REC_LAYOUT16, record_bits8(d0, d1, __uint_as_float(e.w), __uint_as_float(e.z)));
+    }
+    __builtin_amdgcn_wave_barrier();
+    n_parked = 0;
+  };
+
+  // A operands of a row block: tile ti = rows rb 32 + 16 ti + l16, k-step s -> chunk 4 s + quarter at position
+  // chunk ^ (row & 15) = chunk ^ l16
+  auto load_rb = [&](const unsigned char* T, int rb, half8 (&a)[2][4]) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const unsigned char* rowp = T + (rb * 32 + 16 * ti + l16) * 256;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[ti][s] = *reinterpret_cast<const half8*>(rowp + (((4 * s + quarter) ^ l16) << 4));
+    }
+  };
+  // (as instructions: fmaxf() quiets every operand first -- a v_max_f32 x, x per value, 28 vector instructions per block
+  // where 8 do; the dots of finite operands are never NaN)
+  auto max3 = [](float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+  };
+  auto max8 = [&](const v4f& x, const v4f& y) {
+    return max3(max3(max3(x[0], x[1], x[2]), x[3], y[0]), max3(y[1], y[2], y[3]), -__builtin_inff());
+  };
+
+  int side = 0;
+  v4f pend[2][2];
+  float pend_hi = 0.f;
+  int pend_row0 = 0;
+  bool have_pend = false;
+  const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int sel = sel_begin; sel < sel_end; ++sel) {
+    const bool more = sel + 1 < sel_end;
+    if (more) stage(sel + 1, side ^ 1);
+    const unsigned char* T = lds + side * SC_TILE_BYTES;
+    const float* ddp = reinterpret_cast<const float*>(lds + SC_NBUF * SC_TILE_BYTES + side * (SC_DD * 4));
+    const int row_tile = (A.tile_first + sel * A.tile_stride) * SC_TILE;
+    if (MODE == 0) {
+#pragma unroll 1
+      for (int rb = 0; rb < SC_TILE / 32; ++rb) {
+        half8 a[2][4];
+        load_rb(T, rb, a);
+        v4f init[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const float4 v = *reinterpret_cast<const float4*>(ddp + rb * 32 + 16 * ti + 4 * quarter);
+          init[ti] = v4f{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          v4f acc[2][2] = {{init[0], init[0]}, {init[1], init[1]}};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < 2; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][s], bq[nb][tj][s], acc[ti][tj], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) {
+            const float m = max8(acc[0][tj], acc[1][tj]);
+            b2[nb][tj] = __builtin_amdgcn_fmed3f(b1[nb][tj], b2[nb][tj], m);
+            b1[nb][tj] = fmaxf(b1[nb][tj], m);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      const float4 hi4 = *reinterpret_cast<const float4*>(ddp + 128);
+      const float hi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+      for (int rb = 0; rb < SC_TILE / 32; ++rb) {
+        half8 a[2][4];
+        load_rb(T, rb, a);
+        const int row0 = row_tile + rb * 32 + 4 * quarter;
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          const int pnb = (nb + NQB - 1) % NQB;
+          v4f acc[2][2] = {{zero4, zero4}, {zero4, zero4}};
+          float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+          const float t0 = tau_lds[pnb * 32 + l16], t1 = tau_lds[pnb * 32 + 16 + l16];   // the pending block's thresholds
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < 2; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][s], bq[nb][tj][s], acc[ti][tj], 0, 0, 0);
+            // the pending block's maxima in the shadow of the second half of the MFMAs (its values have left the pipe by then)
+            if (have_pend && s == 2) m0 = max8(pend[0][0], pend[1][0]);
+            if (have_pend && s == 3) m1 = max8(pend[0][1], pend[1][1]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (have_pend) {
+            const float thr0 = t0 - pend_hi, thr1 = t1 - pend_hi;
+            emit_block(m0 > thr0, m1 > thr1, pend, pnb, pend_row0, m0, m1, thr0, thr1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) pend[ti][tj] = acc[ti][tj];
+          pend_row0 = row0;
+          pend_hi = hi[rb];
+          have_pend = true;
+        }
+      }
+    }
+    if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    side ^= 1;
+  }
+  if (MODE == 1) {
+    if (have_pend) {
+      const float m0 = max8(pend[0][0], pend[1][0]), m1 = max8(pend[0][1], pend[1][1]);
+      const float thr0 = tau_lds[(NQB - 1) * 32 + l16] - pend_hi, thr1 = tau_lds[(NQB - 1) * 32 + 16 + l16] - pend_hi;
+      emit_block(m0 > thr0, m1 > thr1, pend, NQB - 1, pend_row0, m0, m1, thr0, thr1);
+    }
+    flush_parked();
+  }
+  if (MODE == 0) {
+    // the four quarters of the wavefront hold different rows of the same queries
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        float B = b1[nb][tj], S = b2[nb][tj];
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+          const float ob = __shfl_xor(B, d), os = __shfl_xor(S, d);
+          S = fmaxf(fminf(B, ob), fmaxf(S, os));
+          B = fmaxf(B, ob);
+        }
+        const int q = q0 + nb * 32 + 16 * tj + l16;
+        if (quarter == 0 && q < A.q_pad) A.part[(size_t)split * A.q_pad + q] = make_float2(B, S);
+      }
+  }
+}
+
 // ---- pass C: canonical arithmetic on the candidates ------------------------------------------------
 struct Best {
   float b1, b2;
@@ -792,7 +1086,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
       // largest screen value is at most that, and at least that less the spread of -dd/2 inside a block (`spread`: the
       // largest over the DB's blocks of real rows, ~1e-7 for L2-normalised rows); a block with padding rows (their
       // dot is 0, their -dd/2 is -inf) gives no lower bound.  (screen.h; checked in host arithmetic by the CPU tests)
-      screen_record_bounds((unsigned short)(rec.y >> 16), rec.x, tau_q, spread, N, dmax, lo, hi);
+      screen_record_bounds((unsigned short)(rec.y >> 16), rec.x & 0x7FFFFFFFu, tau_q, spread, N, dmax, lo, hi);
     };
 #pragma unroll
     for (int it = 0; it < RS_ITERS; ++it) {
@@ -828,12 +1122,16 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
         bounds(rec, lo, hi);
         if (hi < keep_from) bits = 0;
       }
+      // which rows a bit stands for: records of the 32x32x16 passes hold 16 rows, row0 + (r & 3) + 8 (r >> 2); those of
+      // the 16x16x32 passes (bit 31 of the row word) 8 rows, row0 + (r & 3) + 16 (r >> 2)
+      const int hi_stride = (rec.x & 0x80000000u) ? 16 : 8;
+      const int row0 = (int)(rec.x & 0x7FFFFFFFu);
       // candidates in any order (the exact top-2 below breaks ties by row number): an LDS counter hands out places
       while (bits) {
         const int r = __builtin_ctz(bits);
         bits &= bits - 1;
         const int w = atomicAdd(&ncand_s[wave], 1);
-        if (w < RS_MAXC) cand_s[wave][w] = (int)rec.x + (r & 3) + 8 * (r >> 2);
+        if (w < RS_MAXC) cand_s[wave][w] = row0 + (r & 3) + hi_stride * (r >> 2);
       }
     }
     wave_lds_sync();
@@ -873,9 +1171,33 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
 // (32 queries, 32 rows), operands straight from the f16 images, the accumulator seeded with the rows' -dd/2, the eight
 // MFMAs of a block in ascending k.  Register r of lane (l32, half) = query l32, row (r & 3) + 8 (r >> 2) + 4 half.
 __global__ __launch_bounds__(64) void screen_values_kernel(const _Float16* __restrict__ qh, const _Float16* __restrict__ dbh,
-                                                           const float* __restrict__ dneg, int n_rows, float* __restrict__ out) {
+                                                           const float* __restrict__ dneg, int n_rows, float* __restrict__ out,
+                                                           int shape16) {
   const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
   const int q0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  if (shape16) {   // screen16_kernel's arithmetic: 2 x 2 tiles of 16 x 16, four k-steps of 32, seeded with -dd/2
+    const int quarter = lane >> 4, l16 = lane & 15;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        v4f acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = r0 + 16 * ti + 4 * quarter + r;
+          acc[r] = dneg[(size_t)(row >> 7) * SC_DD + (row & 127)];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const half8 a = *reinterpret_cast<const half8*>(dbh + (size_t)(r0 + 16 * ti + l16) * DIM + 32 * s + 8 * quarter);
+          const half8 b = *reinterpret_cast<const half8*>(qh + (size_t)(q0 + 16 * tj + l16) * DIM + 32 * s + 8 * quarter);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(q0 + 16 * tj + l16) * n_rows + r0 + 16 * ti + 4 * quarter + r] = acc[r];
+      }
+    return;
+  }
   half8 a[8], b[8];
   const _Float16* arow = dbh + (size_t)(r0 + l32) * DIM + 8 * half;
   const _Float16* brow = qh + (size_t)(q0 + l32) * DIM + 8 * half;
@@ -931,9 +1253,10 @@ void launch_db_to_half(const float* db, const float* dnorm, int N, _Float16* dbh
   hipLaunchKernelGGL(db_zero_query_kernel, dim3(1), dim3(1024), 0, s, dnorm, N, stats);
 }
 
-void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s) {
+void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s, int shape) {
   if (Q <= 0 || n_rows <= 0) return;
-  hipLaunchKernelGGL(screen_values_kernel, dim3(Q / 32, n_rows / 32), dim3(64), 0, s, qh, sdb.dbh, sdb.dneg, n_rows, out);
+  const int shape16 = shape == 2 || (shape == 0 && SC_SHAPE16_LARGE);
+  hipLaunchKernelGGL(screen_values_kernel, dim3(Q / 32, n_rows / 32), dim3(64), 0, s, qh, sdb.dbh, sdb.dneg, n_rows, out, shape16);
 }
 void launch_screen_prepare(const float* qn, const float* qnorm, int Q, int q_pad, _Float16* qh, uint8_t* qbad, hipStream_t s) {
   hipLaunchKernelGGL(screen_prepare_kernel, dim3((q_pad * 16 + 255) / 256), dim3(256), 0, s, qn, qnorm, Q, (const int32_t*)nullptr,
@@ -1020,6 +1343,52 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
   *n_slots_out = 2 * Sb * a.sub_cap;
 }
 
+// the same launch policy for the 16x16x32 kernels (eight wavefronts; a query's slots shared out over 4 x splits sub-lists)
+template <int NQB>
+void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blocks_a, int blocks_b, int* n_slots_out,
+                     hipEvent_t* ev, hipStream_t s) {
+  constexpr int QB = 32 * NQB * 8;
+  static DynLds attr0, attr1;
+  attr0.ensure(screen16_kernel<0, NQB>, SC_LDS16_BYTES);
+  attr1.ensure(screen16_kernel<1, NQB>, SC_LDS16_BYTES);
+  const int nqb = (Q + QB - 1) / QB;
+  const int nqb_e = (qe + QB - 1) / QB;
+  auto splits_for = [&](int n_sel, int target, int s_max) {
+    int S = std::max(1, target / nqb_e);
+    S = std::min(std::min(S, n_sel), s_max);
+    if (S >= 8 && (S / 8 * 8) * 33 >= S * 32) S = S / 8 * 8;
+    return std::max(S, 1);
+  };
+  const int stride = n_tiles >= 4 * sample ? sample : 1;
+  const int n_sel_a = (n_tiles + stride - 1) / stride;
+  const int Sa = splits_for(n_sel_a, blocks_a, screen_max_splits_a());
+  a.n_sel = n_sel_a;
+  a.tile_first = std::min(stride / 2, n_tiles - 1 - (n_sel_a - 1) * stride);
+  if (a.tile_first < 0) a.tile_first = 0;
+  a.tile_stride = stride;
+  a.n_splits = Sa;
+  a.tiles_base = n_sel_a / Sa;
+  a.tiles_rem = n_sel_a % Sa;
+  a.n_splits_a = Sa;
+  hipLaunchKernelGGL((screen16_kernel<0, NQB>), dim3(nqb * Sa), dim3(512), SC_LDS16_BYTES, s, a);
+  if (ev) hipEventRecord(ev[2], s);
+  hipLaunchKernelGGL(screen_tau_kernel, dim3((a.q_pad + 255) / 256), dim3(256), 0, s, a.part, Sa, a.q_pad, a.Q, a.q_count,
+                     a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
+  if (ev) hipEventRecord(ev[3], s);
+  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
+  const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 4);
+  a.n_sel = n_tiles;
+  a.tile_first = 0;
+  a.tile_stride = 1;
+  a.n_splits = Sb;
+  a.tiles_base = n_tiles / Sb;
+  a.tiles_rem = n_tiles % Sb;
+  a.sub_cap = std::max(1, std::min(48, SC_SLOTS_MAX / (4 * Sb)));
+  hipLaunchKernelGGL((screen16_kernel<1, NQB>), dim3(nqb * Sb), dim3(512), SC_LDS16_BYTES, s, a);
+  if (ev) hipEventRecord(ev[4], s);
+  *n_slots_out = 4 * Sb * a.sub_cap;
+}
+
 }  // namespace
 
 void launch_match_screen(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm, int N,
@@ -1077,7 +1446,12 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   // wavefronts per workgroup: four (two workgroups share a CU) for the large launches, see the top of the file
   static const int nw_pin = exp_int("MH_SCREEN_NW", 0);
   const int nw_sel = nw_pin == 4 || nw_pin == 8 ? nw_pin : (nqb_sel == 4 ? SC_NW_LARGE : 8);
-  if (nqb_sel == 4 && nw_sel == 4) launch_passes<4, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
+  // the MFMA shape of the large launches: 16x16x32 (SC_SHAPE16_LARGE; MH_SCREEN_SHAPE = 1 / 2 pins 32x32x16 / 16x16x32 in experiment builds)
+  static const int shape_pin = exp_int("MH_SCREEN_SHAPE", 0);
+  const bool shape16 = shape_pin == 2 || (shape_pin == 0 && SC_SHAPE16_LARGE);
+  if (nqb_sel == 4 && shape16) launch_passes16<4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig);
+  else if (nqb_sel == 2 && shape16 && shape_pin == 2) launch_passes16<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig);
+  else if (nqb_sel == 4 && nw_sel == 4) launch_passes<4, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
   else if (nqb_sel == 4) launch_passes<4, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
   else if (nqb_sel == 3) launch_passes<3, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
   else if (nqb_sel == 2 && nw_sel == 4) launch_passes<2, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);

@@ -1033,87 +1033,101 @@ __device__ __forceinline__ void meanshift_body(MsLds<ND>& L, const float* __rest
 // table in (model, emission) order -- the order POSE walks `clusters[model]`
 // (POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:276-280) -- and publishes the counts.
 __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
-    const mh_corr* __restrict__ corr, const int32_t* __restrict__ model_off, int n_models, float radius,
-    float merge, int min_pts, int max_iter, int32_t* members, int32_t* cl_start, int32_t* ncl,
-    int max_clusters, int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
-    int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out, int32_t* __restrict__ snap,
-    FrameCounts* counts, unsigned int* ticket, int models_div, FrameBatch fbx) {
+    const mh_corr* __restrict__ corr0, const int32_t* __restrict__ model_off0, int n_models, float radius,
+    float merge, int min_pts, int max_iter, int32_t* members0, int32_t* cl_start0, int32_t* ncl0,
+    int max_clusters, int32_t* __restrict__ cl_model0, int32_t* __restrict__ cl_begin0,
+    int32_t* __restrict__ cl_count0, int32_t* __restrict__ n_clusters_out0, int32_t* __restrict__ snap0,
+    FrameCounts* counts0, unsigned int* ticket0, int models_div, FrameBatch fbx, int32_t* __restrict__ feedback) {
   MH_TRACE_SCOPE(mh::TK_CLUSTER);
-  if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot
-    const unsigned long long a = blockIdx.y * fbx.arena;
-    corr = frame_ptr(corr, a); model_off = frame_ptr(model_off, a); members = frame_ptr(members, a);
-    cl_start = frame_ptr(cl_start, a); ncl = frame_ptr(ncl, a); cl_model = frame_ptr(cl_model, a);
-    cl_begin = frame_ptr(cl_begin, a); cl_count = frame_ptr(cl_count, a); n_clusters_out = frame_ptr(n_clusters_out, a);
-    counts = frame_ptr(counts, a); ticket = frame_ptr(ticket, a);
-    if (snap) snap += 4 * blockIdx.y;
-  }
   // models_div > 1: the "models" are (model, image) pairs in (model, image) order -- MeanShift runs per image
   // (CLUSTER_MEAN_SHIFT_CPU.hpp:194-195) -- and the cluster table names the real model
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MsLds<2>& L = *reinterpret_cast<MsLds<2>*>(smem);
-  // A workgroup of this kernel asks for a whole compute unit (its LDS), and a workgroup that only finds an empty model
-  // still has to wait for one to drain -- behind the MATCH kernels of the other frames in flight.  So the grid is a
-  // few workgroups (about as many as the last frame had clusters), not one per model: every workgroup lists the
-  // models that have at least MinPts matches (a bit per model) and takes those whose rank is its own modulo the grid.
+  // A workgroup of this kernel asks for a whole compute unit (its LDS), and one that finds nothing to cluster still has
+  // to wait for a unit to drain -- behind the MATCH kernels of the other frames in flight.  So the grid is ONE row of a
+  // few workgroups for all frames of the launch (about as many as the launches before found models to cluster): every
+  // workgroup walks the frames, lists the models that have at least MinPts matches (a bit per model) and takes those
+  // whose number -- counted through the frames -- is its own modulo the grid.  The workgroup that finishes a frame's
+  // last model lays the frame's cluster table out (a frame with nothing to cluster: workgroup frame mod grid).
   __shared__ unsigned long long busy[MS_WAVES];
-  int rank = 0;
-  for (int c0 = 0; c0 < n_models; c0 += MS_THREADS) {   // 1024 models at a time
-    {
-      const int m = c0 + threadIdx.x;
-      int n = 0;
-      if (m < n_models) {
-        n = model_off[m + 1] - model_off[m];
-        if (n <= 0 || n < min_pts) {   // fewer points than MinPts: no canopy can reach the emission threshold (:151-157)
-          n = 0;
-          if (blockIdx.x == 0) ncl[m] = 0;
+  const int G = (int)gridDim.x;
+  const int n_frames = fbx.n > 1 ? fbx.n : 1;
+  int rank = 0;   // models with work, counted through the frames of the launch
+  for (int f = 0; f < n_frames; ++f) {
+    const unsigned long long a = (unsigned long long)f * fbx.arena;
+    const mh_corr* corr = frame_ptr(corr0, a);
+    const int32_t* model_off = frame_ptr(model_off0, a);
+    int32_t* members = frame_ptr(members0, a);
+    int32_t* cl_start = frame_ptr(cl_start0, a);
+    int32_t* ncl = frame_ptr(ncl0, a);
+    FrameCounts* counts = frame_ptr(counts0, a);
+    unsigned int* ticket = frame_ptr(ticket0, a);
+    int n_busy = 0, mine = 0;
+    for (int c0 = 0; c0 < n_models; c0 += MS_THREADS) {   // 1024 models at a time
+      {
+        const int m = c0 + threadIdx.x;
+        int n = 0;
+        if (m < n_models) {
+          n = model_off[m + 1] - model_off[m];
+          if (n <= 0 || n < min_pts) n = 0;   // fewer points than MinPts: no canopy can reach the emission threshold (:151-157)
+        }
+        const unsigned long long bl = __ballot(n > 0);
+        if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
+      }
+      __syncthreads();
+      for (int wd = 0; wd < MS_WAVES; ++wd) {
+        for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank, ++n_busy) {
+          if (rank % G != (int)blockIdx.x) continue;
+          ++mine;
+          const int m = c0 + wd * 64 + __builtin_ctzll(bits);
+          const int b = model_off[m];
+          int n = model_off[m + 1] - b;
+          if (n > MS_CAP) {
+            if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
+            n = MS_CAP;
+          }
+          __syncthreads();   // the previous model's LDS is done with
+          // cl_start needs n+1 slots inside a region of n: the final offset of the last
+          // cluster is implied by the region, so write starts only (see cluster table).
+          meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
+                            radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
+                            nullptr, nullptr);
         }
       }
-      const unsigned long long bl = __ballot(n > 0);
-      if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
+      __syncthreads();   // (busy[] is rewritten for the next thousand)
     }
-    __syncthreads();
-    for (int wd = 0; wd < MS_WAVES; ++wd) {
-      for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank) {
-        if (rank % (int)gridDim.x != (int)blockIdx.x) continue;
-        const int m = c0 + wd * 64 + __builtin_ctzll(bits);
-        const int b = model_off[m];
-        int n = model_off[m + 1] - b;
-        if (n > MS_CAP) {
-          if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
-          n = MS_CAP;
+    bool last = false;
+    if (mine > 0) last = frame_work_done(ticket, (unsigned)mine, (unsigned)n_busy);
+    else if (n_busy == 0) last = (int)blockIdx.x == f % G;
+    if (!last || threadIdx.x != 0) continue;
+    if (feedback) feedback[f] = n_busy;   // what the next launches size their grids by
+    int32_t* cl_model = frame_ptr(cl_model0, a);
+    int32_t* cl_begin = frame_ptr(cl_begin0, a);
+    int32_t* cl_count = frame_ptr(cl_count0, a);
+    int k = 0;
+    for (int mm = 0; mm < n_models; ++mm) {
+      const int bb = model_off[mm];
+      const int nn = model_off[mm + 1] - bb;
+      const int32_t* st = cl_start + bb + mm;
+      const int nc = (nn > 0 && nn >= min_pts) ? ncl[mm] : 0;   // (a model without work was never clustered)
+      if (!(nn > 0 && nn >= min_pts)) ncl[mm] = 0;
+      for (int c = 0; c < nc; ++c) {
+        if (k >= max_clusters) {
+          atomicOr(&counts->error, ERR_CLUSTER_CAP);
+          break;
         }
-        __syncthreads();   // the previous model's LDS is done with
-        // cl_start needs n+1 slots inside a region of n: the final offset of the last
-        // cluster is implied by the region, so write starts only (see cluster table).
-        meanshift_body<2>(L, reinterpret_cast<const float*>(corr + b), sizeof(mh_corr) / sizeof(float), n,
-                          radius, merge, min_pts, max_iter, members + b, b, cl_start + b + m, ncl + m,
-                          nullptr, nullptr);
+        cl_model[k] = mm / models_div;
+        cl_begin[k] = bb + st[c];
+        cl_count[k] = st[c + 1] - st[c];
+        ++k;
       }
     }
-    __syncthreads();   // (busy[] is rewritten for the next thousand)
-  }
-  if (!last_workgroup(ticket) || threadIdx.x != 0) return;
-  int k = 0;
-  for (int mm = 0; mm < n_models; ++mm) {
-    const int bb = model_off[mm];
-    const int32_t* st = cl_start + bb + mm;
-    const int nc = ncl[mm];
-    for (int c = 0; c < nc; ++c) {
-      if (k >= max_clusters) {
-        atomicOr(&counts->error, ERR_CLUSTER_CAP);
-        break;
-      }
-      cl_model[k] = mm / models_div;
-      cl_begin[k] = bb + st[c];
-      cl_count[k] = st[c + 1] - st[c];
-      ++k;
+    counts->n_clusters = k;
+    *frame_ptr(n_clusters_out0, a) = k;
+    if (snap0) {
+      snap0[4 * f] = counts->n_matches;
+      snap0[4 * f + 1] = k;
     }
-  }
-  counts->n_clusters = k;
-  *n_clusters_out = k;
-  if (snap) {
-    snap[0] = counts->n_matches;
-    snap[1] = k;
   }
 }
 
@@ -1175,15 +1189,17 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
                              FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div, int grid,
-                             const FrameBatch* batch) {
+                             const FrameBatch* batch, int32_t* feedback) {
   static DynLds attr;
   attr.ensure(meanshift_models_kernel, MS_LDS_BYTES);
-  // an empty database still gets one workgroup: it publishes "0 clusters"
-  const int wgs = std::max(1, grid > 0 ? std::min(grid, n_models) : n_models);
-  hipLaunchKernelGGL(meanshift_models_kernel, dim3(wgs, batch ? batch->n : 1), dim3(MS_THREADS), MS_LDS_BYTES, s,
+  // one row of workgroups for all frames of the launch; an empty database still gets one: it publishes "0 clusters"
+  const long n_frames = batch && batch->n > 1 ? batch->n : 1;
+  const long all = std::max(1L, (long)n_models * n_frames);
+  const int wgs = (int)std::max(1L, grid > 0 ? std::min((long)grid, all) : std::min(all, 256L));
+  hipLaunchKernelGGL(meanshift_models_kernel, dim3(wgs), dim3(MS_THREADS), MS_LDS_BYTES, s,
                      corr, model_off, n_models, radius, merge, min_pts, max_iter, members, cl_start, ncl,
                      max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts, ticket,
-                     models_div > 0 ? models_div : 1, batch ? *batch : FrameBatch());
+                     models_div > 0 ? models_div : 1, batch ? *batch : FrameBatch(), feedback);
 }
 
 void launch_meanshift_single(const float* pts, int n, int dim, float radius, float merge,

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "filter_dev.h"
 
@@ -243,6 +244,8 @@ __device__ void p3p(const double (&X)[3][3], const double (&y)[3][3], F&& consid
 }
 
 // camera-frame pose (R,t) -> world pose: Rw = Rc R, tw = Rc t + tc
+// (The camera constants' fp64 images are hoisted out of the hypothesis loops into VGPR pairs; pinning the conversions to
+// their uses with an empty asm was tried in round 3 to free those registers: 12 spilled registers became 92.)
 __device__ __forceinline__ void to_world(const DevCam& cam, const double* R, const double* t, Pose34& o) {
   for (int r = 0; r < 3; ++r) {
     for (int c = 0; c < 3; ++c)
@@ -633,19 +636,36 @@ struct PoseLds {
 
 // One (cluster, replica) task, executed by a whole workgroup.  Every early exit is
 // workgroup-uniform.
+// `fa` = byte offset of the task's frame inside a batch's working arrays (FrameBatch): the pointers are the batch's
+// first frame's and are shifted here, at the task's few uses of them, not in the kernel's loop over the frames (where
+// thirty shifted pointers spilled).
 template <int KIND>
 __device__ void pose_task(
-    PoseLds<KIND>& L, const int cluster, const int replica,
-    const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
-    const int32_t* __restrict__ members,
-    const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
-    const int32_t* __restrict__ cl_count, const DevCam& cam1, const DevCam* __restrict__ cam_table,
-    const int32_t* __restrict__ img_of, int n_images,
-    const mh_pose_params& prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+    PoseLds<KIND>& L, const int cluster, const int replica, const unsigned long long fa,
+    const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
+    const int32_t* __restrict__ members0,
+    const int32_t* __restrict__ cl_model0, const int32_t* __restrict__ cl_begin0,
+    const int32_t* __restrict__ cl_count0, const DevCam& cam1, const DevCam* __restrict__ cam_table,
+    const int32_t* __restrict__ img_of0, int n_images,
+    const mh_pose_params& prm, uint64_t seed,
     const int obj_base, int max_objects,
-    int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
-    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
-    FrameCounts* counts) {
+    int32_t* __restrict__ obj_model0, float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0,
+    float* __restrict__ obj_err0, int32_t* __restrict__ obj_cluster0, int32_t* obj_valid0,
+    FrameCounts* counts0) {
+  const mh_corr* __restrict__ corr = frame_ptr(corr0, fa);
+  const float4* __restrict__ depth = frame_ptr(depth0, fa);
+  const int32_t* __restrict__ members = frame_ptr(members0, fa);
+  const int32_t* __restrict__ cl_model = frame_ptr(cl_model0, fa);
+  const int32_t* __restrict__ cl_begin = frame_ptr(cl_begin0, fa);
+  const int32_t* __restrict__ cl_count = frame_ptr(cl_count0, fa);
+  const int32_t* __restrict__ img_of = frame_ptr(img_of0, fa);
+  int32_t* __restrict__ obj_model = frame_ptr(obj_model0, fa);
+  float* __restrict__ obj_pose = frame_ptr(obj_pose0, fa);
+  int32_t* __restrict__ obj_ninl = frame_ptr(obj_ninl0, fa);
+  float* __restrict__ obj_err = frame_ptr(obj_err0, fa);
+  int32_t* __restrict__ obj_cluster = frame_ptr(obj_cluster0, fa);
+  int32_t* obj_valid = frame_ptr(obj_valid0, fa);
+  FrameCounts* counts = frame_ptr(counts0, fa);
   constexpr int PS = PointStride<KIND>::value;
   const int R_ = prm.max_objects_per_cluster;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -741,7 +761,7 @@ __device__ void pose_task(
     const int model = cl_model[cluster];
     while (ordinal < cluster && cl_model[cluster - ordinal - 1] == model) ++ordinal;
   }
-  const uint64_t task_key = (seed ^ (seed_dev ? *seed_dev : 0ull)) ^ ((uint64_t)(cl_model[cluster] + 1) << 48) ^
+  const uint64_t task_key = seed ^ ((uint64_t)(cl_model[cluster] + 1) << 48) ^
                             ((uint64_t)(ordinal + 1) << 36) ^ ((uint64_t)(replica + 1) << 32);
   auto hypothesis = [&](const int h) {
     uint64_t st = task_key ^ (uint64_t)h;
@@ -932,89 +952,102 @@ __device__ void pose_task(
   }
 }
 
-// Grid-stride loop over the (cluster, replica) tasks: the cluster count lives on the
-// device, so the grid is a fixed small number of workgroups instead of one (mostly
-// idle) workgroup per reserved slot -- every workgroup of this kernel needs a compute unit
-// to itself to start, idle or not, so the grid follows the expected task count
-// (PoseTail::grid).  In a frame the last workgroup to finish advances
-// the object-slot count past this launch's slots and counts the valid objects.
-constexpr int POSE_GRID = 96;
+// The launch: a 1-D grid of workgroups shares ALL (cluster, replica) tasks of the launch -- of one frame, or of the B
+// frames of a batch (FrameBatch): the tasks are numbered through the frames and dealt round-robin, task t to workgroup
+// t mod gridDim.x.  The cluster counts live on the device, so the grid is a guess (PoseTail::grid; the library feeds it
+// from what earlier launches found, PoseTail::feedback); every workgroup of this kernel needs half a compute unit to
+// start, idle or not -- with one grid row per frame (round 2) a batch of eight frames launched 256 workgroups for its
+// ~64 tasks, and a rank that owns a tenth of the models launched as many for a handful.
+// In a frame the workgroup that finishes the frame's LAST task advances the object-slot count past this launch's slots,
+// counts the valid objects and -- fused FILTER -- runs the step that follows (a frame without tasks: workgroup
+// frame mod gridDim.x does).
+constexpr int POSE_GRID = 160;
+
 template <int KIND>
 __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
-    const mh_corr* __restrict__ corr, const float4* __restrict__ depth, float alpha,
-    const int32_t* __restrict__ members,
-    const int32_t* __restrict__ cl_model, const int32_t* __restrict__ cl_begin,
-    const int32_t* __restrict__ cl_count, const int32_t* __restrict__ n_clusters_dev, DevCam cam,
-    const DevCam* __restrict__ cam_table, const int32_t* __restrict__ img_of, int n_images,
-    mh_pose_params prm, uint64_t seed, const uint64_t* __restrict__ seed_dev,
-    const int32_t* obj_base_dev, int max_objects,
-    int32_t* __restrict__ obj_model, float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl,
-    float* __restrict__ obj_err, int32_t* __restrict__ obj_cluster, int32_t* obj_valid,
-    FrameCounts* counts, PoseTail tail, int fuse_filter, FilterBuffers ffb, FilterTail ftail, float f_feature_distance,
-    int f_min_points, float f_min_score, int32_t* f_n_clusters_dev, FrameBatch fbx) {
+    const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
+    const int32_t* __restrict__ members0,
+    const int32_t* __restrict__ cl_model0, const int32_t* __restrict__ cl_begin0,
+    const int32_t* __restrict__ cl_count0, const int32_t* __restrict__ n_clusters_dev0, DevCam cam,
+    const DevCam* __restrict__ cam_table, const int32_t* __restrict__ img_of0, int n_images,
+    mh_pose_params prm, uint64_t seed0,
+    const int32_t* obj_base_dev0, int max_objects,
+    int32_t* __restrict__ obj_model0, float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0,
+    float* __restrict__ obj_err0, int32_t* __restrict__ obj_cluster0, int32_t* obj_valid0,
+    FrameCounts* counts0, PoseTail tail0, const FilterFuseArgs* __restrict__ fuse_args, FrameBatch fbx) {
   static_assert(POSE_THREADS == FT, "the fused FILTER runs on the POSE workgroup's threads");
   MH_TRACE_SCOPE(mh::TK_POSE);
-  if (fbx.n > 1) seed = fbx.seed[blockIdx.y];
-  if (blockIdx.y) {   // frame of a batch: its copy of the working arrays, its counts snapshot and result block
-    const unsigned long long a = blockIdx.y * fbx.arena;
-    corr = frame_ptr(corr, a); depth = frame_ptr(depth, a); members = frame_ptr(members, a);
-    cl_model = frame_ptr(cl_model, a); cl_begin = frame_ptr(cl_begin, a); cl_count = frame_ptr(cl_count, a);
-    n_clusters_dev = frame_ptr(n_clusters_dev, a); obj_base_dev = frame_ptr(obj_base_dev, a);
-    obj_model = frame_ptr(obj_model, a); obj_pose = frame_ptr(obj_pose, a); obj_ninl = frame_ptr(obj_ninl, a);
-    obj_err = frame_ptr(obj_err, a); obj_cluster = frame_ptr(obj_cluster, a); obj_valid = frame_ptr(obj_valid, a);
-    counts = frame_ptr(counts, a);
-    tail.ticket = frame_ptr(tail.ticket, a); tail.n_slots = frame_ptr(tail.n_slots, a);
-    if (tail.snap_valid) tail.snap_valid += 4 * blockIdx.y;
-    ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
-    ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
-    ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
-    ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
-    ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
-    ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
-    ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
-    ftail.ticket = frame_ptr(ftail.ticket, a);
-    if (ftail.snap_kept) ftail.snap_kept += 4 * blockIdx.y;
-    ftail.result = frame_ptr(ftail.result, (unsigned long long)blockIdx.y * fbx.result_bytes);
-    f_n_clusters_dev = frame_ptr(f_n_clusters_dev, a);
-  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PoseLds<KIND>& L = *reinterpret_cast<PoseLds<KIND>*>(smem);
   const int R_ = prm.max_objects_per_cluster;
-  const int n_clusters = *n_clusters_dev;
-  const int n_tasks = n_clusters * R_;
-  const int obj_base = obj_base_dev ? *obj_base_dev : 0;
-  for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-    pose_task<KIND>(L, task / R_, task % R_, corr, depth, alpha, members, cl_model, cl_begin, cl_count, cam,
-                    cam_table, img_of, n_images, prm, seed, seed_dev, obj_base, max_objects, obj_model, obj_pose, obj_ninl, obj_err,
-                    obj_cluster, obj_valid, counts);
-    __syncthreads();  // LDS is reused by the next task
-  }
-  if (!tail.ticket) return;
-  if (!last_workgroup(tail.ticket)) return;
-  int n_slots = obj_base + n_tasks;
-  if (n_slots > max_objects) n_slots = max_objects;
-  if (tail.snap_valid) {
-    int c = 0;
-    for (int i = threadIdx.x; i < n_slots; i += POSE_THREADS) c += obj_valid[i] != 0;
-    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-    __shared__ int wave_c[POSE_THREADS / 64];
-    if ((threadIdx.x & 63) == 0) wave_c[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int w = 0; w < POSE_THREADS / 64; ++w) tot += wave_c[w];
-      *tail.snap_valid = tot;
+  const int G = (int)gridDim.x;
+  const int n_frames = fbx.n > 1 ? fbx.n : 1;
+  int rank_base = 0;   // (mod G) tasks of the frames before the current one
+  for (int f = 0; f < n_frames; ++f) {
+    // frame f of a batch: its copy of the working arrays, its counts snapshot and result block
+    const unsigned long long a = (unsigned long long)f * fbx.arena;
+    const int32_t* obj_base_dev = frame_ptr(obj_base_dev0, a);
+    unsigned int* ticket = frame_ptr(tail0.ticket, a);
+    const uint64_t seed = fbx.n > 1 ? fbx.seed[f] : seed0;
+    const int n_clusters = *frame_ptr(n_clusters_dev0, a);
+    const int n_tasks = n_clusters * R_;
+    const int obj_base = obj_base_dev ? *obj_base_dev : 0;
+    bool last = false;
+    int first = ((int)blockIdx.x - rank_base) % G;
+    if (first < 0) first += G;
+    for (int task = first; task < n_tasks; task += G) {
+      pose_task<KIND>(L, task / R_, task % R_, a, corr0, depth0, alpha, members0, cl_model0, cl_begin0, cl_count0, cam,
+                      cam_table, img_of0, n_images, prm, seed, obj_base, max_objects, obj_model0, obj_pose0, obj_ninl0,
+                      obj_err0, obj_cluster0, obj_valid0, counts0);
+      __syncthreads();  // LDS is reused by the next task
+      if (ticket && frame_work_done(ticket, 1u, (unsigned)n_tasks)) last = true;
     }
-  }
-  if (threadIdx.x == 0) *tail.n_slots = n_slots;
-  if (fuse_filter) {
-    // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
-    // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
-    __shared__ FilterLds FS;
-    __syncthreads();
-    filter_score(FS, ffb, cam, f_feature_distance, n_slots, 0, 1);
-    __syncthreads();
-    filter_finish(FS, ffb, f_min_points, f_min_score, n_slots, tail.n_slots, f_n_clusters_dev, counts, ftail);
+    rank_base = (rank_base + n_tasks) % G;
+    if (ticket && n_tasks == 0) last = (int)blockIdx.x == f % G;   // nobody has a task here: one workgroup still closes the frame
+    if (!last) continue;   // (uniform over the workgroup)
+    int n_slots = obj_base + n_tasks;
+    if (n_slots > max_objects) n_slots = max_objects;
+    if (tail0.feedback && threadIdx.x == 0) tail0.feedback[f] = n_tasks;   // what the next launches size their grids by
+    if (tail0.snap_valid) {
+      const int32_t* obj_valid = frame_ptr(obj_valid0, a);
+      int c = 0;
+      for (int i = threadIdx.x; i < n_slots; i += POSE_THREADS) c += obj_valid[i] != 0;
+      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+      __shared__ int wave_c[POSE_THREADS / 64];
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) wave_c[threadIdx.x >> 6] = c;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < POSE_THREADS / 64; ++w) tot += wave_c[w];
+        tail0.snap_valid[4 * f] = tot;
+      }
+    }
+    int32_t* n_slots_dev = frame_ptr(tail0.n_slots, a);
+    if (threadIdx.x == 0) *n_slots_dev = n_slots;
+    if (fuse_args) {
+      // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
+      // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
+      FilterBuffers ffb = fuse_args->fb;
+      ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
+      ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
+      ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
+      ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
+      ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
+      ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
+      ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
+      FilterTail ftail = fuse_args->tail;
+      ftail.ticket = frame_ptr(ftail.ticket, a);
+      if (ftail.snap_kept) ftail.snap_kept += 4 * f;
+      ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
+      __shared__ FilterLds FS;
+      __syncthreads();
+      filter_score(FS, ffb, cam, fuse_args->feature_distance, n_slots, 0, 1);
+      __syncthreads();
+      filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
+                    frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
+      __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)
+    }
   }
 }
 
@@ -1049,34 +1082,58 @@ extern "C" int mh_debug_pose_prof(unsigned long long out[8], int reset) {
 }
 #endif
 
+// the fused FILTER step's arguments, from the launch's kernel arguments (safe to reuse at once) to where pose_kernel reads them
+__global__ void store_fuse_args_kernel(FilterFuseArgs* dst, FilterFuseArgs v) {
+  const int n = (int)(sizeof(FilterFuseArgs) / 4);
+  for (int i = threadIdx.x; i < n; i += 64) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(&v)[i];
+}
+
 template <int KIND>
 static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alpha, const int32_t* members,
                              const int32_t* cl_model, const int32_t* cl_begin, const int32_t* cl_count,
                              const int32_t* n_clusters_dev, int max_clusters, const DevCam& cam,
                              const DevCam* cam_table, const int32_t* img_of, int n_images,
-                             const mh_pose_params& p, uint64_t seed, const uint64_t* seed_dev,
+                             const mh_pose_params& p, uint64_t seed,
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
                              const PoseTail& tail, hipStream_t s, const FilterFuse* fuse, const FrameBatch* batch) {
   static DynLds attr;   // one per KIND (this function is a template)
   attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
-  const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : POSE_GRID;
-  hipLaunchKernelGGL(pose_kernel<KIND>, dim3(std::max(1, std::min(grid_cap, max_clusters * p.max_objects_per_cluster)), batch ? batch->n : 1), dim3(POSE_THREADS),
+  // the fused FILTER step's arguments: on the device already unless they have changed since this context's last launch
+  const FilterFuseArgs* fuse_dev = nullptr;
+  if (fuse && fuse->fb && fuse->tail && tail.ticket && fuse->dev && fuse->shadow && fuse->shadow_valid) {
+    FilterFuseArgs now;
+    std::memset(&now, 0, sizeof now);   // (padding bytes compare equal)
+    now.fb = *fuse->fb;
+    now.tail = *fuse->tail;
+    now.feature_distance = fuse->feature_distance;
+    now.min_score = fuse->min_score;
+    now.min_points = fuse->min_points;
+    now.n_clusters_dev = fuse->n_clusters_dev;
+    if (!*fuse->shadow_valid || std::memcmp(&now, fuse->shadow, sizeof now) != 0) {
+      hipLaunchKernelGGL(store_fuse_args_kernel, dim3(1), dim3(64), 0, s, fuse->dev, now);
+      std::memcpy(fuse->shadow, &now, sizeof now);
+      *fuse->shadow_valid = true;
+    }
+    fuse_dev = fuse->dev;
+  }
+  // one row of workgroups for all frames of the launch (tail.grid = the caller's guess of the launch's task count)
+  const int n_frames = batch && batch->n > 1 ? batch->n : 1;
+  const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : std::min(POSE_GRID, 96 * n_frames);
+  const long all_slots = (long)max_clusters * p.max_objects_per_cluster * n_frames;
+  hipLaunchKernelGGL(pose_kernel<KIND>, dim3((unsigned)std::max(1L, std::min((long)grid_cap, all_slots))), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
-                     n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, seed_dev, obj_base_dev, max_objects, obj_model,
+                     n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, obj_base_dev, max_objects, obj_model,
                      obj_pose, obj_ninl,
-                     obj_err, obj_cluster, obj_valid, counts, tail, fuse && fuse->fb && tail.ticket ? 1 : 0,
-                     fuse && fuse->fb ? *fuse->fb : FilterBuffers{}, fuse && fuse->tail ? *fuse->tail : FilterTail{},
-                     fuse ? fuse->feature_distance : 0.f, fuse ? fuse->min_points : 0, fuse ? fuse->min_score : 0.f,
-                     fuse ? fuse->n_clusters_dev : nullptr, batch ? *batch : FrameBatch());
+                     obj_err, obj_cluster, obj_valid, counts, tail, fuse_dev, batch ? *batch : FrameBatch());
 }
 
 void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
                  const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
-                 const uint64_t* seed_dev, const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
+                 const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
                  int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s,
                  const PoseImages& images, const FilterFuse* fuse, const FrameBatch* batch) {
@@ -1090,7 +1147,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
   const int kind = depth4 ? depth_kind : 0;
 #define POSE_ARGS corr, d4, alpha, members, cl_model, cl_begin, cl_count, n_clusters_dev, max_clusters, cam, \
                   images.cams, images.img_of, images.n_images, p,                                       \
-                  seed, seed_dev, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
+                  seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
                   obj_valid, counts, tail, s, fuse, batch
   if (images.img_of && images.cams && kind == 0)

@@ -72,9 +72,11 @@ size_t screen_rec_slots();           // record slots per query
 
 float screen_margin_host(float qq, float dmax);   // tau = T - margin (the error model, for tests)
 // The screen values themselves, as the matrix pipe computes them (pass A's arithmetic: f16 operands, accumulator seeded
-// with -dd/2, eight v_mfma_f32_32x32x16_f16 in ascending k): out[q][r] for q < Q, r < n_rows (both multiples of 32; qh =
+// with -dd/2, the block's MFMAs in ascending k -- eight v_mfma_f32_32x32x16_f16 or four k-steps of v_mfma_f32_16x16x32_f16):
+// out[q][r] for q < Q, r < n_rows (both multiples of 32; qh =
 // the queries' f16 image).  For tests of the error model against the HARDWARE's accumulation (mh_screen_values).
-void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s);
+// shape: 0 = the instruction the large launches use, 1 = v_mfma_f32_32x32x16_f16, 2 = v_mfma_f32_16x16x32_f16
+void launch_screen_values(const _Float16* qh, int Q, const ScreenDb& sdb, int n_rows, float* out, hipStream_t s, int shape);
 void launch_screen_prepare(const float* qn, const float* qnorm, int Q, int q_pad, _Float16* qh, uint8_t* qbad, hipStream_t s);
 size_t screen_db_half_elems(int N);
 size_t screen_dneg_elems(int N);   // floats of the -dd/2 array: 192 per 128-row tile (rows, row blocks' extrema)

@@ -111,8 +111,9 @@ void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q,
                    int32_t* out_idx, hipStream_t s);
 
 // ---- mean shift ----------------------------------------------------------------
-// CLUSTER of a frame: `grid` workgroups share the models that have matches (0 = one workgroup per model); the last one
-// to finish also writes the flat
+// CLUSTER of a frame, or of the frames of a batch (`batch`): ONE row of `grid` workgroups shares the models that have
+// matches, counted through the frames (0 = one workgroup per model); the one that finishes a frame's last model also
+// writes the frame's flat
 // cluster table in (model, emission) order, *n_clusters_out, counts->n_clusters and
 // snap[0..1] = (matches, clusters).  *ticket: zero-initialised device word (last_workgroup).
 void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int n_models,
@@ -120,7 +121,8 @@ void launch_meanshift_models(const mh_corr* corr, const int32_t* model_off, int 
                              int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                              int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
                              FrameCounts* counts, unsigned int* ticket, hipStream_t s, int models_div = 1, int grid = 0,
-                             const FrameBatch* batch = nullptr);
+                             const FrameBatch* batch = nullptr,
+                             int32_t* feedback = nullptr /* optional, host-visible: [frame] = models this launch had to cluster */);
 // Frames with several images, between group and CLUSTER: m_img[i] = image of match i; m_rep redone with the
 // image in the key (FILTER's bestPoints map is keyed by (coord2D, image), FILTER_PROJECTION_CPU.hpp:89); and the
 // matches once more in (model, image, query) order -- mi_corr / mi_img, off2[n_models * n_images + 1] -- the point
@@ -179,7 +181,8 @@ struct PoseTail {
   unsigned int* ticket;
   int32_t* n_slots;
   int32_t* snap_valid;
-  int grid;   // workgroups to launch (0 = default cap); more tasks than that are looped over
+  int grid;   // workgroups to launch (0 = default cap) for ALL frames of the launch; more tasks than that are looped over
+  int32_t* feedback = nullptr;   // optional, host-visible: [frame] = (cluster, replica) tasks this launch found (the next grids' guess)
 };
 struct FilterBuffers;
 struct FilterTail;
@@ -191,6 +194,11 @@ struct FilterFuse {
   float feature_distance = 0.f, min_score = 0.f;
   int min_points = 0;
   int32_t* n_clusters_dev = nullptr;
+  // where the step's arguments wait on the device (FilterFuseArgs, below) and the host's copy of what is there:
+  // launch_pose stores them (a one-thread launch) only when they have changed -- for a context's frames, never again
+  struct FilterFuseArgs* dev = nullptr;
+  struct FilterFuseArgs* shadow = nullptr;
+  bool* shadow_valid = nullptr;
 };
 
 // One workgroup per (cluster, replica).  Object slots: obj_base + cluster*R + replica.
@@ -201,7 +209,6 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* members, const int32_t* cl_model,
                  const int32_t* cl_begin, const int32_t* cl_count, const int32_t* n_clusters_dev,
                  int max_clusters, const DevCam& cam, const mh_pose_params& prm, uint64_t seed,
-                 const uint64_t* seed_dev /* optional: XORed into seed, read on the device */,
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages(),
@@ -247,6 +254,17 @@ struct FilterTail {
   unsigned char* result;    // optional: packed result block {int32 n; int32 pad[3]; mh_object[]}
   int grid;                 // workgroups to launch (0 = default cap)
 };
+// The fused FILTER step's arguments as the POSE kernel reads them: from device memory, at the one place that needs them
+// (the closing workgroup of a frame), instead of ~70 scalar registers' worth of kernel arguments held -- and spilled --
+// through the RANSAC code.
+struct FilterFuseArgs {
+  FilterBuffers fb;
+  FilterTail tail;
+  float feature_distance, min_score;
+  int min_points;
+  int32_t* n_clusters_dev;
+};
+
 // n_slots_dev: number of object slots in use; after the call the kept objects are
 // compacted to slots [0, kept) in list order, *n_slots_dev = kept, and the cluster
 // table holds their rewritten clusters.  fb.best[0, n_matches) must be zero on entry and

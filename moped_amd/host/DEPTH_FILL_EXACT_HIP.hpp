@@ -5,9 +5,11 @@
 // Same constructor arguments (scaleFactor, doBilinearInterpolation).  For every IMAGE_TYPE_DEPTH_MAP image of the
 // frame: its holes (z < 0) are filled in place and a distance map named "<name>.distance" (IMAGE_TYPE_PROB_MAP, one
 // Float per pixel) is appended to frameData.images (:416-428) -- the map DEPTHMAP_PROP_CPU and CLUSTER_LINKAGE look
-// up by that name.  Bit-identical to the CPU step (mh_depth_fill, include/moped_hip.h).  A map whose downscaled
-// size exceeds what the device fill holds (8192 pixels: 640 x 480 needs a factor >= 8) is left to the CPU step
-// behind this one: process() then does nothing for it and says so.
+// up by that name.  Bit-identical to the CPU step (mh_depth_fill, include/moped_hip.h).  A map the device fill cannot
+// take (its downscaled size exceeds 8192 pixels: 640 x 480 needs a factor >= 8; or any device error) makes this step
+// say so and declare itself NOT capable: the pipeline's getAlgs(true) then hands the slot to the next algorithm
+// registered under "DEPTHFILL" -- the CPU step of the second line above -- from the next frame on (util.hpp:151-159);
+// the frame at hand keeps its holes and gets no distance map, exactly what a frame without this step would have.
 #pragma once
 #include "hip_session.hpp"
 
@@ -26,7 +28,9 @@ class DEPTH_FILL_EXACT_HIP : public MopedAlg {
   void getConfig(map<string, string>& config) const {
     hipGetConfig(config, _stepName, _alg, "DEPTH_FILL_EXACT_HIP", "scaleFactor", scaleFactor);
   }
-  void setConfig(map<string, string>&) {}
+  void setConfig(map<string, string>& config) {
+    if (hipSetConfig(config, _stepName, _alg, "DEPTH_FILL_EXACT_HIP", "scaleFactor", scaleFactor)) configUpdated = true;
+  }
 
   void process(FrameData& frameData) {
     mh_ctx* ctx = HipSession::get();
@@ -47,6 +51,7 @@ class DEPTH_FILL_EXACT_HIP : public MopedAlg {
       if (mh_depth_fill_host(ctx, (float*)&image->data[0], w, h, scaleFactor, doBilinearInterpolation ? 1 : 0, K,
                              (float*)&distance->data[0], 0) != MH_OK) {
         HipSession::warn("mh_depth_fill_host");
+        capable = false;   // the CPU step registered behind this one takes the slot from the next frame on
         continue;
       }
       frameData.images.push_back(distance);

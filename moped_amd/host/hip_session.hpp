@@ -6,6 +6,9 @@
 #include <moped_hip.h>
 
 #include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
 #include <vector>
 
 namespace MopedNS {
@@ -73,6 +76,21 @@ template <typename T>
 inline void hipGetConfig(std::map<std::string, std::string>& config, const std::string& step, int alg,
                          const char* header, const char* var, const T& value) {
   config[step + ":" + toString(alg) + ":" + header + "/" + var] = toString(value);
+}
+
+// The counterpart for setConfig: takes `value` from the key hipGetConfig writes; true if it was there and parsed.
+// (The reference's SET_CONFIG builds its key with another substring length than GET_CONFIG, src/util.hpp:62-63, so a
+// value set through Moped::setConfig never reaches a CPU step -- SURVEY F5; the HIP steps honour the key they publish.)
+template <typename T>
+inline bool hipSetConfig(std::map<std::string, std::string>& config, const std::string& step, int alg, const char* header,
+                         const char* var, T& value) {
+  std::map<std::string, std::string>::iterator it = config.find(step + ":" + toString(alg) + ":" + header + "/" + var);
+  if (it == config.end() || it->second.empty()) return false;
+  std::istringstream in(it->second);
+  T v;
+  if (!(in >> v)) return false;
+  value = v;
+  return true;
 }
 
 }  // namespace MopedNS

@@ -170,15 +170,20 @@ def test_error_model_holds_on_the_hardware_matrix_pipe():
         big = np.ascontiguousarray(np.concatenate([d] * reps)[:4096], np.float32)     # an f16 image needs >= 4096 rows
         n_rows = len(d) // 32 * 32
         c.db_upload(big, np.zeros(len(big), np.int32), np.zeros((len(big), 3), np.float32), 1)
-        wt, dmax, spread = c.screen_values(q, n_rows)
         dd = orclib.row_norms(big[:n_rows])
-        assert abs(dmax - float(np.sqrt(orclib.row_norms(big).max()))) <= 1e-6 * dmax
-        w = T._chain_f32(q, big[:n_rows]).astype(np.float64) - 0.5 * dd.astype(np.float64)[None, :]
-        err = np.abs(wt.astype(np.float64) - w).max(1)
-        qq = (q.astype(np.float64) ** 2).sum(1)
-        half = np.array([0.5 * T._margin(np.float32(x), dmax) for x in qq])
-        assert np.all(err <= half), (name, float((err / half).max()))
-        # and against the emulation: the hardware is not (much) worse than one rounding per product
-        emu = T._screen_f32(q, big[:n_rows], dd).astype(np.float64)
-        assert np.abs(wt - emu).max() <= 0.25 * half.min() + 1e-7, name
+        for shape in (1, 2):        # both MFMA shapes the passes exist in
+            wt, dmax, spread = c.screen_values(q, n_rows, shape)
+            _check_values(T, name, q, big, n_rows, dd, wt, dmax)
     c.close()
+
+
+def _check_values(T, name, q, big, n_rows, dd, wt, dmax):
+    assert abs(dmax - float(np.sqrt(orclib.row_norms(big).max()))) <= 1e-6 * dmax
+    w = T._chain_f32(q, big[:n_rows]).astype(np.float64) - 0.5 * dd.astype(np.float64)[None, :]
+    err = np.abs(wt.astype(np.float64) - w).max(1)
+    qq = (q.astype(np.float64) ** 2).sum(1)
+    half = np.array([0.5 * T._margin(np.float32(x), dmax) for x in qq])
+    assert np.all(err <= half), (name, float((err / half).max()))
+    # and against the emulation: the hardware is not (much) worse than one rounding per product
+    emu = T._screen_f32(q, big[:n_rows], dd).astype(np.float64)
+    assert np.abs(wt - emu).max() <= 0.25 * half.min() + 1e-7, name
