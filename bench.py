@@ -327,6 +327,8 @@ class Job:
             self.uv_b = [torch.cat(self.uvs[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
             self.work_b = [torch.empty_like(self.pristine_b[0]) for _ in range(args.depth)]
             self.depths_b = None if self.depths is None else [torch.cat(self.depths[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
+        # the inputs were put together on torch's default stream (torch.cat); the slots' streams do not wait for it
+        torch.cuda.synchronize(dev)
         self.active_slots = args.depth   # slots in use (the calibration may settle on fewer)
         self.host_desc = None            # h2d measurement: the same descriptors in pinned host memory
         self.last_slots = {}             # slot -> pool group of the batch it ran last

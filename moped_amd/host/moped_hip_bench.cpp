@@ -11,7 +11,10 @@
 //   int32 n_models, Q, n_frames ; float K[4] ; float cam[7]
 //   per model: int32 n_pts ; float xyz[n_pts][3] ; float desc[n_pts][128]
 //   per frame: float q_uv[Q][2] ; float q_desc[Q][128]
+#include <execinfo.h>
 #include <hip/hip_runtime_api.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -49,7 +52,18 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static void on_fault(int sig) {   // a crash says where (the binary is linked -rdynamic)
+  void* pc[48];
+  const int n = backtrace(pc, 48);
+  static const char msg[] = "moped_hip_bench: fatal signal, call stack:\n";
+  if (write(2, msg, sizeof msg - 1) < 0) _exit(128 + sig);
+  backtrace_symbols_fd(pc, n, 2);
+  _exit(128 + sig);
+}
+
 int main(int argc, char** argv) {
+  signal(SIGSEGV, on_fault);
+  signal(SIGBUS, on_fault);
   // one hardware queue per slot: the HIP runtime reads this when it creates its queues
   setenv("GPU_MAX_HW_QUEUES", "16", 0);
   if (argc < 2) {
@@ -123,10 +137,11 @@ int main(int argc, char** argv) {
   const int groups = std::max(pool_groups, frames_per_step / B);
   vector<uint64_t> seeds(B);
   vector<int> last_pg(slots, -1);
+  unsigned long issued = 0;   // batches handed out so far: batch i goes to slot i mod slots
   // one step = `groups` batches, round-robin over the slots; from_host: the descriptors cross PCIe inside the loop
   auto run_step = [&](int step, bool from_host) -> int {
     for (int g = 0; g < groups; ++g) {
-      const int s = (step * groups + g) % slots, pg = g % pool_groups;
+      const int s = (int)(issued++ % (unsigned long)slots), pg = g % pool_groups;
       const float* src = (from_host ? h_desc : d_pristine) + fd * B * pg;
       CK_HIP(hipMemcpyAsync(work[s], src, fd * B * 4, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream[s]));
       for (int k = 0; k < B; ++k) seeds[k] = 1000ull * (uint64_t)(step + 7) + (uint64_t)g * B + k + 1;
