@@ -53,7 +53,7 @@ constexpr int exp_int(const char*, int def) { return def; }
 // records scripts/cu_trace.py rebuilds every compute unit's timeline -- how long it held a MATCH workgroup, how long
 // only small ones (that a MATCH workgroup cannot join), how long nothing.  Nothing of this exists in the product build.
 #ifdef MH_TRACE
-enum TraceKernel : unsigned { TK_NORMALIZE = 1, TK_PREPARE, TK_PASS_A, TK_TAU, TK_PASS_B, TK_PASS_C, TK_GROUP, TK_CLUSTER, TK_POSE, TK_OTHER };
+enum TraceKernel : unsigned { TK_NORMALIZE = 1, TK_PREPARE, TK_PASS_A, TK_TAU, TK_PASS_B, TK_PASS_C, TK_GROUP, TK_CLUSTER, TK_POSE, TK_OTHER, TK_PASS_B_LOOP };
 typedef void (*TraceBindFn)(unsigned long long*);
 inline std::atomic<int>& trace_n_binds() { static std::atomic<int> n{0}; return n; }
 inline TraceBindFn* trace_binds() { static TraceBindFn fns[32]; return fns; }
@@ -92,10 +92,12 @@ constexpr unsigned long long TRACE_CAP = 1ull << 21;   // records (32 bytes each
   };                                                                                                               \
   }
 #define MH_TRACE_SCOPE(kid) TraceScope trace_scope_(kid)
+#define MH_TRACE_PHASE(name, kid) TraceScope name(kid)   // a part of a workgroup's life (ends with the enclosing block)
 #endif
 #else
 #define MH_TRACE_TU()
 #define MH_TRACE_SCOPE(kid) do { } while (0)
+#define MH_TRACE_PHASE(name, kid) do { } while (0)
 #endif
 
 // ---- match ------------------------------------------------------------------

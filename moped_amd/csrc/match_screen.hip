@@ -844,11 +844,14 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
   };
 
   int side = 0;
-  v4f pend[2][2];
+  // the pending block starts as one no threshold lets through (its dots -inf): the loop needs no "is there one yet"
+  const v4f ninf4 = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  v4f pend[2][2] = {{ninf4, ninf4}, {ninf4, ninf4}};
   float pend_hi = 0.f;
   int pend_row0 = 0;
-  bool have_pend = false;
   const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+  {
+  MH_TRACE_PHASE(trace_loop_, MODE == 1 ? mh::TK_PASS_B_LOOP : mh::TK_OTHER);
   for (int sel = sel_begin; sel < sel_end; ++sel) {
     const bool more = sel + 1 < sel_end;
     if (more) stage(sel + 1, side ^ 1);
@@ -908,8 +911,8 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
               for (int tj = 0; tj < 2; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][s], bq[nb][tj][s], acc[ti][tj], 0, 0, 0);
             // the pending block's maxima in the shadow of the second half of the MFMAs (its values have left the pipe by then)
-            if (have_pend && s == 2) m0 = max8(pend[0][0], pend[1][0]);
-            if (have_pend && s == 3) m1 = max8(pend[0][1], pend[1][1]);
+            if (s == 2) m0 = max8(pend[0][0], pend[1][0]);
+            if (s == 3) m1 = max8(pend[0][1], pend[1][1]);
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #pragma unroll
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (have_pend) {
+          {
             const float thr0 = t0 - pend_hi, thr1 = t1 - pend_hi;
             emit_block(m0 > thr0, m1 > thr1, pend, pnb, pend_row0, m0, m1, thr0, thr1);
           }
@@ -929,7 +932,6 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
             for (int tj = 0; tj < 2; ++tj) pend[ti][tj] = acc[ti][tj];
           pend_row0 = row0;
           pend_hi = hi[rb];
-          have_pend = true;
         }
       }
     }
@@ -937,8 +939,9 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
     __syncthreads();
     side ^= 1;
   }
+  }
   if (MODE == 1) {
-    if (have_pend) {
+    {
       const float m0 = max8(pend[0][0], pend[1][0]), m1 = max8(pend[0][1], pend[1][1]);
       const float thr0 = tau_lds[(NQB - 1) * 32 + l16] - pend_hi, thr1 = tau_lds[(NQB - 1) * 32 + 16 + l16] - pend_hi;
       emit_block(m0 > thr0, m1 > thr1, pend, NQB - 1, pend_row0, m0, m1, thr0, thr1);
@@ -1374,6 +1377,10 @@ void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int b
   if (ev) hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(screen_tau_kernel, dim3((a.q_pad + 255) / 256), dim3(256), 0, s, a.part, Sa, a.q_pad, a.Q, a.q_count,
                      a.qnorm, a.qbad, a.dmax, const_cast<float*>(a.tau));
+#ifdef MH_EXPERIMENTS
+  // what the records cost pass B: thresholds no value reaches (WRONG results: timing only)
+  if (exp_int("MH_SCREEN_NO_HITS", 0)) hipMemsetAsync(const_cast<float*>(a.tau), 0x7f, (size_t)a.q_pad * sizeof(float), s);
+#endif
   if (ev) hipEventRecord(ev[3], s);
   if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
   const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 4);
