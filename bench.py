@@ -33,7 +33,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32-input MFMA peak
 PEAK_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA (the F16 forms take the same cycles)
-SUSTAINED_F16_TFLOPS = 1940.0   # measured: a register-only loop of v_mfma_f32_32x32x16_f16 on all 1024 SIMDs (profiles/r02_mfma_f16_rate.txt)
+# What the matrix pipes sustain on RANDOM operands out of registers, two wavefronts per SIMD, every CU (the clock the power
+# budget allows under matrix load): v_mfma_f32_16x16x32_f16 (pass B's instruction) 1 842-1 994 TFLOP/s over the boxes of the
+# pool, v_mfma_f32_32x32x16_f16 1 625-1 771 (profiles/r03_mfma_shapes_rate.txt).  bench.py measures the box it runs on
+# (moped_amd/host/mfma_rate --json) and falls back to this figure.
+SUSTAINED_F16_TFLOPS = 1900.0
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 N_CU = 256
 
@@ -742,6 +746,26 @@ def host_side_figures(args, db, frames):
     return out
 
 
+def sustained_mfma(ach_tf):
+    """achieved / what a register-only loop of pass B's MFMA sustains on THIS box right now (a child process: our own
+    streams are idle while it runs)."""
+    tool = os.path.join(ROOT, "moped_amd", "host", "mfma_rate")
+    tf, src = SUSTAINED_F16_TFLOPS, "profiles/r03_mfma_shapes_rate.txt (typical; moped_amd/host/mfma_rate not built)"
+    shapes = None
+    if os.path.exists(tool):
+        try:
+            res = subprocess.run([tool, "--json"], capture_output=True, text=True, timeout=60)
+            shapes = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+            tf, src = float(shapes["f16_16x16x32_tflops"]), "moped_amd/host/mfma_rate --json, this box, after the timed region"
+        except Exception as e:   # the figure is a secondary one: never fail the line for it
+            src += f" ({type(e).__name__})"
+    out = {"tflops": round(tf, 1), "frac": round(ach_tf / tf, 4), "source": src,
+           "what": "v_mfma_f32_16x16x32_f16 on random operands out of registers, two wavefronts per SIMD, all CUs"}
+    if shapes:
+        out["f16_32x32x16_tflops"] = shapes["f16_32x32x16_tflops"]
+    return out
+
+
 def roofline(job, fps, out):
     import torch
     args, pipe, B = job.args, job.pipe, job.B
@@ -791,8 +815,8 @@ def roofline(job, fps, out):
         rec_bytes = 8.0 * st["candidates"] / max(st["queries"], 1) * Qr / 1.3   # ~1.3 rows per record
         b_alg = 256.0 * n_local + 256.0 * Qr + rec_bytes      # f16 DB once + f16 queries once + candidate records
         return {
-            "kernel": "screen_kernel<1> = pass B of the two-stage MATCH: f16 x f16 -> f32 on the matrix pipe over every "
-                      "(query, row) pair",
+            "kernel": "screen16_kernel<1, 4> = pass B of the two-stage MATCH: f16 x f16 -> f32 (v_mfma_f32_16x16x32_f16) over "
+                      "every (query, row) pair",
             "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
             "ms_per_launch": round(t_b, 4),
@@ -810,10 +834,8 @@ def roofline(job, fps, out):
                         "profiles/r03_*_depth1_kernel_stats.* is the same command under rocprofv3 with --depth 1",
             "whole_pipeline_tflops_per_gpu": round(flops / B * fps / 1e12, 2),   # F_alg of this rank's shard x frames/s
             # `peak` is the data sheet's 2.5 PFLOP/s (2.4 GHz); a loop of nothing but this MFMA out of registers on every
-            # SIMD sustains 1 940 TFLOP/s on this part (scripts/experiments/mfma_f16_rate.hip,
-            # profiles/r02_mfma_f16_rate.txt: the clock the power budget allows under matrix load)
-            "sustained_mfma_only": {"tflops": SUSTAINED_F16_TFLOPS, "frac": round(ach_tf / SUSTAINED_F16_TFLOPS, 4),
-                                    "source": "profiles/r02_mfma_f16_rate.txt"},
+            # SIMD sustains 74-80% of it (the clock the power budget allows under matrix load), measured on this box:
+            "sustained_mfma_only": sustained_mfma(ach_tf),
             "hbm": {"achieved": round(b_alg / (t_b * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(b_alg / (t_b * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "algorithmic_bytes": int(b_alg)},
         }

@@ -1382,8 +1382,26 @@ void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int b
   if (exp_int("MH_SCREEN_NO_HITS", 0)) hipMemsetAsync(const_cast<float*>(a.tau), 0x7f, (size_t)a.q_pad * sizeof(float), s);
 #endif
   if (ev) hipEventRecord(ev[3], s);
-  if (blocks_b <= 0) blocks_b = (long)n_tiles * nqb_e >= (NQB >= 4 ? 16L : 24L) * 512 ? 512 : 256;
-  const int Sb = splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 4);
+  // Pass B's splits.  A query's 256 record slots are shared out over 4 x Sb lane-private sub-lists here (the 32x32x16
+  // passes: 2 x Sb), and a sub-list needs room for three records or queries spill into the overflow list and from there
+  // into pass C's brute-force search (12 000 queries x 250 000 rows ran 42 splits with ONE slot per sub-list for a while:
+  // 42 brute-force queries per launch, pass C 10 ms instead of 0.03): Sb <= 21.  One workgroup per compute unit, so the
+  // launch takes ceil(workgroups / 256) rounds of n_tiles / Sb tiles each: the Sb with the least rounds x tiles, the
+  // larger of equals.  (blocks_b > 0: an experiment's request, capped the same way.)
+  constexpr int SB16_MAX = SC_SLOTS_MAX / 12;
+  int Sb = 1;
+  if (blocks_b > 0) {
+    Sb = std::min(splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 4), SB16_MAX);
+  } else {
+    double best = 1e30;
+    for (int c = 1; c <= std::min(SB16_MAX, std::max(1, n_tiles / 8)); ++c) {
+      const double cost = (double)((nqb_e * c + 255) / 256) * (double)((n_tiles + c - 1) / c);
+      if (cost <= best) {
+        best = cost;
+        Sb = c;
+      }
+    }
+  }
   a.n_sel = n_tiles;
   a.tile_first = 0;
   a.tile_stride = 1;
@@ -1456,7 +1474,8 @@ void launch_match_screen(const float* qn, const float* qnorm, int Q, const float
   // the MFMA shape of the large launches: 16x16x32 (SC_SHAPE16_LARGE; MH_SCREEN_SHAPE = 1 / 2 pins 32x32x16 / 16x16x32 in experiment builds)
   static const int shape_pin = exp_int("MH_SCREEN_SHAPE", 0);
   const bool shape16 = shape_pin == 2 || (shape_pin == 0 && SC_SHAPE16_LARGE);
-  if (nqb_sel == 4 && shape16) launch_passes16<4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig);
+  // (16x16x32 from 12 query blocks of 1024: with fewer, 21 splits leave compute units without a workgroup)
+  if (nqb_sel == 4 && shape16 && (shape_pin == 2 || (qe + 1023) / 1024 >= 12)) launch_passes16<4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig);
   else if (nqb_sel == 2 && shape16 && shape_pin == 2) launch_passes16<2>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig);
   else if (nqb_sel == 4 && nw_sel == 4) launch_passes<4, 4>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);
   else if (nqb_sel == 4) launch_passes<4, 8>(a, Q, qe, n_tiles, sample, blocks_a, blocks_b, &n_slots, sb.ev, sbig, 256);

@@ -2,9 +2,12 @@
 // (eight different A and B fragments per wavefront, cycled), two wavefronts per SIMD on every CU: v_mfma_f32_32x32x16_f16
 // (pass B's instruction) against v_mfma_f32_16x16x32_f16 (MI355X_MICROARCH.md: ~1.15x in bare loops).
 //   hipcc --offload-arch=gfx950 -O2 scripts/experiments/mfma_shapes_rate.hip -o /tmp/mfma_shapes && /tmp/mfma_shapes
+// make -C moped_amd/host builds it as moped_amd/host/mfma_rate; `mfma_rate --json` is what bench.py runs for
+// roofline.sustained_mfma_only (the rate THIS box's matrix pipes sustain: boxes of the pool differ by 8%).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -57,8 +60,10 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(float* out, int iters) {
   if (s == 12345.678f) out[0] = s;   // keep the loop
 }
 
+static bool g_quiet = false;
 template <int SHAPE>
-static void run(int blocks, int iters, const char* label) {
+static double run(int blocks, int iters, const char* label) {
+  double best = 0.0;
   float* out;
   hipMalloc(&out, 4);
   hipEvent_t e0, e1;
@@ -76,15 +81,24 @@ static void run(int blocks, int iters, const char* label) {
     // per iteration and wavefront: SHAPE 0: 32 MFMAs x 2*32*32*16 flops; SHAPE 1: 64 MFMAs x 2*16*16*32 flops
     const double per_iter = SHAPE == 0 ? 32.0 * 2 * 32 * 32 * 16 : 64.0 * 2 * 16 * 16 * 32;
     const double flops = per_iter * iters * 8.0 * blocks;
-    std::printf("%s: %.1f ms: %.0f TFLOP/s\n", label, ms, flops / ms * 1e-9);
+    if (!g_quiet) std::printf("%s: %.1f ms: %.0f TFLOP/s\n", label, ms, flops / ms * 1e-9);
+    if (rep > 0 && flops / ms * 1e-9 > best) best = flops / ms * 1e-9;   // (the first repetition still ramps)
   }
   hipFree(out);
+  return best;
 }
 
-int main() {
+int main(int argc, char** argv) {
   int cus = 256;
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, 0) == hipSuccess) cus = p.multiProcessorCount;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 3;
+  cus = p.multiProcessorCount;
+  if (argc > 1 && !std::strcmp(argv[1], "--json")) {
+    g_quiet = true;
+    const double r32 = run<0>(cus, 8000, ""), r16 = run<1>(cus, 8000, "");
+    std::printf("{\"f16_32x32x16_tflops\": %.1f, \"f16_16x16x32_tflops\": %.1f, \"cus\": %d}\n", r32, r16, cus);
+    return 0;
+  }
   std::printf("%d CUs\n", cus);
   run<0>(cus, 20000, "32x32x16 f16, random operands, two wavefronts per SIMD");
   run<1>(cus, 20000, "16x16x32 f16, random operands, two wavefronts per SIMD");

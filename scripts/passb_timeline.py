@@ -86,6 +86,36 @@ for k, name in ((3, "pass A"), (5, "pass B")):
     print(f"  compute units used {med[4]:.0f}, workgroups per unit {med[5]:.0f}..{med[6]:.0f}; a unit's first workgroup starts "
           f"{med[7]:.1f} us after the launch's first (worst {med[8]:.1f}); its last ends {med[9]:.1f} us before the launch's last "
           f"(worst {med[10]:.1f}); empty between its workgroups {med[11]:.1f} us; units busy {med[12]:.1f}% of the span")
+# what do slow workgroups have in common?  (blockIdx.x rides in the trace record: XCD = L & 7; the kernel's unit map gives
+# split and query block)
+m5 = kid == 5
+if m5.any():
+    bx = ((r[:, 1] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)[m5]
+    d5 = (tb[m5] - ta[m5]) * 1e-2
+    a5 = ta[m5]
+    U = 504 if True else 0
+    U = int(bx.max()) + 1
+    nqb = -(-Qr // 1024)
+    x, j = bx & 7, bx >> 3
+    unit = x * (U >> 3) + np.minimum(x, U & 7) + j
+    split, qb = unit // nqb, unit % nqb
+    # round: is it the first or the second workgroup of its unit in its launch?
+    order = np.argsort(a5)
+    launch = np.empty(len(a5), np.int64); launch[order] = np.arange(len(a5)) // U
+    first = np.ones(len(a5), bool)
+    cu5 = cu[m5]
+    seen = {}
+    for i in order:
+        k = (int(launch[i]), int(cu5[i]))
+        first[i] = k not in seen
+        seen[k] = 1
+    def table(name, key):
+        print(f"  mean residence by {name}: " + " ".join(f"{int(k)}:{d5[key == k].mean():.0f}" for k in np.unique(key)))
+    print(f"pass B workgroups ({U} per launch, {nqb} query blocks):")
+    table("XCD", x)
+    table("round on its unit (1 = first)", np.where(first, 1, 2))
+    table("query block", qb)
+    table("split", split)
 # the tile loop inside pass B's workgroups (kernel id 11, trace build): what is left is prologue (the queries' operands
 # into registers, thresholds into LDS, the first tile's DMA issued) and epilogue (pending block, parked records)
 m5, m11 = kid == 5, kid == 11

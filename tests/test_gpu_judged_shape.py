@@ -105,6 +105,41 @@ def test_raw_match_of_24000_queries_screen_vs_exact_kernel_vs_oracle(world):
     assert np.array_equal(res[1][2][pick].view(np.uint32), o2.view(np.uint32))
     c.close()
 
+@pytest.mark.parametrize("n_models,n_q", [(50, 12000), (50, 16000), (120, 12000)])
+def test_other_large_launch_shapes_keep_every_query_on_the_screened_path(n_models, n_q):
+    """Config 5's launch (4 frames x 3000 queries against 250 000 rows) and its neighbours: the 16x16x32 passes share a
+    query's record slots out over 4 x splits sub-lists, and with 42 splits a sub-list held ONE record -- queries spilled
+    into the overflow list and from there into pass C's brute-force search (exact, and 20x slower: config 5 ran at half
+    its round-2 rate for a while in round 3).  Same bits as the exact kernel, and no query searched by brute force."""
+    import torch
+    db = synth.make_db(n_models, 5000)
+    dev = torch.device("cuda:0")
+    c = capi.Context(0)
+    dbn = c.normalize(db.desc)
+    c.db_upload(dbn, db.model_of, db.xyz, db.n_models)
+    c.reserve(n_q)
+    per = 3000 if n_q % 3000 == 0 else 4000
+    frs = [synth.make_frame(db, n_vis=2, seed=70 + s, Q=per) for s in range(n_q // per)]
+    qn = np.concatenate([orclib.normalize(f.desc) for f in frs])
+    tq = torch.from_numpy(qn).to(dev)
+    qnorm = torch.from_numpy(orclib.row_norms(qn)).to(dev)
+    res = {}
+    for mode in (1, 0):
+        out = [torch.empty(n_q, dtype=t, device=dev) for t in (torch.int32, torch.float32, torch.float32)]
+        c.match_set_mode(mode)
+        c.match_stats(reset=True)
+        c.match_local_dev(tq.data_ptr(), qnorm.data_ptr(), n_q, *[o.data_ptr() for o in out])
+        c.synchronize()
+        res[mode] = [o.cpu().numpy() for o in out]
+        if mode == 1:
+            st = c.match_stats()
+            assert st["queries"] == n_q and st["brute_force_queries"] == 0
+    c.match_set_mode(-1)
+    c.close()
+    assert np.array_equal(res[1][0], res[0][0])
+    assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    assert np.array_equal(res[1][2].view(np.uint32), res[0][2].view(np.uint32))
+
 
 @pytest.mark.parametrize("assign", ["block", "round-robin"])
 def test_rest_frames_of_eight_at_eight_ranks_equal_the_single_context(world, assign):
