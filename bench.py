@@ -517,6 +517,15 @@ def main():
     if args.depth > 4:
         # one HW queue per frame in flight (+ RCCL's); the HIP runtime reads this when it initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.depth, 16)))
+    # The C++ hosts (moped_hip_bench, the STEP-plugin harness) are measured FIRST, as child processes, while this
+    # process has not touched the GPU: a C++ host runs alone in production, and one that shares the chip's hardware
+    # queues with this file's 16 streams loses a third of its pinned-host rate (8 300 against 12 400 frames/s).
+    host_figs = None
+    if rank == 0 and world == 1 and not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
+        from moped_amd import synth as _synth
+        _db = _synth.make_db(args.models, 5000)
+        _pool = max(1, min(args.frame_pool, args.frames_per_step))
+        host_figs = host_side_figures(args, _db, [_synth.make_frame(_db, n_vis=args.n_vis, seed=s, Q=args.queries) for s in range(_pool)])
     import torch
     import torch.distributed as dist
     from moped_amd import capi, synth
@@ -674,8 +683,8 @@ def main():
                                                  "descriptors, sharded by model; a reported figure, not `value`"}
             j3.close()
 
-    if rank == 0 and world == 1 and not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
-        out.update(host_side_figures(args, db, [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]))
+    if host_figs:
+        out.update(host_figs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if job is None:
             frames_cpu = [synth.make_frame(db, n_vis=args.n_vis, seed=s, Q=Q) for s in range(n_pool)]

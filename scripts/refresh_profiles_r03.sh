@@ -25,12 +25,12 @@ if has prof; then
     a=""; [ $d = 1 ] && a="--depth 1 --frames-per-step 128"
     rm -rf /tmp/rp_$d
     timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$d -- python3 $root/bench.py --no-cpu-baseline --no-secondary --h2d-steps 0 $a 2>/tmp/rp_$d.err | line > $out/r03_bench_20models_depth${d}_under_rocprof.json || { tail -3 /tmp/rp_$d.err; exit 1; }
-    cp $(find /tmp/rp_$d -name "*kernel_stats.csv" | head -1) $out/r03_bench_20models_depth${d}_kernel_stats.csv
+    cp $(grep -l screen $(find /tmp/rp_$d -name "*kernel_stats.csv") | head -1) $out/r03_bench_20models_depth${d}_kernel_stats.csv   # (the bench's own process: rocprofv3 also writes a file for the mfma_rate child)
     echo "rocprof depth $d done"
   done
   rm -rf /tmp/rp_200
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_200 -- python3 $root/bench.py --models 200 --depth 1 --frames-per-step 32 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --h2d-steps 0 2>/tmp/rp_200.err | line > $out/r03_bench_200models_depth1_under_rocprof.json || { tail -3 /tmp/rp_200.err; exit 1; }
-  cp $(find /tmp/rp_200 -name "*kernel_stats.csv" | head -1) $out/r03_bench_200models_depth1_kernel_stats.csv
+  cp $(grep -l screen $(find /tmp/rp_200 -name "*kernel_stats.csv") | head -1) $out/r03_bench_200models_depth1_kernel_stats.csv
   cd $root
 fi
 if has traffic; then
