@@ -75,9 +75,9 @@ def parse(argv=None):
                     help="N > 1: 'models' (the north-star design, and what 'auto' means) shards the DB by model with one "
                          "all-gather per batch of frames; 'frames' replicates the DB and gives every rank its own frames (no "
                          "exchange: SURVEY 8(e)'s alternative for DBs too small to shard)")
-    ap.add_argument("--assign", choices=("block", "round-robin"), default="block",
-                    help="model -> rank assignment of a sharded DB: contiguous blocks, or round-robin (SURVEY 8(e): spreads the "
-                         "visible models' POSE work over the ranks)")
+    ap.add_argument("--assign", choices=("block", "round-robin"), default="round-robin",
+                    help="model -> rank assignment of a sharded DB: round-robin (rank r owns models r, r + N, ...; SURVEY 8(e): spreads the "
+                         "visible models' POSE work over the ranks) or contiguous blocks")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per MATCH launch and exchange (default: the library's choice for the partition; 1 = every "
                          "frame on its own)")

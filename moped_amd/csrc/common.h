@@ -53,7 +53,7 @@ constexpr int exp_int(const char*, int def) { return def; }
 // records scripts/cu_trace.py rebuilds every compute unit's timeline -- how long it held a MATCH workgroup, how long
 // only small ones (that a MATCH workgroup cannot join), how long nothing.  Nothing of this exists in the product build.
 #ifdef MH_TRACE
-enum TraceKernel : unsigned { TK_NORMALIZE = 1, TK_PREPARE, TK_PASS_A, TK_TAU, TK_PASS_B, TK_PASS_C, TK_GROUP, TK_CLUSTER, TK_POSE, TK_OTHER, TK_PASS_B_LOOP };
+enum TraceKernel : unsigned { TK_NORMALIZE = 1, TK_PREPARE, TK_PASS_A, TK_TAU, TK_PASS_B, TK_PASS_C, TK_GROUP, TK_CLUSTER, TK_POSE, TK_OTHER, TK_PASS_B_LOOP, TK_PASS_A_LOOP };   // (the last two: phases INSIDE a pass workgroup)
 typedef void (*TraceBindFn)(unsigned long long*);
 inline std::atomic<int>& trace_n_binds() { static std::atomic<int> n{0}; return n; }
 inline TraceBindFn* trace_binds() { static TraceBindFn fns[32]; return fns; }

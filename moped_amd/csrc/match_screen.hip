@@ -851,7 +851,7 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
   int pend_row0 = 0;
   const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
   {
-  MH_TRACE_PHASE(trace_loop_, MODE == 1 ? mh::TK_PASS_B_LOOP : mh::TK_OTHER);
+  MH_TRACE_PHASE(trace_loop_, MODE == 1 ? mh::TK_PASS_B_LOOP : mh::TK_PASS_A_LOOP);
   for (int sel = sel_begin; sel < sel_end; ++sel) {
     const bool more = sel + 1 < sel_end;
     if (more) stage(sel + 1, side ^ 1);

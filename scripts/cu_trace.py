@@ -70,6 +70,7 @@ L.mh_trace_enable(0)
 print(f"{models} models, {B} frames per batch, {depth} slots, {batches} batches ({mode}): {batches * B / dt:.0f} frames/s traced, "
       f"{fps_untraced:.0f} untraced; {n} workgroup records")
 r = buf[:min(n, buf.shape[0])]
+r = r[(r[:, 0] >> np.uint64(32)) <= np.uint64(10)]   # (ids above 10 are phases inside a pass A / B workgroup: scripts/passb_timeline.py)
 if os.environ.get("CU_TRACE_SAVE"):
     np.save(os.environ["CU_TRACE_SAVE"], r)
 kid = (r[:, 0] >> np.uint64(32)).astype(np.int64)

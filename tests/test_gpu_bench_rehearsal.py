@@ -47,11 +47,12 @@ def test_plain_python_gpus_2_starts_two_ranks_and_shards_the_models():
     assert s200["parallelism"] == "model-shard x2" and s200["models_per_rank"] == 100 and s200["objects_per_frame"] == 2.0
 
 
-def test_under_the_drivers_launcher_round_robin_models():
-    d = _run(["--models", "50", "--assign", "round-robin", "--frames-per-step", "32", "--no-secondary"], launcher=True,
+def test_under_the_drivers_launcher_block_models():
+    """(the default assignment is round-robin: the first test; here the contiguous blocks, under the driver's launcher)"""
+    d = _run(["--models", "50", "--assign", "block", "--frames-per-step", "32", "--no-secondary"], launcher=True,
              port=29741 + os.getpid() % 100)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x2"
-    assert d["config"]["model_assignment"] == "round-robin" and d["config"]["ranks_launched_by"] == "torch.distributed.run"
+    assert d["config"]["model_assignment"] == "block" and d["config"]["ranks_launched_by"] == "torch.distributed.run"
     assert d["config"]["objects_per_frame"] == 2.0 and d["config"]["frames_per_match_launch"] == 8
 
 
