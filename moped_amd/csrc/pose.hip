@@ -983,15 +983,24 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
   const int G = (int)gridDim.x;
   const int n_frames = fbx.n > 1 ? fbx.n : 1;
   int rank_base = 0;   // (mod G) tasks of the frames before the current one
+  // Every frame's task count and first object slot, fetched by one thread per frame in ONE round trip: both are final
+  // when the launch starts (the cluster count of POSE2 is FILTER's, written by the launch before this one).  Walking the
+  // frames with two dependent global loads each kept every workgroup of a 32-frame batch resident for ~50 us it spent
+  // on nothing else -- on half a compute unit that no MATCH workgroup could use meanwhile.
+  __shared__ int fr_tasks[MH_MAX_BATCH], fr_obj_base[MH_MAX_BATCH];
+  if ((int)threadIdx.x < n_frames) {
+    const unsigned long long a = (unsigned long long)threadIdx.x * fbx.arena;
+    fr_tasks[threadIdx.x] = *frame_ptr(n_clusters_dev0, a) * R_;
+    fr_obj_base[threadIdx.x] = obj_base_dev0 ? *frame_ptr(obj_base_dev0, a) : 0;
+  }
+  __syncthreads();
   for (int f = 0; f < n_frames; ++f) {
     // frame f of a batch: its copy of the working arrays, its counts snapshot and result block
     const unsigned long long a = (unsigned long long)f * fbx.arena;
-    const int32_t* obj_base_dev = frame_ptr(obj_base_dev0, a);
     unsigned int* ticket = frame_ptr(tail0.ticket, a);
     const uint64_t seed = fbx.n > 1 ? fbx.seed[f] : seed0;
-    const int n_clusters = *frame_ptr(n_clusters_dev0, a);
-    const int n_tasks = n_clusters * R_;
-    const int obj_base = obj_base_dev ? *obj_base_dev : 0;
+    const int n_tasks = fr_tasks[f];
+    const int obj_base = fr_obj_base[f];
     bool last = false;
     int first = ((int)blockIdx.x - rank_base) % G;
     if (first < 0) first += G;
