@@ -93,6 +93,9 @@ def parse(argv=None):
                     help="skip the secondary measurements (replicated_frames, sharded_200_models, single-frame latency, "
                          "the C++ hosts)")
     ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--watchdog", type=int, default=-1,
+                    help="seconds after which a rank that is still running dumps every thread's Python stack to stderr and "
+                         "exits with an error instead of hanging (default: 900 for N > 1, off for N = 1; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args(argv)
@@ -507,6 +510,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world                    # n_gpus = the ranks that run, whatever --gpus said
+    wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
+    if wd > 0:   # a collective that never completes must end the job with a stack, not hold the node
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     if args.parallelism == "auto":
         args.parallelism = choose_parallelism(args.models, world)
     by_frames = args.parallelism == "frames" and not args.force_exchange
@@ -624,7 +631,8 @@ def main():
         dist.barrier()
 
     # ---- POSE: occupancy, hypotheses/s, share of the chip's CU time ----
-    if rank == 0 and not args.no_roofline and "roofline" in out and not (args.depth_kind or args.moped3d_frontend):
+    # (N = 1 only: with a sharded DB a batch on rank 0's pipeline is a collective the other ranks would have to join)
+    if rank == 0 and world == 1 and not args.no_roofline and "roofline" in out and not (args.depth_kind or args.moped3d_frontend):
         try:
             pm = measure_pose(job, out["config"])
         except Exception as e:   # a reported extra, never a reason to lose the line

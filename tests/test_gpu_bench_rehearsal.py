@@ -14,13 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra, launcher=False, port=0):
+def _run(extra, launcher=False, port=0, gpus=2, roofline=False):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MH_BENCH_REHEARSE"] = "1"
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-            "--no-roofline", "--h2d-steps", "0"] + extra
+    # --watchdog: a rank that waits for a collective the others never issue ends with its stack, not with the suite's timeout
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--h2d-steps", "0", "--watchdog", "300"] + ([] if roofline else ["--no-roofline"]) + extra
     if launcher:   # the way the driver starts N > 1
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr",
                "127.0.0.1", "--master-port", str(port)] + tail
     else:
         cmd = [sys.executable] + tail
@@ -60,3 +61,15 @@ def test_frames_partition_is_an_option():
     d = _run(["--parallelism", "frames", "--frames-per-step", "64", "--no-secondary"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("frame-parallel x2")
     assert d["config"]["objects_per_frame"] == 2.0
+
+
+def test_four_ranks_with_every_leg_of_the_default_run():
+    """The line exactly as the driver asks for it -- roofline, POSE figures, secondary partitions -- with four ranks: every
+    leg that only rank 0 runs must be free of collectives (round 3: the POSE measurement enqueued a sharded batch on rank
+    0 alone and the job hung in its all-gather; the two-rank tests had run with --no-roofline)."""
+    d = _run(["--frames-per-step", "128", "--secondary-steps", "1"], gpus=4, roofline=True)
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x4"
+    assert d["config"]["model_assignment"] == "round-robin" and d["config"]["exchange"]["world"] == 4
+    assert d["config"]["objects_per_frame"] == 2.0 and "suspect" not in d
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
+    assert d["replicated_frames"]["objects_per_frame"] == 2.0 and d["sharded_200_models"]["models_per_rank"] == 50
