@@ -720,6 +720,7 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
   const int Qe = A.q_count ? min(A.Q, *A.q_count) : A.Q;
   if (qblock * QB >= Qe) return;   // uniform over the workgroup
   const int q0 = qblock * QB + wave * QW;
+  const bool live = q0 < Qe;   // uniform over the wavefront
   const int sel_begin = split * A.tiles_base + min(split, A.tiles_rem);
   const int sel_end = min(sel_begin + A.tiles_base + (split < A.tiles_rem ? 1 : 0), A.n_sel);
 
@@ -858,7 +859,10 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
     const unsigned char* T = lds + side * SC_TILE_BYTES;
     const float* ddp = reinterpret_cast<const float*>(lds + SC_NBUF * SC_TILE_BYTES + side * (SC_DD * 4));
     const int row_tile = (A.tile_first + sel * A.tile_stride) * SC_TILE;
-    if (MODE == 0) {
+    // (a wavefront none of whose 128 queries exists -- the tail of the last query block -- only helps with the staging
+    // and the barriers: the SIMD's matrix pipe is then its neighbour's alone)
+    if (!live) {
+    } else if (MODE == 0) {
 #pragma unroll 1
       for (int rb = 0; rb < SC_TILE / 32; ++rb) {
         half8 a[2][4];
