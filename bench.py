@@ -756,6 +756,18 @@ def host_side_figures(args, db, frames):
                                                   "through host FrameData (the PCIe-inclusive figure of the literal drop-in)"}
                 else:
                     out["plugin_path"] = {"error": (r.stderr or r.stdout)[-300:]}
+                # the same frame through ONE step (FRAME_RESIDENT_HIP -> mh_frame_run_host): the frame stays on the device
+                # between MATCH and FILTER2
+                r = subprocess.run([exe, "--resident", path, "30"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                times = {l.split()[1]: float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("TIME ")}
+                n_obj = sum(1 for l in r.stdout.splitlines() if l.startswith("OBJ "))
+                if r.returncode == 0 and times:
+                    tot = sum(times.values())
+                    out["plugin_resident_fps"] = round(1.0 / tot, 1)
+                    out["plugin_resident"] = {"ms_per_frame": round(1e3 * tot, 4), "objects": n_obj,
+                                              "note": "moped_hip_test --resident: MopedPipeline with FRAME_RESIDENT_HIP as its one "
+                                                      "step (MATCH_SIFT .. FILTER2 in one call of the C ABI), one synchronous "
+                                                      "frame at a time, features in pageable host memory, objects back on the host"}
             except Exception as e:
                 out["plugin_path"] = {"error": str(e)[:300]}
         else:

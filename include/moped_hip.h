@@ -314,6 +314,16 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
  * (mh_frame_set_depth) are then [B Q] like the queries, and so is the per-query image index of frames with several
  * images (mh_frame_set_images: q_image_dev [B Q]; one camera table for the batch); depth maps (and the depth rules that
  * read them) come one per frame through mh_frame_set_depth_image_batch. */
+/* The same frame from HOST memory, objects back on return: the body of the frame loop of
+ * MopedPimpl::processImages (src/moped.cpp:183-191 -- MATCH_SIFT, CLUSTER, POSE, FILTER, POSE2, FILTER2 on one
+ * FrameData) as one call.  q_desc_host [Q][128] raw descriptors (written back L2-normalised if write_back, as
+ * MATCH_ANN_CPU.hpp:157 leaves them), q_uv_host [Q][2], q_image_host [Q] or NULL (FrameData::DetectedFeature::imageIdx,
+ * renumbered into cams[]; needed when n_images > 1), cams[n_images] (1 <= n_images <= MH_MAX_IMAGES).  Results as
+ * mh_frame_fetch.  What the STEP plugins move over PCIe between the steps (matches, clusters, objects, twice) stays on
+ * the device; FRAME_RESIDENT_HIP (moped_amd/host) is the MopedAlg that calls this. */
+int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
+                      const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back,
+                      mh_object* objects_host, int max_objects, int32_t* n_objects, int32_t* counts);
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):

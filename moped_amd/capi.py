@@ -106,7 +106,7 @@ EXPORTS = [
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
     "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch", "mh_frame_set_depth_image_batch",
     "mh_pose_kernel_info", "mh_db_upload_blocks", "mh_frame_fetch_matches_slot",
-    "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch",
+    "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch", "mh_frame_run_host",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -166,6 +166,8 @@ def load():
     L.mh_frame_default_params.argtypes = [C.POINTER(mh_frame_params)]
     L.mh_frame_default_params.restype = None
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
+    L.mh_frame_run_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), i32, C.POINTER(mh_frame_params), C.c_uint64, i32,
+                                    vp, i32, C.POINTER(C.c_int32), vp]
     L.mh_sift_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
@@ -771,6 +773,23 @@ class Context:
         c = make_cam(K, cam)
         self._ck(self.L.mh_frame_enqueue(self.h, C.c_void_p(q_desc_ptr), C.c_void_p(q_uv_ptr), Q,
                                          C.byref(c), C.byref(params), seed), "mh_frame_enqueue")
+
+    def frame_run_host(self, q_desc, q_uv, Ks, cams, params: mh_frame_params, seed=1, q_image=None, write_back=True,
+                       max_objects=4096):
+        """The whole frame from host arrays, objects back on return (mh_frame_run_host: what FRAME_RESIDENT_HIP calls).
+        q_desc [Q,128] float32 C-contiguous (normalised in place if write_back), q_uv [Q,2]; Ks [n,4], cams [n,7];
+        q_image [Q] int32 when n > 1.  -> (objects, counts)."""
+        assert q_desc.dtype == np.float32 and q_desc.flags.c_contiguous and q_desc.shape[1] == 128
+        uv = np.ascontiguousarray(q_uv, np.float32)
+        arr = make_cams(Ks, cams)
+        img = None if q_image is None else np.ascontiguousarray(q_image, np.int32)
+        objs = np.zeros(max_objects, OBJECT_DTYPE)
+        n = C.c_int32(0)
+        counts = np.zeros(4, np.int32)
+        self._ck(self.L.mh_frame_run_host(self.h, _ptr(q_desc), _ptr(uv), None if img is None else _ptr(img), q_desc.shape[0],
+                                          arr, len(Ks), C.byref(params), C.c_uint64(int(seed)), int(bool(write_back)),
+                                          _ptr(objs), max_objects, C.byref(n), _ptr(counts)), "mh_frame_run_host")
+        return objs[:min(n.value, max_objects)].copy(), counts
 
     def frame_enqueue_image(self, gray_ptr, w, h, double_size, max_keypoints, K, cam, params: mh_frame_params,
                             seed=1, _cam_struct=None):

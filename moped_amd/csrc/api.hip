@@ -196,7 +196,7 @@ void mh_destroy(mh_ctx* ctx) {
   void* ptrs[] = {ctx->q_desc, ctx->q_norm,
                   ctx->q_uv,    ctx->nn_idx,  ctx->nn_d1,  ctx->nn_d2,    ctx->match_scratch,
                   ctx->scratch, ctx->match_pack, ctx->rules.ratio_table, ctx->rules.inv_size, ctx->rules.cnt,
-                  ctx->rules.keep1, ctx->lk_scratch, ctx->own_depth, ctx->own_fill, ctx->cams_dev, ctx->df_buf, ctx->img_counts};
+                  ctx->rules.keep1, ctx->lk_scratch, ctx->own_depth, ctx->own_fill, ctx->cams_dev, ctx->df_buf, ctx->img_counts, ctx->hf_img};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (ctx->pinned) hipHostFree(ctx->pinned);

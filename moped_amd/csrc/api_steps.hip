@@ -1221,6 +1221,44 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
 }
 
+// The whole frame for a host that holds its features in HOST memory and wants the objects back before it goes on: the
+// loop body of MopedPimpl::processImages (src/moped.cpp:183-191: MATCH .. FILTER2 one after the other on one FrameData)
+// as ONE call -- two uploads, one stream-ordered chain of launches, one synchronisation -- instead of six steps with the
+// frame's lists crossing PCIe between them (FRAME_RESIDENT_HIP, moped_amd/host).
+int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
+                      const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back,
+                      mh_object* objects_host, int max_objects, int32_t* n_objects, int32_t* counts) {
+  if (!ctx || Q <= 0 || !q_desc_host || !q_uv_host || !cams || n_images < 1 || n_images > MH_MAX_IMAGES || !prm || !n_objects ||
+      (n_images > 1 && !q_image_host)) {
+    if (ctx) ctx->err = "mh_frame_run_host: bad argument";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  int rc = ensure_frame_buffers(ctx, Q);
+  if (rc) return rc;
+  MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_desc_host, (size_t)Q * DIM * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(ctx->q_uv, q_uv_host, (size_t)Q * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (n_images > 1) {
+    if (ctx->hf_img_cap < Q) {
+      MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->hf_img) hipFree(ctx->hf_img);
+      ctx->hf_img = nullptr;
+      ctx->hf_img_cap = 0;
+      MH_HIP(ctx, hipMalloc(&ctx->hf_img, (size_t)ctx->max_q * sizeof(int32_t)));
+      ctx->hf_img_cap = ctx->max_q;
+    }
+    MH_HIP(ctx, hipMemcpyAsync(ctx->hf_img, q_image_host, (size_t)Q * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = mh_frame_set_images(ctx, ctx->hf_img, cams, n_images))) return rc;
+  } else if (ctx->q_img) {
+    if ((rc = mh_frame_set_images(ctx, nullptr, nullptr, 0))) return rc;
+  }
+  if ((rc = mh_frame_enqueue(ctx, ctx->q_desc, ctx->q_uv, Q, &cams[0], prm, seed))) return rc;
+  if (write_back)   // the reference normalises the frame's descriptors in place (MATCH_ANN_CPU.hpp:157)
+    MH_HIP(ctx, hipMemcpyAsync(q_desc_host, ctx->q_desc, (size_t)Q * DIM * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  return mh_frame_fetch(ctx, objects_host, max_objects, n_objects, counts);
+}
+
 int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,
                            int max_keypoints, const mh_cam* cam, const mh_frame_params* prm, uint64_t seed) {
   if (!ctx || !gray_dev || width <= 0 || height <= 0 || max_keypoints <= 0 || !cam || !prm) return MH_ERR_ARG;

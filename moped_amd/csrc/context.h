@@ -121,6 +121,8 @@ struct mh_ctx {
 
   // frames with several images (mh_frame_set_images): image of every query + the cameras; n_images == 1 = off
   const int32_t* q_img = nullptr;     // device, [Q]
+  int32_t* hf_img = nullptr;          // mh_frame_run_host's copy of the per-query image indices
+  int hf_img_cap = 0;
   mh::DevCam* cams_dev = nullptr;     // device, [MH_MAX_IMAGES]
   int n_images = 1;
 

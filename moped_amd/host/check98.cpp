@@ -8,4 +8,5 @@ namespace std { using tr1::shared_ptr; }
 #include "CLUSTER_MEAN_SHIFT_HIP.hpp"
 #include "POSE_RANSAC_P3P_HIP.hpp"
 #include "FILTER_PROJECTION_HIP.hpp"
+#include "FRAME_RESIDENT_HIP.hpp"
 int main() { return 0; }

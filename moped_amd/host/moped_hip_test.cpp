@@ -5,6 +5,7 @@
 //
 //   moped_hip_test scene.bin [repeats]
 //   moped_hip_test --images scene.bin [repeats]   (frame with several Images, second format below)
+//   moped_hip_test --resident [--images] scene.bin [repeats]   (FRAME_RESIDENT_HIP: MATCH .. FILTER2 as one step)
 //   moped_hip_test --sift image.pgm      (FEAT step only: binary P5 image -> keypoints)
 //   moped_hip_test --world W scene.bin [repeats]
 //       the model DB sharded over W ranks, device-resident frames through mh_frame_enqueue_sharded*: the frame
@@ -37,8 +38,15 @@
 #include "CLUSTER_MEAN_SHIFT_HIP.hpp"
 #include "POSE_RANSAC_P3P_HIP.hpp"
 #include "FILTER_PROJECTION_HIP.hpp"
+#include "FRAME_RESIDENT_HIP.hpp"
 
 using namespace MopedNS;
+
+// The same slots' work as ONE step (FRAME_RESIDENT_HIP: the frame stays on the device between MATCH and FILTER2).
+static void createResidentPipeline(MopedPipeline& pipeline) {
+  pipeline.addAlg("MATCH_SIFT", new FRAME_RESIDENT_HIP(128, "SIFT", 0.8, 200, 20, 7, 100, 1024, 4, 5, 6, 10, 5, 4096., 2,
+                                                       1024, 4, 6, 8, 5, 7, 4096., 3));
+}
 
 // The pipeline slots of src/config.hpp:83-120 with the HIP steps in place.
 static void createPipeline(MopedPipeline& pipeline) {
@@ -277,6 +285,8 @@ int main(int argc, char** argv) {
     argc -= 2;
     argv += 2;
   }
+  const bool resident = argc >= 3 && std::string(argv[1]) == "--resident";   // one step for the whole frame
+  if (resident) { --argc; ++argv; }
   const bool multi = argc >= 3 && std::string(argv[1]) == "--images";
   if (multi) { --argc; ++argv; }
   if (argc < 2) {
@@ -344,7 +354,8 @@ int main(int argc, char** argv) {
   }
 
   MopedPipeline pipeline;
-  createPipeline(pipeline);
+  if (resident) createResidentPipeline(pipeline);
+  else createPipeline(pipeline);
   list<MopedAlg*> all = pipeline.getAlgs();
   for (list<MopedAlg*>::iterator a = all.begin(); a != all.end(); ++a) {
     if (!(*a)->isCapable()) {

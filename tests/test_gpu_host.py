@@ -148,3 +148,77 @@ def test_depthfill_plugin_through_pipeline(tmp_path):
         want, want_dist, _ = orclib.depth_fill(d, Kd, scale, bool(bilinear))
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert np.array_equal(got_dist.view(np.uint32), want_dist.view(np.uint32))
+
+
+def _harness_objects(args):
+    out = subprocess.check_output([os.path.join(HOST, "moped_hip_test")] + args, text=True)
+    objs = []
+    for line in out.splitlines():
+        w = line.split()
+        if w[0] == "OBJ":
+            objs.append((int(w[1].replace("model", "")), np.array([float(x) for x in w[5:9] + w[2:5]], np.float64), float(w[9])))
+    return objs, out
+
+
+@pytest.mark.gpu
+def test_frame_resident_plugin_is_the_device_resident_frame(tmp_path):
+    """FRAME_RESIDENT_HIP -- MATCH_SIFT .. FILTER2 as ONE step of the pipeline (mh_frame_run_host) -- gives the objects
+    of the device-resident frame with the plugin's seed, bit for bit at the C ABI and to the harness's six printed
+    digits through the MopedPipeline; the step-by-step plugins find the same models."""
+    from moped_amd import capi
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    db = synth.make_db(6, 2000)
+    fr = synth.make_frame(db, n_vis=2, seed=5, Q=1500, pts_per_obj=120)
+    scene = str(tmp_path / "scene.bin")
+    dump_scene.dump(scene, db, fr)
+    got, out = _harness_objects(["--resident", scene, "1"])
+    steps, _ = _harness_objects([scene, "1"])
+    assert "TIME MATCH_SIFT" in out and "TIME POSE" not in out          # one step ran
+    seed = 1 * 2654435761 + 0                                            # frameCounter * 2654435761 + _alg, first frame
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    prm = capi.default_frame_params()
+    desc = fr.desc.copy()
+    objs, counts = c.frame_run_host(desc, fr.uv, [K], [CAM0], prm, seed)
+    assert np.array_equal(desc.view(np.uint32), c.normalize(fr.desc).view(np.uint32))    # written back normalised
+    dev = torch.device("cuda:0")
+    c.reserve(len(fr.uv))
+    qd, uv = torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev)
+    c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), len(fr.uv), K, CAM0, prm, seed)
+    want, wcounts = c.frame_fetch()
+    c.close()
+    assert np.array_equal(counts, wcounts) and len(objs) == len(want) == 2
+    assert np.array_equal(objs["model"], want["model"])
+    assert np.array_equal(objs["pose"].view(np.uint32), want["pose"].view(np.uint32))
+    assert np.array_equal(objs["score"].view(np.uint32), want["score"].view(np.uint32))
+    assert [m for m, _, _ in got] == objs["model"].tolist()
+    for (m, pose, score), o in zip(got, objs):
+        assert np.allclose(pose, o["pose"].astype(np.float64), atol=2e-6) and abs(score - float(o["score"])) < 1e-3
+    assert sorted(m for m, _, _ in steps) == sorted(objs["model"].tolist())
+
+
+@pytest.mark.gpu
+def test_frame_resident_plugin_two_cameras_among_maps(tmp_path):
+    """The same step on a frame whose features lie in two cameras listed among maps (FrameData::images = [camera, depth
+    map, distance map, camera]): the planted objects, poses under a pixel over both cameras' matches."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    db = synth.make_db(6, 1500, seed=8)
+    cams = [synth.camera_pose(0.0), synth.camera_pose(-0.12, (0.10, 0.0, 0.0))]
+    fr = synth.make_frame_images(db, cams, n_vis=2, seed=5, q_per_image=900, pts_per_obj=130)
+    junk = (1, [1.0, 1.0, 0.0, 0.0], CAM0)
+    images = [(0, fr.Ks[0], fr.cams[0]), junk, junk, (0, fr.Ks[1], fr.cams[1])]
+    scene = str(tmp_path / "scene2.bin")
+    dump_scene.dump_images(scene, db, fr, images, np.where(fr.image == 0, 0, 3))
+    got, _ = _harness_objects(["--resident", "--images", scene, "2"])
+    assert sorted(m for m, _, _ in got) == sorted(fr.visible.tolist())
+    for m, pose, score in got:
+        rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+        rows = rows[db.model_of[fr.src_point[rows]] == m]
+        xyz, uv, img = db.xyz[fr.src_point[rows]], fr.uv[rows], fr.image[rows]
+        e = np.sqrt(((orclib.project_images(pose.astype(np.float32), xyz, img, fr.Ks, fr.cams) - uv) ** 2).sum(1)).mean()
+        assert e < 1.0 and score > 0
