@@ -1412,10 +1412,13 @@ void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int b
   a.n_splits = Sb;
   a.tiles_base = n_tiles / Sb;
   a.tiles_rem = n_tiles % Sb;
-  // slots per sub-list: room for three records, and ~96 slots per query in all (a query gets ~20 records); NOT everything
-  // the 256 slots allow -- pass C reads (and re-empties) every slot of every query, and on a shard of a few models, where
-  // few splits fill the chip, 8 slots per sub-list made that scan 2 KB per query where 768 bytes do
-  a.sub_cap = std::max(1, std::min(std::max(3, (96 + 4 * Sb - 1) / (4 * Sb)), SC_SLOTS_MAX / (4 * Sb)));
+  // slots per sub-list: room for three records, and on a small DB ~96 slots per query in all (a query gets ~20 records)
+  // rather than everything the 256 slots allow -- pass C reads (and re-empties) every slot of every query, and on a
+  // shard of a few models, where few splits fill the chip, 8 slots per sub-list made that scan 2 KB per query where 768
+  // bytes do.  Large DBs keep all 256: their queries' record counts have a long tail (1 M rows, 32 000 queries, 8
+  // splits: 96 slots sent 117 queries per launch into pass C's brute-force search, 69 ms instead of 3).
+  const int slots_target = n_tiles >= 2048 ? SC_SLOTS_MAX : (n_tiles >= 512 ? 160 : 96);
+  a.sub_cap = std::max(1, std::min(std::max(3, (slots_target + 4 * Sb - 1) / (4 * Sb)), SC_SLOTS_MAX / (4 * Sb)));
   hipLaunchKernelGGL((screen16_kernel<1, NQB>), dim3(nqb * Sb), dim3(512), SC_LDS16_BYTES, s, a);
   if (ev) hipEventRecord(ev[4], s);
   *n_slots_out = 4 * Sb * a.sub_cap;

@@ -38,7 +38,7 @@ if has traffic; then
   # doubled as MI355X_MICROARCH.md prescribes for gfx950
   cd /tmp && export TMPDIR=/tmp
   echo "{" > $out/traffic_r03.json
-  for mq in "20 24000" "200 24000" "20 3000" "50 12000"; do
+  for mq in "20 48000" "200 48000" "20 24000" "200 24000" "20 3000" "50 12000"; do
     set -- $mq; m=$1; q=$2
     for c in FETCH_SIZE WRITE_SIZE; do
       rm -rf /tmp/trs_$m$c
@@ -72,8 +72,8 @@ PY
   cd $root
 fi
 if has sq; then
-  # SQ counters of pass B at the judged launch shape (20 models, 8 frames = 24 000 queries: screen16_kernel<1, 4>)
-  bash scripts/pmc_screen.sh gpurun_out/profiles_r03/r03_screen_sq_counters.txt 20 24000 "screen16_kernel<1" > /dev/null 2>&1
+  # SQ counters of pass B at the judged launch shape (20 models, 16 frames = 48 000 queries: screen16_kernel<1, 4>)
+  bash scripts/pmc_screen.sh gpurun_out/profiles_r03/r03_screen_sq_counters.txt 20 48000 "screen16_kernel<1" > /dev/null 2>&1
   echo "sq done"; head -40 $out/r03_screen_sq_counters.txt
 fi
 if has ranks; then
@@ -91,12 +91,14 @@ fi
 if has misc; then
   { for i in 1 2; do moped_amd/host/mfma_rate 2>/dev/null; done; } > $out/r03_mfma_shapes_rate.txt 2>&1
   # who holds the compute units (trace build) and an isolated pass B launch from the inside
-  timeout -k 10 300 python scripts/cu_trace.py 20 8 16 96 full 2>&1 | grep -v amdgpu.ids > $out/r03_cu_trace_config1.txt
-  timeout -k 10 300 python scripts/passb_timeline.py 20 8 2>&1 | grep -v amdgpu.ids > $out/r03_passb_timeline_20models.txt
-  timeout -k 10 300 python scripts/passb_timeline.py 200 8 2>&1 | grep -v amdgpu.ids > $out/r03_passb_timeline_200models.txt
+  timeout -k 10 300 python scripts/cu_trace.py 20 16 16 64 full 2>&1 | grep -v amdgpu.ids > $out/r03_cu_trace_config1.txt
+  timeout -k 10 300 python scripts/passb_timeline.py 20 16 2>&1 | grep -v amdgpu.ids > $out/r03_passb_timeline_20models.txt
+  timeout -k 10 300 python scripts/passb_timeline.py 200 16 2>&1 | grep -v amdgpu.ids > $out/r03_passb_timeline_200models.txt
   # pass B's ablations at the judged shape (experiment build): MFMA shape, no records at all
   { echo "# scripts/ab_env.sh: bench.py --no-secondary, experiment build; per setting: frames/s, pass B ms (isolated, HIP events), frac of 2.5 PFLOP/s, the stage's kernels"
     timeout -k 10 500 scripts/ab_env.sh 2 "" - MH_SCREEN_SHAPE=1 MH_SCREEN_SHAPE=2 MH_SCREEN_NO_HITS=1 MH_SCREEN_SHAPE=1,MH_SCREEN_NW=4 2>&1 | cut -c1-300
+    echo "# eight frames per launch sequence (the default until the end of round 3)"
+    timeout -k 10 500 scripts/ab_env.sh 1 "--batch 8" - MH_SCREEN_SHAPE=1 MH_SCREEN_NO_HITS=1 2>&1 | cut -c1-300
     echo "# config 2 (200 models)"
     timeout -k 10 500 scripts/ab_env.sh 1 "--models 200 --frames-per-step 256 --steps 5" - MH_SCREEN_SHAPE=1 MH_SCREEN_NO_HITS=1 2>&1 | cut -c1-300; } > $out/r03_passb_ablations.txt
   # the C++ hosts

@@ -1,8 +1,10 @@
-"""Parity at the launch shape bench.py is judged on: 8 frames of 3 000 queries against the 20-model / 100 000-row DB
-through ONE MATCH launch sequence (24 000 queries: screen_kernel<1, 4> over 512 workgroups) and ONE launch per stage
-of the rest chain (blockIdx.y = frame, eight working arenas).  Reference behaviour: one frame at a time through
-MATCH_ANN_CPU::process (moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:155-176) .. FILTER2; every frame of a batch must be
-bit for bit what it is alone, its accepted matches what the oracle accepts."""
+"""Parity at the launch shapes bench.py is judged on: 16 frames of 3 000 queries (its default since the end of round 3;
+8 until then, and still what a rank of a large sharded DB runs) against the 20-model / 100 000-row DB through ONE MATCH
+launch sequence (48 000 / 24 000 queries: screen16_kernel<1, 4>, one workgroup per compute unit at a time) and ONE
+launch per stage of the rest chain (the tasks of all frames over one row of workgroups, per-frame working arenas).
+Reference behaviour: one frame at a time through MATCH_ANN_CPU::process
+(moped2/libmoped/src/match/MATCH_ANN_CPU.hpp:155-176) .. FILTER2; every frame of a batch must be bit for bit what it is
+alone, its accepted matches what the oracle accepts."""
 import numpy as np
 import pytest
 
@@ -12,15 +14,16 @@ from moped_amd.pipeline import FramePipeline, ShardedDB
 
 pytestmark = pytest.mark.gpu
 K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
-B, Q = 8, 3000
+Q = 3000
 
 
-@pytest.fixture(scope="module")
-def world():
+@pytest.fixture(scope="module", params=[16, 8], ids=["16 frames per launch (the bench's default)", "8 frames per launch"])
+def world(request):
     import torch
     db = synth.make_db(20, 5000)
     dbn = orclib.normalize(db.desc)
-    frs = [synth.make_frame(db, n_vis=n, seed=200 + i, Q=Q) for i, n in enumerate((2, 2, 5, 1, 2, 3, 0, 2))]
+    n_vis = (2, 2, 5, 1, 2, 3, 0, 2, 4, 2, 0, 1, 2, 2, 3, 2)[:request.param]
+    frs = [synth.make_frame(db, n_vis=n, seed=200 + i, Q=Q) for i, n in enumerate(n_vis)]
     yield db, dbn, frs, torch
 
 
@@ -31,8 +34,9 @@ def _same_objects(a, b):
             np.array_equal(a["n_points"], b["n_points"]))
 
 
-def test_eight_frames_per_launch_equal_the_frames_alone_and_the_oracles_matches(world):
+def test_frames_of_one_launch_sequence_equal_the_frames_alone_and_the_oracles_matches(world):
     db, dbn, frs, torch = world
+    B = len(frs)
     dev = torch.device("cuda:0")
     pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=B * Q)
     seeds = [900 + f for f in range(B)]
@@ -57,7 +61,7 @@ def test_eight_frames_per_launch_equal_the_frames_alone_and_the_oracles_matches(
             mq, mm = c.frame_fetch_matches_slot(f)
             assert np.array_equal(mq, alone_matches[f][0]) and np.array_equal(mm, alone_matches[f][1])
     assert sum(len(a[0]) for a in alone) >= 12
-    # the accepted match lists of all eight frames against the oracle's exact search + ratio test
+    # the accepted match lists of all frames against the oracle's exact search + ratio test
     for f, fr in enumerate(frs):
         qn = orclib.normalize(fr.desc)
         assert np.array_equal(qd[f * Q:(f + 1) * Q].cpu().numpy().view(np.uint32), qn.view(np.uint32))   # A1 in place
@@ -71,10 +75,11 @@ def test_eight_frames_per_launch_equal_the_frames_alone_and_the_oracles_matches(
     pipe.close()
 
 
-def test_raw_match_of_24000_queries_screen_vs_exact_kernel_vs_oracle(world):
+def test_raw_match_of_a_whole_launch_screen_vs_exact_kernel_vs_oracle(world):
     """screen_kernel<1, 4> at the bench's launch shape (24 query blocks x splits = 512 workgroups) against
-    match_mfma_kernel on the same 24 000 queries, bit for bit; 384 sampled queries against the oracle."""
+    match_mfma_kernel on the same queries, bit for bit; 384 sampled queries against the oracle."""
     db, dbn, frs, torch = world
+    B = len(frs)
     dev = torch.device("cuda:0")
     c = capi.Context(0)
     c.db_upload(dbn, db.model_of, db.xyz, db.n_models)
@@ -105,7 +110,7 @@ def test_raw_match_of_24000_queries_screen_vs_exact_kernel_vs_oracle(world):
     assert np.array_equal(res[1][2][pick].view(np.uint32), o2.view(np.uint32))
     c.close()
 
-@pytest.mark.parametrize("n_models,n_q", [(50, 12000), (50, 16000), (120, 12000)])
+@pytest.mark.parametrize("n_models,n_q", [(50, 12000), (50, 16000), (120, 12000), (200, 32000), (200, 48000)])
 def test_other_large_launch_shapes_keep_every_query_on_the_screened_path(n_models, n_q):
     """Config 5's launch (4 frames x 3000 queries against 250 000 rows) and its neighbours: the 16x16x32 passes share a
     query's record slots out over 4 x splits sub-lists, and with 42 splits a sub-list held ONE record -- queries spilled
@@ -142,10 +147,11 @@ def test_other_large_launch_shapes_keep_every_query_on_the_screened_path(n_model
 
 
 @pytest.mark.parametrize("assign", ["block", "round-robin"])
-def test_rest_frames_of_eight_at_eight_ranks_equal_the_single_context(world, assign):
-    """mh_frame_enqueue_rest_frames with B = 8 on each of W = 8 shard contexts (the per-rank work of bench.py --gpus 8:
-    2-3 models per rank) = the single context's eight frames, objects bit for bit."""
+def test_rest_frames_of_a_batch_at_eight_ranks_equal_the_single_context(world, assign):
+    """mh_frame_enqueue_rest_frames with the whole batch on each of W = 8 shard contexts (the per-rank work of bench.py --gpus 8:
+    2-3 models per rank) = the single context's frames, objects bit for bit."""
     db, dbn, frs, torch = world
+    B = len(frs)
     dev = torch.device("cuda:0")
     W = 8
     prm = capi.default_frame_params()
