@@ -231,7 +231,7 @@ def default_batch(args, sharded: bool) -> int:
     if sharded:
         # a shard of a few thousand rows does not fill the chip for one frame's queries, and every launch of the rest
         # chain is shared by the frames of a batch: as many as the library takes
-        return capi.MAX_BATCH if args.models // max(args.gpus, 1) < 25 else 8
+        return capi.MAX_BATCH if args.models // max(args.gpus, 1) < 25 else 16
     # sixteen frames per MATCH launch sequence (48 000 queries: three rounds of pass B workgroups that sweep 49 tiles each
     # instead of two rounds of 38 for eight frames -- fewer prologues and a fuller last query block per frame: +2.7% on
     # config 1, +1.6% on config 2); a batch of plain frames also shares the launches of its rest chain (one group /

@@ -49,7 +49,7 @@ def test_default_batch_follows_the_partition():
     a = b.parse(["--gpus", "8"])
     assert b.default_batch(a, True) == capi.MAX_BATCH      # 2.5 models per rank: as many frames per launch as the library takes
     a = b.parse(["--gpus", "8", "--models", "200"])
-    assert b.default_batch(a, True) == 8                   # configs[3]: 25 models per rank, MATCH fills the chip
+    assert b.default_batch(a, True) == 16                  # configs[3]: 25 models per rank, MATCH fills the chip
     a = b.parse([])
     assert b.default_batch(a, False) == 16
     a = b.parse(["--depth-kind", "1"])

@@ -54,7 +54,7 @@ def test_under_the_drivers_launcher_block_models():
              port=29741 + os.getpid() % 100)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x2"
     assert d["config"]["model_assignment"] == "block" and d["config"]["ranks_launched_by"] == "torch.distributed.run"
-    assert d["config"]["objects_per_frame"] == 2.0 and d["config"]["frames_per_match_launch"] == 8
+    assert d["config"]["objects_per_frame"] == 2.0 and d["config"]["frames_per_match_launch"] == 16
 
 
 def test_frames_partition_is_an_option():
