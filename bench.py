@@ -40,6 +40,7 @@ PEAK_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense BF16/F16 MFMA (the F16 f
 SUSTAINED_F16_TFLOPS = 1900.0
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
 N_CU = 256
+DELIVER_CAP = 32           # objects per frame a delivery record carries (mh_frame_fetch_batch_async); n_objects says if there were more
 
 
 def parse(argv=None):
@@ -327,7 +328,6 @@ class Job:
                 wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
                 d = capi.pack_depth(wpts, wgt)
                 self.depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
-        self.counts_host = torch.zeros(n_pool, dtype=torch.int32).pin_memory()
         if B > 1:
             assert n_pool % B == 0 and n_frames % B == 0
             self.groups = n_frames // B
@@ -340,7 +340,79 @@ class Job:
         torch.cuda.synchronize(dev)
         self.active_slots = args.depth   # slots in use (the calibration may settle on fewer)
         self.host_desc = None            # h2d measurement: the same descriptors in pinned host memory
-        self.last_slots = {}             # slot -> pool group of the batch it ran last
+        # Delivery (the reference's loop hands every frame's objects to its caller, moped2/libmoped/src/moped.cpp:166-194):
+        # behind every batch one stream-ordered copy of its B result heads into the slot's pinned host block; the host
+        # reads the block -- object counts, the planted models among the objects -- before it reuses the slot.
+        self.pipe.attach_delivery(DELIVER_CAP, max(B, 1))
+        nv = max(1, max(len(f.visible) for f in self.frames))
+        self.planted = np.full((n_pool, nv), -1, np.int32)
+        for i, f in enumerate(self.frames):
+            self.planted[i, :len(f.visible)] = f.visible
+        self.slot_pending = {}           # slot -> pool index of the first frame of the delivery in flight (None: not counted)
+        self.slot_last = {}              # sharded: slot -> pool index of the batch whose objects ride on the slot's NEXT exchange
+        self.reset_delivered()
+
+    # ---- delivered results ----------------------------------------------------------------------------------
+    def reset_delivered(self):
+        self.dl = {"frames": 0, "objects": 0, "hist": np.zeros(64, np.int64), "planted_missed": 0, "frames_missing": 0}
+
+    def _count(self, first, n_per_frame, models, valid):
+        """n_per_frame [B], models / valid [B][cap]: the delivered objects of frames first .. first + B - 1 of the pool."""
+        st = self.dl
+        B = len(n_per_frame)
+        st["frames"] += B
+        st["objects"] += int(n_per_frame.sum())
+        st["hist"] += np.bincount(np.minimum(n_per_frame, 63), minlength=64)
+        pl = self.planted[first:first + B]
+        found = ((models[:, None, :] == pl[:, :, None]) & valid[:, None, :]).any(-1) | (pl < 0)
+        st["planted_missed"] += int((~found).sum())
+        st["frames_missing"] += int((~found.all(-1)).sum())
+
+    def _consume(self, slot, count=True):
+        recs = self.pipe.take_delivery(slot)    # waits for the delivery's event only; raises on capacity / exchange flags
+        if recs is None:
+            return
+        first = self.slot_pending.pop(slot, None)
+        if first is None or not count:
+            return
+        n = recs["head"]["n_objects"]
+        self._count(first, n, recs["objects"]["model"], np.arange(DELIVER_CAP)[None, :] < n[:, None])
+
+    def _deliver(self, slot, first, tag):
+        """Behind the batch just enqueued in `slot` (pool frames first ..): its delivery.  With a sharded DB what arrives
+        is the slot's PREVIOUS batch, all ranks' objects (they rode on this batch's exchange)."""
+        pipe = self.pipe
+        pipe.deliver(slot, tag)
+        if pipe.exchange:
+            self.slot_pending[slot] = self.slot_last.get(slot)
+            self.slot_last[slot] = first
+        else:
+            self.slot_pending[slot] = first
+
+    def drain(self, count=True):
+        """Every delivery in flight reaches the host; with a sharded DB the slots' last batches too (exchange 2 on its own:
+        nothing follows to carry them).  Every rank calls this at the same point."""
+        pipe, B = self.pipe, max(self.B, 1)
+        for slot in sorted(self.slot_pending):
+            self._consume(slot, count)
+        if pipe.exchange:
+            for slot in sorted(self.slot_last):
+                first = self.slot_last.pop(slot)
+                per = pipe.flush_objects_batch(slot, B)
+                if count:
+                    n = np.array([len(o) for o in per], np.int64)
+                    models = np.full((B, max(1, int(n.max()))), -1, np.int32)
+                    for f, o in enumerate(per):
+                        models[f, :len(o)] = o["model"]
+                    self._count(first, n, models, models >= 0)
+
+    def delivered_summary(self):
+        st = self.dl
+        hist = st["hist"]
+        top = int(np.nonzero(hist)[0].max()) + 1 if hist.any() else 0
+        return {"frames": int(st["frames"]), "objects": int(st["objects"]),
+                "objects_per_frame_histogram": hist[:top].tolist(),
+                "planted_objects_missed": int(st["planted_missed"]), "frames_missing_a_planted_object": int(st["frames_missing"])}
 
     # ---- one step -----------------------------------------------------------------------------------------
     def _run_step_batched(self, step, from_host=False):
@@ -350,6 +422,7 @@ class Job:
         for g in range(self.groups):
             slot = (step * self.groups + g) % self.active_slots
             pg = g % self.pool_groups
+            self._consume(slot)   # the slot's previous batch is on the host before the slot is reused
             with torch.cuda.stream(pipe.streams[slot]):
                 self.work_b[slot].copy_(self.host_desc[pg] if from_host else self.pristine_b[pg], non_blocking=True)
             if self.depths_b is not None:
@@ -366,9 +439,9 @@ class Job:
                 pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
                                                             a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
             pipe.enqueue_batch(slot, self.work_b[slot], self.uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
-            self.last_slots[slot] = pg
+            self._deliver(slot, pg * B, step * self.groups + g)
 
-    def run_step(self, step, record=False, from_host=False):
+    def run_step(self, step, from_host=False):
         import torch
         if self.B > 1:
             return self._run_step_batched(step, from_host)
@@ -379,6 +452,7 @@ class Job:
             b = f % self.n_pool
             slot = f % a.depth
             s = pipe.streams[slot]
+            self._consume(slot)
             with torch.cuda.stream(s):
                 # fresh raw descriptors (normalise is in place): from HBM (the headline) or over PCIe from pinned memory
                 self.work[slot].copy_(self.host_desc[b] if from_host else self.pristine[b], non_blocking=True)
@@ -394,11 +468,7 @@ class Job:
                 pipe.ctxs[slot].frame_set_depth_image(mb[0].data_ptr(), mb[1].data_ptr(), 640, 480,
                                                       a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
             pipe.enqueue(slot, self.work[slot], self.uvs[b], seed=1000 * step + f + 1)
-            if record and f >= self.n_frames - self.n_pool and not pipe.exchange:
-                ptr, nbytes = pipe.ctxs[slot].frame_result_dev()
-                with torch.cuda.stream(s):
-                    from moped_amd.pipeline import _wrap_int32
-                    self.counts_host[b:b + 1].copy_(_wrap_int32(ptr, 1, self.env["dev"]), non_blocking=True)
+            self._deliver(slot, b, step * self.n_frames + f)
 
     def sync_all(self):
         import torch
@@ -425,24 +495,32 @@ class Job:
         for cand in (16, 12):
             self.active_slots = cand
             self.run_step(-100)
+            self.drain(count=False)
             self.sync_all()
             t0c = time.perf_counter()
             for k in range(8):
                 self.run_step(-101 - k)
+            self.drain(count=False)
             self.sync_all()
             timing[cand] = self.max_over_ranks(time.perf_counter() - t0c)
         self.active_slots = 16 if timing[16] <= timing[12] * 1.03 else 12
 
     def timed(self, steps, warmup, from_host=False, step_base=0):
         """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier +
-        synchronize on both sides, max over ranks.  Returns (seconds, host issue seconds)."""
+        synchronize on both sides, max over ranks.  Inside it every batch's objects are delivered to the host (one
+        stream-ordered copy of the batch's result heads into pinned memory; read and counted before the slot's next
+        batch) and the clock stops only when the last batch's have arrived.  Returns (seconds, host issue seconds);
+        self.dl = what was delivered."""
         for w in range(warmup):
             self.run_step(step_base - 1 - w, from_host=from_host)
+        self.drain(count=False)
         self.sync_all()
+        self.reset_delivered()
         t0 = time.perf_counter()
         for k in range(steps):
-            self.run_step(step_base + k, record=(k == steps - 1), from_host=from_host)
+            self.run_step(step_base + k, from_host=from_host)
         t_issue = time.perf_counter() - t0   # the host's share: the enqueue loop alone (behind full queues it waits for the GPU)
+        self.drain(count=True)
         self.sync_all()
         dt = self.max_over_ranks(time.perf_counter() - t0)
         return dt, t_issue
@@ -451,20 +529,10 @@ class Job:
         return steps * self.n_frames * (self.env["world"] if self.by_frames else 1)
 
     def detections_per_frame(self):
-        """Objects per frame over the last batch of EVERY slot in use (sanity: the planted objects are found).  With a
-        sharded DB the objects of all ranks (exchange 2); every rank calls this in the same order."""
-        pipe, B = self.pipe, self.B
-        if B > 1:
-            per = []
-            for slot in sorted(self.last_slots):
-                objs = pipe.flush_objects_batch(slot, B) if pipe.exchange else [r[0] for r in pipe.fetch_batch(slot, B)]
-                per += [len(o) for o in objs]
-            self.detections_detail = {"frames": len(per), "min": int(min(per)) if per else 0, "max": int(max(per)) if per else 0,
-                                      "histogram": np.bincount(per, minlength=3).tolist() if per else []}
-            return float(np.mean(per)) if per else 0.0
-        if not pipe.exchange:
-            return float(self.counts_host.float().mean().item())
-        return float(len(pipe.gather_objects((self.n_frames - 1) % self.args.depth)))
+        """Objects per frame over EVERY frame of the last timed region, as delivered to the host inside it."""
+        st = self.dl
+        self.detections_detail = self.delivered_summary()
+        return st["objects"] / st["frames"] if st["frames"] else 0.0
 
     def close(self):
         self.pipe.close()
@@ -565,8 +633,9 @@ def main():
     if B > 1 and not depth_given and args.depth == 16:
         job.calibrate_slots()
     dt, t_issue = job.timed(args.steps, args.warmup)
-    fps = job.total_frames(args.steps) / dt
+    fps = job.total_frames(args.steps) / dt    # every one of these frames' objects reached the host inside dt (checked below)
     det_per_frame = job.detections_per_frame()
+    delivered = job.detections_detail
 
     # what POSE actually evaluated (device-side counters of the last frame of every slot)
     ctr = [c.frame_counters() for c in pipe.ctxs[:job.active_slots if B > 1 else args.depth]]
@@ -603,7 +672,13 @@ def main():
                    "model_assignment": (args.assign if sharded else None),
                    "ranks_launched_by": os.environ.get("MH_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "none"),
                    "exchange": comm_info,
-                   "objects_per_frame": det_per_frame,
+                   "results_delivered": "every frame",
+                   "results_delivery": (f"one stream-ordered copy of each batch's result heads ({B if B > 1 else 1} frames x up to {DELIVER_CAP} objects) "
+                                        "into pinned host memory behind the batch (mh_frame_fetch_batch_async"
+                                        + (" / mh_frame_fetch_previous_async: all ranks' objects ride on the slot's next exchange; the "
+                                           "slots' last batches by mh_frame_gather_objects" if pipe.exchange else "")
+                                        + "), read and counted on the host before the slot's next batch; the clock stops after the last one"),
+                   "objects_per_frame": det_per_frame, "objects_detail": delivered,
                    "hypotheses_per_task": round(hyp_per_task, 1), "hypotheses_per_frame": round(float(np.mean([c["hypotheses"] for c in ctr])), 1),
                    "match": ("two-stage: f16 MFMA screen + canonical f32 arithmetic on the candidates (bit-identical to the exact kernels)"
                              if ms["two_stage"] else "exact f32 kernels"),
@@ -611,7 +686,12 @@ def main():
                    "env_overrides": overrides},
     }
     # sanity of the line itself: a pipeline that stops finding the planted objects must not print a clean metric
-    if det_per_frame < args.n_vis - 0.5:
+    if delivered["frames"] != args.steps * n_frames:
+        out["suspect"] = f"{delivered['frames']} frames were delivered to the host, {args.steps * n_frames} were timed"
+    elif delivered["frames_missing_a_planted_object"]:
+        out["suspect"] = (f"{delivered['frames_missing_a_planted_object']} of {delivered['frames']} delivered frames miss a planted "
+                          f"object ({delivered['planted_objects_missed']} objects)")
+    elif det_per_frame < args.n_vis - 0.5:
         out["suspect"] = f"only {det_per_frame:.2f} objects per frame found of {args.n_vis} planted"
 
     # ---- secondary: the same frames with the descriptors in pinned HOST memory (1.5 MB over PCIe per frame, the copy
@@ -623,8 +703,10 @@ def main():
         job.host_desc = host_desc
         dth, _ = job.timed(args.h2d_steps, 1, from_host=True, step_base=-600)
         out["h2d_inclusive"] = {"value": round(args.h2d_steps * n_frames / dth, 2), "unit": "frames/s", "steps": args.h2d_steps,
+                                "objects_per_frame": job.detections_per_frame(),
                                 "note": "descriptors start in pinned host memory: one 1.5 MB hipMemcpyAsync per frame on the frame's "
-                                        "stream (keypoint coordinates resident); a reported figure, not the metric's `value`"}
+                                        "stream (keypoint coordinates resident), objects delivered to the host like the headline's; "
+                                        "a reported figure, not the metric's `value`"}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the stream it is launched on ----
     if rank == 0 and not args.no_roofline:
@@ -669,7 +751,7 @@ def main():
             det2 = j2.detections_per_frame()
             out["replicated_frames"] = {"value": round(j2.total_frames(sec_steps) / dt2, 2), "unit": "frames/s", "steps": sec_steps,
                                         "parallelism": f"frame-parallel x{world} (DB replicated)", "scaling": "weak",
-                                        "objects_per_frame": det2, "objects_detail": getattr(j2, "detections_detail", None),
+                                        "objects_per_frame": det2, "objects_detail": j2.detections_detail,
                                         "note": "SURVEY 8(e)'s alternative for a DB too small to shard: no collective, every rank "
                                                 "its own frames; a reported figure, not `value`"}
             j2.close()

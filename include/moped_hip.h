@@ -476,6 +476,49 @@ int mh_frame_result_copy_dev(mh_ctx* ctx, void* dst_dev, int max_objects);
  * matches, clusters, objects after POSE, objects after FILTER. */
 int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects,
                    int32_t* n_objects, int32_t* counts);
+/* ---- delivery: the objects of EVERY frame of a batch to the host, without stopping the stream -------------------
+ *
+ * The reference's frame loop hands each frame's list<SP_Object> to its caller (MopedPimpl::processImages,
+ * src/moped.cpp:166-194; the test node prints them, moped2/moped_test.cpp:205-207).  For a host that keeps batches in
+ * flight the per-frame fetches above cost a stream synchronisation each; these two move a whole batch in ONE
+ * stream-ordered operation into a block of PINNED host memory the caller owns (hipHostMalloc / hipHostRegister /
+ * torch's pin_memory), and a wait that touches only that delivery's event:
+ *
+ *   mh_frame_enqueue_batch(ctx, ..., B, ...);                      // batch k on this context
+ *   mh_frame_fetch_batch_async(ctx, B, cap, block, tag);           // behind it, on the same stream: no host wait
+ *   ... other contexts' batches ...
+ *   mh_frame_fetch_wait(ctx, &flags);                              // before the context's next batch: usually done long ago
+ *   for f < B: head f = (const mh_frame_head*)((char*)block + f * mh_frame_block_stride(cap)); objects follow it
+ *
+ * Block layout: B records of mh_frame_block_stride(max_objects) bytes, record f = mh_frame_head {n_objects, flags,
+ * counts[4] (accepted matches, clusters, objects after POSE, after FILTER; -1 where unknown), tag, frame} followed
+ * by mh_object[max_objects] of which the first min(n_objects, max_objects) are written (model ids as
+ * mh_frame_fetch gives them).  `tag` is the caller's: a block that still holds an older delivery is recognisable.
+ * A block the device can address (pinned) is written by the delivering kernel itself over PCIe; any other host
+ * memory goes through a device staging buffer and one hipMemcpyAsync (pageable memory makes that copy synchronous).
+ * The next batch on the context may be enqueued at once -- the delivery is ordered before it on the stream -- but the
+ * BLOCK must not be handed to another delivery before mh_frame_fetch_wait returned.  One delivery per context in
+ * flight: a second async call before the wait -> MH_ERR_ARG. */
+typedef struct {
+  int32_t n_objects;
+  int32_t flags;       /* capacity / exchange flags of the frame; 0 = clean */
+  int32_t counts[4];
+  uint32_t tag;
+  int32_t frame;       /* 0 .. B-1 */
+} mh_frame_head;
+size_t mh_frame_block_stride(int max_objects);   /* sizeof(mh_frame_head) + max_objects * sizeof(mh_object) */
+int mh_frame_fetch_batch_async(mh_ctx* ctx, int B, int max_objects, void* host_block, uint32_t tag);
+/* The same for a SHARDED context (mh_frame_enqueue_sharded[_batch]): the objects of ALL ranks, in rank order, of
+ * the B frames this context ran BEFORE the current batch, as they arrived with the current batch's exchange
+ * (mh_frame_previous_objects without its stream synchronisation).  counts[3] = n_objects, the others -1; flags = the
+ * ranks' flags or-ed, bit 30 set when a rank had more than MH_EX2_OBJECTS objects (its surplus did not travel). */
+int mh_frame_fetch_previous_async(mh_ctx* ctx, int max_objects, void* host_block, uint32_t tag);
+/* Blocks until the context's pending delivery has landed (returns at once if there is none).  *flags_or (optional)
+ * = the or of the B heads' flags; any set -> MH_ERR_CAPACITY with the text mh_frame_fetch_slot gives.
+ * mh_frame_fetch_query: MH_OK when the delivery has landed (or none is pending), 1 while it is still in flight. */
+int mh_frame_fetch_wait(mh_ctx* ctx, int32_t* flags_or);
+int mh_frame_fetch_query(mh_ctx* ctx);
+
 /* The frame's accepted matches after MATCH (+ the depth rules): query index and model of each,
  * sorted by (model, query) = the reference's `matches[model]` lists one after the other
  * (MATCH_ANN_CPU.hpp:165-176).  Synchronises the stream; *n_matches = their number. */

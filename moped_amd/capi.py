@@ -107,6 +107,8 @@ EXPORTS = [
     "mh_frame_previous_objects", "mh_frame_gather_objects", "mh_frame_enqueue_batch", "mh_frame_set_depth_image_batch",
     "mh_pose_kernel_info", "mh_db_upload_blocks", "mh_frame_fetch_matches_slot",
     "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch", "mh_frame_run_host",
+    "mh_frame_block_stride", "mh_frame_fetch_batch_async", "mh_frame_fetch_previous_async", "mh_frame_fetch_wait",
+    "mh_frame_fetch_query",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -257,6 +259,12 @@ def load():
     L.mh_screen_record_bounds.argtypes = [C.c_uint16, C.c_uint32, f32, f32, i32, f32, C.POINTER(f32), C.POINTER(f32)]
     L.mh_screen_record_bounds.restype = None
     L.mh_db_upload_blocks.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, i32, i32]
+    L.mh_frame_block_stride.argtypes = [i32]
+    L.mh_frame_block_stride.restype = C.c_size_t
+    L.mh_frame_fetch_batch_async.argtypes = [vp, i32, i32, vp, C.c_uint32]
+    L.mh_frame_fetch_previous_async.argtypes = [vp, i32, vp, C.c_uint32]
+    L.mh_frame_fetch_wait.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mh_frame_fetch_query.argtypes = [vp]
     _lib = L
     return L
 
@@ -319,6 +327,18 @@ def screen_record_bounds(value_bits, row0, tau, spread, N, dmax):
     load().mh_screen_record_bounds(int(value_bits), int(row0), float(tau), float(spread), int(N), float(dmax),
                                    C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+FRAME_HEAD_DTYPE = np.dtype([("n_objects", "<i4"), ("flags", "<i4"), ("counts", "<i4", (4,)), ("tag", "<u4"), ("frame", "<i4")])
+
+
+def frame_block_dtype(max_objects: int) -> np.dtype:
+    """One record of a delivery block (mh_frame_fetch_batch_async): mh_frame_head + mh_object[max_objects]."""
+    return np.dtype([("head", FRAME_HEAD_DTYPE), ("objects", OBJECT_DTYPE, (max_objects,))])
+
+
+def frame_block_bytes(B: int, max_objects: int) -> int:
+    return B * (FRAME_HEAD_DTYPE.itemsize + OBJECT_DTYPE.itemsize * max_objects)
 
 
 def comm_unique_id() -> bytes:
@@ -964,6 +984,27 @@ class Context:
         self._ck(self.L.mh_frame_fetch_slot(self.h, slot, _ptr(objs), max_objects, C.byref(n), _ptr(counts)),
                  "mh_frame_fetch_slot")
         return objs[:min(n.value, max_objects)].copy(), counts
+
+    # ---- delivery of whole batches into pinned host memory (mh_frame_fetch_batch_async) ----
+    def frame_fetch_batch_async(self, B, max_objects, host_ptr, tag=0):
+        self._ck(self.L.mh_frame_fetch_batch_async(self.h, B, max_objects, C.c_void_p(host_ptr), tag & 0xFFFFFFFF),
+                 "mh_frame_fetch_batch_async")
+
+    def frame_fetch_previous_async(self, max_objects, host_ptr, tag=0):
+        self._ck(self.L.mh_frame_fetch_previous_async(self.h, max_objects, C.c_void_p(host_ptr), tag & 0xFFFFFFFF),
+                 "mh_frame_fetch_previous_async")
+
+    def frame_fetch_wait(self):
+        """Blocks until the context's pending delivery has landed; raises on capacity / exchange flags."""
+        fl = C.c_int32(0)
+        self._ck(self.L.mh_frame_fetch_wait(self.h, C.byref(fl)), "mh_frame_fetch_wait")
+
+    def frame_fetch_query(self) -> bool:
+        """True when the pending delivery (if any) has landed."""
+        rc = self.L.mh_frame_fetch_query(self.h)
+        if rc < 0:
+            self._ck(rc, "mh_frame_fetch_query")
+        return rc == 0
 
     def frame_result_copy_slots_dev(self, dst_ptr, n_slots, max_objects):
         self._ck(self.L.mh_frame_result_copy_slots_dev(self.h, C.c_void_p(dst_ptr), n_slots, max_objects),

@@ -205,6 +205,8 @@ void mh_destroy(mh_ctx* ctx) {
   for (auto& set : ctx->mev)
     for (auto& e : set)
       if (e) hipEventDestroy(e);
+  if (ctx->dlv.done) hipEventDestroy(ctx->dlv.done);
+  if (ctx->dlv.stage) hipFree(ctx->dlv.stage);
   if (ctx->lane_in) hipEventDestroy(ctx->lane_in);
   if (ctx->lane_out) hipEventDestroy(ctx->lane_out);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);

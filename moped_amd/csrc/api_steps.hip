@@ -562,9 +562,137 @@ int prepare_frame(mh_ctx* ctx, int Q, int q_frame = 0, int frames = 1) {
                    ctx->n_models * (ctx->n_images > 1 ? ctx->n_images : 1), frames);
 }
 
+// mh_frame_fetch_batch_async: frame f's head {n, flags, counts[4], tag, f} + its first min(n, max_objects) objects out of
+// result slot f into record f of the caller's block (dst: device-visible host memory, or the staging buffer).
+__global__ void __launch_bounds__(128) deliver_kernel(const unsigned char* __restrict__ result, size_t result_bytes,
+                                                      const int32_t* __restrict__ snap, unsigned char* __restrict__ dst,
+                                                      int max_objects, int result_objects, uint32_t tag) {
+  const int f = blockIdx.x;
+  const int32_t* src = reinterpret_cast<const int32_t*>(result + (size_t)f * result_bytes);
+  int32_t* out = reinterpret_cast<int32_t*>(dst + (size_t)f * (sizeof(mh_frame_head) + sizeof(mh_object) * (size_t)max_objects));
+  const int n = src[0];
+  const int take = max(0, min(n, min(max_objects, result_objects)));
+  const int t = threadIdx.x;
+  if (t < 8) {
+    int32_t w;
+    if (t == 0) w = n;
+    else if (t == 1) w = src[1];
+    else if (t < 6) w = snap[4 * f + t - 2];
+    else if (t == 6) w = (int32_t)tag;
+    else w = f;
+    out[t] = w;
+  }
+  constexpr int OW = (int)(sizeof(mh_object) / 4);
+  for (int w = t; w < take * OW; w += blockDim.x) out[8 + w] = src[4 + w];
+  __threadfence_system();
+}
+
 }  // namespace
 
+namespace mh {
+
+int delivery_begin(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char** dst_dev) {
+  auto& d = ctx->dlv;
+  if (d.pending) {
+    ctx->err = "delivery: the context's previous delivery has not been waited for (mh_frame_fetch_wait)";
+    return MH_ERR_ARG;
+  }
+  if (!d.done) MH_HIP(ctx, hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, host_block, 0) == hipSuccess && dev) {
+    *dst_dev = static_cast<unsigned char*>(dev);
+    return MH_OK;
+  }
+  (void)hipGetLastError();   // not pinned / not mapped: through the staging buffer
+  if (d.stage_cap < bytes) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d.stage) hipFree(d.stage);
+    d.stage = nullptr;
+    d.stage_cap = 0;
+    MH_HIP(ctx, hipMalloc(&d.stage, bytes));
+    d.stage_cap = bytes;
+  }
+  *dst_dev = d.stage;
+  return MH_OK;
+}
+
+int delivery_end(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char* dst_dev, int B, int max_objects, uint32_t tag) {
+  auto& d = ctx->dlv;
+  MH_HIP(ctx, hipGetLastError());
+  if (dst_dev == d.stage)
+    MH_HIP(ctx, hipMemcpyAsync(host_block, d.stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipEventRecord(d.done, ctx->stream));
+  d.pending = true;
+  d.host_block = static_cast<unsigned char*>(host_block);
+  d.B = B;
+  d.max_objects = max_objects;
+  d.tag = tag;
+  return MH_OK;
+}
+
+}  // namespace mh
+
 extern "C" {
+
+size_t mh_frame_block_stride(int max_objects) {
+  return sizeof(mh_frame_head) + sizeof(mh_object) * (size_t)(max_objects > 0 ? max_objects : 0);
+}
+
+int mh_frame_fetch_batch_async(mh_ctx* ctx, int B, int max_objects, void* host_block, uint32_t tag) {
+  static_assert(sizeof(mh_frame_head) == 32 && sizeof(mh_object) == 40, "block layout");
+  if (!ctx || !ctx->fs || !host_block || B < 1 || B > MH_MAX_BATCH || max_objects < 0) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  FrameState* fs = ctx->fs;
+  const size_t bytes = mh_frame_block_stride(max_objects) * (size_t)B;
+  unsigned char* dst = nullptr;
+  if (int rc = delivery_begin(ctx, host_block, bytes, &dst)) return rc;
+  hipLaunchKernelGGL(deliver_kernel, dim3(B), dim3(128), 0, ctx->stream, fs->result, fs->result_bytes, fs->snap, dst,
+                     max_objects, fs->max_objects, tag);
+  return delivery_end(ctx, host_block, bytes, dst, B, max_objects, tag);
+}
+
+int mh_frame_fetch_query(mh_ctx* ctx) {
+  if (!ctx) return MH_ERR_ARG;
+  if (!ctx->dlv.pending) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  const hipError_t e = hipEventQuery(ctx->dlv.done);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  MH_HIP(ctx, e);
+  return MH_OK;
+}
+
+int mh_frame_fetch_wait(mh_ctx* ctx, int32_t* flags_or) {
+  if (!ctx) return MH_ERR_ARG;
+  if (flags_or) *flags_or = 0;
+  auto& d = ctx->dlv;
+  if (!d.pending) return MH_OK;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipEventSynchronize(d.done));
+  d.pending = false;
+  int32_t flags = 0;
+  const size_t stride = mh_frame_block_stride(d.max_objects);
+  for (int f = 0; f < d.B; ++f) {
+    const mh_frame_head* h = reinterpret_cast<const mh_frame_head*>(d.host_block + (size_t)f * stride);
+    flags |= h->flags;
+    if (h->tag != d.tag || h->frame != f) {   // the block was written by something else in the meantime
+      ctx->err = "mh_frame_fetch_wait: the host block does not hold the delivery that was enqueued into it";
+      return MH_ERR_ARG;
+    }
+  }
+  if (flags_or) *flags_or = flags;
+  if (flags) {
+    ctx->err = (flags & ERR_EXCHANGE)
+                   ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
+                                 "their collectives in different orders (every rank must enqueue its slots in the same order)")
+                   : "frame: capacity exceeded (flags " + std::to_string(flags) + ")";
+    return MH_ERR_CAPACITY;
+  }
+  return MH_OK;
+}
 
 void mh_free_frame_state(mh_ctx* ctx) {
   free_fs(ctx->fs);

@@ -216,6 +216,47 @@ int unpack_head(mh_ctx* ctx, const int32_t* head, int head_objects, mh_object* o
   return MH_OK;
 }
 
+// mh_frame_fetch_previous_async: frame f of the batch BEFORE the current one -- every rank's head behind its top-2 words in
+// the gathered exchange block -> one record of the caller's block: the ranks' objects one after the other in rank order.
+constexpr int DELIVER_MAX_WORLD = 64;
+__global__ void __launch_bounds__(128) deliver_previous_kernel(const int32_t* __restrict__ gathered, size_t stride_words, int bq,
+                                                               int world, unsigned char* __restrict__ dst, int max_objects,
+                                                               uint32_t tag) {
+  __shared__ int base[DELIVER_MAX_WORLD + 1];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int32_t* head0 = gathered + 3 * (size_t)bq + (size_t)f * EX2_WORDS;
+  if (t == 0) {
+    int tot = 0, carried = 0, flags = 0;
+    for (int r = 0; r < world; ++r) {
+      const int32_t* h = head0 + (size_t)r * stride_words;
+      const int n = h[0] > 0 ? h[0] : 0;
+      flags |= h[1];
+      if (n > MH_EX2_OBJECTS) flags |= 1 << 30;
+      base[r] = carried;
+      carried += n < MH_EX2_OBJECTS ? n : MH_EX2_OBJECTS;
+      tot += n;
+    }
+    base[world] = carried;
+    int32_t* out = reinterpret_cast<int32_t*>(dst + (size_t)f * (sizeof(mh_frame_head) + sizeof(mh_object) * (size_t)max_objects));
+    out[0] = tot;
+    out[1] = flags;
+    out[2] = out[3] = out[4] = -1;
+    out[5] = tot;
+    out[6] = (int32_t)tag;
+    out[7] = f;
+  }
+  __syncthreads();
+  constexpr int OW = (int)(sizeof(mh_object) / 4);
+  int32_t* out = reinterpret_cast<int32_t*>(dst + (size_t)f * (sizeof(mh_frame_head) + sizeof(mh_object) * (size_t)max_objects)) + 8;
+  for (int r = 0; r < world; ++r) {
+    const int32_t* h = head0 + (size_t)r * stride_words;
+    const int first = base[r];
+    const int take = min(base[r + 1], max_objects) - first;   // objects of rank r that fit
+    for (int w = t; w < take * OW; w += blockDim.x) out[first * OW + w] = h[4 + w];
+  }
+  __threadfence_system();
+}
+
 }  // namespace
 
 namespace mh {
@@ -384,6 +425,23 @@ int mh_frame_previous_objects(mh_ctx* ctx, int frame_in_batch, mh_object* object
     if (int rc = unpack_head(ctx, ex.host.data() + (size_t)r * EX2_WORDS, MH_EX2_OBJECTS, objects_host, cap, n_objects))
       return rc;
   return MH_OK;
+}
+
+int mh_frame_fetch_previous_async(mh_ctx* ctx, int max_objects, void* host_block, uint32_t tag) {
+  if (!ctx || !host_block || max_objects < 0 || !ctx->ex.gathered || ctx->ex.batch < 1) return MH_ERR_ARG;
+  auto& ex = ctx->ex;
+  if (ex.world > DELIVER_MAX_WORLD) {
+    ctx->err = "mh_frame_fetch_previous_async: more than 64 ranks";
+    return MH_ERR_CAPACITY;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc = mh::use_stream(ctx)) return rc;
+  const size_t bytes = mh_frame_block_stride(max_objects) * (size_t)ex.batch;
+  unsigned char* dst = nullptr;
+  if (int rc = mh::delivery_begin(ctx, host_block, bytes, &dst)) return rc;
+  hipLaunchKernelGGL(deliver_previous_kernel, dim3(ex.batch), dim3(128), 0, ctx->stream, ex.gathered, ex.stride, ex.bq, ex.world,
+                     dst, max_objects, tag);
+  return mh::delivery_end(ctx, host_block, bytes, dst, ex.batch, max_objects, tag);
 }
 
 int mh_frame_gather_objects(mh_ctx* ctx, mh_comm* comm, int slot, mh_object* objects_host, int cap,

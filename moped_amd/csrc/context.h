@@ -159,6 +159,17 @@ struct mh_ctx {
   unsigned char* df_buf = nullptr; // mh_depth_fill: [status words | downscaled depths | downscaled distances]
   size_t lk_scratch_floats = 0;
 
+  // mh_frame_fetch_batch_async / mh_frame_fetch_previous_async: delivery of a batch's objects into the caller's pinned block
+  struct Delivery {
+    hipEvent_t done = nullptr;          // recorded behind the delivery on the context's stream
+    bool pending = false;
+    unsigned char* stage = nullptr;     // device staging for blocks the device cannot write directly
+    size_t stage_cap = 0;
+    unsigned char* host_block = nullptr;   // the pending delivery's destination, as the caller knows it
+    int B = 0, max_objects = 0;
+    uint32_t tag = 0;
+  } dlv;
+
   bool timing = false;
   hipEvent_t ev[10] = {};
   static constexpr int MEV_SETS = 32;
@@ -189,6 +200,11 @@ int ensure_match_scratch(mh_ctx* ctx, int Q);
 // two-stage screen when it pays and the DB allows it, else by the exact kernels (bit-identical results either way).
 int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* idx1, float* d1, float* d2,
               const int32_t* q_count = nullptr, int q_expected = 0);
+// Delivery of a batch's heads into a caller's host block (api_steps.hip): delivery_begin -> where the delivering kernel
+// writes (the block itself when the device can address it, else the context's staging buffer); delivery_end -> the copy
+// out of the staging buffer if one is needed, and the event behind it all.
+int delivery_begin(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char** dst_dev);
+int delivery_end(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char* dst_dev, int B, int max_objects, uint32_t tag);
 int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
               float* desc_dev, float* xy_dev, int32_t** n_dev_out, int32_t* count_word = nullptr);
 

@@ -2,10 +2,16 @@
 // that keeps frames in flight: no Python, no torch, nothing but libmoped_hip.so's C ABI and the HIP runtime's memory /
 // stream calls.  `slots` contexts share ONE copy of the model database (mh_db_share), each carries batches of `batch`
 // frames through mh_frame_enqueue_batch on its own stream; the frames' descriptors start in PINNED HOST memory (one
-// hipMemcpyAsync per batch on the slot's stream) or, for the resident figure, in device memory; objects come back
-// through mh_frame_fetch_slot.  Also: the latency of ONE frame alone (copy + mh_frame_enqueue + mh_frame_fetch).
+// hipMemcpyAsync per batch on the slot's stream) or, for the resident figure, in device memory.  EVERY batch's objects
+// come back to the host inside the timed loops (the reference's loop hands each frame's list<SP_Object> to its caller,
+// moped.cpp:166-194; moped2/moped_test.cpp:205-207 prints them): mh_frame_fetch_batch_async behind each batch into the
+// slot's pinned block, mh_frame_fetch_wait + a pass over the heads before the slot's next batch; the clock stops when
+// the last batch's have arrived.  Also: the latency of ONE frame alone (copy + mh_frame_enqueue + mh_frame_fetch).
 //
 //   moped_hip_bench frames.bin [--slots 16] [--batch 8] [--steps 10] [--frames-per-step 1024] [--json]
+//                              [--objects-out objs.bin]
+// --objects-out: one more (untimed) pass over the file's frames, step number 1000, through the same delivered path;
+// per frame int32 n + n mh_object, in file order (tests/test_gpu_cpp_host.py compares them with the Python pipeline's).
 //
 // frames.bin (little endian, scripts/dump_scene.py dump_frames):
 //   int32 n_models, Q, n_frames ; float K[4] ; float cam[7]
@@ -72,6 +78,7 @@ int main(int argc, char** argv) {
   }
   int slots = 16, B = 8, steps = 10, frames_per_step = 1024;
   bool json = false;
+  std::string objects_out;
   for (int i = 2; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--slots" && i + 1 < argc) slots = std::atoi(argv[++i]);
@@ -79,6 +86,7 @@ int main(int argc, char** argv) {
     else if (a == "--steps" && i + 1 < argc) steps = std::atoi(argv[++i]);
     else if (a == "--frames-per-step" && i + 1 < argc) frames_per_step = std::atoi(argv[++i]);
     else if (a == "--json") json = true;
+    else if (a == "--objects-out" && i + 1 < argc) objects_out = argv[++i];
   }
   if (slots < 1 || slots > 64 || B < 1 || B > MH_MAX_BATCH || steps < 1) return 2;
 
@@ -136,18 +144,49 @@ int main(int argc, char** argv) {
 
   const int groups = std::max(pool_groups, frames_per_step / B);
   vector<uint64_t> seeds(B);
-  vector<int> last_pg(slots, -1);
+  // delivery: one pinned block per slot; pending[s] = pool group of the batch whose objects are on their way into it
+  const int CAP = 32;   // objects per frame a record carries (n_objects says if there were more)
+  const size_t rec = mh_frame_block_stride(CAP);
+  vector<unsigned char*> block(slots, (unsigned char*)0);
+  for (int s = 0; s < slots; ++s) CK_HIP(hipHostMalloc((void**)&block[s], rec * B, hipHostMallocDefault));
+  vector<int> pending(slots, -1);
+  long objects = 0, frames_delivered = 0, max_per_frame = 0, min_per_frame = 1 << 30;
+  FILE* dump = 0;               // --objects-out pass: the delivered records in file order
+  vector<vector<unsigned char> > dump_by_group;
+  // the slot's delivery reaches the host: wait for ITS event, read the heads
+  auto consume = [&](int s) -> int {
+    if (pending[s] < 0) return 0;
+    int32_t flags = 0;
+    CK_MH(ctx[s], mh_frame_fetch_wait(ctx[s], &flags));
+    for (int k = 0; k < B; ++k) {
+      const mh_frame_head* h = (const mh_frame_head*)(block[s] + rec * k);
+      objects += h->n_objects;
+      max_per_frame = std::max<long>(max_per_frame, h->n_objects);
+      min_per_frame = std::min<long>(min_per_frame, h->n_objects);
+      ++frames_delivered;
+    }
+    if (!dump_by_group.empty()) dump_by_group[pending[s]].assign(block[s], block[s] + rec * B);
+    pending[s] = -1;
+    return 0;
+  };
   unsigned long issued = 0;   // batches handed out so far: batch i goes to slot i mod slots
   // one step = `groups` batches, round-robin over the slots; from_host: the descriptors cross PCIe inside the loop
-  auto run_step = [&](int step, bool from_host) -> int {
-    for (int g = 0; g < groups; ++g) {
+  auto run_step = [&](int step, bool from_host, int n_groups) -> int {
+    for (int g = 0; g < n_groups; ++g) {
       const int s = (int)(issued++ % (unsigned long)slots), pg = g % pool_groups;
+      if (int rc = consume(s)) return rc;   // the slot's previous batch is on the host before the slot is reused
       const float* src = (from_host ? h_desc : d_pristine) + fd * B * pg;
       CK_HIP(hipMemcpyAsync(work[s], src, fd * B * 4, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream[s]));
       for (int k = 0; k < B; ++k) seeds[k] = 1000ull * (uint64_t)(step + 7) + (uint64_t)g * B + k + 1;
       CK_MH(ctx[s], mh_frame_enqueue_batch(ctx[s], work[s], d_uv + fu * B * pg, Q, B, &cam, &prm, &seeds[0]));
-      last_pg[s] = pg;
+      CK_MH(ctx[s], mh_frame_fetch_batch_async(ctx[s], B, CAP, block[s], (uint32_t)issued));
+      pending[s] = pg;
     }
+    return 0;
+  };
+  auto drain = [&]() -> int {
+    for (int s = 0; s < slots; ++s)
+      if (int rc = consume(s)) return rc;
     return 0;
   };
   auto sync_all = [&]() -> int {
@@ -155,28 +194,44 @@ int main(int argc, char** argv) {
     return 0;
   };
   double fps[2] = {0, 0};
+  long frames_timed = 0;
   for (int mode = 0; mode < 2; ++mode) {   // 0: inputs resident in HBM, 1: descriptors from pinned host memory
     for (int w = 0; w < 3; ++w)
-      if (int rc = run_step(-1 - w, mode == 1)) return rc;
+      if (int rc = run_step(-1 - w, mode == 1, groups)) return rc;
+    if (int rc = drain()) return rc;
     if (int rc = sync_all()) return rc;
+    objects = frames_delivered = 0;
     const double t0 = now_s();
     for (int k = 0; k < steps; ++k)
-      if (int rc = run_step(k, mode == 1)) return rc;
+      if (int rc = run_step(k, mode == 1, groups)) return rc;
+    if (int rc = drain()) return rc;       // the clock stops when the last batch's objects are on the host
     if (int rc = sync_all()) return rc;
     fps[mode] = (double)steps * groups * B / (now_s() - t0);
-  }
-  // objects of every slot's last batch
-  long objects = 0, frames_counted = 0;
-  vector<mh_object> objs(4096);
-  for (int s = 0; s < slots; ++s) {
-    if (last_pg[s] < 0) continue;
-    for (int k = 0; k < B; ++k) {
-      int32_t n = 0, counts[4];
-      CK_MH(ctx[s], mh_frame_fetch_slot(ctx[s], k, &objs[0], (int)objs.size(), &n, counts));
-      objects += n;
-      ++frames_counted;
+    frames_timed = (long)steps * groups * B;
+    if (frames_delivered != frames_timed) {
+      std::fprintf(stderr, "delivered %ld frames of %ld timed\n", frames_delivered, frames_timed);
+      return 5;
     }
   }
+  const long frames_counted = frames_delivered;
+  const long objects_counted = objects;
+  if (!objects_out.empty()) {
+    dump = std::fopen(objects_out.c_str(), "wb");
+    if (!dump) { std::perror(objects_out.c_str()); return 2; }
+    dump_by_group.assign(pool_groups, vector<unsigned char>());
+    if (int rc = run_step(1000, false, pool_groups)) return rc;
+    if (int rc = drain()) return rc;
+    for (int pg = 0; pg < pool_groups; ++pg)
+      for (int k = 0; k < B; ++k) {
+        const mh_frame_head* h = (const mh_frame_head*)(&dump_by_group[pg][0] + rec * k);
+        const int32_t n = h->n_objects, take = std::min<int32_t>(n, CAP);
+        std::fwrite(&n, 4, 1, dump);
+        std::fwrite(h + 1, sizeof(mh_object), (size_t)take, dump);
+      }
+    std::fclose(dump);
+    dump_by_group.clear();
+  }
+  vector<mh_object> objs(4096);
   // one frame alone: pinned host descriptors -> objects on the host
   vector<double> lat;
   for (int i = 0; i < 60; ++i) {
@@ -190,17 +245,19 @@ int main(int argc, char** argv) {
   }
   std::sort(lat.begin(), lat.end());
   const double lat_ms = 1e3 * lat[lat.size() / 2];
-  const double opf = frames_counted ? (double)objects / frames_counted : 0.0;
+  const double opf = frames_counted ? (double)objects_counted / frames_counted : 0.0;
   if (json)
     std::printf("{\"host\": \"moped_hip_bench (C++, C ABI only)\", \"slots\": %d, \"frames_per_batch\": %d, \"steps\": %d, "
                 "\"frames_per_step\": %d, \"fps_resident\": %.2f, \"fps_pinned_host\": %.2f, \"single_frame_latency_ms\": %.4f, "
-                "\"objects_per_frame\": %.3f, \"models\": %d, \"rows\": %d, \"queries\": %d}\n",
-                slots, B, steps, groups * B, fps[0], fps[1], lat_ms, opf, nm, N, Q);
+                "\"results_delivered\": \"every frame\", \"frames_delivered\": %ld, \"objects_per_frame\": %.3f, "
+                "\"min_objects_per_frame\": %ld, \"max_objects_per_frame\": %ld, \"models\": %d, \"rows\": %d, \"queries\": %d}\n",
+                slots, B, steps, groups * B, fps[0], fps[1], lat_ms, frames_counted, opf, min_per_frame, max_per_frame, nm, N, Q);
   else
     std::printf("slots %d x %d frames: %.0f frames/s (inputs in HBM), %.0f frames/s (descriptors from pinned host memory); one "
                 "frame alone %.3f ms; %.2f objects per frame\n", slots, B, fps[0], fps[1], lat_ms, opf);
   for (int s = 0; s < slots; ++s) {
     hipFree(work[s]);
+    hipHostFree(block[s]);
     mh_destroy(ctx[s]);
     hipStreamDestroy(stream[s]);
   }

@@ -163,10 +163,10 @@ class FramePipeline:
         self._inputs[slot] = (q_desc, q_uv)   # kept until the slot's next enqueue (stream order: the old ones are done by then)
         if after is not None:
             s.wait_stream(after)
+        self._batch[slot] = 1
         if not self.exchange:
             c.frame_enqueue(q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params, seed)
             return
-        self._batch[slot] = 1
         c.frame_enqueue_sharded(self._comm(slot), q_desc.data_ptr(), q_uv.data_ptr(), Q, self.K, self.cam, self.params,
                                 seed, _cam_struct=self._cam)
 
@@ -191,6 +191,37 @@ class FramePipeline:
 
     def fetch_batch(self, slot: int, B: int):
         return [self.ctxs[slot].frame_fetch_slot(f) for f in range(B)]
+
+    # ---- delivery: every batch's objects into pinned host memory, no stream synchronisation ---------------
+    def attach_delivery(self, max_objects: int = 16, B: int = capi.MAX_BATCH):
+        """One pinned host block per slot for mh_frame_fetch_batch_async / _previous_async: records of
+        mh_frame_head + mh_object[max_objects] for up to B frames."""
+        self._dlv_cap = max_objects
+        self._dlv_dtype = capi.frame_block_dtype(max_objects)
+        self._dlv_host = [torch.zeros(capi.frame_block_bytes(B, max_objects), dtype=torch.uint8).pin_memory()
+                          for _ in range(self.depth)]
+        self._dlv_view = [t.numpy().view(self._dlv_dtype) for t in self._dlv_host]
+        self._dlv_pending = [0] * self.depth   # frames of the slot's delivery in flight
+
+    def deliver(self, slot: int, tag: int = 0):
+        """Behind the batch just enqueued in `slot`: its objects (single GPU) or, with a sharded DB, all ranks' objects of
+        the slot's PREVIOUS batch (they arrived with this batch's exchange) into the slot's host block."""
+        c, B = self.ctxs[slot], self._batch[slot]
+        if self.exchange:
+            c.frame_fetch_previous_async(self._dlv_cap, self._dlv_host[slot].data_ptr(), tag)
+        else:
+            c.frame_fetch_batch_async(B, self._dlv_cap, self._dlv_host[slot].data_ptr(), tag)
+        self._dlv_pending[slot] = B
+
+    def take_delivery(self, slot: int):
+        """Waits for the slot's delivery; the B records (a view of the pinned block: copy what must outlive the slot's
+        next delivery) or None if nothing was pending."""
+        B = self._dlv_pending[slot]
+        if not B:
+            return None
+        self.ctxs[slot].frame_fetch_wait()
+        self._dlv_pending[slot] = 0
+        return self._dlv_view[slot][:B]
 
     def previous_objects_batch(self, slot: int):
         """Objects of the B frames of the batch enqueued in `slot` BEFORE the current one, from all ranks."""

@@ -8,7 +8,7 @@ db = synth.make_db(20, 5000)
 frames = [synth.make_frame(db, n_vis=2, seed=s, Q=3000) for s in range(32)]
 dump_scene.dump_frames("/tmp/frames.bin", db, frames)
 def run(tag):
-    out = subprocess.check_output([os.path.join(ROOT, "moped_amd/host/moped_hip_bench"), "/tmp/frames.bin", "--json", "--steps", "3", "--frames-per-step", "512"], text=True)
+    out = subprocess.check_output([os.path.join(ROOT, "moped_amd/host/moped_hip_bench"), "/tmp/frames.bin", "--json", "--steps", "5", "--frames-per-step", "1024", "--batch", "16"], text=True)
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     print(tag, "affinity", len(os.sched_getaffinity(0)), "resident", d["fps_resident"], "pinned", d["fps_pinned_host"], flush=True)
 run("before torch:")

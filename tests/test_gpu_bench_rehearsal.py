@@ -40,6 +40,10 @@ def test_plain_python_gpus_2_starts_two_ranks_and_shards_the_models():
     assert ex["world"] == 2 and ex["rank"] == 0        # the transport of the frames' exchange saw two ranks
     assert d["config"]["objects_per_frame"] == 2.0 and d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1
     assert "suspect" not in d
+    # every timed frame's objects (all ranks') reached the host inside the timed region
+    det = d["config"]["objects_detail"]
+    assert d["config"]["results_delivered"] == "every frame" and det["frames"] == 2 * d["config"]["frames_per_step"]
+    assert det["frames_missing_a_planted_object"] == 0 and det["objects_per_frame_histogram"] == [0, 0, det["frames"]]
     assert d["config"]["env_overrides"].get("MH_BENCH_REHEARSE") == "1"
     # the other partition and the other workload ride in the same line
     assert d["replicated_frames"]["parallelism"].startswith("frame-parallel x2") and d["replicated_frames"]["value"] > 0
@@ -61,6 +65,7 @@ def test_frames_partition_is_an_option():
     d = _run(["--parallelism", "frames", "--frames-per-step", "64", "--no-secondary"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("frame-parallel x2")
     assert d["config"]["objects_per_frame"] == 2.0
+    assert d["config"]["objects_detail"]["frames"] == 2 * d["config"]["frames_per_step"] and "suspect" not in d
 
 
 def test_four_ranks_with_every_leg_of_the_default_run():

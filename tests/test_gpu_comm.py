@@ -114,6 +114,18 @@ def test_python_comm_create_all_and_sharded_all(scene, single):
     qd2 = torch.from_numpy(np.concatenate([fr.desc, fr.desc])).to(dev)
     capi.frame_enqueue_sharded_all([c], comms, [qd2.data_ptr()], [uv.data_ptr()], Q, 2, synth.K_DEFAULT,
                                    synth.CAM_IDENTITY, prm, [9, 7])
+    # ... and the delivery form of the same: both frames of the previous batch in one stream-ordered copy into pinned
+    # host memory, no stream synchronisation (mh_frame_fetch_previous_async / mh_frame_fetch_wait)
+    cap = 8
+    block = torch.zeros(capi.frame_block_bytes(2, cap), dtype=torch.uint8).pin_memory()
+    c.frame_fetch_previous_async(cap, block.data_ptr(), tag=0xABCD)
+    c.frame_fetch_wait()
+    recs = block.numpy().view(capi.frame_block_dtype(cap))
+    assert np.all(recs["head"]["tag"] == 0xABCD) and np.array_equal(recs["head"]["frame"], [0, 1])
+    for f in (0, 1):
+        n = int(recs[f]["head"]["n_objects"])
+        assert n == len(c.frame_previous_objects(f)) and recs[f]["head"]["flags"] == 0
+        assert _same(recs[f]["objects"][:n], c.frame_previous_objects(f))
     assert _same(c.frame_previous_objects(0), single[0])
     assert _same(c.frame_gather_objects(comms[0], 1), single[0])     # slot 1 of the current batch: seed 7 again
     c.synchronize()

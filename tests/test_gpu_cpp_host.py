@@ -1,13 +1,15 @@
 """The C++ streaming host (moped_amd/host/moped_hip_bench.cpp): no Python and no torch between the frames and the C ABI.
 A C++ host that keeps frames in flight -- 16 contexts sharing one model database, batches through
 mh_frame_enqueue_batch, descriptors resident or crossing PCIe from pinned memory -- must find what the Python
-pipeline finds on the same scene, and deliver the throughput bench.py's h2d-inclusive figure claims for the C ABI
-(within 5% of it; checked in bench.py's own line as `cpp_host`, here at a size the suite affords)."""
+pipeline finds on the same scene -- the same objects, bit for bit, delivered to the host for EVERY frame inside its
+timed loops -- and deliver the throughput bench.py's h2d-inclusive figure claims for the C ABI (checked in bench.py's own
+line as `cpp_host`, here at the bench's batch shape)."""
 import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from moped_amd import synth
@@ -26,7 +28,7 @@ def frames_file(tmp_path_factory):
     frames = [synth.make_frame(db, n_vis=2, seed=s, Q=3000) for s in range(32)]
     path = str(tmp_path_factory.mktemp("cpp") / "frames.bin")
     dump_scene.dump_frames(path, db, frames)
-    return path
+    return path, db, frames
 
 
 def _run(path, *args):
@@ -34,19 +36,63 @@ def _run(path, *args):
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
 
-def test_streaming_host_finds_every_object_and_streams(frames_file):
-    d = _run(frames_file, "--steps", "3", "--frames-per-step", "512")
-    assert d["slots"] == 16 and d["frames_per_batch"] == 8 and d["queries"] == 3000 and d["rows"] == 100000
-    assert d["objects_per_frame"] == 2.0                  # both visible objects of every frame, in every slot's last batch
-    # config 1 runs at ~13 000 frames/s from Python; a C++ host must not be far below, resident or from pinned memory
-    assert d["fps_resident"] > 8000 and d["fps_pinned_host"] > 2500
-    # (alone on the chip the pinned-host rate is within 10% of the resident one -- 12 400 against 13 000 frames/s --, and
-    # bench.py measures it that way, before it touches the GPU itself; as a child of this suite's process, whose earlier
-    # tests left streams and queues behind, it has been seen between 5 000 and 8 700)
-    assert 0.3 < d["single_frame_latency_ms"] < 3.0
+def _read_objects(path, n_frames, cap=32):
+    from moped_amd import capi
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    for _ in range(n_frames):
+        n = int(np.frombuffer(raw, "<i4", 1, off)[0])
+        off += 4
+        k = min(n, cap)
+        out.append(np.frombuffer(raw, capi.OBJECT_DTYPE, k, off).copy())
+        off += k * capi.OBJECT_DTYPE.itemsize
+    assert off == len(raw)
+    return out
+
+
+def test_streaming_host_delivers_every_frame_and_its_objects_are_the_python_pipelines(frames_file, tmp_path):
+    """The bench's own shape: 16 slots x 16 frames per batch.  Every timed frame's objects reach the host inside the timed
+    loops (mh_frame_fetch_batch_async / mh_frame_fetch_wait; the reference hands every frame's objects to its caller,
+    moped2/libmoped/src/moped.cpp:166-194), and the objects of one pass over the file are, bit for bit, what the Python
+    pipeline gets for the same frames and seeds."""
+    import torch
+    from moped_amd import capi
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    path, db, frames = frames_file
+    objs_path = str(tmp_path / "objs.bin")
+    d = _run(path, "--steps", "5", "--frames-per-step", "1024", "--batch", "16", "--objects-out", objs_path)
+    if d["fps_pinned_host"] < 0.9 * d["fps_resident"]:   # a timed region of a third of a second on a shared box: once more
+        d = _run(path, "--steps", "5", "--frames-per-step", "1024", "--batch", "16", "--objects-out", objs_path)
+    assert d["slots"] == 16 and d["frames_per_batch"] == 16 and d["queries"] == 3000 and d["rows"] == 100000
+    assert d["results_delivered"] == "every frame" and d["frames_delivered"] == 5 * 1024
+    assert d["objects_per_frame"] == 2.0 and d["min_objects_per_frame"] == 2 and d["max_objects_per_frame"] == 2
+    # config 1 runs at ~14 000 frames/s from Python; a C++ host must not be far below, and descriptors that cross PCIe
+    # inside the loop (1.5 MB per frame, overlapped with the other slots' work) must cost less than a tenth
+    assert d["fps_resident"] > 8000
+    assert d["fps_pinned_host"] >= 0.9 * d["fps_resident"], d
+    assert 0.2 < d["single_frame_latency_ms"] < 3.0
+    got = _read_objects(objs_path, len(frames))
+    B, Q = 16, 3000
+    dev = torch.device("cuda:0")
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=B * Q, batch=B)
+    for g in range(len(frames) // B):
+        qd = torch.cat([torch.from_numpy(f.desc) for f in frames[g * B:(g + 1) * B]]).to(dev)
+        uv = torch.cat([torch.from_numpy(f.uv) for f in frames[g * B:(g + 1) * B]]).to(dev)
+        torch.cuda.synchronize()
+        pipe.enqueue_batch(0, qd, uv, B, [1000 * (1000 + 7) + g * B + k + 1 for k in range(B)])   # moped_hip_bench's seeds
+        for k, (objs, _) in enumerate(pipe.fetch_batch(0, B)):
+            o = got[g * B + k]
+            assert len(o) == len(objs) == 2, (g, k)
+            assert np.array_equal(o["model"], objs["model"]) and np.array_equal(o["n_points"], objs["n_points"])
+            assert np.array_equal(o["pose"].view(np.uint32), objs["pose"].view(np.uint32))
+            assert np.array_equal(o["score"].view(np.uint32), objs["score"].view(np.uint32))
+            assert set(o["model"].tolist()) == set(frames[g * B + k].visible.tolist())
+    pipe.close()
 
 
 def test_streaming_host_other_shapes(frames_file):
-    for args in (("--slots", "4", "--batch", "1"), ("--slots", "2", "--batch", "32")):
-        d = _run(frames_file, "--steps", "2", "--frames-per-step", "128", *args)
+    path = frames_file[0]
+    for args in (("--slots", "4", "--batch", "1"), ("--slots", "2", "--batch", "32"), ("--slots", "16", "--batch", "8")):
+        d = _run(path, "--steps", "2", "--frames-per-step", "128", *args)
         assert d["objects_per_frame"] == 2.0 and d["fps_resident"] > 0
+        assert d["frames_delivered"] == 2 * d["frames_per_step"]
