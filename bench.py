@@ -52,7 +52,8 @@ def parse(argv=None):
     ap.add_argument("--queries", type=int, default=3000)
     ap.add_argument("--frames-per-step", type=int, default=1024,
                     help="frames per step (20 steps = 20,480 frames: a timed region of seconds, not milliseconds)")
-    ap.add_argument("--frame-pool", type=int, default=32, help="distinct synthetic frames the steps cycle through")
+    ap.add_argument("--frame-pool", type=int, default=100,
+                    help="distinct synthetic frames the steps cycle through (SURVEY 8(d): 100 frames, seeds 0..99)")
     ap.add_argument("--depth", type=int, default=0,
                     help="frame slots (streams) per GPU (default 16: one stream per hardware queue; a frame is a chain of "
                          "~13 short launches, most of them latency bound -- 32 are faster on most boxes and 2.4x slower on some)")
@@ -105,15 +106,50 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: start the ranks, relay rank 0's line
 # ------------------------------------------------------------------------------------------------------------
+def count_devices() -> int:
+    """GPUs this process could use, WITHOUT a HIP call (torch.cuda.device_count() falls back to hipGetDeviceCount on
+    builds without amdsmi, which initialises the runtime in this parent): the visible-devices lists if set, else the KFD
+    topology's nodes with SIMDs.  The topology may show more devices than a container may open; a rank that cannot get
+    its device then fails at start-up, which is an error exit like the one below.  Unknown -> torch's count."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip()])
+    n, base = 0, "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += int(line.split()[1]) > 0
+                        break
+    except (OSError, ValueError):
+        n = 0
+    if n:
+        return n
+    import torch
+    return torch.cuda.device_count()
+
+
+def arm_watchdog(seconds: int):
+    """(Re-)arm the hang watchdog for the leg that starts now: a rank still inside it after `seconds` dumps every
+    thread's stack and exits with an error.  Per leg, not per job: a long --steps or a slow host must not be killed for
+    the sum of its legs."""
+    if seconds > 0:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(seconds, exit=True)
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: one rank per GPU as a child
     `python -m torch.distributed.run`, started before this process has made any GPU call (a process that has
-    initialised the GPU must not be replaced or forked into ranks).  Returns the exit code to leave with; rank 0's
+    initialised the GPU must not be replaced or forked into ranks: the ranks are a fresh child process, never an exec of
+    this one, and the device count below comes from sysfs, not from HIP).  Returns the exit code to leave with; rank 0's
     JSON line is the only thing written to stdout.  Fewer devices than ranks is an error (never a line that names
     more GPUs than ran) unless MH_BENCH_REHEARSE=1 puts every rank on cuda:0 on purpose."""
     import socket
-    import torch
-    n_dev = torch.cuda.device_count()   # counts devices without initialising the runtime
+    n_dev = count_devices()
     rehearse = os.environ.get("MH_BENCH_REHEARSE") == "1"
     if n_dev < args.gpus and not rehearse:
         print(f"bench.py: --gpus {args.gpus} but this host shows {n_dev} device(s); not printing a line for ranks that "
@@ -140,6 +176,25 @@ def launch_ranks(args) -> int:
     if line is not None and rc == 0:
         print(line, flush=True)
     return rc
+
+
+def host_cpu():
+    """The box the CPU figure was taken on (north_star: "core count stated"): model name, logical CPUs the OS shows, CPUs
+    this process may run on."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cpus": usable}
 
 
 def cpu_baseline(db, frames, args):
@@ -191,6 +246,7 @@ def cpu_baseline(db, frames, args):
     fps = n_frames / (t_match + t_rest)
     return {
         "value": round(fps, 3), "unit": "frames/s", "cores": max(1 if use_ref else cores, best_threads or 1), "kind": "port",
+        "host": host_cpu(),
         "sample": (f"{n_frames} frames of the same workload; MATCH = "
                    + ("reference ANN 1.1.1 kd-tree eps=5 via oracle/_ref (shipped default, 1 thread: omp critical)"
                       if use_ref else f"oracle exact matcher, {cores} threads, 300-query subset scaled")
@@ -255,13 +311,15 @@ class Job:
         n_pool = max(1, min(args.frame_pool, n_frames))
         B = batch
         if B > 1:
-            n_pool = max(B, n_pool // B * B)
-            n_frames = max(n_pool, n_frames // n_pool * n_pool)
+            # a batch = B consecutive frames of the pool, the pool taken cyclically: lcm(pool, B) / B distinct batches
+            # (100 frames, B = 16: 25 batches, every frame in four of them); a step = n_frames / B batches
+            n_frames = max(B, n_frames // B * B)
+            n_pool = max(1, min(n_pool, n_frames))
         self.n_frames, self.n_pool = n_frames, n_pool
-        self.frames = [synth.make_frame(db, n_vis=args.n_vis, seed=seeds_base + s, Q=Q) for s in range(n_pool)]
+        self.seeds_base = seeds_base
         if by_frames:   # every rank holds the whole DB and works on its own frames
             if rank:
-                self.frames = [synth.make_frame(db, n_vis=args.n_vis, seed=seeds_base + 1000 * rank + s, Q=Q) for s in range(n_pool)]
+                self.seeds_base = seeds_base + 1000 * rank
             self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
         else:
             self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world, assign=args.assign)
@@ -290,14 +348,43 @@ class Job:
                                   lane=parse_lane(args.lane))
         torch.cuda.synchronize(dev)
         self.hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
-        frames = self.frames
+        self.work = [torch.empty((Q, 128), dtype=torch.float32, device=dev) for _ in range(args.depth)]
+        if B > 1:
+            self.work_b = [torch.empty((Q * B, 128), dtype=torch.float32, device=dev) for _ in range(args.depth)]
+        if args.depth_kind and args.moped3d_frontend:
+            from moped_amd import moped3d
+            if args.depthfill:   # per slot: the B working maps DEPTHFILL fills in place + the distance maps it writes
+                self.fill_work = [[(torch.empty((480, 640, 4), dtype=torch.float32, device=dev),
+                                    torch.empty((480, 640), dtype=torch.float32, device=dev)) for _ in range(max(B, 1))]
+                                  for _ in range(args.depth)]
+            table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
+            for c in self.pipe.ctxs:
+                c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
+                c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45
+        self.active_slots = args.depth   # slots in use (the calibration may settle on fewer)
+        # Delivery (the reference's loop hands every frame's objects to its caller, moped2/libmoped/src/moped.cpp:166-194):
+        # behind every batch one stream-ordered copy of its B result heads into the slot's pinned host block; the host
+        # reads the block -- object counts, the planted models among the objects -- before it reuses the slot.
+        self.pipe.attach_delivery(DELIVER_CAP, max(B, 1))
+        self.slot_pending = {}           # slot -> pool indices of the frames of the delivery in flight (None: not counted)
+        self.slot_last = {}              # sharded: slot -> pool indices of the batch whose objects ride on the slot's NEXT exchange
+        self.load_frames(args.n_vis)
+
+    def load_frames(self, n_vis):
+        """The workload's frames (`n_vis` planted objects each, seeds seeds_base ..) resident in HBM; the
+        pipeline stays.  Nothing may be in flight."""
+        import math
+        import torch
+        from moped_amd import capi, synth
+        args, db, dev, B, n_pool = self.args, self.db, self.env["dev"], self.B, self.n_pool
+        Q = args.queries
+        self.n_vis = n_vis
+        self.frames = frames = [synth.make_frame(db, n_vis=n_vis, seed=self.seeds_base + s, Q=Q) for s in range(n_pool)]
         self.pristine = [torch.from_numpy(f.desc).to(dev) for f in frames]
         self.uvs = [torch.from_numpy(f.uv).to(dev) for f in frames]
-        self.work = [torch.empty_like(self.pristine[0]) for _ in range(args.depth)]
         self.depths = None
         self.maps = None
         if args.depth_kind and args.moped3d_frontend:
-            from moped_amd import moped3d
             self.maps = []
             for i, f in enumerate(frames):
                 img, fill = synth.depth_image(db, f, seed=i, fill_max=0.3)
@@ -313,13 +400,6 @@ class Job:
                     hole[np.clip(f.uv[rows, 1].astype(np.int32), 0, 479), np.clip(f.uv[rows, 0].astype(np.int32), 0, 639)] = False
                     img[hole, 2] = -1.0
                 self.maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
-            if args.depthfill:   # per slot: the B working maps DEPTHFILL fills in place + the distance maps it writes
-                self.fill_work = [[(torch.empty_like(self.maps[0][0]), torch.empty_like(self.maps[0][1])) for _ in range(max(B, 1))]
-                                  for _ in range(args.depth)]
-            table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
-            for c in self.pipe.ctxs:
-                c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)      # config.hpp:41-44
-                c.frame_set_cluster_linkage(capi.default_linkage_params())          # config.hpp:45
         elif args.depth_kind:
             self.depths = []
             for i, f in enumerate(frames):
@@ -328,42 +408,37 @@ class Job:
                 wgt = (1.0 / (1.0 + (fill / f32(0.1 if args.depth_kind == 1 else 25.0)) ** 2)).astype(f32)  # getCauchyWeight
                 d = capi.pack_depth(wpts, wgt)
                 self.depths.append(torch.from_numpy(d.view(np.float32).reshape(-1, 4)).to(dev))
+        # group_frames[g]: the pool frames of batch g (one frame per "batch" without batches)
         if B > 1:
-            assert n_pool % B == 0 and n_frames % B == 0
-            self.groups = n_frames // B
-            self.pool_groups = n_pool // B
-            self.pristine_b = [torch.cat(self.pristine[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
-            self.uv_b = [torch.cat(self.uvs[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
-            self.work_b = [torch.empty_like(self.pristine_b[0]) for _ in range(args.depth)]
-            self.depths_b = None if self.depths is None else [torch.cat(self.depths[g * B:(g + 1) * B]) for g in range(self.pool_groups)]
+            self.groups = self.n_frames // B
+            self.pool_groups = n_pool // math.gcd(n_pool, B)
+            self.group_frames = [np.array([(g * B + f) % n_pool for f in range(B)]) for g in range(self.pool_groups)]
+            self.pristine_b = [torch.cat([self.pristine[i] for i in gf]) for gf in self.group_frames]
+            self.uv_b = [torch.cat([self.uvs[i] for i in gf]) for gf in self.group_frames]
+            self.depths_b = None if self.depths is None else [torch.cat([self.depths[i] for i in gf]) for gf in self.group_frames]
+        else:
+            self.group_frames = [np.array([i]) for i in range(n_pool)]
         # the inputs were put together on torch's default stream (torch.cat); the slots' streams do not wait for it
         torch.cuda.synchronize(dev)
-        self.active_slots = args.depth   # slots in use (the calibration may settle on fewer)
         self.host_desc = None            # h2d measurement: the same descriptors in pinned host memory
-        # Delivery (the reference's loop hands every frame's objects to its caller, moped2/libmoped/src/moped.cpp:166-194):
-        # behind every batch one stream-ordered copy of its B result heads into the slot's pinned host block; the host
-        # reads the block -- object counts, the planted models among the objects -- before it reuses the slot.
-        self.pipe.attach_delivery(DELIVER_CAP, max(B, 1))
-        nv = max(1, max(len(f.visible) for f in self.frames))
+        nv = max(1, max(len(f.visible) for f in frames))
         self.planted = np.full((n_pool, nv), -1, np.int32)
-        for i, f in enumerate(self.frames):
+        for i, f in enumerate(frames):
             self.planted[i, :len(f.visible)] = f.visible
-        self.slot_pending = {}           # slot -> pool index of the first frame of the delivery in flight (None: not counted)
-        self.slot_last = {}              # sharded: slot -> pool index of the batch whose objects ride on the slot's NEXT exchange
         self.reset_delivered()
 
     # ---- delivered results ----------------------------------------------------------------------------------
     def reset_delivered(self):
         self.dl = {"frames": 0, "objects": 0, "hist": np.zeros(64, np.int64), "planted_missed": 0, "frames_missing": 0}
 
-    def _count(self, first, n_per_frame, models, valid):
-        """n_per_frame [B], models / valid [B][cap]: the delivered objects of frames first .. first + B - 1 of the pool."""
+    def _count(self, which, n_per_frame, models, valid):
+        """n_per_frame [B], models / valid [B][cap]: the delivered objects of the pool frames `which` [B]."""
         st = self.dl
         B = len(n_per_frame)
         st["frames"] += B
         st["objects"] += int(n_per_frame.sum())
         st["hist"] += np.bincount(np.minimum(n_per_frame, 63), minlength=64)
-        pl = self.planted[first:first + B]
+        pl = self.planted[which]
         found = ((models[:, None, :] == pl[:, :, None]) & valid[:, None, :]).any(-1) | (pl < 0)
         st["planted_missed"] += int((~found).sum())
         st["frames_missing"] += int((~found.all(-1)).sum())
@@ -379,7 +454,7 @@ class Job:
         self._count(first, n, recs["objects"]["model"], np.arange(DELIVER_CAP)[None, :] < n[:, None])
 
     def _deliver(self, slot, first, tag):
-        """Behind the batch just enqueued in `slot` (pool frames first ..): its delivery.  With a sharded DB what arrives
+        """Behind the batch just enqueued in `slot` (pool frames `first`, an index array): its delivery.  With a sharded DB what arrives
         is the slot's PREVIOUS batch, all ranks' objects (they rode on this batch's exchange)."""
         pipe = self.pipe
         pipe.deliver(slot, tag)
@@ -421,14 +496,14 @@ class Job:
         from moped_amd import synth
         for g in range(self.groups):
             slot = (step * self.groups + g) % self.active_slots
-            pg = g % self.pool_groups
+            pg = (step * self.groups + g) % self.pool_groups
             self._consume(slot)   # the slot's previous batch is on the host before the slot is reused
             with torch.cuda.stream(pipe.streams[slot]):
                 self.work_b[slot].copy_(self.host_desc[pg] if from_host else self.pristine_b[pg], non_blocking=True)
             if self.depths_b is not None:
                 pipe.ctxs[slot].frame_set_depth(self.depths_b[pg].data_ptr(), a.depth_kind, 0.5)
             if self.maps is not None:   # the B frames' own depth and distance maps
-                mm = self.maps[pg * B:(pg + 1) * B]
+                mm = [self.maps[i] for i in self.group_frames[pg]]
                 if a.depthfill:
                     for j, m in enumerate(mm):
                         wd, wf = self.fill_work[slot][j]
@@ -439,7 +514,7 @@ class Job:
                 pipe.ctxs[slot].frame_set_depth_image_batch([m[0].data_ptr() for m in mm], [m[1].data_ptr() for m in mm], 640, 480,
                                                             a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
             pipe.enqueue_batch(slot, self.work_b[slot], self.uv_b[pg], B, [1000 * step + g * B + f + 1 for f in range(B)])
-            self._deliver(slot, pg * B, step * self.groups + g)
+            self._deliver(slot, self.group_frames[pg], step * self.groups + g)
 
     def run_step(self, step, from_host=False):
         import torch
@@ -468,7 +543,7 @@ class Job:
                 pipe.ctxs[slot].frame_set_depth_image(mb[0].data_ptr(), mb[1].data_ptr(), 640, 480,
                                                       a.depth_kind, 0.5, 0.1 if a.depth_kind == 1 else 25.0)
             pipe.enqueue(slot, self.work[slot], self.uvs[b], seed=1000 * step + f + 1)
-            self._deliver(slot, b, step * self.n_frames + f)
+            self._deliver(slot, self.group_frames[b], step * self.n_frames + f)
 
     def sync_all(self):
         import torch
@@ -581,9 +656,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world                    # n_gpus = the ranks that run, whatever --gpus said
     wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
-    if wd > 0:   # a collective that never completes must end the job with a stack, not hold the node
-        import faulthandler
-        faulthandler.dump_traceback_later(wd, exit=True)
+    arm_watchdog(wd)   # a collective that never completes must end the job with a stack, not hold the node; re-armed per leg
     if args.parallelism == "auto":
         args.parallelism = choose_parallelism(args.models, world)
     by_frames = args.parallelism == "frames" and not args.force_exchange
@@ -632,6 +705,7 @@ def main():
     pipe, params = job.pipe, job.params
     if B > 1 and not depth_given and args.depth == 16:
         job.calibrate_slots()
+    arm_watchdog(wd + 2 * args.steps)
     dt, t_issue = job.timed(args.steps, args.warmup)
     fps = job.total_frames(args.steps) / dt    # every one of these frames' objects reached the host inside dt (checked below)
     det_per_frame = job.detections_per_frame()
@@ -697,9 +771,10 @@ def main():
     # ---- secondary: the same frames with the descriptors in pinned HOST memory (1.5 MB over PCIe per frame, the copy
     # on the frame's own stream, overlapped with the other frames in flight).  Never `value`.
     if world == 1 and args.h2d_steps > 0:
-        host_desc = [torch.from_numpy(f.desc).pin_memory() for f in job.frames]
         if B > 1:
-            host_desc = [torch.cat(host_desc[g * B:(g + 1) * B]).pin_memory() for g in range(job.pool_groups)]
+            host_desc = [torch.from_numpy(np.concatenate([job.frames[i].desc for i in gf])).pin_memory() for gf in job.group_frames]
+        else:
+            host_desc = [torch.from_numpy(f.desc).pin_memory() for f in job.frames]
         job.host_desc = host_desc
         dth, _ = job.timed(args.h2d_steps, 1, from_host=True, step_base=-600)
         out["h2d_inclusive"] = {"value": round(args.h2d_steps * n_frames / dth, 2), "unit": "frames/s", "steps": args.h2d_steps,
@@ -709,6 +784,7 @@ def main():
                                         "a reported figure, not the metric's `value`"}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the stream it is launched on ----
+    arm_watchdog(wd)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(job, fps, out)
     if world > 1:
@@ -739,11 +815,51 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- the workload breadth SURVEY 8(d) defines, same DB, same pipeline, same launch shape (all ranks take part):
+    # 5 and 10 visible objects per frame (POSE's cost grows with what is visible,
+    # POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:188-211), and every one of the 4 x 1024 hypotheses evaluated ----
+    if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend) and not args.no_adaptive:
+        sec_steps = max(1, args.secondary_steps)
+
+        def side(n_vis, no_adaptive):
+            if n_vis != job.n_vis:
+                job.load_frames(n_vis)
+            h1, h2 = params.pose1.n_hypotheses, params.pose2.n_hypotheses
+            if no_adaptive:
+                params.pose1.n_hypotheses, params.pose2.n_hypotheses = -abs(h1), -abs(h2)
+            try:
+                dts, _ = job.timed(sec_steps, 1, step_base=-2000)
+            finally:
+                params.pose1.n_hypotheses, params.pose2.n_hypotheses = h1, h2
+            det = job.detections_per_frame()
+            cs = [c.frame_counters() for c in pipe.ctxs[:job.active_slots if B > 1 else args.depth]]
+            r = {"value": round(job.total_frames(sec_steps) / dts, 2), "unit": "frames/s", "steps": sec_steps,
+                 "planted_objects": n_vis, "objects_per_frame": round(det, 3), "objects_detail": job.detections_detail,
+                 "hypotheses_per_task": round(float(np.sum([c["hypotheses"] for c in cs]) / max(1, np.sum([c["pose_tasks"] for c in cs]))), 1),
+                 "pose_tasks_per_frame": round(float(np.mean([c["pose_tasks"] for c in cs])), 1)}
+            d = job.detections_detail
+            if d["frames"] != sec_steps * job.n_frames or d["frames_missing_a_planted_object"]:
+                r["suspect"] = (f"{d['frames']} of {sec_steps * job.n_frames} frames delivered, "
+                                f"{d['frames_missing_a_planted_object']} miss a planted object")
+            return r
+        for label, nv, na in (("no_adaptive", args.n_vis, True), ("n_vis_5", 5, False), ("n_vis_10", 10, False)):
+            arm_watchdog(wd)
+            try:
+                out[label] = side(nv, na)
+            except Exception as e:    # a reported extra: the line survives, the failure is in it
+                if world > 1:
+                    raise
+                out[label] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["no_adaptive"]["note"] = "all 1024 hypotheses of every (cluster, replica) task evaluated (bench.py --no-adaptive as a whole line)"
+        if job.n_vis != args.n_vis:
+            job.load_frames(args.n_vis)
+
     # ---- secondary partitions / workloads in the same line (all ranks take part) ----
     if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
         sec_steps = max(1, args.secondary_steps)
         if world > 1 and not by_frames:
             job.close()
+            arm_watchdog(wd)
             a2 = argparse.Namespace(**vars(args))
             a2.parallelism = "frames"
             j2 = Job(a2, env, db, args.models, True, False, default_batch(a2, False), args.frames_per_step)
@@ -760,6 +876,7 @@ def main():
             if job is not None:
                 job.close()
                 job = None
+            arm_watchdog(wd)
             a3 = argparse.Namespace(**vars(args))
             a3.models, a3.parallelism = 200, "models"
             db200 = synth.make_db(200, 5000)

@@ -130,9 +130,16 @@ int mh_normalize_match(mh_ctx* ctx, float* q_host, int Q, float ratio, int32_t* 
  * takes the exact kernels.  Synchronises the context's stream. */
 int mh_match_stats(mh_ctx* ctx, int Q, uint32_t stats[4], int reset);
 /* Which kernels search: -1 (default) = the two-stage path when the work is large enough (Q x N >= 8e6,
- * N >= 4096) and every DB row is finite and inside f16's range, 0 = always the exact f32 kernels,
- * 1 = the two-stage path whenever the DB allows.  The results are the same bits either way. */
+ * N >= 4096) and every DB row is finite and inside f16's range, 0 = always the exact f32 kernels (the
+ * VALU kernel below 1536 queries, the f32 matrix-pipe kernel from there), 1 = the two-stage path whenever
+ * the DB allows, 2 = the exact VALU kernel (match_kernel) whatever the query count, 3 = the exact f32
+ * matrix-pipe kernel (match_mfma_kernel) whatever the query count.  The results are the same bits in every
+ * mode (tests/test_gpu_match_kernels.py compares them). */
 int mh_match_set_mode(mh_ctx* ctx, int mode);
+/* MATCH launch sequences this context has issued, by the kernel that searched: out[0] = match_kernel (VALU),
+ * out[1] = match_mfma_kernel (f32 matrix pipe), out[2] = the two-stage path.  Host counters, no synchronisation;
+ * for tests that must know which kernel produced a result. */
+int mh_match_launches(mh_ctx* ctx, uint32_t out[3]);
 /* The two-stage path's error model (host arithmetic, no device needed): a row can be one of a query's
  * two nearest only if its f16 screen value exceeds T - mh_screen_margin(dot(q,q), max row norm), T =
  * any lower bound of the second largest screen value.  Exposed so that tests can check the bound. */

@@ -100,7 +100,7 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_match_launches", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
     "mh_pose_ransac_images",
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
@@ -222,6 +222,7 @@ def load():
     L.mh_db_share.argtypes = [vp, vp]
     L.mh_match_stats.argtypes = [vp, i32, vp, i32]
     L.mh_match_set_mode.argtypes = [vp, i32]
+    L.mh_match_launches.argtypes = [vp, vp]
     L.mh_frame_counters.argtypes = [vp, vp]
     L.mh_frame_set_images.argtypes = [vp, vp, vp, i32]
     L.mh_filter_images.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f32, f32,
@@ -535,8 +536,15 @@ class Context:
         return out, dmax.value, spread.value
 
     def match_set_mode(self, mode: int):
-        """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible."""
+        """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible,
+        2 / 3 the exact VALU / f32 matrix-pipe kernel whatever the query count."""
         self._ck(self.L.mh_match_set_mode(self.h, int(mode)), "mh_match_set_mode")
+
+    def match_kernel_launches(self) -> dict:
+        """MATCH launch sequences of this context by the kernel that searched (mh_match_launches)."""
+        o = np.zeros(3, np.uint32)
+        self._ck(self.L.mh_match_launches(self.h, _ptr(o)), "mh_match_launches")
+        return {"valu": int(o[0]), "mfma": int(o[1]), "screen": int(o[2])}
 
     def match_stats(self, Q=0, reset=False) -> dict:
         """Two-stage MATCH statistics since the last reset + which path Q queries would take."""

@@ -116,7 +116,9 @@ int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* 
   int rc = ensure_match_scratch(ctx, Q);
   if (rc) return rc;
   const int qe = (q_expected > 0 && q_expected < Q) ? q_expected : Q;
-  if (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(qe, ctx->N, ctx->match_mode)) {
+  const int screen_mode = ctx->match_mode >= 2 ? 0 : ctx->match_mode;        // modes 2 / 3 pin one of the exact kernels
+  const int kernel_pin = ctx->match_mode >= 2 ? ctx->match_mode - 2 : -1;
+  if (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(qe, ctx->N, screen_mode)) {
     ctx->sbuf.ev = nullptr;
     if (ctx->timing && ctx->ev_made) {   // one event set per launch sequence, a ring of them (mh_match_timing)
       ctx->sbuf.ev = ctx->mev[ctx->mev_next];
@@ -128,9 +130,12 @@ int ctx_match(mh_ctx* ctx, const float* qn, const float* qnorm, int Q, int32_t* 
     ctx->sbuf.ev_out = ctx->lane_out;
     launch_match_screen(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->sdb, ctx->sbuf, idx1, d1,
                         d2, ctx->stream, q_count, q_expected);
-  } else
-    launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->match_scratch,
-                 ctx->match_pack, idx1, d1, d2, ctx->stream, q_count, q_expected);
+    ++ctx->match_launches[2];
+  } else {
+    const int k = launch_match(qn, qnorm, Q, ctx->db_desc, ctx->db_norm, ctx->N, ctx->rmap, ctx->match_scratch,
+                               ctx->match_pack, idx1, d1, d2, ctx->stream, q_count, q_expected, kernel_pin);
+    if (k >= 0) ++ctx->match_launches[k];
+  }
   return MH_OK;
 }
 
@@ -653,8 +658,14 @@ int mh_screen_values(mh_ctx* ctx, const float* q_host, int Q, int n_rows, float*
 }
 
 int mh_match_set_mode(mh_ctx* ctx, int mode) {
-  if (!ctx || mode < -1 || mode > 1) return MH_ERR_ARG;
+  if (!ctx || mode < -1 || mode > 3) return MH_ERR_ARG;
   ctx->match_mode = mode;
+  return MH_OK;
+}
+
+int mh_match_launches(mh_ctx* ctx, uint32_t out[3]) {
+  if (!ctx || !out) return MH_ERR_ARG;
+  for (int k = 0; k < 3; ++k) out[k] = ctx->match_launches[k];
   return MH_OK;
 }
 
@@ -666,7 +677,7 @@ int mh_match_stats(mh_ctx* ctx, int Q, uint32_t stats[4], int reset) {
   if (Q > 0) {
     int rc = ensure_match_scratch(ctx, Q);
     if (rc) return rc;
-    stats[3] = (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(Q, ctx->N, ctx->match_mode)) ? 1u : 0u;
+    stats[3] = (ctx->sdb.usable && ctx->sbuf.q_pad >= screen_q_pad(Q) && screen_wanted(Q, ctx->N, ctx->match_mode >= 2 ? 0 : ctx->match_mode)) ? 1u : 0u;
   }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->sbuf.stats) {

@@ -159,9 +159,12 @@ size_t match_scratch_elems(int Q, int N);
 // Local top-2 of Q queries vs N rows.
 // Floats of packed-query scratch launch_match needs for Q queries.
 size_t match_pack_floats(int Q);
-void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
-                  float* d2, hipStream_t s, const int32_t* q_count = nullptr, int q_expected = 0);
+// Returns the kernel that searched: 0 = match_kernel (VALU), 1 = match_mfma_kernel, -1 = none (no queries / no rows).
+int launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
+                 int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                 float* d2, hipStream_t s, const int32_t* q_count = nullptr, int q_expected = 0,
+                 int kernel_pin = -1);
+// kernel_pin: -1 = by query count, 0 = match_kernel (VALU), 1 = match_mfma_kernel (mh_match_set_mode 2 / 3).
 // q_count (optional): device-side query count; queries [min(Q, *q_count), Q) get "no neighbour"
 // (idx -1) without being searched.  q_expected: host estimate of it (sizes the DB splits).
 // shard k's arrays start k * shard_stride elements after the given pointers

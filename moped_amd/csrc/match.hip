@@ -457,9 +457,11 @@ void launch_match_mfma(const float* qn, const float* qnorm, int Q, const float* 
                        Top2* scratch, int S, const int32_t* q_count, hipStream_t s);
 // Which kernel searches: the matrix-pipe one when there are enough queries to fill its 256-query
 // blocks (measured cross-over between 600 and 3000 queries), the VALU one below that.  Both give the
-// same bits.  MH_MATCH_MFMA = 0 / 1 pins the choice (A/B runs).
-bool match_uses_mfma(int q_expected) {
+// same bits.  A context pins the choice with mh_match_set_mode 2 / 3 (kernel_pin 0 / 1); MH_MATCH_MFMA = 0 / 1 pins
+// it for a process of an experiment build (A/B runs).
+bool match_uses_mfma(int q_expected, int kernel_pin) {
   static const int pinned = exp_int("MH_MATCH_MFMA", -1);
+  if (kernel_pin >= 0) return kernel_pin != 0;
   return pinned >= 0 ? pinned != 0 : q_expected >= 1536;
 }
 
@@ -471,18 +473,18 @@ size_t match_scratch_elems(int Q, int N) {
 
 size_t match_pack_floats(int Q) { return (size_t)((Q + TQ - 1) / TQ) * TQ * (DIM + 1); }
 
-void launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
-                  int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
-                  float* d2, hipStream_t s, const int32_t* q_count, int q_expected) {
-  if (Q <= 0) return;
+int launch_match(const float* qn, const float* qnorm, int Q, const float* db, const float* dnorm,
+                 int N, const RowMap& rmap, Top2* scratch, float* pack, int32_t* idx1, float* d1,
+                 float* d2, hipStream_t s, const int32_t* q_count, int q_expected, int kernel_pin) {
+  if (Q <= 0) return -1;
   // the split count follows the number of queries expected (device-side counts: the caller's
   // estimate), the grid covers the capacity
-  if (N > 0 && match_uses_mfma(expected_queries(Q, q_expected))) {
+  if (N > 0 && match_uses_mfma(expected_queries(Q, q_expected), kernel_pin)) {
     const int Sm = mfma_splits_for(expected_queries(Q, q_expected), N);
     launch_match_mfma(qn, qnorm, Q, db, dnorm, N, scratch, Sm, q_count, s);
     hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, Sm, Q, q_count, idx1, d1,
                        d2, rmap);
-    return;
+    return 1;
   }
   const int S = (N > 0) ? splits_for(expected_queries(Q, q_expected), N) : 0;
   if (S > 0) {
@@ -503,6 +505,7 @@ void launch_match(const float* qn, const float* qnorm, int Q, const float* db, c
   }
   hipLaunchKernelGGL(combine_splits_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, scratch, S, Q,
                      q_count, idx1, d1, d2, rmap);
+  return S > 0 ? 0 : -1;
 }
 
 void launch_match_merge(const int32_t* idx1_s, const float* d1_s, const float* d2_s, int S, int Q,

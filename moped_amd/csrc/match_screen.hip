@@ -776,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void screen16_kernel(const ScreenArgs A) {
   };
   auto emit = [&](const v4f& d0, const v4f& d1, unsigned& nrec_word, int shift, int q, int row0, float top, float thr, int pos) {
     const int nrec = (int)((nrec_word >> shift) & 0xFFu);
-    if (nrec < A.sub_cap) {   // (sub_cap <= 48: the byte cannot wrap)
+    if (nrec < A.sub_cap) {   // (sub_cap <= SC_SLOTS_MAX / 4 = 64 < 256, static_assert at SB16_MAX: the byte cannot wrap)
       const unsigned dst = (unsigned)q * SC_SLOTS_MAX + (4 * split + quarter) * A.sub_cap + nrec;
       nrec_word += 1u << shift;
       if (pos < SC_RECBUF16) {
@@ -1393,6 +1393,8 @@ void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int b
   // launch takes ceil(workgroups / 256) rounds of n_tiles / Sb tiles each: the Sb with the least rounds x tiles, the
   // larger of equals.  (blocks_b > 0: an experiment's request, capped the same way.)
   constexpr int SB16_MAX = SC_SLOTS_MAX / 12;
+  // screen16_kernel counts a query's records per sub-list in one byte of n_rec[]; sub_cap <= SC_SLOTS_MAX / (4 * Sb)
+  static_assert(SC_SLOTS_MAX / 4 < 256, "a sub-list's record count must fit the byte screen16_kernel keeps it in");
   int Sb = 1;
   if (blocks_b > 0) {
     Sb = std::min(splits_for(n_tiles, blocks_b, SC_SLOTS_MAX / 4), SB16_MAX);

@@ -935,6 +935,21 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
                    const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
                    int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
                    int32_t* counts) {
+  return orc_frame_rest_inliers(q_uv, idx1, d1, d2, Q, ratio, model_of, db_xyz, n_models, K, cam, fp, n_threads,
+                                obj_model, obj_pose, obj_score, max_obj, counts, NULL, NULL, 0);
+}
+
+// The same frame, and with every final object its INLIER SET as the reference defines one
+// (testAllPoints, POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:166-180): the correspondences of the object's final
+// cluster (what FILTER2 left it, FILTER_PROJECTION_CPU.hpp:136-160) whose squared reprojection error under the
+// object's final pose is below the last POSE stage's ErrorThreshold.  inl_off [n_objects + 1], inl_q = query
+// indices (rows of q_uv), capacity inl_cap; both may be NULL.  This is the point set north_star's pose bar
+// ("within 1 px mean reprojection error of the reference pose over the reference's inlier set") is taken over.
+int orc_frame_rest_inliers(const float* q_uv, const int32_t* idx1, const float* d1, const float* d2, int Q,
+                           float ratio, const int32_t* model_of, const float* db_xyz, int n_models,
+                           const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
+                           int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
+                           int32_t* counts, int32_t* inl_off, int32_t* inl_q, int inl_cap) {
 #ifdef _OPENMP
   if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -1047,6 +1062,26 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
     obj_model[o] = objects[o].model;
     memcpy(obj_pose + 7 * (size_t)o, objects[o].pose, 28);
     obj_score[o] = scores[o];
+  }
+  if (inl_off && inl_q) {
+    // after a filter stage clusters[m] holds one cluster per kept object of model m, in list order
+    Camera c;
+    camera_init(c, K, cam);
+    const float thr = fp->run_stage2 ? fp->pose2.error_threshold : fp->pose1.error_threshold;
+    std::vector<int> seen(n_models, 0);
+    int w = 0;
+    for (int o = 0; o < n_out; o++) {
+      inl_off[o] = w;
+      const int m = objects[o].model;
+      if (!fp->run_stage2 || seen[m] >= (int)clusters[m].size()) continue;  // (no per-object clusters without a filter stage)
+      const std::vector<int>& cl = clusters[m][seen[m]++];
+      for (size_t i = 0; i < cl.size(); i++) {
+        const int g = model_off[m] + cl[i];
+        if (test_all_points(objects[o].pose, &uv[2 * (size_t)g], &xyz[3 * (size_t)g], 1, c, thr, NULL) && w < inl_cap)
+          inl_q[w++] = out_q[g];
+      }
+    }
+    inl_off[n_out] = w;
   }
   return (int)objects.size();
 }

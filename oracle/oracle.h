@@ -165,6 +165,13 @@ int orc_frame_rest(const float* q_uv, const int32_t* idx1, const float* d1, cons
                    const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
                    int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
                    int32_t* counts);
+/* orc_frame_rest + every final object's inlier set (testAllPoints of its final pose over its final cluster,
+ * POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:166-180): inl_off [n_objects + 1], inl_q = rows of q_uv. */
+int orc_frame_rest_inliers(const float* q_uv, const int32_t* idx1, const float* d1, const float* d2, int Q,
+                           float ratio, const int32_t* model_of, const float* db_xyz, int n_models,
+                           const float K[4], const float cam[7], const orc_frame_params* fp, int n_threads,
+                           int32_t* obj_model, float* obj_pose, float* obj_score, int max_obj,
+                           int32_t* counts, int32_t* inl_off, int32_t* inl_q, int inl_cap);
 
 /* ---- frames with several images (cameras): every feature / match / correspondence carries its image.
  * Ks [n_images][4], cam_poses [n_images][7]; with one image these are the functions above. ---- */

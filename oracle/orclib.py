@@ -85,6 +85,8 @@ def lib():
                                      _f32p, _f32p, C.POINTER(FrameParams), C.c_int, _i32p, _f32p, _f32p,
                                      C.c_int, _i32p]
         L.orc_frame_rest.restype = C.c_int
+        L.orc_frame_rest_inliers.argtypes = L.orc_frame_rest.argtypes + [_i32p, _i32p, C.c_int]
+        L.orc_frame_rest_inliers.restype = C.c_int
         L.srand = C.CDLL(None).srand
         _lib = L
     return _lib
@@ -376,6 +378,31 @@ def frame_rest(q_uv, idx1, d1, d2, model_of, db_xyz, n_models, K, cam, params=No
                              om, op, osc, max_obj, counts)
     n = min(n, max_obj)
     return om[:n].copy(), op[:7 * n].reshape(n, 7).copy(), osc[:n].copy(), counts
+
+
+def frame_rest_inliers(q_uv, idx1, d1, d2, model_of, db_xyz, n_models, K, cam, params=None, n_threads=1,
+                       seed=None, max_obj=4096):
+    """frame_rest + the inlier set of every final object: (models, poses, scores, counts, inliers) with inliers[o] =
+    rows of q_uv (testAllPoints of the object's final pose over its final cluster at the last POSE stage's
+    ErrorThreshold, POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:166-180)."""
+    if seed is not None:
+        lib().srand(C.c_uint(seed))
+    fp = params or default_frame_params()
+    om = np.zeros(max_obj, np.int32)
+    op = np.zeros(max_obj * 7, np.float32)
+    osc = np.zeros(max_obj, np.float32)
+    counts = np.zeros(4, np.int32)
+    q_uv = _c(q_uv, np.float32)
+    Q = q_uv.shape[0]
+    off = np.zeros(max_obj + 1, np.int32)
+    inl = np.zeros(max(Q, 1), np.int32)    # every correspondence belongs to at most one final cluster
+    n = lib().orc_frame_rest_inliers(q_uv.reshape(-1), _c(idx1, np.int32), _c(d1, np.float32), _c(d2, np.float32),
+                                     Q, fp.ratio, _c(model_of, np.int32), _c(db_xyz, np.float32).reshape(-1),
+                                     n_models, _c(K, np.float32), _c(cam, np.float32), C.byref(fp), n_threads,
+                                     om, op, osc, max_obj, counts, off, inl, inl.shape[0])
+    n = min(n, max_obj)
+    return (om[:n].copy(), op[:7 * n].reshape(n, 7).copy(), osc[:n].copy(), counts,
+            [inl[off[o]:off[o + 1]].copy() for o in range(n)])
 
 
 # ---- the reference's own libraries (only where oracle/_ref was built) ----------

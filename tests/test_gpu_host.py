@@ -39,11 +39,16 @@ def test_step_plugins_through_pipeline(tmp_path):
             counts = (int(w[1]), int(w[3]))
     dbn, qn = orclib.normalize(db.desc), orclib.normalize(fr.desc)
     idx, d1, d2 = orclib.match_2nn(dbn, qn)
-    om, op, osc, oc = orclib.frame_rest(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=2, seed=1)
+    om, op, osc, oc, oinl = orclib.frame_rest_inliers(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=2, seed=1)
     assert counts == (int(oc[0]), int(oc[1]))          # matches and clusters: index-exact stages
     assert sorted(m for m, _, _ in objs) == sorted(om.tolist())
     for m, pose, score in objs:
         j = list(om).index(m)
+        # the pose bar over the oracle's inlier set (north_star), then over the planted points
+        inl = oinl[j]
+        ei_g = np.sqrt(((orclib.project(pose, db.xyz[idx[inl]], K, CAM0) - fr.uv[inl]) ** 2).sum(1)).mean()
+        ei_o = np.sqrt(((orclib.project(op[j], db.xyz[idx[inl]], K, CAM0) - fr.uv[inl]) ** 2).sum(1)).mean()
+        assert len(inl) >= 7 and ei_g <= ei_o + 1.0
         rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
         rows = rows[db.model_of[fr.src_point[rows]] == m]
         xyz, uv = db.xyz[fr.src_point[rows]], fr.uv[rows]

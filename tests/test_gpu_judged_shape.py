@@ -17,12 +17,22 @@ K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
 Q = 3000
 
 
-@pytest.fixture(scope="module", params=[16, 8], ids=["16 frames per launch (the bench's default)", "8 frames per launch"])
+N_VIS = {
+    "16": (2, 2, 5, 1, 2, 3, 0, 2, 4, 2, 0, 1, 2, 2, 3, 2),
+    "8": (2, 2, 5, 1, 2, 3, 0, 2),
+    # SURVEY 8(d)'s n_vis in {2, 5, 10}: the bench's n_vis_5 / n_vis_10 lines run this launch shape with 80-160 objects
+    # in a batch (every frame's tasks over one row of POSE workgroups, the arenas of ten visible models)
+    "16 busy": (10, 5, 7, 2, 10, 8, 3, 5, 10, 6, 0, 9, 5, 10, 4, 7),
+}
+
+
+@pytest.fixture(scope="module", params=["16", "8", "16 busy"],
+                ids=["16 frames per launch (the bench's default)", "8 frames per launch", "16 frames, up to 10 objects each"])
 def world(request):
     import torch
     db = synth.make_db(20, 5000)
     dbn = orclib.normalize(db.desc)
-    n_vis = (2, 2, 5, 1, 2, 3, 0, 2, 4, 2, 0, 1, 2, 2, 3, 2)[:request.param]
+    n_vis = N_VIS[request.param]
     frs = [synth.make_frame(db, n_vis=n, seed=200 + i, Q=Q) for i, n in enumerate(n_vis)]
     yield db, dbn, frs, torch
 
@@ -61,6 +71,7 @@ def test_frames_of_one_launch_sequence_equal_the_frames_alone_and_the_oracles_ma
             mq, mm = c.frame_fetch_matches_slot(f)
             assert np.array_equal(mq, alone_matches[f][0]) and np.array_equal(mm, alone_matches[f][1])
     assert sum(len(a[0]) for a in alone) >= 12
+    assert [len(a[0]) for a in alone] == [fr.visible.size for fr in frs]   # every planted object, nothing else
     # the accepted match lists of all frames against the oracle's exact search + ratio test
     for f, fr in enumerate(frs):
         qn = orclib.normalize(fr.desc)

@@ -1,39 +1,20 @@
-"""The two match kernels against each other and against the oracle on the SAME input: the VALU kernel
-(`match_kernel`, below 1536 queries by default) and the matrix-pipe kernel (`match_mfma_kernel`) must
-give the same bits -- indices, d1, d2 -- whatever the query count.  The choice is read once per process
-(`MH_MATCH_MFMA`), so each kernel runs in a child process of its own (one at a time) and writes its
-results to a file; the parent compares them bit for bit and checks a sample against the oracle."""
-import os
-import subprocess
-import sys
-
+"""The two exact match kernels against each other and against the oracle on the SAME input: the VALU kernel
+(`match_kernel`, below 1536 queries by default) and the f32 matrix-pipe kernel (`match_mfma_kernel`) must give the
+same bits -- indices, d1, d2 -- whatever the query count.  Each is pinned per context through the C ABI
+(mh_match_set_mode 2 = VALU, 3 = matrix pipe; the process-wide MH_MATCH_MFMA switch only exists in experiment builds),
+and the launch counters of the library say which kernel actually ran."""
 import numpy as np
 import pytest
 
 import orclib
-from moped_amd import synth
+from moped_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1])
-from moped_amd import capi
-z = np.load(sys.argv[2])
-c = capi.Context(0)
-c.db_upload(z["dbn"], z["model_of"], z["xyz"], int(z["n_models"]))
-out = {}
-for name in ("q_small", "q_ragged", "q_big"):
-    acc, raw, d1, d2 = c.match(z[name], ratio=0.8)
-    out[name + "_acc"], out[name + "_raw"], out[name + "_d1"], out[name + "_d2"] = acc, raw, d1, d2
-np.savez(sys.argv[3], **out)
-c.close()
-"""
+MODES = {"0": 2, "1": 3}     # "0" = VALU kernel, "1" = matrix-pipe kernel
 
 
 @pytest.fixture(scope="module")
-def problem(tmp_path_factory):
+def problem():
     db = synth.make_db(6, 3000)                      # 18000 rows: 141 tiles, not a multiple of any split count
     fr = synth.make_frame(db, n_vis=2, seed=5, Q=2600)
     dbn = orclib.normalize(db.desc)
@@ -41,19 +22,24 @@ def problem(tmp_path_factory):
     dbn[9000] = dbn[3]
     q = orclib.normalize(fr.desc)                    # mh_match takes normalised queries (A1 is its own entry point)
     q[11] = dbn[3]                                   # a query that IS a database row (distance 0 after the clamp)
-    d = tmp_path_factory.mktemp("mk")
-    inp = os.path.join(d, "in.npz")
-    np.savez(inp, dbn=dbn, model_of=db.model_of, xyz=db.xyz, n_models=db.n_models,
-             q_small=q[:70], q_ragged=q[:1537], q_big=q)
+    qs = {"q_small": q[:70], "q_ragged": q[:1537], "q_big": q}
     outs = {}
-    for flag in ("0", "1"):
-        out = os.path.join(d, f"out{flag}.npz")
-        env = dict(os.environ, MH_MATCH_MFMA=flag)
-        r = subprocess.run([sys.executable, "-c", CHILD, ROOT, inp, out], env=env, capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[flag] = dict(np.load(out))
-    return dbn, {"q_small": q[:70], "q_ragged": q[:1537], "q_big": q}, outs
+    for flag, mode in MODES.items():
+        c = capi.Context(0)
+        c.db_upload(dbn, db.model_of, db.xyz, db.n_models)
+        c.match_set_mode(mode)
+        out = {}
+        for name, qq in qs.items():
+            before = c.match_kernel_launches()
+            acc, raw, d1, d2 = c.match(qq, ratio=0.8)
+            after = c.match_kernel_launches()
+            # the pinned kernel ran, the other one and the two-stage path did not
+            ran = {k: after[k] - before[k] for k in after}
+            assert ran["valu" if mode == 2 else "mfma"] == 1 and ran["mfma" if mode == 2 else "valu"] == 0 and ran["screen"] == 0, (flag, name, ran)
+            out[name + "_acc"], out[name + "_raw"], out[name + "_d1"], out[name + "_d2"] = acc, raw, d1, d2
+        outs[flag] = out
+        c.close()
+    return dbn, qs, outs
 
 
 @pytest.mark.parametrize("name", ["q_small", "q_ragged", "q_big"])

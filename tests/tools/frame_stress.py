@@ -51,19 +51,22 @@ while done < scenes:
         objs, counts = pipe.fetch(0)
         qn = orclib.normalize(fr.desc)
         idx, d1, d2 = orclib.match_2nn(dbn, qn)
-        om, op, osc, oc = orclib.frame_rest(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed)
+        om, op, osc, oc, oinl = orclib.frame_rest_inliers(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed)
         why = []
         if counts[0] != oc[0]: why.append(f"matches {counts[0]} vs {oc[0]}")
         if counts[1] != oc[1]: why.append(f"clusters {counts[1]} vs {oc[1]}")
         # objects: RANSAC is randomised on both sides (the oracle keeps the reference's 5-point LM starts, the device
         # samples P3P hypotheses) -- compared where the planted objects are unambiguous (>= 40 points), and a
         # difference only counts when the oracle does not show the same outcome under another seed of its own
-        def objects_differ(om, op, osc):
+        def objects_differ(om, op, osc, oinl):
             w = []
             if sorted(objs["model"].tolist()) != sorted(om.tolist()):
                 return [f"models {sorted(objs['model'].tolist())} vs {sorted(om.tolist())}"]
-            for m, p, sc in zip(om, op, osc):
+            for m, p, sc, inl in zip(om, op, osc, oinl):
                 g = objs[objs["model"] == m][0]
+                if len(inl) >= 7:   # the bar over the oracle's own inlier set
+                    ei = lambda pose: float(np.sqrt(((orclib.project(pose, db.xyz[idx[inl]], K, CAM0) - fr.uv[inl]) ** 2).sum(1)).mean())
+                    if ei(g["pose"]) > ei(p) + 1.0: w.append(f"model {m}: pose {ei(g['pose']):.2f} px vs oracle {ei(p):.2f} over the oracle's inliers")
                 rows = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
                 rows = rows[db.model_of[fr.src_point[rows]] == m]
                 if len(rows) < 8: continue
@@ -73,11 +76,11 @@ while done < scenes:
                 if abs(g["score"] - sc) > 0.05 * sc + 1e-3: w.append(f"model {m}: score {g['score']:.3f} vs {sc:.3f}")
             return w
         if pts >= 40:
-            w = objects_differ(om, op, osc)
+            w = objects_differ(om, op, osc, oinl)
             if w:
                 for alt in (1, 2, 3, 4, 5):   # the oracle's own spread
-                    om2, op2, osc2, _ = orclib.frame_rest(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed + 7919 * alt)
-                    if not objects_differ(om2, op2, osc2):
+                    om2, op2, osc2, _, oinl2 = orclib.frame_rest_inliers(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0, n_threads=8, seed=seed + 7919 * alt)
+                    if not objects_differ(om2, op2, osc2, oinl2):
                         print(f"note scene {done}: " + "; ".join(w) + f" -- the oracle gives the device's outcome with seed + {7919 * alt}", flush=True)
                         w = []
                         spread += 1
