@@ -50,7 +50,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "liboracle.so")
+        # ORC_LIB_PATH: another build of the same sources (`make -C oracle asan`: liboracle_asan.so under LD_PRELOAD=libasan)
+        path = os.environ.get("ORC_LIB_PATH") or os.path.join(HERE, "liboracle.so")
         if not os.path.exists(path):
             build_oracle()
         L = C.CDLL(path)
