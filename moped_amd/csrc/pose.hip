@@ -546,14 +546,60 @@ __device__ bool solve6(const float* Hp, const float* g, float mu, float* x) {
   return true;
 }
 
+#ifdef POSE_PROF   // phase timing build (make EXTRA=-DPOSE_PROF): cycles of thread 0 per phase, summed over tasks;
+__device__ unsigned long long g_pose_prof[32];   // [6] = LM iterations (accepted or not) over all refines;
+// inside an iteration: [8] Jacobian pass, [9] the 27 wave sums, [10] solve + pose update, [11] cost of the new pose,
+// [12] attempts, [13] the cost before the first iteration; [16 + 4 * phase + e] = refines of that phase that ended by
+// e = 0 iteration cap, 1 eight rejections, 2 converged (or nothing promised), 3 zero gradient; [24 + phase] iterations, [26 + phase] attempts
+#define LP_T(k) do { if (lane == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_pose_prof[k], now_ - t_lm); t_lm = now_; } } while (0)
+#define LP_N(k) do { if (lane == 0) atomicAdd(&g_pose_prof[k], 1ull); } while (0)
+#else
+#define LP_T(k) do { } while (0)
+#define LP_N(k) do { } while (0)
+#endif
+
 // Runs on one full wavefront; pose in/out is wave-uniform.
 template <int KIND>
 __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* pts, const int* list,
                            int n, float alpha, int phase, int iters, int lane) {
   constexpr int PS = PointStride<KIND>::value;
+#ifdef POSE_PROF
+  unsigned long long t_lm = clock64();
+#endif
   float cost = lm_cost<KIND>(R, t, cams, pts, list, n, alpha, phase, lane);
+  LP_T(13);
   float mu = -1.f, nu = 2.f;
+  // Phase 1's residuals are squares, r = d^2 (KIND 0 / 3: d = du, dv): the Hessian of sum r^2 = sum d^4 is
+  // 12 d^2 grad d grad d^T, Gauss-Newton's 2 J^T J (J = 2 d grad d) is 8 d^2 grad d grad d^T -- two thirds of it, so every
+  // Gauss-Newton step overshoots by half and the iteration converges linearly (error x -1/2 per step: 7.8 iterations
+  // per refine measured, a third of them ending in eight rejected attempts).  With J^T J scaled by 3/2 the step is
+  // Newton's for these residuals: same minimiser, quadratic convergence.  (The depth classes' phase-1 rows are sums of
+  // squares of several terms; they keep Gauss-Newton.)
+#ifndef LM_HS
+#define LM_HS 1.5f
+#endif
+#ifndef LM_TOL0
+#define LM_TOL0 1e-4f
+#endif
+#ifndef LM_TOL1
+#define LM_TOL1 1e-5f
+#endif
+#ifndef LM_STOP
+#define LM_STOP 1
+#endif
+#ifndef DRAW_MULHI
+#define DRAW_MULHI 1
+#endif
+  const float hs = (phase == 1 && (KIND == 0 || KIND == 3)) ? LM_HS : 1.f;
+  // Phase 0 only hands phase 1 a start: it stops at a relative gain of 1e-4 per step (1e-6 cost two more iterations per
+  // refine and moved phase 1's end state by nothing); phase 1 at 1e-5, the resolution of its cost (below)
+  const float tol = phase == 0 ? LM_TOL0 : LM_TOL1;
   for (int it = 0; it < iters; ++it) {
+#ifdef POSE_PROF
+    if (lane == 0) atomicAdd(&g_pose_prof[6], 1ull);
+    LP_N(24 + phase);
+    t_lm = clock64();
+#endif
     Accum acc;
     for (int i = 0; i < 21; ++i) acc.H[i] = 0.f;
     for (int i = 0; i < 6; ++i) acc.g[i] = 0.f;
@@ -569,8 +615,10 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
         }
       }
     }
-    for (int i = 0; i < 21; ++i) acc.H[i] = wave_sum(acc.H[i]);
+    LP_T(8);
+    for (int i = 0; i < 21; ++i) acc.H[i] = hs * wave_sum(acc.H[i]);
     for (int i = 0; i < 6; ++i) acc.g[i] = wave_sum(acc.g[i]);
+    LP_T(9);
     if (mu < 0.f) {  // tau * max diagonal (lm_core.c:672-676)
       float mx = 0.f;
       const int di[6] = {0, 6, 11, 15, 18, 20};
@@ -579,15 +627,22 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
     }
     float ginf = 0.f;
     for (int i = 0; i < 6; ++i) ginf = fmaxf(ginf, fabsf(acc.g[i]));
-    if (!(ginf > 0.f)) break;
+    if (!(ginf > 0.f)) { LP_N(16 + 4 * phase + 3); return cost; }
     bool accepted = false, converged = false;
     for (int attempt = 0; attempt < 8 && !accepted; ++attempt) {
       float dx[6];
+#ifdef POSE_PROF
+      if (lane == 0) atomicAdd(&g_pose_prof[12], 1ull);
+      LP_N(26 + phase);
+      t_lm = clock64();
+#endif
       if (solve6(acc.H, acc.g, mu, dx)) {
         float Rn[9], tn[3];
         rotate_left(dx, R, Rn);
         for (int i = 0; i < 3; ++i) tn[i] = t[i] + dx[3 + i];
+        LP_T(10);
         const float c2 = lm_cost<KIND>(Rn, tn, cams, pts, list, n, alpha, phase, lane);
+        LP_T(11);
         float dL = 0.f;
         for (int i = 0; i < 6; ++i) dL += dx[i] * (mu * dx[i] - acc.g[i]);
         const float dF = cost - c2;
@@ -598,7 +653,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
           // the iteration started with says so: one that needed rejections first is short because mu grew, not
           // because the minimum is near (tests/tools/frame_stress.py: two objects in 600 frames stopped 1 degree short
           // of the optimum in a narrow valley, FILTER2 score 10-15% under the oracle's)
-          converged = attempt == 0 && dF <= 1e-6f * cost;
+          converged = attempt == 0 && dF <= tol * cost;
           cost = c2;
           float tt = 2.f * dF / dL - 1.f;
           tt = 1.f - tt * tt * tt;
@@ -607,17 +662,25 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
           accepted = true;
           break;
         }
+        // At the minimum, at fp32 resolution: the rejected step promised nothing (predicted gain below 1e-6 of the
+        // cost; the cost itself is only known to ~1e-5: a pixel error of 0.3 at u ~ 300 carries 1e-4 of rounding).
+        // Heavier damping only shortens the step and its promise: the further attempts the loop used to make here
+        // -- a solve, a pose update and a pass over the points each, all rejected -- were two thirds of a refine's time
+        // (POSE_PROF: 2.0 attempts per iteration on average, the last iteration of most refines nothing but eight
+        // rejections).  A rejected step that did promise a gain (the model is off, not exhausted) goes on as before.
+        if (LM_STOP && dL <= 1e-6f * cost) { converged = true; break; }
       }
       mu *= nu;
       nu *= 2.f;
     }
-    if (!accepted || converged) break;
+    if (converged) { LP_N(16 + 4 * phase + 2); return cost; }
+    if (!accepted) { LP_N(16 + 4 * phase + 1); return cost; }
   }
+  LP_N(16 + 4 * phase + 0);
   return cost;
 }
 
-#ifdef POSE_PROF   // phase timing build (make EXTRA=-DPOSE_PROF): cycles of thread 0 per phase, summed over tasks
-__device__ unsigned long long g_pose_prof[8];
+#ifdef POSE_PROF
 #define PP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_pose_prof[k], now_ - t_prof); t_prof = now_; } } while (0)
 #else
 #define PP_T(k) do { } while (0)
@@ -774,19 +837,22 @@ __device__ void pose_task(
       if (KIND == 3 && __float_as_int(L.pts[PS * a + 5]) != __float_as_int(L.pts[PS * b + 5])) return true;
       return L.pts[PS * a] == L.pts[PS * b] && L.pts[PS * a + 1] == L.pts[PS * b + 1];
     };
-    i0 = (int)(splitmix64(st) % (uint64_t)k);
+    // uniform in [0, k): the high word of (upper 32 random bits) x k -- one v_mul_hi_u32 (a 64-bit `% k` by a runtime k is
+    // a ~100-instruction sequence, four to seven times per hypothesis)
+    auto draw = [&](uint64_t& s_) { return DRAW_MULHI ? (int)(((splitmix64(s_) >> 32) * (uint64_t)(unsigned)k) >> 32) : (int)(splitmix64(s_) % (uint64_t)k); };
+    i0 = draw(st);
     for (int tries = 0; tries < 16 && i1 < 0; ++tries) {
-      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      const int c = draw(st);
       if (!same_uv(c, i0)) i1 = c;
     }
     if (i1 < 0) return;
     for (int tries = 0; tries < 16 && i2 < 0; ++tries) {
-      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      const int c = draw(st);
       if (!same_uv(c, i0) && !same_uv(c, i1)) i2 = c;
     }
     if (i2 < 0) return;
     for (int tries = 0; tries < 16 && i3 < 0; ++tries) {
-      const int c = (int)(splitmix64(st) % (uint64_t)k);
+      const int c = draw(st);
       if (!same_uv(c, i0) && !same_uv(c, i1) && !same_uv(c, i2)) i3 = c;
     }
     if (i3 < 0) return;
@@ -874,7 +940,15 @@ __device__ void pose_task(
     }
   }
   const int best_cnt = (int)(gkey >> 32);
-  if (best_cnt <= prm.min_n_pts_object) return;  // needs MORE than MinNPtsObject inliers (:204)
+  // needs MORE than MinNPtsObject inliers (:204).  A winner that falls short by one or two is not given up yet: the
+  // reference's hypothesis is a least-squares fit of n_pts_align (5) points, a P3P pose of three noisy points is a
+  // cruder judge of a small cluster -- with 7 inliers among 9 points, all 7 required, no triple's pose may reach every
+  // one of them (tests/tools/frame_stress.py scene 241: the oracle finds the object with every seed, the P3P stage with
+  // none of 6 x 4 x 1024 hypotheses).  Such a near miss gets the local optimisation the reference's hypothesis has built
+  // in: a plain-residual refine on the inliers it has (at least n_pts_align of them), then the count again.
+  const bool near_miss = best_cnt <= prm.min_n_pts_object && best_cnt >= prm.n_pts_align && best_cnt >= 5 &&
+                         best_cnt + 2 > prm.min_n_pts_object;
+  if (best_cnt <= prm.min_n_pts_object && !near_miss) return;
   if (best_key == gkey) {                        // unique: the key embeds the hypothesis id
     for (int i = 0; i < 9; ++i) L.best_pose[i] = best_pose.r[i];
     for (int i = 0; i < 3; ++i) L.best_pose[9 + i] = best_pose.t[i];
@@ -915,6 +989,11 @@ __device__ void pose_task(
   PP_T(3);
   const bool repass = prm.lm_iters_l2 >= 0;   // (launch_pose: MH_POSE_REPASS=0 hands the cap over negated = one pass, for A/B runs)
   const int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
+  if (near_miss) {
+    lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2 > 0 ? iters_l2 : 10, lane);
+    n_inl = collect(same);
+    if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
+  }
   lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2, lane);
   PP_T(4);
   float err = lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
@@ -1081,10 +1160,10 @@ __global__ void project_test_kernel(const float* __restrict__ pose7, const mh_co
 }  // namespace
 
 #ifdef POSE_PROF
-extern "C" int mh_debug_pose_prof(unsigned long long out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int mh_debug_pose_prof(unsigned long long out[32], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[8] = {};
+    unsigned long long z[32] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_pose_prof), z, sizeof z) != hipSuccess) return -1;
   }
   return 0;
