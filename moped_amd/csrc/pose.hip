@@ -681,7 +681,9 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
 }
 
 #ifdef POSE_PROF
-#define PP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_pose_prof[k], now_ - t_prof); t_prof = now_; } } while (0)
+// (kept in registers and added to the totals only by a task that runs to the end of its refine: the totals then describe the
+// tasks on the critical path of a launch, [7] counts them, [14] counts all tasks, [15] the cycles of those that ended early)
+#define PP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); pp_loc[k] += now_ - t_prof; t_prof = now_; } } while (0)
 #else
 #define PP_T(k) do { } while (0)
 #endif
@@ -739,7 +741,13 @@ __device__ void pose_task(
   }
 #ifdef POSE_PROF
   unsigned long long t_prof = clock64();
-  if (threadIdx.x == 0) atomicAdd(&g_pose_prof[7], 1ull);
+  unsigned long long pp_loc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long t_task0 = t_prof;
+  if (threadIdx.x == 0) atomicAdd(&g_pose_prof[14], 1ull);
+  struct PpEnd {   // a task that leaves early: its cycles into [15]
+    unsigned long long t0; bool done = false;
+    __device__ ~PpEnd() { if (threadIdx.x == 0 && !done) atomicAdd(&g_pose_prof[15], clock64() - t0); }
+  } pp_end{t_task0};
 #endif
   int k = cl_count[cluster];
   const int begin = cl_begin[cluster];
@@ -812,7 +820,14 @@ __device__ void pose_task(
   // ---- hypotheses: one per lane ------------------------------------------------------
   // n_hypotheses < 0: that many, all of them (no adaptive stop after the first 256)
   const bool always_all = prm.n_hypotheses < 0;
-  const int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : (always_all ? -prm.n_hypotheses : 1024);
+  int H = prm.n_hypotheses > 0 ? prm.n_hypotheses : (always_all ? -prm.n_hypotheses : 1024);
+  // A small cluster has fewer distinct samples than that: C(k, 3) triples x (k - 3) points to pick the root with -- 140
+  // for the 7 points mean shift's MinPts lets through, 280, 504, 840 for 8, 9, 10.  Those are ENUMERATED, every one
+  // once, instead of H random draws with repetitions: nothing a random draw could find is missed, and the clusters of
+  // clutter -- which never settle and so ran all 1024 -- take one to four rounds of 256 instead of four.
+  const int n_enum = (k >= 4 && k <= 10) ? k * (k - 1) * (k - 2) / 6 * (k - 3) : 0;
+  const bool enumerate = n_enum > 0 && n_enum <= H;
+  if (enumerate) H = n_enum;
   unsigned long long best_key = 0ull;  // (inliers << 32) | ~hypothesis id
   Pose34 best_pose;
   // The random stream of a task is keyed by (model id, number of the cluster among its model's
@@ -840,6 +855,31 @@ __device__ void pose_task(
     // uniform in [0, k): the high word of (upper 32 random bits) x k -- one v_mul_hi_u32 (a 64-bit `% k` by a runtime k is
     // a ~100-instruction sequence, four to seven times per hypothesis)
     auto draw = [&](uint64_t& s_) { return DRAW_MULHI ? (int)(((splitmix64(s_) >> 32) * (uint64_t)(unsigned)k) >> 32) : (int)(splitmix64(s_) % (uint64_t)k); };
+    if (enumerate) {
+      // h = triple * (k - 3) + f: the triple by its rank among the C(k, 3) in lexicographic order, the fourth point the
+      // f-th of the others
+      int tr = h / (k - 3);
+      const int f = h - tr * (k - 3);
+      int a = 0;
+      for (; a < k - 2; ++a) {
+        const int c = (k - 1 - a) * (k - 2 - a) / 2;   // triples that start at a
+        if (tr < c) break;
+        tr -= c;
+      }
+      int b = a + 1;
+      for (; b < k - 1; ++b) {
+        const int c = k - 1 - b;                       // triples (a, b, *)
+        if (tr < c) break;
+        tr -= c;
+      }
+      const int c3 = b + 1 + tr;
+      int d = f;                                       // the f-th index outside {a, b, c3}
+      if (d >= a) ++d;
+      if (d >= b) ++d;
+      if (d >= c3) ++d;
+      if (same_uv(a, b) || same_uv(a, c3) || same_uv(b, c3) || same_uv(d, a) || same_uv(d, b) || same_uv(d, c3)) return;
+      i0 = a; i1 = b; i2 = c3; i3 = d;
+    } else {
     i0 = draw(st);
     for (int tries = 0; tries < 16 && i1 < 0; ++tries) {
       const int c = draw(st);
@@ -856,6 +896,7 @@ __device__ void pose_task(
       if (!same_uv(c, i0) && !same_uv(c, i1) && !same_uv(c, i2)) i3 = c;
     }
     if (i3 < 0) return;
+    }
     double X[3][3], y[3][3];
     const DevCam& cam = cam_of<KIND>(cams, L.pts + PS * i0);   // the sample's camera
     auto load = [&](int s, int pi) {
@@ -1014,6 +1055,13 @@ __device__ void pose_task(
     }
   }
   PP_T(5);
+#ifdef POSE_PROF
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_pose_prof[i], pp_loc[i]);
+    atomicAdd(&g_pose_prof[7], 1ull);
+    pp_end.done = true;
+  }
+#endif
   if (lane == 0) {
     float q[4];
     rot_to_quat(R, q);
@@ -1195,6 +1243,8 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
     std::memset(&now, 0, sizeof now);   // (padding bytes compare equal)
     now.fb = *fuse->fb;
     now.tail = *fuse->tail;
+    now.tail.grid = 0;   // (the stand-alone FILTER launch's grid: follows the launches' feedback from frame to frame, unused here --
+                         //  left in, it made every frame's arguments "new" and cost two one-wavefront launches per frame)
     now.feature_distance = fuse->feature_distance;
     now.min_score = fuse->min_score;
     now.min_points = fuse->min_points;

@@ -15,7 +15,7 @@ for rep in range(3):
     pipe.enqueue(0, q.clone(), uv, seed=rep + 1); pipe.fetch(0); L.mh_debug_pose_prof(out, 1)
 names = ["load+distinct", "hypotheses", "argmax", "inlier list", "LM plain", "LM squared", "-", "tasks"]
 n = max(out[7], 1)
-print(f"tasks {out[7]} (POSE + POSE2); cycles per task: " + "  ".join(f"{nm}={v // n}" for nm, v in zip(names[:6], out))
+print(f"tasks {out[14]} (POSE + POSE2), {out[7]} of them refined an object, the others took {out[15] // max(out[14] - out[7], 1)} cycles each; cycles per refined task: " + "  ".join(f"{nm}={v // n}" for nm, v in zip(names[:6], out))
       + f"  LM iterations per task={out[6] / n:.1f}")
 it = max(out[6], 1)
 print(f"per LM iteration: Jacobian pass={out[8] // it}  27 wave sums={out[9] // it}  attempts={out[12] / it:.2f}  "
