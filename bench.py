@@ -293,7 +293,9 @@ def default_batch(args, sharded: bool) -> int:
     # instead of two rounds of 38 for eight frames -- fewer prologues and a fuller last query block per frame: +2.7% on
     # config 1, +1.6% on config 2); a batch of plain frames also shares the launches of its rest chain (one group /
     # CLUSTER / POSE / POSE2 launch for all of them).  Frames with depth maps go frame after frame: four
-    return 16 if not (args.depth_kind or args.moped3d_frontend) else 4
+    # (round 4: frames with depth ATTRIBUTES share their launches like plain frames -- sixteen; frames that bring the depth
+    # map itself and run moped3d's front end on it still go frame after frame: four)
+    return 4 if args.moped3d_frontend else 16
 
 
 class Job:

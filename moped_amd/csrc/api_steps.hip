@@ -534,10 +534,13 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
 // The frames of a batch can share their launches when nothing of the frame is per-context state: no depth
 // attributes / map / rules (one map per context), one image, the fused FILTER tails (the stand-alone FILTER and
 // result-packing kernels are per frame), no stage timing, no graph replay.  MH_MERGE_BATCH=0: frame after frame.
-bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm) {
+// Per-query depth ATTRIBUTES (mh_frame_set_depth: B Q entries, frame after frame like the queries) travel with a merged
+// batch where the caller says so (`attrs_ok`: mh_frame_enqueue_batch) -- group_kernel takes frame f's slice, the per-frame
+// arenas hold every frame's m_depth, pose_kernel<1 | 2> shifts its pointers like pose_kernel<0>.
+bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm, bool attrs_ok = false) {
   static const bool on = exp_int("MH_MERGE_BATCH", 1) != 0;
   static const bool fuse_filter = exp_int("MH_FUSE_FILTER", 1) != 0;
-  return on && fuse_filter && prm->run_stage2 && !ctx->timing && !ctx->q_depth && !ctx->depth_img.img &&
+  return on && fuse_filter && prm->run_stage2 && !ctx->timing && (attrs_ok || !ctx->q_depth) && !ctx->depth_img.img &&
          !ctx->rules.on && !ctx->linkage_on && !(ctx->q_img && ctx->n_images > 1);
 }
 
@@ -1485,14 +1488,15 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  int rc = prepare_frame(ctx, B * Q, Q, B > 1 && merged_batch_ok(ctx, prm) ? B : 1);   // (the arenas before any work is enqueued)
+  const bool merge = B > 1 && merged_batch_ok(ctx, prm, true);
+  int rc = prepare_frame(ctx, B * Q, Q, merge ? B : 1);   // (the arenas before any work is enqueued)
   if (rc) return rc;
   ctx->feat_count_dev = nullptr;
   stamp(ctx, 0);
   launch_normalize(q_desc_dev, ctx->q_norm, B * Q, ctx->stream);
   if ((rc = ctx_match(ctx, q_desc_dev, ctx->q_norm, B * Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2))) return rc;
   stamp(ctx, 1);
-  if (B > 1 && merged_batch_ok(ctx, prm)) {   // the B frames through group / CLUSTER / POSE / POSE2 in one launch each
+  if (merge) {   // the B frames through group / CLUSTER / POSE / POSE2 in one launch each
     if ((rc = ensure_batch_arenas(ctx, B))) return rc;
     ctx->batch_q0 = 0;
     ctx->fs->slot = 0;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     const unsigned long long a = blockIdx.y * fbx.arena;
     const size_t q0 = (size_t)blockIdx.y * fbx.q;
     idx1 += q0; d1 += q0; d2 += q0; q_uv += 2 * q0;
+    if (q_depth) q_depth += q0;       // (per-query depth attributes lie frame after frame like the queries)
     if (gathered) gathered += q0;   // (the frames' columns of every shard's [3][B Q] block)
     acc_q = frame_ptr(acc_q, a); acc_model = frame_ptr(acc_model, a); m_q = frame_ptr(m_q, a);
     m_model = frame_ptr(m_model, a); m_corr = frame_ptr(m_corr, a); m_rep = frame_ptr(m_rep, a);

@@ -162,3 +162,55 @@ def test_frame_from_depth_image_equals_host_side_depthmap_prop(kind, scale, with
             assert np.linalg.norm(o["pose"][4:] - fr.poses[j][4:]) < 0.01
     c.frame_set_depth_image(0, 0, 0, 0, 0)      # depth off again
     pipe.close()
+
+
+@pytest.mark.parametrize("kind", [capi.DEPTH_BACKPROJECTION, capi.DEPTH_REPROJECTION])
+def test_batch_of_distinct_frames_with_depth_attributes_equals_the_frames_alone(kind):
+    """Eight DIFFERENT frames, each with its own per-query depth attributes, through ONE MATCH launch sequence and one
+    launch per stage of the rest chain (mh_frame_enqueue_batch with mh_frame_set_depth: the attributes lie frame after
+    frame like the queries): every frame's objects bit for bit what the frame gives alone.  Reference behaviour: one
+    frame at a time, `depthInformation` attached to every match (moped3d/libmoped/src/util.hpp:73-107,
+    DEPTHMAP_PROP_CPU.hpp:101-134) before POSE_RANSAC_LM_DIFF_*_DEPTH_CPU::process."""
+    import torch
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    db = synth.make_db(8, 2500)
+    B, Q = 8, 2000
+    frs = [synth.make_frame(db, n_vis=n, seed=40 + i, Q=Q, pts_per_obj=120) for i, n in enumerate((2, 1, 3, 0, 2, 4, 1, 2))]
+    dev = torch.device("cuda:0")
+    depths = []
+    for i, fr in enumerate(frs):
+        wpts, fill = synth.frame_depth(db, fr, seed=i)
+        wgt = (1.0 / (1.0 + (fill / np.float32(0.1 if kind == 1 else 25.0)) ** 2)).astype(np.float32)
+        depths.append(torch.from_numpy(capi.pack_depth(wpts, wgt).view(np.float32).reshape(-1, 4)).to(dev))
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=B * Q, batch=B)
+    seeds = [700 + f for f in range(B)]
+    alone = []
+    c0 = pipe.ctxs[0]
+    for f, fr in enumerate(frs):
+        c0.frame_set_depth(depths[f].data_ptr(), kind, 0.5)
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seeds[f])
+        alone.append(pipe.fetch(0))
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    dall = torch.cat(depths)
+    torch.cuda.synchronize()
+    c1 = pipe.ctxs[1]
+    c1.frame_set_depth(dall.data_ptr(), kind, 0.5)
+    for rep in range(2):
+        qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        pipe.enqueue_batch(1, qd, uv, B, seeds)
+        got = pipe.fetch_batch(1, B)
+        for f in range(B):
+            (objs, counts), (a, ac) = got[f], alone[f]
+            assert np.array_equal(counts, ac), (rep, f, counts, ac)
+            assert len(objs) == len(a) and np.array_equal(objs["model"], a["model"]), (rep, f)
+            assert np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32)), (rep, f)
+            assert np.array_equal(objs["score"].view(np.uint32), a["score"].view(np.uint32)), (rep, f)
+    assert sum(len(a[0]) for a in alone) >= 12
+    # the attributes matter: the same batch without them gives other poses
+    c1.frame_set_depth(0, 0, 0.5)
+    qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+    pipe.enqueue_batch(1, qd, uv, B, seeds)
+    plain = pipe.fetch_batch(1, B)
+    assert any(len(p[0]) and not np.array_equal(p[0]["pose"], a[0]["pose"]) for p, a in zip(plain, alone))
+    pipe.close()
