@@ -808,11 +808,17 @@ def main():
                 "kernel": "pose_kernel<0> (POSE and POSE2 launches of one batch, isolated, HIP events by the library)",
                 "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "threads_per_workgroup": info["threads"],
                 "waves_per_simd": info["waves_per_simd"], "workgroups_per_cu": info["workgroups_per_cu"],
-                "tasks_per_batch": round(pm["tasks"], 1), "hypotheses_per_batch": round(pm["hyp"], 1),
+                "tasks_per_frame": round(pm["tasks"], 1), "hypotheses_per_frame": round(pm["hyp"], 1),
                 "ms_per_batch_both_stages": round(pm["pose_ms"], 4),
-                "hypotheses_per_s_isolated": round(pm["hyp"] / (pm["pose_ms"] * 1e-3), 0) if pm["pose_ms"] > 0 else None,
+                "hypotheses_per_s_isolated": round(pm["hyp"] * frames_per_batch / (pm["pose_ms"] * 1e-3), 0) if pm["pose_ms"] > 0 else None,
                 "hypotheses_per_s_pipeline": round(float(np.mean([c["hypotheses"] for c in ctr])) * fps, 0),
-                "cu_time_share": info.get("cu_time_share"),
+                # POSE's share of the chip's CU time in the pipeline, an upper bound: every task charged the whole isolated
+                # launch of its stage (half the two launches' time) on the half compute unit a POSE workgroup occupies,
+                # over the CU time the chip has in the period the pipeline takes for one batch
+                "cu_time_share": round((pm["tasks"] * frames_per_batch * (pm["pose_ms"] / 2.0) / max(info["workgroups_per_cu"], 1))
+                                       / (N_CU * (frames_per_batch / fps * 1e3)), 4) if fps > 0 else None,
+                "cu_time_share_note": "upper bound: (tasks of a frame x frames of a batch) x the isolated launch time of a stage x "
+                                      "1/workgroups_per_cu of a compute unit, over 256 CUs x the pipeline's time per batch",
             }
     if world > 1:
         dist.barrier()

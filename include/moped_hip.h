@@ -425,6 +425,7 @@ typedef struct mh_linkage_params {
   int32_t use3d_filter; /* 2: multiply (1: add, 0: skip) the distance-consistency kernel */
   float sigma2d;        /* -1: average nearest-neighbour distance */
   float sigma3d;        /* -1 */
+  int32_t linkage_type; /* 1: average linkage (config.hpp:45); 0 minimum, 2 maximum (CLUSTER_LINKAGE_CPU.hpp:506-526) */
 } mh_linkage_params;
 /* CLUSTER of the following frames: linkage with *prm, or mean shift again when prm == NULL. */
 int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm);
@@ -530,6 +531,9 @@ int mh_frame_fetch_query(mh_ctx* ctx);
  * sorted by (model, query) = the reference's `matches[model]` lists one after the other
  * (MATCH_ANN_CPU.hpp:165-176).  Synchronises the stream; *n_matches = their number. */
 int mh_frame_fetch_matches(mh_ctx* ctx, int32_t* query_host, int32_t* model_host, int cap, int32_t* n_matches);
+/* The same matches as correspondences {u, v, x, y, z} (FrameData::Match's coord2D and coord3D, src/util.hpp:81-88), in the
+ * same order, of the last frame: what a host needs to fill `frameData.matches` the way MATCH_ANN_CPU::process does. */
+int mh_frame_fetch_match_points(mh_ctx* ctx, mh_corr* corr_host, int cap, int32_t* n_matches);
 /* The same for frame `slot` of the last batch (mh_frame_enqueue_batch / _rest_frames / _sharded_batch): the B frames of a
  * batch that shared their launches keep their lists side by side; of frames that went through the steps one after the
  * other (depth maps per frame, stage timing) only the last one's remain -> MH_ERR_ARG for the others. */

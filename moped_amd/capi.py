@@ -71,12 +71,16 @@ MAX_BATCH = 32   # MH_MAX_BATCH
 
 class mh_linkage_params(C.Structure):
     _fields_ = [("cutoff", C.c_float), ("min_pts", C.c_int32), ("use3d_filter", C.c_int32), ("sigma2d", C.c_float),
-                ("sigma3d", C.c_float)]
+                ("sigma3d", C.c_float), ("linkage_type", C.c_int32)]
+
+    def __init__(self, cutoff=0.1, min_pts=7, use3d_filter=2, sigma2d=-1.0, sigma3d=-1.0, linkage_type=1):
+        # (average linkage unless said otherwise: a positional call with the five older fields must not mean "minimum")
+        super().__init__(cutoff, min_pts, use3d_filter, sigma2d, sigma3d, linkage_type)
 
 
 def default_linkage_params():
     """CLUSTER_LINKAGE_CPU( 0.1, 7, 2, 1, 0.0, 1, -1, -1 ) (moped3d/libmoped/src/config.hpp:45)."""
-    return mh_linkage_params(0.1, 7, 2, -1.0, -1.0)
+    return mh_linkage_params(0.1, 7, 2, -1.0, -1.0, 1)
 
 
 class mh_depth_rules(C.Structure):
@@ -100,7 +104,7 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_match_launches", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_match_launches", "mh_frame_fetch_match_points", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
     "mh_pose_ransac_images",
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",

@@ -1076,6 +1076,8 @@ int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {
     ctx->linkage.use3d_filter = prm->use3d_filter;
     ctx->linkage.sigma2d = prm->sigma2d;
     ctx->linkage.sigma3d = prm->sigma3d;
+    if (prm->linkage_type < 0 || prm->linkage_type > 2) return MH_ERR_ARG;
+    ctx->linkage.linkage_type = prm->linkage_type;
   }
   return MH_OK;
 }
@@ -1141,6 +1143,8 @@ int mh_cluster_linkage(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* de
   lp.use3d_filter = prm->use3d_filter;
   lp.sigma2d = prm->sigma2d;
   lp.sigma3d = prm->sigma3d;
+  if (prm->linkage_type < 0 || prm->linkage_type > 2) return MH_ERR_ARG;
+  lp.linkage_type = prm->linkage_type;
   launch_linkage_batch(d_corr, d_depth, d_off, n_problems, ctx->depth_img, lp, ctx->lk_scratch, ctx->lk_scratch_floats,
                        d_members, d_start, d_ncl, d_label, s);
   MH_HIP(ctx, hipGetLastError());
@@ -1729,6 +1733,24 @@ int mh_frame_fetch_matches_slot(mh_ctx* ctx, int slot, int32_t* query_host, int3
                           hipMemcpyDeviceToHost));
   if (take > 0 && model_host)
     MH_HIP(ctx, hipMemcpy(model_host, reinterpret_cast<const unsigned char*>(fs->m_model) + a, sizeof(int32_t) * (size_t)take,
+                          hipMemcpyDeviceToHost));
+  return MH_OK;
+}
+
+int mh_frame_fetch_match_points(mh_ctx* ctx, mh_corr* corr_host, int cap, int32_t* n_matches) {
+  if (!ctx || !ctx->fs || !n_matches || cap < 0 || (cap > 0 && !corr_host)) return MH_ERR_ARG;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  FrameState* fs = ctx->fs;
+  const int slot = fs->list_first + fs->list_n - 1;
+  const size_t a = (size_t)(slot - fs->list_first) * fs->arena_bytes;
+  int32_t snap[4] = {0, 0, 0, 0};
+  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap + 4 * slot, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_matches = snap[0];
+  const int take = std::min(snap[0], cap);
+  if (take > 0)
+    MH_HIP(ctx, hipMemcpy(corr_host, reinterpret_cast<const unsigned char*>(fs->m_corr) + a, sizeof(mh_corr) * (size_t)take,
                           hipMemcpyDeviceToHost));
   return MH_OK;
 }

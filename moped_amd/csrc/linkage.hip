@@ -337,8 +337,22 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
       const int i = tid + u * LK_THREADS;
       nv[u] = 0.f;
       if (i < N) {
-        const float a = __fmul_rn((float)S1, Dm[(size_t)first * N + i]), b = __fmul_rn((float)S2, Dm[(size_t)second * N + i]);
-        nv[u] = (float)((1.0 / (double)(S1 + S2)) * (double)__fadd_rn(a, b));
+        const float da = Dm[(size_t)first * N + i], db = Dm[(size_t)second * N + i];
+        if (P.linkage_type == 1) {
+          const float a = __fmul_rn((float)S1, da), b = __fmul_rn((float)S2, db);
+          nv[u] = (float)((1.0 / (double)(S1 + S2)) * (double)__fadd_rn(a, b));
+        } else {
+          // minimum / maximum linkage (:506-507, :525): the reference recomputes min / max of K over the merged
+          // cluster's pairs (minimumLinkage :404-413, maximumLinkage :390-399); min over a union is the min of the two
+          // clusters' minima -- the row entries hold exactly those (singletons start as K itself) -- so the update is
+          // exact, no arithmetic.  A cluster i that is EMPTY (absorbed earlier) gets the reference's empty-loop value.
+          // (`second` is empty by the time the reference's loop runs; a merge may also have absorbed a cluster that was
+          // empty already -- the stale list entry of the scan, S2 = 0 -- and then changes nothing)
+          const bool empty = L.clsize[i] == 0 || i == second;
+          if (empty) nv[u] = P.linkage_type == 0 ? 1e20f : -1.f;
+          else if (S2 == 0) nv[u] = da;
+          else nv[u] = P.linkage_type == 0 ? fminf(da, db) : fmaxf(da, db);
+        }
       }
     }
     __threadfence_block();

@@ -142,11 +142,12 @@ void launch_meanshift_batch(const float* pts, const int32_t* off, int n_problems
 
 // ---- linkage (moped3d CLUSTER_LINKAGE_CPU; linkage.hip) -----------------------------------
 constexpr int LK_CAP = 1024;   // matches of one model
-struct LinkageParams {         // the constructor arguments used (config.hpp:45); average linkage only
+struct LinkageParams {         // the constructor arguments used (config.hpp:45)
   float cutoff = 0.1f;
   int min_pts = 7;             // clusters need MORE than this many members
   int use3d_filter = 2;        // 0 none, 1 add, 2 multiply the model/world distance-consistency kernel
   float sigma2d = -1.f, sigma3d = -1.f;   // -1: average nearest-neighbour distance
+  int linkage_type = 1;        // 0 minimum, 1 average (config.hpp:45), 2 maximum linkage (CLUSTER_LINKAGE_CPU.hpp:506-526)
 };
 // Floats of scratch the models kernel needs for match lists of the given sizes: 3 n^2 each.
 // depth4: per match (wx, wy, wz, weight) aligned with corr.  Outputs as launch_meanshift_models.

@@ -3,8 +3,8 @@
 //     pipeline.addAlg( "CLUSTER", new CLUSTER_LINKAGE_HIP( 0.1, 7, 2, 1, 0.0, 1, -1, -1 ) );
 //     pipeline.addAlg( "CLUSTER", new CLUSTER_LINKAGE_CPU( 0.1, 7, 2, 1, 0.0, 1, -1, -1 ) );   // fallback
 // Same constructor arguments (WeightGamma and Alpha are unused by the reference as well: its
-// adaptiveWeightSum call passes 0.5 and 25, :697).  Average linkage (LinkageType 1) is what the
-// GPU implements; any other type makes the step not capable, so the CPU step behind it runs.
+// adaptiveWeightSum call passes 0.5 and 25, :697).  LinkageType 0 (minimum), 1 (average: the shipped
+// configuration) and 2 (maximum) as the reference's update loop has them (:506-526).
 // Reads matches[model] (coord2D, coord3D, depthData.coord3D), the depth map and its ".distance"
 // map (:577-593); writes clusters[model] in the reference's cluster and member order; sets
 // oldClusters when the step is named "CLUSTER" (:703).
@@ -28,7 +28,7 @@ class CLUSTER_LINKAGE_HIP : public MopedAlg {
                       Float Sigma2D, Float Sigma3D)
       : Cutoff(Cutoff), MinPts(MinPts), Use3DFilter(Use3DFilter), WeightGamma(WeightGamma), Alpha(Alpha),
         LinkageType(LinkageType), Sigma2D(Sigma2D), Sigma3D(Sigma3D) {
-    capable = LinkageType == 1 && HipSession::get() != 0;
+    capable = LinkageType >= 0 && LinkageType <= 2 && HipSession::get() != 0;
   }
 
   void getConfig(map<string, string>& config) const {
@@ -85,6 +85,7 @@ class CLUSTER_LINKAGE_HIP : public MopedAlg {
       prm.use3d_filter = Use3DFilter;
       prm.sigma2d = Sigma2D;
       prm.sigma3d = Sigma3D;
+      prm.linkage_type = LinkageType;
       vector<int32_t> label(total), order(total), ncl(n_problems);
       if (mh_cluster_linkage(ctx, &corr[0], &depth[0], &off[0], n_problems, &prm, &label[0], &order[0], &ncl[0]) != MH_OK) {
         HipSession::warn("mh_cluster_linkage");

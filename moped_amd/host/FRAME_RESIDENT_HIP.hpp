@@ -11,8 +11,9 @@
 // plugins (MATCH_BRUTE_HIP .. FILTER_PROJECTION_HIP) for pipelines that read matches / clusters in between.
 // Contract kept: reads detectedFeatures[DescriptorType] (all images of the frame), L2-normalises the query descriptors
 // in place (MATCH_ANN_CPU.hpp:157), appends the frame's final objects {model, pose, score} to *frameData.objects in
-// FILTER2's list order; frameData.matches is sized to models->size() and left empty, clusters stay empty (they never
-// leave the device).  capable = false without a gfx950 device, as for every HIP step.
+// FILTER2's list order; frameData.matches is sized to models->size() and left empty unless FillMatches is set (setConfig:
+// the frame's match lists are then copied back for a display / bookkeeping step behind this one), clusters stay empty
+// (they never leave the device).  capable = false without a gfx950 device, as for every HIP step.
 #pragma once
 #include "hip_session.hpp"
 
@@ -24,8 +25,9 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
   mh_frame_params prm;
   bool skipCalculation;
   unsigned long frameCounter;
+  int FillMatches;
   vector<float> packed, uv;
-  vector<int32_t> imageOf;
+  vector<int32_t> imageOf, matchQuery, matchModel;
 
   void Update() {
     skipCalculation = true;
@@ -68,7 +70,7 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
                      int MinPoints1, Float FeatureDistance1, Float MinScore1,                                // FILTER
                      int NHyp2, int MaxObj2, int NPtsAlign2, int MinNPts2, Float ErrorThreshold2,            // POSE2
                      int MinPoints2, Float FeatureDistance2, Float MinScore2)                                // FILTER2
-      : DescriptorSize(DescriptorSize), DescriptorType(DescriptorType), skipCalculation(true), frameCounter(0) {
+      : DescriptorSize(DescriptorSize), DescriptorType(DescriptorType), skipCalculation(true), frameCounter(0), FillMatches(0) {
     mh_frame_default_params(&prm);
     prm.ratio = (float)Ratio;
     prm.ms_radius = (float)Radius;
@@ -95,19 +97,36 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
     capable = (DescriptorSize == MH_DESC_DIM) && HipSession::get() != 0;
   }
 
+  // Every constant the six reference steps publish (GET_CONFIG in MATCH_ANN_CPU.hpp:122-125, CLUSTER_MEAN_SHIFT_CPU.hpp:168-171,
+  // POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:248-252, FILTER_PROJECTION_CPU.hpp:68-70), under the reference's names; the second
+  // POSE / FILTER stage's carry a 2.  NHypotheses stands where the reference has MaxRANSACTests / MaxLMTests.
+  // FillMatches = 1: frameData.matches is filled from the device's match lists after the frame (one more copy; for a
+  // STATUS_DISPLAY-like step behind this one), 0 (default): sized and left empty.
+#define MH_FR_CONFIG(OP)                                                          \
+  OP("Ratio", prm.ratio)                                                          \
+  OP("Radius", prm.ms_radius) OP("Merge", prm.ms_merge) OP("MinPts", prm.ms_min_pts) OP("MaxIterations", prm.ms_max_iter) \
+  OP("NHypotheses", prm.pose1.n_hypotheses) OP("MaxObjectsPerCluster", prm.pose1.max_objects_per_cluster)                 \
+  OP("NPtsAlign", prm.pose1.n_pts_align) OP("MinNPtsObject", prm.pose1.min_n_pts_object)                                  \
+  OP("ErrorThreshold", prm.pose1.error_threshold)                                                                         \
+  OP("MinPoints", prm.f1_min_points) OP("FeatureDistance", prm.f1_feature_distance) OP("MinScore", prm.f1_min_score)      \
+  OP("NHypotheses2", prm.pose2.n_hypotheses) OP("MaxObjectsPerCluster2", prm.pose2.max_objects_per_cluster)               \
+  OP("NPtsAlign2", prm.pose2.n_pts_align) OP("MinNPtsObject2", prm.pose2.min_n_pts_object)                                \
+  OP("ErrorThreshold2", prm.pose2.error_threshold)                                                                        \
+  OP("MinPoints2", prm.f2_min_points) OP("FeatureDistance2", prm.f2_feature_distance) OP("MinScore2", prm.f2_min_score)   \
+  OP("FillMatches", FillMatches)
   void getConfig(map<string, string>& config) const {
     hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "DescriptorType", DescriptorType);
-    hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "Ratio", prm.ratio);
-    hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "Radius", prm.ms_radius);
-    hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "NHypotheses", prm.pose1.n_hypotheses);
-    hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "MinScore2", prm.f2_min_score);
+    hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "DescriptorSize", DescriptorSize);
+#define MH_FR_GET(NAME, VAR) hipGetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", NAME, VAR);
+    MH_FR_CONFIG(MH_FR_GET)
+#undef MH_FR_GET
   }
   void setConfig(map<string, string>& config) {
-    hipSetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "Ratio", prm.ratio);
-    hipSetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "Radius", prm.ms_radius);
-    hipSetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "NHypotheses", prm.pose1.n_hypotheses);
-    hipSetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", "MinScore2", prm.f2_min_score);
+#define MH_FR_SET(NAME, VAR) hipSetConfig(config, _stepName, _alg, "FRAME_RESIDENT_HIP", NAME, VAR);
+    MH_FR_CONFIG(MH_FR_SET)
+#undef MH_FR_SET
   }
+#undef MH_FR_CONFIG
 
   void process(FrameData& frameData) {
     if (configUpdated) Update();
@@ -164,6 +183,26 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
     if (rc != MH_OK) { HipSession::warn("mh_frame_run_host"); return; }
     for (int i = 0; i < Q; ++i)
       for (int j = 0; j < MH_DESC_DIM; ++j) feats[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
+    if (FillMatches) {
+      // frameData.matches as MATCH_ANN_CPU::process leaves it (MATCH_ANN_CPU.hpp:165-176): per model, in ascending
+      // query order, {imageIdx, coord2D, coord3D of the nearest model point} -- from the device's lists of the frame
+      matchQuery.resize(Q);
+      matchModel.resize(Q);
+      int32_t nm = 0;
+      vector<mh_corr> pts(Q);
+      if (mh_frame_fetch_matches(ctx, &matchQuery[0], &matchModel[0], Q, &nm) == MH_OK &&
+          mh_frame_fetch_match_points(ctx, &pts[0], Q, &nm) == MH_OK) {
+        for (int k = 0; k < nm && k < Q; ++k) {
+          const int q = matchQuery[k], m = matchModel[k];
+          if (q < 0 || q >= Q || m < 0 || m >= (int)models->size()) continue;
+          FrameData::Match mt;
+          mt.imageIdx = feats[q].imageIdx;
+          mt.coord2D = feats[q].coord2D;
+          mt.coord3D.init(pts[k].x, pts[k].y, pts[k].z);
+          frameData.matches[m].push_back(mt);
+        }
+      }
+    }
     for (int o = 0; o < n && o < (int)out.size(); ++o) {
       if (out[o].model < 0 || out[o].model >= (int)models->size()) continue;
       SP_Object obj(new Object);

@@ -287,6 +287,8 @@ int main(int argc, char** argv) {
   }
   const bool resident = argc >= 3 && std::string(argv[1]) == "--resident";   // one step for the whole frame
   if (resident) { --argc; ++argv; }
+  const bool fill_matches = resident && argc >= 3 && std::string(argv[1]) == "--fill-matches";   // + frameData.matches filled
+  if (fill_matches) { --argc; ++argv; }
   const bool multi = argc >= 3 && std::string(argv[1]) == "--images";
   if (multi) { --argc; ++argv; }
   if (argc < 2) {
@@ -363,6 +365,16 @@ int main(int argc, char** argv) {
       return 3;
     }
     (*a)->modelsUpdated(models);  // as MopedPimpl::addModel does (src/moped.cpp:94-99)
+  }
+  {
+    // Moped::getConfig / setConfig (src/moped.cpp:196-220): every step publishes its constants, a host sets some back
+    map<string, string> config;
+    for (list<MopedAlg*>::iterator a = all.begin(); a != all.end(); ++a) (*a)->getConfig(config);
+    std::printf("CONFIG_KEYS %zu\n", config.size());
+    if (fill_matches) {
+      config["MATCH_SIFT:0:FRAME_RESIDENT_HIP/FillMatches"] = "1";
+      for (list<MopedAlg*>::iterator a = all.begin(); a != all.end(); ++a) (*a)->setConfig(config);
+    }
   }
 
   list<SP_Object> objects;

@@ -227,3 +227,30 @@ def test_frame_resident_plugin_two_cameras_among_maps(tmp_path):
         xyz, uv, img = db.xyz[fr.src_point[rows]], fr.uv[rows], fr.image[rows]
         e = np.sqrt(((orclib.project_images(pose.astype(np.float32), xyz, img, fr.Ks, fr.cams) - uv) ** 2).sum(1)).mean()
         assert e < 1.0 and score > 0
+
+
+@pytest.mark.gpu
+def test_frame_resident_plugin_publishes_every_constant_and_fills_matches_on_request(tmp_path):
+    """getConfig carries all 23 constants of the six steps it stands for (+ DescriptorSize, FillMatches) under the
+    reference's names (GET_CONFIG lists: MATCH_ANN_CPU.hpp:122-125, CLUSTER_MEAN_SHIFT_CPU.hpp:168-171,
+    POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:248-252, FILTER_PROJECTION_CPU.hpp:68-70), and with FillMatches set through
+    setConfig a step behind it finds frameData.matches filled like MATCH_ANN_CPU::process leaves it (:165-176) -- the same
+    number of matches the six-step pipeline reports, the same objects."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    db = synth.make_db(6, 1500, seed=3)
+    fr = synth.make_frame(db, n_vis=2, seed=11, Q=1200, pts_per_obj=120)
+    scene = str(tmp_path / "scene.bin")
+    dump_scene.dump(scene, db, fr)
+    outs = {}
+    for name, args in (("steps", [scene, "1"]), ("resident", ["--resident", scene, "1"]),
+                       ("filled", ["--resident", "--fill-matches", scene, "1"])):
+        out = subprocess.check_output([os.path.join(HOST, "moped_hip_test"), *args], text=True)
+        kv = {l.split()[0]: l.split()[1:] for l in out.splitlines() if l.split() and l.split()[0] in ("CONFIG_KEYS", "MATCHES")}
+        objs = sorted(l.split()[1] for l in out.splitlines() if l.startswith("OBJ "))
+        outs[name] = (int(kv["CONFIG_KEYS"][0]), int(kv["MATCHES"][0]), objs)
+    assert outs["resident"][0] == 24 and outs["filled"][0] == 24      # the 23 constructor constants + FillMatches
+    assert outs["resident"][1] == 0                                   # sized, left empty (the default)
+    assert outs["filled"][1] == outs["steps"][1] > 100                # what MATCH_BRUTE_HIP put there step by step
+    assert outs["filled"][2] == outs["resident"][2] and len(outs["filled"][2]) == 2

@@ -47,22 +47,25 @@ def _same(got, want):
         assert np.array_equal(g, w)          # same members in the same (reference) order
 
 
-@pytest.mark.parametrize("params", [(0.1, 7, 2), (0.1, 7, 1), (0.3, 3, 0), (0.05, 0, 2)])
+@pytest.mark.parametrize("params", [(0.1, 7, 2, 1), (0.1, 7, 1, 1), (0.3, 3, 0, 1), (0.05, 0, 2, 1),
+                                    # LinkageType 0 / 2: minimum / maximum linkage (CLUSTER_LINKAGE_CPU.hpp:506-526)
+                                    (0.1, 7, 2, 0), (0.02, 3, 2, 0), (0.1, 7, 2, 2), (0.3, 3, 1, 2), (0.05, 0, 0, 0)])
 def test_linkage_step_matches_oracle(scene, params):
     s = scene
-    cutoff, min_pts, use3d = params
-    prm = capi.mh_linkage_params(cutoff, min_pts, use3d, -1.0, -1.0)
+    cutoff, min_pts, use3d, ltype = params
+    prm = capi.mh_linkage_params(cutoff, min_pts, use3d, -1.0, -1.0, ltype)
     got = s["c"].cluster_linkage(s["problems"], prm)
     total = 0
     for (uv, mx, wx), (clusters, label) in zip(s["problems"], got):
-        want = orclib.cluster_linkage(uv, mx, wx, s["img"], s["fill"], cutoff=cutoff, min_pts=min_pts, use3d_filter=use3d)
+        want = orclib.cluster_linkage(uv, mx, wx, s["img"], s["fill"], cutoff=cutoff, min_pts=min_pts, use3d_filter=use3d,
+                                      linkage_type=ltype)
         _same(clusters, want)
         lab = np.full(len(uv), -1, np.int32)
         for k, cl in enumerate(want):
             lab[cl] = k
         assert np.array_equal(label, lab)
         total += len(want)
-    assert total >= 2
+    assert total >= (2 if ltype == 1 else 1)
 
 
 def test_linkage_fixed_sigmas_and_edge_cases(scene):

@@ -94,3 +94,66 @@ def test_degenerate_inputs():
     assert orclib.cluster_linkage(one, _world(img, one), _world(img, one), img, None, min_pts=0)[0].tolist() == [0]
     same = np.array([[10.2, 10.7]] * 9, np.float32)        # identical pixels: sigma = 0, similarities NaN/0 -> no merges
     assert orclib.cluster_linkage(same, _world(img, same), _world(img, same), img, None) == []
+
+
+def _agglomerate(Km, cutoff, min_pts, ltype):
+    """CLUSTER_LINKAGE_CPU's merge loop (:437-540) written down a second time, in Python, over a similarity matrix --
+    including what its list handling does: the absorbed cluster's index stays in the list of live indices until the NEXT
+    scan reaches it (:456-459: erased there, and the element behind it is skipped as a first index of that scan), so
+    earlier first indices still pair with it, through the matrix row the last update gave it.  Linkage of two clusters
+    = minimum (0) / maximum (2) of K over their pairs, recomputed from K (minimumLinkage :404-413: 1e20 over an empty
+    cluster, maximumLinkage :390-399: -1)."""
+    n = len(Km)
+    cl = [[i] for i in range(n)]
+    live = list(range(n))
+    D = Km.astype(np.float32).copy()
+    def link(A, B):
+        v = [Km[b, a] for a in A for b in B]
+        return np.float32((min(v) if ltype == 0 else max(v)) if v else (1e20 if ltype == 0 else -1.0))
+    remove = -1
+    while True:
+        best, pair = np.float32(-1), (0, 0)
+        x = 0
+        while x < len(live):
+            i = live[x]
+            if i == remove:
+                del live[x]          # erase; the loop's increment then skips the element that moved into this place
+                x += 1
+                continue
+            for j in live[x + 1:]:
+                if D[i, j] > best:
+                    best, pair = D[i, j], (i, j)
+            x += 1
+        if best < cutoff:
+            break
+        i, j = pair
+        cl[i] += cl[j][::-1]
+        cl[j] = []
+        remove = j
+        for k in range(n):
+            D[i, k] = D[k, i] = link(cl[k], cl[i])
+    return [c for c in cl if len(c) > min_pts]
+
+
+def test_minimum_and_maximum_linkage_against_an_independent_agglomeration():
+    """LinkageType 0 / 2 (CLUSTER_LINKAGE_CPU.hpp:506-507, :525; the shipped configuration uses 1): the oracle's clusters,
+    members in its order, equal a from-scratch agglomeration over the oracle's own similarity matrix."""
+    img = _plane()
+    img[:, 320:, :3] *= 2.0
+    rng = np.random.default_rng(11)
+    uv = np.concatenate([rng.uniform([60, 60], [200, 200], (14, 2)), rng.uniform([380, 250], [520, 400], (12, 2)),
+                         rng.uniform([0, 0], [639, 479], (6, 2))]).astype(np.float32)
+    world = _world(img, uv)
+    fill = np.zeros((480, 640), np.float32)
+    seen = set()
+    for ltype in (0, 2):
+        for cutoff in (0.05, 0.2, 0.45, 0.7):
+            got, Km = orclib.cluster_linkage(uv, world, world, img, fill, cutoff=cutoff, min_pts=1, linkage_type=ltype, want_k=True)
+            want = _agglomerate(Km, np.float32(cutoff), 1, ltype)
+            assert [c.tolist() for c in got] == want, (ltype, cutoff)
+            seen.add((ltype, len(want)))
+    assert len({n for _, n in seen}) >= 2            # the cutoffs do produce different partitions
+    # minimum linkage merges no further than maximum linkage at the same cutoff
+    n0 = len(orclib.cluster_linkage(uv, world, world, img, fill, cutoff=0.45, min_pts=0, linkage_type=0))
+    n2 = len(orclib.cluster_linkage(uv, world, world, img, fill, cutoff=0.45, min_pts=0, linkage_type=2))
+    assert n0 >= n2
