@@ -323,3 +323,18 @@ def depth_image(db: ModelDB, frame: Frame, seed: int = 0, K=K_DEFAULT, fill_max:
     img[invalid, 3] = -1.0
     fill = rng.uniform(0, fill_max, (IMG_H, IMG_W)) * (rng.random((IMG_H, IMG_W)) < 0.3)
     return np.ascontiguousarray(img, np.float32), np.ascontiguousarray(fill, np.float32)
+
+
+def textured_image(seed: int = 0, height: int = 480, width: int = 640, fine: float = 0.42):
+    """A 640x480 gray image that yields about 3 000 SIFT keypoints (with the first octave doubled, as FEAT_SIFT_CPU
+    extracts: moped2/libmoped/src/feat/FEAT_SIFT_CPU.hpp:78-112) -- the keypoint count BASELINE.json's metric names;
+    the reference's bundled frames give ~590.  Band-limited noise over four octaves, the finest band at weight `fine`
+    (1.0: ~8 500 keypoints, 0.25: ~2 000).  uint8 [height, width]."""
+    from scipy import ndimage
+    rng = np.random.default_rng([0x5157, seed])
+    img = np.zeros((height, width))
+    for k, a in enumerate((fine, 1.0, 1.0, 1.0)):
+        s = 1.2 * 2 ** k
+        img += a * s * ndimage.gaussian_filter(rng.normal(size=(height, width)), s)
+    img = (img - img.min()) / (img.max() - img.min())
+    return np.round(255 * img).astype(np.uint8)

@@ -88,6 +88,24 @@ def test_hip_sift_many_keypoints(ctx):
     assert np.array_equal(j[ok], np.sort(j[ok]))
 
 
+def test_hip_sift_at_the_metrics_keypoint_count(ctx):
+    """BASELINE.json's frames carry ~3 000 keypoints; the bundled ones ~590.  A 640x480 texture that yields ~3 200
+    (synth.textured_image) through FEAT as FEAT_SIFT_CPU runs it (first octave doubled, FEAT_SIFT_CPU.hpp:78-112): the
+    same keypoints in the same order as the oracle (which is the reference's libsiftfast bit for bit on the bundled
+    frames, tests/test_sift_cpu.py), descriptors to rounding."""
+    from moped_amd import synth
+    gray = synth.textured_image(0)
+    want = orclib.sift(gray)
+    got = ctx.sift(gray)
+    n = len(want[0])
+    assert 2800 <= n <= 3600
+    assert abs(len(got[0]) - n) <= max(2, n // 100)
+    ok, j = _agreement(got, want)
+    assert ok.sum() >= 0.99 * n
+    assert np.abs(got[2][ok] - want[2][j[ok]]).max() < 5e-3
+    assert np.array_equal(j[ok], np.sort(j[ok]))
+
+
 def test_hip_sift_flat_image_and_capacity(ctx):
     flat = np.full((64, 80), 128, np.uint8)
     assert len(ctx.sift(flat)[0]) == 0
