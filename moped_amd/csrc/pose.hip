@@ -666,7 +666,8 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
           break;
         }
         // At the minimum, at fp32 resolution: the step of the damping this iteration started with was rejected, it is
-        // itself below what the pose resolves (2e-6 rad / 2e-6 m: 0.003 px at this geometry), and so is the UNDAMPED
+        // itself below anything the 1 px bar could notice (2e-5 rad / 2e-5 m: 0.03 px at this geometry; at 2e-6, the pose's
+        // own resolution, three refines in sixteen still burnt their eight attempts), and so is the UNDAMPED
         // Gauss-Newton step (one more 6 x 6 solve, once per refine).  Heavier damping only shortens the step: the seven
         // further attempts the loop used to make here -- a solve, a pose update and a pass over the points each, all
         // rejected -- were two thirds of a refine's time (POSE_PROF: 2.0 attempts per iteration, the last iteration of
@@ -677,7 +678,7 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
         auto tiny = [](const float* d) {
           float m = 0.f;
           for (int i = 0; i < 6; ++i) m = fmaxf(m, fabsf(d[i]));
-          return m < 2e-6f;
+          return m < 2e-5f;
         };
         if (LM_STOP && attempt == 0 && tiny(dx)) {
           float dx0[6], mxd = 0.f;
