@@ -290,7 +290,7 @@ def make_cams(Ks, cams):
 
 
 def make_pose_params(n_hypotheses=1024, max_objects_per_cluster=4, n_pts_align=5,
-                     min_n_pts_object=6, error_threshold=10.0, lm_iters_l2=10, lm_iters_l4=10):
+                     min_n_pts_object=6, error_threshold=10.0, lm_iters_l2=2, lm_iters_l4=10):
     return mh_pose_params(n_hypotheses, max_objects_per_cluster, n_pts_align, min_n_pts_object,
                           error_threshold, lm_iters_l2, lm_iters_l4)
 

@@ -1051,7 +1051,7 @@ __device__ void pose_task(
   const bool repass = prm.lm_iters_l2 >= 0;   // (launch_pose: MH_POSE_REPASS=0 hands the cap over negated = one pass, for A/B runs)
   const int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
   if (near_miss) {
-    lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2 > 0 ? iters_l2 : 10, lane);
+    lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, 10, lane);   // (to convergence: the count is taken under this pose)
     n_inl = collect(same);
     if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
   }
@@ -1065,7 +1065,7 @@ __device__ void pose_task(
     // reprojection residuals -- the test its inliers are DEFINED by (:166-180) -- and the inliers are taken again
     // under the polished pose; the depth refine then starts from a least-squares pose and its own inlier set, like
     // the reference's does.
-    lm_refine<KIND, 0>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2 > 0 ? iters_l2 : 10, lane);
+    lm_refine<KIND, 0>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, 10, lane);   // (to convergence, whatever the plain phase's cap)
     n_inl = collect(same);
     if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
   }

@@ -49,7 +49,7 @@ class POSE_RANSAC_P3P_DEPTH_HIP : public MopedAlg {
     prm.n_pts_align = NPtsAlign;
     prm.min_n_pts_object = MinNPtsObject;
     prm.error_threshold = ErrorThreshold;
-    prm.lm_iters_l2 = 10;
+    prm.lm_iters_l2 = 2;
     prm.lm_iters_l4 = 10;
     const Float scale = (Kind == MH_DEPTH_BACKPROJECTION) ? 0.100 : 25.0;  // FillInCauchyScale of the class
     for (int img = 0; img < (int)frameData.images.size(); ++img) {

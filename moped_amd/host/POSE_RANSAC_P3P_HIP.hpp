@@ -46,7 +46,7 @@ class POSE_RANSAC_P3P_HIP : public MopedAlg {
     prm.n_pts_align = NPtsAlign;
     prm.min_n_pts_object = MinNPtsObject;
     prm.error_threshold = ErrorThreshold;
-    prm.lm_iters_l2 = 10;
+    prm.lm_iters_l2 = 2;
     prm.lm_iters_l4 = 10;
     // every cluster of the frame in ONE launch, in the reference's task order (model, cluster) (:275-303); each
     // correspondence carries its own image (LmData::image, :228-237): CLUSTER's clusters live in one image,

@@ -15,7 +15,11 @@ def run(models=20, n_vis=2, frames=80):
     db = synth.make_db(models, 5000)
     frs = [synth.make_frame(db, n_vis=n_vis, seed=s) for s in range(8)]
     dev = torch.device("cuda:0")
-    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=3000)
+    from moped_amd import capi
+    prm = capi.default_frame_params()
+    if "TIMELINE_L2" in os.environ:   # experiment: cap of POSE's plain-residual phase
+        prm.pose1.lm_iters_l2 = prm.pose2.lm_iters_l2 = int(os.environ["TIMELINE_L2"])
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=3000, params=prm)
     q = [torch.from_numpy(f.desc).to(dev) for f in frs]
     uv = [torch.from_numpy(f.uv).to(dev) for f in frs]
     work = torch.empty_like(q[0])

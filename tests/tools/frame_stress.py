@@ -36,6 +36,8 @@ while done < scenes:
     prm = capi.default_frame_params()
     if "FRAME_STRESS_LM" in os.environ:   # experiment: LM iteration caps of both POSE stages
         prm.pose1.lm_iters_l2 = prm.pose1.lm_iters_l4 = prm.pose2.lm_iters_l2 = prm.pose2.lm_iters_l4 = int(os.environ["FRAME_STRESS_LM"])
+    if "FRAME_STRESS_L2" in os.environ:   # experiment: cap of the plain-residual phase alone (0 = the squared-residual phase starts at the P3P pose)
+        prm.pose1.lm_iters_l2 = prm.pose2.lm_iters_l2 = int(os.environ["FRAME_STRESS_L2"])
     pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=Qmax, params=prm)
     pipe.ctxs[1].reserve(3 * Qmax)
     group = []
