@@ -44,6 +44,10 @@ struct FrameState {
   // filter
   unsigned long long* best = nullptr;
   int32_t* new_members = nullptr;
+  // POSE as two launches (PoseSplit, steps.h): the tasks' winning hypotheses, scratch for clusters past the refine's LDS cache
+  PoseHyp* hyp = nullptr;
+  float* rf_pts = nullptr;
+  int32_t* rf_list = nullptr;
   // packed result {int32 n; int32 pad[3]; mh_object[max_objects]}
   unsigned char* result = nullptr;
   size_t result_bytes = 0;
@@ -162,6 +166,9 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
     carve(fs->obj_score_raw, max_objects);
     carve(fs->best, max_m);
     carve(fs->new_members, max_m);
+    carve(fs->hyp, max_objects);
+    carve(fs->rf_pts, (size_t)9 * max_m);
+    carve(fs->rf_list, (size_t)4 * max_m);
     if (pass == 0) {
       fs->arena_bytes = off;
       rc |= dev_alloc(ctx, fs->arena, off * n_arenas);
@@ -496,11 +503,16 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   ff2.min_points = prm->f2_min_points;
   ff2.feature_distance = prm->f2_feature_distance;
   ff2.min_score = prm->f2_min_score;
+  PoseSplit split;
+  split.hyp = fused ? fs->hyp : nullptr;   // (the refine launch closes the frames through the fused FILTER tail)
+  split.pts = fs->rf_pts;
+  split.list = fs->rf_list;
+  split.max_m = fs->max_m;
   launch_pose(multi ? fs->mi_corr : fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model,
               fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
               fs->obj_valid, fs->counts, PoseTail{fs->tickets + 1, fs->n_slots, snap + 2, grid, fs->fb}, s, img1,
-              fused ? &ff1 : nullptr, b1);
+              fused ? &ff1 : nullptr, b1, &split);
   stamp(ctx, 4);
   if (prm->run_stage2) {
     // FILTER (snap[3] = objects kept)
@@ -513,7 +525,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                 fs->cl_begin, fs->cl_count, fs->n_clusters2, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
                 fs->obj_ninl, fs->obj_err, fs->obj_cluster, fs->obj_valid, fs->counts,
-                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid2, fs->fb + MH_MAX_BATCH}, s, img2, fused ? &ff2 : nullptr, b2);
+                PoseTail{fs->tickets + 3, fs->n_slots, nullptr, grid2, fs->fb + MH_MAX_BATCH}, s, img2, fused ? &ff2 : nullptr, b2,
+                &split);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
     if (!fused)

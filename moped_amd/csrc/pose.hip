@@ -708,6 +708,110 @@ __device__ float lm_refine(float* R, float* t, const DevCam* cams, const float* 
 #define PP_T(k) do { } while (0)
 #endif
 
+// The refine of one (cluster, replica) task on ONE wavefront: the winner's inliers, LM on plain then squared residuals,
+// the inliers again, once more if the set changed; writes the slot's pose / count / error and marks it valid.  `pts`
+// (PointStride<KIND> floats per cluster point) and `list` (k ints of scratch) may live in LDS or in global memory.
+#ifdef POSE_PROF
+#define PR_PROF_PARAMS , unsigned long long* pp_loc, unsigned long long* t_prof_p
+#undef PP_T
+#define PP_T(k) do { if (lane == 0 && pp_loc) { const unsigned long long now_ = clock64(); pp_loc[k] += now_ - *t_prof_p; *t_prof_p = now_; } } while (0)
+#else
+#define PR_PROF_PARAMS
+#endif
+template <int KIND>
+__device__ void pose_refine(const float* pts, int* list, const int k, float* R, float* t, const bool near_miss,
+                            const DevCam* cams, const mh_pose_params& prm, const float alpha, const int lane, const int slot,
+                            float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl, float* __restrict__ obj_err,
+                            int32_t* obj_valid PR_PROF_PARAMS) {
+  constexpr int PS = PointStride<KIND>::value;
+  // The inliers of a pose, in point order, into list; `same` = the list already held exactly these points.
+  auto collect = [&](bool& same) {
+    int n = 0;
+    bool eq = true;
+    for (int base = 0; base < k; base += 64) {
+      const int i = base + lane;
+      bool in = false;
+      if (i < k) {
+        const float* p = pts + PS * i;
+        in = reproj_err2(R, t, cam_of<KIND>(cams, p), p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
+      }
+      const unsigned long long m = __ballot(in);
+      if (in) {
+        const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+        if (list[at] != i) eq = false;
+        list[at] = i;
+      }
+      n += __popcll(m);
+    }
+    same = __ballot(!eq) == 0ull;
+    __builtin_amdgcn_wave_barrier();
+    return n;
+  };
+  bool same;
+  int n_inl = collect(same);
+  PP_T(3);
+  const bool repass = prm.lm_iters_l2 >= 0;   // (launch_pose: MH_POSE_REPASS=0 hands the cap over negated = one pass, for A/B runs)
+  const int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
+  if (near_miss) {
+    lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 0, 10, lane);   // (to convergence: the count is taken under this pose)
+    n_inl = collect(same);
+    if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
+  }
+  if (KIND == 1 || KIND == 2) {
+    // The depth classes' refine works on 3-D residuals in metres, squared: ONE inlier whose depth attribute belongs to
+    // something else (a clutter match 2.7 px from where the winner projects its model point, anywhere on its ray in
+    // depth) outweighs the hundred true ones and drags the pose centimetres away -- and the winner is the hypothesis with
+    // the MOST inliers, i.e. the one that reaches such borderline points (the reference takes the FIRST hypothesis over
+    // MinNPtsObject, :204, an average one).  Frame 6 of the 50-model pool: 118 true inliers + 1, half of all (seed,
+    // replica) results 12 px off where the oracle's are inside 1.6 px.  So the winner is first polished on plain
+    // reprojection residuals -- the test its inliers are DEFINED by (:166-180) -- and the inliers are taken again
+    // under the polished pose; the depth refine then starts from a least-squares pose and its own inlier set, like
+    // the reference's does.
+    lm_refine<KIND, 0>(R, t, cams, pts, list, n_inl, alpha, 0, 10, lane);   // (to convergence, whatever the plain phase's cap)
+    n_inl = collect(same);
+    if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
+  }
+  lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 0, iters_l2, lane);
+  PP_T(4);
+  float err = lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
+  // The reference refines on the inliers of a least-squares fit of 5-6 points (:199-207); a P3P pose of three noisy
+  // points is a worse judge of which points belong to the object, so the inliers are taken again under the refined pose
+  // and, if the set changed, the refine is repeated on it (once: tests/tools/frame_stress.py found objects whose FILTER2
+  // score stayed 10-15% under the oracle's because a tenth of their points never entered the refine).
+  if (repass) {
+    const int n0 = n_inl;
+    const int n1 = collect(same);
+    if (n1 > prm.min_n_pts_object && !(same && n1 == n0)) {
+      n_inl = n1;
+      lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 0, iters_l2, lane);
+      err = lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
+    } else if (!(same && n1 == n0)) {
+      // too few points under the refined pose: keep the refined pose, report the first set's size
+      n_inl = n0;
+    }
+  }
+  PP_T(5);
+  if (lane == 0) {
+    float q[4];
+    rot_to_quat(R, q);
+    float* o = obj_pose + 7 * (size_t)slot;
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+    o[3] = q[3];
+    o[4] = t[0];
+    o[5] = t[1];
+    o[6] = t[2];
+    obj_ninl[slot] = n_inl;
+    obj_err[slot] = err;
+    obj_valid[slot] = 1;
+  }
+}
+#ifdef POSE_PROF   // (back to the task-level form for pose_task below)
+#undef PP_T
+#define PP_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); pp_loc[k] += now_ - t_prof; t_prof = now_; } } while (0)
+#endif
+
 template <int KIND>
 struct PoseLds {
   float pts[POSE_MAX_PTS * PointStride<KIND>::value];  // u,v,x,y,z[,wx,wy,wz,w] of the cluster
@@ -736,7 +840,8 @@ __device__ void pose_task(
     const int obj_base, int max_objects,
     int32_t* __restrict__ obj_model0, float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0,
     float* __restrict__ obj_err0, int32_t* __restrict__ obj_cluster0, int32_t* obj_valid0,
-    FrameCounts* counts0) {
+    FrameCounts* counts0, PoseHyp* hyp_out0) {
+  PoseHyp* hyp_out = frame_ptr(hyp_out0, fa);
   const mh_corr* __restrict__ corr = frame_ptr(corr0, fa);
   const float4* __restrict__ depth = frame_ptr(depth0, fa);
   const int32_t* __restrict__ members = frame_ptr(members0, fa);
@@ -833,6 +938,7 @@ __device__ void pose_task(
     obj_valid[slot] = 0;
     obj_cluster[slot] = cluster;
     obj_model[slot] = cl_model[cluster];
+    if (hyp_out) hyp_out[slot].n_best = 0;   // (no winner unless the task gets that far)
   }
   if (!enough) return;
   PP_T(0);
@@ -1017,100 +1123,32 @@ __device__ void pose_task(
   __syncthreads();
 
   PP_T(2);
+  if (hyp_out) {
+    // split launch (PoseSplit): the winner goes to memory, the refine is pose_refine_kernel's -- one wavefront per task
+    // there, several tasks per compute unit, instead of this workgroup's half compute unit held by one wavefront of four
+    if (tid < 12) hyp_out[slot].pose[tid] = L.best_pose[tid];
+    if (tid == 0) {
+      hyp_out[slot].n_best = best_cnt;
+      hyp_out[slot].flags = near_miss ? 1 : 0;
+    }
+    return;
+  }
   // ---- refine on the winner's inliers, wavefront 0 ----------------------------------------
   if (wave != 0) return;
   float R[9], t[3];
   for (int i = 0; i < 9; ++i) R[i] = L.best_pose[i];
   for (int i = 0; i < 3; ++i) t[i] = L.best_pose[9 + i];
-  // The inliers of a pose, in point order, into L.list; `same` = the list already held exactly these points.
-  auto collect = [&](bool& same) {
-    int n = 0;
-    bool eq = true;
-    for (int base = 0; base < k; base += 64) {
-      const int i = base + lane;
-      bool in = false;
-      if (i < k) {
-        const float* p = L.pts + PS * i;
-        in = reproj_err2(R, t, cam_of<KIND>(cams, p), p[2], p[3], p[4], p[0], p[1]) < prm.error_threshold;
-      }
-      const unsigned long long m = __ballot(in);
-      if (in) {
-        const int at = n + __popcll(m & ((1ull << lane) - 1ull));
-        if (L.list[at] != i) eq = false;
-        L.list[at] = i;
-      }
-      n += __popcll(m);
-    }
-    same = __ballot(!eq) == 0ull;
-    __builtin_amdgcn_wave_barrier();
-    return n;
-  };
-  bool same;
-  int n_inl = collect(same);
-  PP_T(3);
-  const bool repass = prm.lm_iters_l2 >= 0;   // (launch_pose: MH_POSE_REPASS=0 hands the cap over negated = one pass, for A/B runs)
-  const int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
-  if (near_miss) {
-    lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, 10, lane);   // (to convergence: the count is taken under this pose)
-    n_inl = collect(same);
-    if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
-  }
-  if (KIND == 1 || KIND == 2) {
-    // The depth classes' refine works on 3-D residuals in metres, squared: ONE inlier whose depth attribute belongs to
-    // something else (a clutter match 2.7 px from where the winner projects its model point, anywhere on its ray in
-    // depth) outweighs the hundred true ones and drags the pose centimetres away -- and the winner is the hypothesis with
-    // the MOST inliers, i.e. the one that reaches such borderline points (the reference takes the FIRST hypothesis over
-    // MinNPtsObject, :204, an average one).  Frame 6 of the 50-model pool: 118 true inliers + 1, half of all (seed,
-    // replica) results 12 px off where the oracle's are inside 1.6 px.  So the winner is first polished on plain
-    // reprojection residuals -- the test its inliers are DEFINED by (:166-180) -- and the inliers are taken again
-    // under the polished pose; the depth refine then starts from a least-squares pose and its own inlier set, like
-    // the reference's does.
-    lm_refine<KIND, 0>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, 10, lane);   // (to convergence, whatever the plain phase's cap)
-    n_inl = collect(same);
-    if (n_inl <= prm.min_n_pts_object) return;   // (wave-uniform; the slot stays invalid)
-  }
-  lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2, lane);
-  PP_T(4);
-  float err = lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
-  // The reference refines on the inliers of a least-squares fit of 5-6 points (:199-207); a P3P pose of three noisy
-  // points is a worse judge of which points belong to the object, so the inliers are taken again under the refined pose
-  // and, if the set changed, the refine is repeated on it (once: tests/tools/frame_stress.py found objects whose FILTER2
-  // score stayed 10-15% under the oracle's because a tenth of their points never entered the refine).
-  if (repass) {
-    const int n0 = n_inl;
-    const int n1 = collect(same);
-    if (n1 > prm.min_n_pts_object && !(same && n1 == n0)) {
-      n_inl = n1;
-      lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 0, iters_l2, lane);
-      err = lm_refine<KIND>(R, t, cams, L.pts, L.list, n_inl, alpha, 1, prm.lm_iters_l4, lane);
-    } else if (!(same && n1 == n0)) {
-      // too few points under the refined pose: keep the refined pose, report the first set's size
-      n_inl = n0;
-    }
-  }
-  PP_T(5);
 #ifdef POSE_PROF
-  if (threadIdx.x == 0) {
+  pose_refine<KIND>(L.pts, L.list, k, R, t, near_miss, cams, prm, alpha, lane, slot, obj_pose, obj_ninl, obj_err, obj_valid,
+                    pp_loc, &t_prof);
+  if (threadIdx.x == 0 && obj_valid[slot]) {
     for (int i = 0; i < 6; ++i) atomicAdd(&g_pose_prof[i], pp_loc[i]);
     atomicAdd(&g_pose_prof[7], 1ull);
     pp_end.done = true;
   }
+#else
+  pose_refine<KIND>(L.pts, L.list, k, R, t, near_miss, cams, prm, alpha, lane, slot, obj_pose, obj_ninl, obj_err, obj_valid);
 #endif
-  if (lane == 0) {
-    float q[4];
-    rot_to_quat(R, q);
-    float* o = obj_pose + 7 * (size_t)slot;
-    o[0] = q[0];
-    o[1] = q[1];
-    o[2] = q[2];
-    o[3] = q[3];
-    o[4] = t[0];
-    o[5] = t[1];
-    o[6] = t[2];
-    obj_ninl[slot] = n_inl;
-    obj_err[slot] = err;
-    obj_valid[slot] = 1;
-  }
 }
 
 // The launch: a 1-D grid of workgroups shares ALL (cluster, replica) tasks of the launch -- of one frame, or of the B
@@ -1124,6 +1162,56 @@ __device__ void pose_task(
 // frame mod gridDim.x does).
 constexpr int POSE_GRID = 160;
 
+// What the workgroup that finishes a frame's LAST task does (all POSE_THREADS threads): the object-slot count past this
+// launch's slots, the count of valid objects, the feedback word -- and, fused FILTER, the step that follows.
+__device__ void pose_close_frame(const int f, const unsigned long long a, const int n_tasks, const int obj_base,
+                                 const int max_objects, int32_t* obj_valid0, FrameCounts* counts0, const PoseTail& tail0,
+                                 const FilterFuseArgs* __restrict__ fuse_args, const DevCam& cam, const FrameBatch& fbx) {
+  int n_slots = obj_base + n_tasks;
+  if (n_slots > max_objects) n_slots = max_objects;
+  if (tail0.feedback && threadIdx.x == 0) tail0.feedback[f] = n_tasks;   // what the next launches size their grids by
+  if (tail0.snap_valid) {
+    const int32_t* obj_valid = frame_ptr(obj_valid0, a);
+    int c = 0;
+    for (int i = threadIdx.x; i < n_slots; i += POSE_THREADS) c += obj_valid[i] != 0;
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ int wave_c[POSE_THREADS / 64];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wave_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < POSE_THREADS / 64; ++w) tot += wave_c[w];
+      tail0.snap_valid[4 * f] = tot;
+    }
+  }
+  int32_t* n_slots_dev = frame_ptr(tail0.n_slots, a);
+  if (threadIdx.x == 0) *n_slots_dev = n_slots;
+  if (fuse_args) {
+    // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
+    // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
+    FilterBuffers ffb = fuse_args->fb;
+    ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
+    ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
+    ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
+    ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
+    ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
+    ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
+    ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
+    FilterTail ftail = fuse_args->tail;
+    ftail.ticket = frame_ptr(ftail.ticket, a);
+    if (ftail.snap_kept) ftail.snap_kept += 4 * f;
+    ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
+    __shared__ FilterLds FS;
+    __syncthreads();
+    filter_score(FS, ffb, cam, fuse_args->feature_distance, n_slots, 0, 1);
+    __syncthreads();
+    filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
+                  frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
+    __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
@@ -1135,7 +1223,8 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     const int32_t* obj_base_dev0, int max_objects,
     int32_t* __restrict__ obj_model0, float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0,
     float* __restrict__ obj_err0, int32_t* __restrict__ obj_cluster0, int32_t* obj_valid0,
-    FrameCounts* counts0, PoseTail tail0, const FilterFuseArgs* __restrict__ fuse_args, FrameBatch fbx) {
+    FrameCounts* counts0, PoseTail tail0, const FilterFuseArgs* __restrict__ fuse_args, FrameBatch fbx,
+    PoseHyp* hyp0 /* split launch: winners go here, pose_refine_kernel refines and closes the frames */) {
   static_assert(POSE_THREADS == FT, "the fused FILTER runs on the POSE workgroup's threads");
   MH_TRACE_SCOPE(mh::TK_POSE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1158,7 +1247,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
   for (int f = 0; f < n_frames; ++f) {
     // frame f of a batch: its copy of the working arrays, its counts snapshot and result block
     const unsigned long long a = (unsigned long long)f * fbx.arena;
-    unsigned int* ticket = frame_ptr(tail0.ticket, a);
+    unsigned int* ticket = hyp0 ? nullptr : frame_ptr(tail0.ticket, a);
     const uint64_t seed = fbx.n > 1 ? fbx.seed[f] : seed0;
     const int n_tasks = fr_tasks[f];
     const int obj_base = fr_obj_base[f];
@@ -1168,56 +1257,168 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     for (int task = first; task < n_tasks; task += G) {
       pose_task<KIND>(L, task / R_, task % R_, a, corr0, depth0, alpha, members0, cl_model0, cl_begin0, cl_count0, cam,
                       cam_table, img_of0, n_images, prm, seed, obj_base, max_objects, obj_model0, obj_pose0, obj_ninl0,
-                      obj_err0, obj_cluster0, obj_valid0, counts0);
+                      obj_err0, obj_cluster0, obj_valid0, counts0, hyp0);
       __syncthreads();  // LDS is reused by the next task
       if (ticket && frame_work_done(ticket, 1u, (unsigned)n_tasks)) last = true;
     }
     rank_base = (rank_base + n_tasks) % G;
     if (ticket && n_tasks == 0) last = (int)blockIdx.x == f % G;   // nobody has a task here: one workgroup still closes the frame
     if (!last) continue;   // (uniform over the workgroup)
-    int n_slots = obj_base + n_tasks;
-    if (n_slots > max_objects) n_slots = max_objects;
-    if (tail0.feedback && threadIdx.x == 0) tail0.feedback[f] = n_tasks;   // what the next launches size their grids by
-    if (tail0.snap_valid) {
-      const int32_t* obj_valid = frame_ptr(obj_valid0, a);
-      int c = 0;
-      for (int i = threadIdx.x; i < n_slots; i += POSE_THREADS) c += obj_valid[i] != 0;
-      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-      __shared__ int wave_c[POSE_THREADS / 64];
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) wave_c[threadIdx.x >> 6] = c;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < POSE_THREADS / 64; ++w) tot += wave_c[w];
-        tail0.snap_valid[4 * f] = tot;
+    pose_close_frame(f, a, n_tasks, obj_base, max_objects, obj_valid0, counts0, tail0, fuse_args, cam, fbx);
+  }
+}
+
+// ---- the refine of a split launch -----------------------------------------------------------------------------------
+// One wavefront per task, four tasks per workgroup at a time, RCAP cluster points of each cached in LDS (larger clusters
+// work out of the frame's global scratch): a refine needs a sixteenth of a compute unit's wavefront slots where the fused
+// kernel holds half a unit -- 255 registers x 4 wavefronts, three of them gone, 52 KB of LDS -- for the 55% of a task's
+// time that one wavefront refines.  The tasks of the batch are numbered through the frames like pose_kernel's; workgroup b
+// takes tasks 4 (round G + b) + wave in round `round`.  After every round the workgroup counts its finished tasks into
+// the frames' tickets; a frame whose last task that was is closed by this workgroup (pose_close_frame, all threads).
+constexpr int POSE_RCAP = 320;
+template <int KIND>
+struct RefineLds {
+  float pts[POSE_THREADS / 64][POSE_RCAP * PointStride<KIND>::value];
+  int list[POSE_THREADS / 64][POSE_RCAP];
+  int fr_tasks[MH_MAX_BATCH], fr_obj_base[MH_MAX_BATCH], fr_first[MH_MAX_BATCH + 1];
+  int done_frame[POSE_THREADS / 64];
+  int closed[POSE_THREADS / 64], n_closed;
+  DevCam cams[MH_MAX_IMAGES];
+};
+template <int KIND>
+__global__ __launch_bounds__(POSE_THREADS) void pose_refine_kernel(
+    const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
+    const int32_t* __restrict__ members0, const int32_t* __restrict__ cl_begin0, const int32_t* __restrict__ cl_count0,
+    const int32_t* __restrict__ n_clusters_dev0, DevCam cam, const DevCam* __restrict__ cam_table,
+    const int32_t* __restrict__ img_of0, int n_images, mh_pose_params prm, const int32_t* obj_base_dev0, int max_objects,
+    float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0, float* __restrict__ obj_err0, int32_t* obj_valid0,
+    FrameCounts* counts0, PoseTail tail0, const FilterFuseArgs* __restrict__ fuse_args, FrameBatch fbx, PoseSplit sp) {
+  MH_TRACE_SCOPE(mh::TK_POSE);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RefineLds<KIND>& L = *reinterpret_cast<RefineLds<KIND>*>(smem);
+  constexpr int PS = PointStride<KIND>::value;
+  constexpr int NW = POSE_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R_ = prm.max_objects_per_cluster;
+  const int G = (int)gridDim.x;
+  const int n_frames = fbx.n > 1 ? fbx.n : 1;
+  if (tid < n_frames) {
+    const unsigned long long a = (unsigned long long)tid * fbx.arena;
+    L.fr_tasks[tid] = *frame_ptr(n_clusters_dev0, a) * R_;
+    L.fr_obj_base[tid] = obj_base_dev0 ? *frame_ptr(obj_base_dev0, a) : 0;
+  }
+  const DevCam* cams = &cam;
+  if (KIND == 3) {
+    for (int i = tid; i < n_images * (int)(sizeof(DevCam) / 4); i += POSE_THREADS)
+      reinterpret_cast<float*>(L.cams)[i] = reinterpret_cast<const float*>(cam_table)[i];
+    cams = L.cams;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int f = 0; f < n_frames; ++f) {
+      L.fr_first[f] = run;
+      run += L.fr_tasks[f];
+    }
+    L.fr_first[n_frames] = run;
+  }
+  __syncthreads();
+  const int total = L.fr_first[n_frames];
+  // frames without a task: nobody will count them down -- workgroup f mod G closes them now
+  for (int f = 0; f < n_frames; ++f) {
+    if (L.fr_tasks[f] == 0 && (int)blockIdx.x == f % G)   // (uniform over the workgroup)
+      pose_close_frame(f, (unsigned long long)f * fbx.arena, 0, L.fr_obj_base[f], max_objects, obj_valid0, counts0, tail0,
+                       fuse_args, cam, fbx);
+  }
+  const int n_rounds = (total + NW * G - 1) / (NW * G);
+  for (int round = 0; round < n_rounds; ++round) {
+    const int T = NW * (round * G + (int)blockIdx.x) + wave;
+    int f_mine = -1;
+    if (T < total) {
+      int f = 0;
+      while (T >= L.fr_first[f + 1]) ++f;   // (wave-uniform)
+      f_mine = f;
+      const int task = T - L.fr_first[f];
+      const int cluster = task / R_, replica = task - cluster * R_;
+      const unsigned long long fa = (unsigned long long)f * fbx.arena;
+      const int slot = L.fr_obj_base[f] + cluster * R_ + replica;
+      const PoseHyp* hyp = frame_ptr(sp.hyp, fa);
+      if (slot < max_objects && hyp[slot].n_best > 0) {
+        const mh_corr* __restrict__ corr = frame_ptr(corr0, fa);
+        const float4* __restrict__ depth = frame_ptr(depth0, fa);
+        const int32_t* __restrict__ members = frame_ptr(members0, fa);
+        const int32_t* __restrict__ img_of = frame_ptr(img_of0, fa);
+        int k = frame_ptr(cl_count0, fa)[cluster];
+        const int begin = frame_ptr(cl_begin0, fa)[cluster];
+        if (k > POSE_MAX_PTS) k = POSE_MAX_PTS;   // (pose_task has raised ERR_POSE_CAP)
+        // the cluster's points: this wavefront's LDS cache, or the frame's scratch in global memory (every replica of a
+        // cluster writes the same values there; the inlier lists are per replica)
+        float* pts = L.pts[wave];
+        int* list = L.list[wave];
+        if (k > POSE_RCAP) {
+          pts = frame_ptr(sp.pts, fa) + (size_t)begin * PS;
+          list = frame_ptr(sp.list, fa) + (size_t)(replica & 3) * sp.max_m + begin;
+        }
+        for (int i = lane; i < k; i += 64) {
+          const int mi = members[begin + i];
+          const mh_corr c = corr[mi];
+          float* p = pts + PS * i;
+          p[0] = c.u;
+          p[1] = c.v;
+          p[2] = c.x;
+          p[3] = c.y;
+          p[4] = c.z;
+          if (KIND == 3) p[5] = __int_as_float(img_of[mi]);
+          if (KIND == 1 || KIND == 2) {
+            const float4 d = depth[mi];
+            p[5] = d.x;
+            p[6] = d.y;
+            p[7] = d.z;
+            p[8] = d.w;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (k > POSE_RCAP) __threadfence();   // (global scratch written by other lanes of this wavefront)
+        float R[9], t[3];
+        for (int i = 0; i < 9; ++i) R[i] = hyp[slot].pose[i];
+        for (int i = 0; i < 3; ++i) t[i] = hyp[slot].pose[9 + i];
+#ifdef POSE_PROF
+        pose_refine<KIND>(pts, list, k, R, t, hyp[slot].flags & 1, cams, prm, alpha, lane, slot, frame_ptr(obj_pose0, fa),
+                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa), nullptr, nullptr);
+#else
+        pose_refine<KIND>(pts, list, k, R, t, hyp[slot].flags & 1, cams, prm, alpha, lane, slot, frame_ptr(obj_pose0, fa),
+                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa));
+#endif
       }
     }
-    int32_t* n_slots_dev = frame_ptr(tail0.n_slots, a);
-    if (threadIdx.x == 0) *n_slots_dev = n_slots;
-    if (fuse_args) {
-      // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
-      // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
-      FilterBuffers ffb = fuse_args->fb;
-      ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
-      ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
-      ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
-      ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
-      ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
-      ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
-      ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
-      FilterTail ftail = fuse_args->tail;
-      ftail.ticket = frame_ptr(ftail.ticket, a);
-      if (ftail.snap_kept) ftail.snap_kept += 4 * f;
-      ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
-      __shared__ FilterLds FS;
-      __syncthreads();
-      filter_score(FS, ffb, cam, fuse_args->feature_distance, n_slots, 0, 1);
-      __syncthreads();
-      filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
-                    frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
-      __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)
+    if (lane == 0) L.done_frame[wave] = f_mine;
+    __threadfence();   // release: this round's results
+    __syncthreads();
+    if (tid == 0) {
+      int nc = 0;
+      for (int w = 0; w < NW; ++w) {
+        const int f = L.done_frame[w];
+        if (f < 0) continue;
+        unsigned int* ticket = frame_ptr(tail0.ticket, (unsigned long long)f * fbx.arena);
+        const unsigned int n = (unsigned)L.fr_tasks[f];
+        const unsigned int was = atomicAdd(ticket, 1u);
+        if (was + 1u == n) {
+          atomicExch(ticket, 0u);
+          L.closed[nc++] = f;
+        }
+      }
+      L.n_closed = nc;
     }
+    __syncthreads();
+    const int nc = L.n_closed;
+    if (nc) __threadfence();   // acquire: everybody else's results
+    for (int c = 0; c < nc; ++c) {
+      const int f = L.closed[c];
+      pose_close_frame(f, (unsigned long long)f * fbx.arena, L.fr_tasks[f], L.fr_obj_base[f], max_objects, obj_valid0,
+                       counts0, tail0, fuse_args, cam, fbx);
+    }
+    __syncthreads();   // (done_frame / closed are rewritten by the next round)
   }
 }
 
@@ -1267,7 +1468,8 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              const int32_t* obj_base_dev,
                              int max_objects, int32_t* obj_model, float* obj_pose, int32_t* obj_ninl,
                              float* obj_err, int32_t* obj_cluster, int32_t* obj_valid, FrameCounts* counts,
-                             const PoseTail& tail, hipStream_t s, const FilterFuse* fuse, const FrameBatch* batch) {
+                             const PoseTail& tail, hipStream_t s, const FilterFuse* fuse, const FrameBatch* batch,
+                             const PoseSplit* split) {
   static DynLds attr;   // one per KIND (this function is a template)
   attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
   // the fused FILTER step's arguments: on the device already unless they have changed since this context's last launch
@@ -1294,11 +1496,27 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   const int n_frames = batch && batch->n > 1 ? batch->n : 1;
   const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : std::min(POSE_GRID, 96 * n_frames);
   const long all_slots = (long)max_clusters * p.max_objects_per_cluster * n_frames;
+  // Two launches (PoseSplit: the frame paths hand in the scratch; MH_POSE_SPLIT=0 in experiment builds: one): the
+  // hypotheses of every task, then the refines one wavefront each
+  static const bool split_on = exp_int("MH_POSE_SPLIT", 1) != 0;
+  const bool two = split_on && split && split->hyp && tail.ticket && p.max_objects_per_cluster <= 4;
   hipLaunchKernelGGL(pose_kernel<KIND>, dim3((unsigned)std::max(1L, std::min((long)grid_cap, all_slots))), dim3(POSE_THREADS),
                      sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
                      n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, obj_base_dev, max_objects, obj_model,
                      obj_pose, obj_ninl,
-                     obj_err, obj_cluster, obj_valid, counts, tail, fuse_dev, batch ? *batch : FrameBatch());
+                     obj_err, obj_cluster, obj_valid, counts, tail, fuse_dev, batch ? *batch : FrameBatch(),
+                     two ? split->hyp : (PoseHyp*)nullptr);
+  if (two) {
+    static DynLds attr_r;
+    attr_r.ensure(pose_refine_kernel<KIND>, sizeof(RefineLds<KIND>));
+    // four tasks per workgroup and round; the guess of the task count sizes the grid, more tasks take more rounds
+    const long guess = tail.grid > 0 ? tail.grid : 96L * n_frames;
+    const unsigned g2 = (unsigned)std::max(1L, std::min(std::min(256L, (guess + 3) / 4), (all_slots + 3) / 4));
+    hipLaunchKernelGGL(pose_refine_kernel<KIND>, dim3(g2), dim3(POSE_THREADS), sizeof(RefineLds<KIND>), s, corr, depth, alpha,
+                       members, cl_begin, cl_count, n_clusters_dev, cam, cam_table, img_of, n_images, p, obj_base_dev,
+                       max_objects, obj_pose, obj_ninl, obj_err, obj_valid, counts, tail, fuse_dev,
+                       batch ? *batch : FrameBatch(), *split);
+  }
 }
 
 void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float alpha,
@@ -1308,7 +1526,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model,
                  float* obj_pose, int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster,
                  int32_t* obj_valid, FrameCounts* counts, const PoseTail& tail, hipStream_t s,
-                 const PoseImages& images, const FilterFuse* fuse, const FrameBatch* batch) {
+                 const PoseImages& images, const FilterFuse* fuse, const FrameBatch* batch, const PoseSplit* split) {
   if (max_clusters <= 0) return;
   mh_pose_params p = prm;
   p.max_objects_per_cluster = prm.max_objects_per_cluster > 0 ? prm.max_objects_per_cluster : 1;
@@ -1321,7 +1539,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                   images.cams, images.img_of, images.n_images, p,                                       \
                   seed, obj_base_dev, max_objects, obj_model, obj_pose, obj_ninl, obj_err,         \
                   obj_cluster,                                                                             \
-                  obj_valid, counts, tail, s, fuse, batch
+                  obj_valid, counts, tail, s, fuse, batch, split
   if (images.img_of && images.cams && kind == 0)
     launch_pose_kind<3>(POSE_ARGS);
   else if (kind == 1)

@@ -178,6 +178,21 @@ struct PoseImages {
 // Work of the last workgroup of a POSE launch inside a frame (ticket == nullptr: none):
 // *n_slots = min(max_objects, *obj_base_dev + n_clusters * R); optionally the number of
 // valid objects in [0, *n_slots) -> *snap_valid.
+// POSE as two launches (round 4): pose_kernel stops at a task's winning hypothesis and leaves it here, pose_refine_kernel
+// refines it -- one wavefront per task.  hyp [frame arena][object slot]; pts / list = per-frame scratch for clusters
+// whose points do not fit a wavefront's LDS cache (pts [max_m][9], list [4][max_m]).  hyp == nullptr: one launch.
+struct PoseHyp {
+  float pose[12];     // R (row major), t of the winner (world frame)
+  int32_t n_best;     // its inlier count; 0 = the task has no winner
+  int32_t flags;      // 1 = near miss (pose_task)
+  int32_t pad[2];
+};
+struct PoseSplit {
+  PoseHyp* hyp = nullptr;
+  float* pts = nullptr;
+  int32_t* list = nullptr;
+  int max_m = 0;
+};
 struct PoseTail {
   unsigned int* ticket;
   int32_t* n_slots;
@@ -213,7 +228,7 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
                  const int32_t* obj_base_dev, int max_objects, int32_t* obj_model, float* obj_pose,
                  int32_t* obj_ninl, float* obj_err, int32_t* obj_cluster, int32_t* obj_valid,
                  FrameCounts* counts, const PoseTail& tail, hipStream_t s, const PoseImages& images = PoseImages(),
-                 const FilterFuse* fuse = nullptr, const FrameBatch* batch = nullptr);
+                 const FilterFuse* fuse = nullptr, const FrameBatch* batch = nullptr, const PoseSplit* split = nullptr);
 // pose_kernel<kind>'s registers / LDS / threads / resident workgroups per compute unit / spill bytes (mh_pose_kernel_info)
 int pose_kernel_info(int kind, int32_t out[8]);
 void launch_project_test(const float* pose7, const mh_corr* corr, int n, const DevCam& cam,
