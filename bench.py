@@ -805,7 +805,8 @@ def main():
             frames_per_batch = B
             cu_s_per_frame = pm["pose_ms"] * 1e-3 / frames_per_batch   # wall time of the two launches per frame, isolated
             out["roofline"]["pose"] = {
-                "kernel": "pose_kernel<0> (POSE and POSE2 launches of one batch, isolated, HIP events by the library)",
+                "kernel": "pose_kernel<0> (POSE and POSE2 of one batch, isolated, HIP events by the library; stage timing keeps the "
+                          "steps apart, so this is the one-launch form -- the pipeline runs hypotheses and refines as two launches)",
                 "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "threads_per_workgroup": info["threads"],
                 "waves_per_simd": info["waves_per_simd"], "workgroups_per_cu": info["workgroups_per_cu"],
                 "tasks_per_frame": round(pm["tasks"], 1), "hypotheses_per_frame": round(pm["hyp"], 1),

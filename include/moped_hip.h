@@ -136,6 +136,11 @@ int mh_match_stats(mh_ctx* ctx, int Q, uint32_t stats[4], int reset);
  * matrix-pipe kernel (match_mfma_kernel) whatever the query count.  The results are the same bits in every
  * mode (tests/test_gpu_match_kernels.py compares them). */
 int mh_match_set_mode(mh_ctx* ctx, int mode);
+/* POSE / POSE2 of the device-resident frame paths as two launches (1, the default: the hypotheses of every (cluster,
+ * replica) task, then the refines on one wavefront each) or as one (0: the workgroup that found a task's winner refines it
+ * on one of its four wavefronts).  The objects are the same bits either way (tests/test_gpu_frame.py); the per-step entry
+ * points (mh_pose_ransac*) and frames with stage timing always run the one-launch form. */
+int mh_pose_set_split(mh_ctx* ctx, int on);
 /* MATCH launch sequences this context has issued, by the kernel that searched: out[0] = match_kernel (VALU),
  * out[1] = match_mfma_kernel (f32 matrix pipe), out[2] = the two-stage path.  Host counters, no synchronisation;
  * for tests that must know which kernel produced a result. */

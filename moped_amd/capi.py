@@ -104,7 +104,7 @@ EXPORTS = [
     "mh_models_create", "mh_models_destroy", "mh_models_last_error", "mh_models_add_xml",
     "mh_models_add_xml_buffer", "mh_models_count", "mh_models_rows", "mh_models_name", "mh_models_range",
     "mh_models_desc", "mh_models_xyz", "mh_models_save", "mh_models_load", "mh_db_upload_models",
-    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_match_launches", "mh_frame_fetch_match_points", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
+    "mh_db_upload_raw", "mh_db_share", "mh_match_stats", "mh_match_set_mode", "mh_match_launches", "mh_pose_set_split", "mh_frame_fetch_match_points", "mh_screen_margin", "mh_frame_counters", "mh_match_timing", "mh_frame_set_images", "mh_filter_images",
     "mh_pose_ransac_images",
     "mh_comm_unique_id", "mh_comm_create", "mh_comm_create_all", "mh_comm_create_host", "mh_comm_destroy", "mh_comm_info",
     "mh_frame_enqueue_sharded", "mh_frame_enqueue_sharded_batch", "mh_frame_enqueue_sharded_all",
@@ -227,6 +227,7 @@ def load():
     L.mh_match_stats.argtypes = [vp, i32, vp, i32]
     L.mh_match_set_mode.argtypes = [vp, i32]
     L.mh_match_launches.argtypes = [vp, vp]
+    L.mh_pose_set_split.argtypes = [vp, i32]
     L.mh_frame_counters.argtypes = [vp, vp]
     L.mh_frame_set_images.argtypes = [vp, vp, vp, i32]
     L.mh_filter_images.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f32, f32,
@@ -543,6 +544,10 @@ class Context:
         """-1 auto, 0 exact f32 kernels only, 1 two-stage (f16 screen + exact rescoring) whenever possible,
         2 / 3 the exact VALU / f32 matrix-pipe kernel whatever the query count."""
         self._ck(self.L.mh_match_set_mode(self.h, int(mode)), "mh_match_set_mode")
+
+    def pose_set_split(self, on: bool):
+        """POSE of the frame paths as two launches (hypotheses, then one-wavefront refines; the default) or as one."""
+        self._ck(self.L.mh_pose_set_split(self.h, int(bool(on))), "mh_pose_set_split")
 
     def match_kernel_launches(self) -> dict:
         """MATCH launch sequences of this context by the kernel that searched (mh_match_launches)."""

@@ -663,6 +663,12 @@ int mh_match_set_mode(mh_ctx* ctx, int mode) {
   return MH_OK;
 }
 
+int mh_pose_set_split(mh_ctx* ctx, int on) {
+  if (!ctx) return MH_ERR_ARG;
+  ctx->pose_split = on ? 1 : 0;
+  return MH_OK;
+}
+
 int mh_match_launches(mh_ctx* ctx, uint32_t out[3]) {
   if (!ctx || !out) return MH_ERR_ARG;
   for (int k = 0; k < 3; ++k) out[k] = ctx->match_launches[k];

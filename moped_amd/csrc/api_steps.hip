@@ -504,7 +504,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   ff2.feature_distance = prm->f2_feature_distance;
   ff2.min_score = prm->f2_min_score;
   PoseSplit split;
-  split.hyp = fused ? fs->hyp : nullptr;   // (the refine launch closes the frames through the fused FILTER tail)
+  split.hyp = (fused && ctx->pose_split) ? fs->hyp : nullptr;   // (the refine launch closes the frames through the fused FILTER tail)
   split.pts = fs->rf_pts;
   split.list = fs->rf_list;
   split.max_m = fs->max_m;

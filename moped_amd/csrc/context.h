@@ -69,6 +69,7 @@ struct mh_ctx {
   mh::ScreenDb sdb;
   mh::ScreenBufs sbuf;           // the screen's per-frame scratch
   int match_mode = -1;           // mh_match_set_mode
+  int pose_split = 1;            // mh_pose_set_split: POSE as two launches (hypotheses, one-wavefront refines) in the frame paths
   uint32_t match_launches[3] = {0, 0, 0};   // MATCH launch sequences by kernel: VALU, f32 matrix pipe, two-stage (mh_match_launches)
   struct mh_lane* lane = nullptr;   // mh_set_lane: where the chip-filling MATCH passes run (not owned)
   hipStream_t lane_stream = nullptr;

@@ -828,7 +828,9 @@ struct PoseLds {
 // `fa` = byte offset of the task's frame inside a batch's working arrays (FrameBatch): the pointers are the batch's
 // first frame's and are shifted here, at the task's few uses of them, not in the kernel's loop over the frames (where
 // thirty shifted pointers spilled).
-template <int KIND>
+// SPLIT: the task ends at its winning hypothesis (PoseHyp), the refine is pose_refine_kernel's -- the instantiation
+// then carries no LM code at all
+template <int KIND, bool SPLIT>
 __device__ void pose_task(
     PoseLds<KIND>& L, const int cluster, const int replica, const unsigned long long fa,
     const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
@@ -1123,7 +1125,7 @@ __device__ void pose_task(
   __syncthreads();
 
   PP_T(2);
-  if (hyp_out) {
+  if (SPLIT) {
     // split launch (PoseSplit): the winner goes to memory, the refine is pose_refine_kernel's -- one wavefront per task
     // there, several tasks per compute unit, instead of this workgroup's half compute unit held by one wavefront of four
     if (tid < 12) hyp_out[slot].pose[tid] = L.best_pose[tid];
@@ -1133,6 +1135,7 @@ __device__ void pose_task(
     }
     return;
   }
+  if (SPLIT) return;   // (not reached)
   // ---- refine on the winner's inliers, wavefront 0 ----------------------------------------
   if (wave != 0) return;
   float R[9], t[3];
@@ -1212,7 +1215,7 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
   }
 }
 
-template <int KIND>
+template <int KIND, bool SPLIT>
 __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
     const int32_t* __restrict__ members0,
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
   for (int f = 0; f < n_frames; ++f) {
     // frame f of a batch: its copy of the working arrays, its counts snapshot and result block
     const unsigned long long a = (unsigned long long)f * fbx.arena;
-    unsigned int* ticket = hyp0 ? nullptr : frame_ptr(tail0.ticket, a);
+    unsigned int* ticket = SPLIT ? nullptr : frame_ptr(tail0.ticket, a);
     const uint64_t seed = fbx.n > 1 ? fbx.seed[f] : seed0;
     const int n_tasks = fr_tasks[f];
     const int obj_base = fr_obj_base[f];
@@ -1255,7 +1258,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     int first = ((int)blockIdx.x - rank_base) % G;
     if (first < 0) first += G;
     for (int task = first; task < n_tasks; task += G) {
-      pose_task<KIND>(L, task / R_, task % R_, a, corr0, depth0, alpha, members0, cl_model0, cl_begin0, cl_count0, cam,
+      pose_task<KIND, SPLIT>(L, task / R_, task % R_, a, corr0, depth0, alpha, members0, cl_model0, cl_begin0, cl_count0, cam,
                       cam_table, img_of0, n_images, prm, seed, obj_base, max_objects, obj_model0, obj_pose0, obj_ninl0,
                       obj_err0, obj_cluster0, obj_valid0, counts0, hyp0);
       __syncthreads();  // LDS is reused by the next task
@@ -1285,8 +1288,11 @@ struct RefineLds {
   int closed[POSE_THREADS / 64], n_closed;
   DevCam cams[MH_MAX_IMAGES];
 };
+#ifndef MH_REFINE_MIN_WAVES
+#define MH_REFINE_MIN_WAVES 3
+#endif
 template <int KIND>
-__global__ __launch_bounds__(POSE_THREADS) void pose_refine_kernel(
+__global__ __launch_bounds__(POSE_THREADS, MH_REFINE_MIN_WAVES) void pose_refine_kernel(
     const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
     const int32_t* __restrict__ members0, const int32_t* __restrict__ cl_begin0, const int32_t* __restrict__ cl_count0,
     const int32_t* __restrict__ n_clusters_dev0, DevCam cam, const DevCam* __restrict__ cam_table,
@@ -1471,7 +1477,9 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
                              const PoseTail& tail, hipStream_t s, const FilterFuse* fuse, const FrameBatch* batch,
                              const PoseSplit* split) {
   static DynLds attr;   // one per KIND (this function is a template)
-  attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
+  static DynLds attr_s;
+  attr.ensure(pose_kernel<KIND, false>, sizeof(PoseLds<KIND>));
+  attr_s.ensure(pose_kernel<KIND, true>, sizeof(PoseLds<KIND>));
   // the fused FILTER step's arguments: on the device already unless they have changed since this context's last launch
   const FilterFuseArgs* fuse_dev = nullptr;
   if (fuse && fuse->fb && fuse->tail && tail.ticket && fuse->dev && fuse->shadow && fuse->shadow_valid) {
@@ -1494,24 +1502,30 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   }
   // one row of workgroups for all frames of the launch (tail.grid = the caller's guess of the launch's task count)
   const int n_frames = batch && batch->n > 1 ? batch->n : 1;
-  const int grid_cap = tail.grid > 0 ? std::min(tail.grid, POSE_GRID) : std::min(POSE_GRID, 96 * n_frames);
+  static const int pose_grid = std::max(8, exp_int("MH_POSE_GRID", POSE_GRID));
+  const int grid_cap = tail.grid > 0 ? std::min(tail.grid, pose_grid) : std::min(pose_grid, 96 * n_frames);
   const long all_slots = (long)max_clusters * p.max_objects_per_cluster * n_frames;
   // Two launches (PoseSplit: the frame paths hand in the scratch; MH_POSE_SPLIT=0 in experiment builds: one): the
   // hypotheses of every task, then the refines one wavefront each
   static const bool split_on = exp_int("MH_POSE_SPLIT", 1) != 0;
   const bool two = split_on && split && split->hyp && tail.ticket && p.max_objects_per_cluster <= 4;
-  hipLaunchKernelGGL(pose_kernel<KIND>, dim3((unsigned)std::max(1L, std::min((long)grid_cap, all_slots))), dim3(POSE_THREADS),
-                     sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin, cl_count,
-                     n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, obj_base_dev, max_objects, obj_model,
-                     obj_pose, obj_ninl,
-                     obj_err, obj_cluster, obj_valid, counts, tail, fuse_dev, batch ? *batch : FrameBatch(),
-                     two ? split->hyp : (PoseHyp*)nullptr);
+#define MH_POSE_LAUNCH(SPLIT_)                                                                                             \
+  hipLaunchKernelGGL((pose_kernel<KIND, SPLIT_>), dim3((unsigned)std::max(1L, std::min((long)grid_cap, all_slots))),       \
+                     dim3(POSE_THREADS), sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin,        \
+                     cl_count, n_clusters_dev, cam, cam_table, img_of, n_images, p, seed, obj_base_dev, max_objects,      \
+                     obj_model, obj_pose, obj_ninl, obj_err, obj_cluster, obj_valid, counts, tail, fuse_dev,              \
+                     batch ? *batch : FrameBatch(), two ? split->hyp : (PoseHyp*)nullptr)
+  if (two) MH_POSE_LAUNCH(true);
+  else MH_POSE_LAUNCH(false);
+#undef MH_POSE_LAUNCH
   if (two) {
     static DynLds attr_r;
     attr_r.ensure(pose_refine_kernel<KIND>, sizeof(RefineLds<KIND>));
     // four tasks per workgroup and round; the guess of the task count sizes the grid, more tasks take more rounds
     const long guess = tail.grid > 0 ? tail.grid : 96L * n_frames;
-    const unsigned g2 = (unsigned)std::max(1L, std::min(std::min(256L, (guess + 3) / 4), (all_slots + 3) / 4));
+    static const long g2_cap = std::max(1, exp_int("MH_POSE_RGRID", 256));
+    static const int g2_div = std::max(1, exp_int("MH_POSE_RDIV", 4));   // tasks per workgroup the grid is sized for
+    const unsigned g2 = (unsigned)std::max(1L, std::min(std::min(g2_cap, (guess + g2_div - 1) / g2_div), (all_slots + 3) / 4));
     hipLaunchKernelGGL(pose_refine_kernel<KIND>, dim3(g2), dim3(POSE_THREADS), sizeof(RefineLds<KIND>), s, corr, depth, alpha,
                        members, cl_begin, cl_count, n_clusters_dev, cam, cam_table, img_of, n_images, p, obj_base_dev,
                        max_objects, obj_pose, obj_ninl, obj_err, obj_valid, counts, tail, fuse_dev,
@@ -1556,11 +1570,11 @@ void launch_pose(const mh_corr* corr, const float* depth4, int depth_kind, float
 template <int KIND>
 static int pose_info_kind(int32_t out[8]) {
   static DynLds attr;
-  attr.ensure(pose_kernel<KIND>, sizeof(PoseLds<KIND>));
+  attr.ensure(pose_kernel<KIND, true>, sizeof(PoseLds<KIND>));   // (the hypothesis kernel of the frame paths' two launches)
   hipFuncAttributes fa;
-  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pose_kernel<KIND>)) != hipSuccess) return MH_ERR_HIP;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pose_kernel<KIND, true>)) != hipSuccess) return MH_ERR_HIP;
   int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pose_kernel<KIND>, POSE_THREADS, sizeof(PoseLds<KIND>)) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, pose_kernel<KIND, true>, POSE_THREADS, sizeof(PoseLds<KIND>)) != hipSuccess)
     blocks = 0;
   out[0] = fa.numRegs;
   out[1] = (int32_t)(fa.sharedSizeBytes + sizeof(PoseLds<KIND>));

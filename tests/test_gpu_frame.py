@@ -140,3 +140,39 @@ def test_randomised_frames_against_the_oracle_pipeline():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "frame_stress.py"), "18", "5"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_pose_as_two_launches_gives_the_bits_of_the_one_launch_form(world):
+    """mh_pose_set_split: the hypotheses of every task in pose_kernel and the refines in pose_refine_kernel (one wavefront
+    per task; the default of the frame paths since round 4) against the workgroup that found a task's winner refining it
+    itself -- frames alone and the same frames as one batch, 0 to 10 visible objects: the same objects bit for bit (the
+    refine is the same code on the same points, in LDS or, for clusters past the refine's cache, in global scratch)."""
+    db, dbn, pipe, torch = world
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    dev = torch.device("cuda:0")
+    frs = [synth.make_frame(db, n_vis=n, seed=300 + i) for i, n in enumerate((2, 5, 10, 0, 1, 3, 2, 7))]
+    big = synth.make_frame(db, n_vis=1, seed=77, pts_per_obj=420, outlier_frac=0.0)     # one cluster past the 320-point cache
+    B = len(frs)
+    p2 = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=2, max_queries=B * 3000, batch=B)
+    qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    res = {}
+    for split in (0, 1):
+        for c in p2.ctxs:
+            c.pose_set_split(split)
+        out = []
+        for i, fr in enumerate(frs + [big]):
+            p2.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=50 + i)
+            out.append(p2.fetch(0))
+        qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        p2.enqueue_batch(1, qd, uv, B, [50 + i for i in range(B)])
+        out += p2.fetch_batch(1, B)
+        res[split] = out
+    n_obj = 0
+    for (o0, c0), (o1, c1) in zip(res[0], res[1]):
+        assert np.array_equal(c0, c1) and np.array_equal(o0["model"], o1["model"])
+        assert np.array_equal(o0["pose"].view(np.uint32), o1["pose"].view(np.uint32))
+        assert np.array_equal(o0["score"].view(np.uint32), o1["score"].view(np.uint32))
+        n_obj += len(o1)
+    assert n_obj >= 2 * 30 and len(res[1][B][0]) == 1     # the 420-point object is found (its cluster does not fit the cache)
+    p2.close()
