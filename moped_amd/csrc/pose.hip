@@ -1508,7 +1508,10 @@ static void launch_pose_kind(const mh_corr* corr, const float4* depth, float alp
   // Two launches (PoseSplit: the frame paths hand in the scratch; MH_POSE_SPLIT=0 in experiment builds: one): the
   // hypotheses of every task, then the refines one wavefront each
   static const bool split_on = exp_int("MH_POSE_SPLIT", 1) != 0;
-  const bool two = split_on && split && split->hyp && tail.ticket && p.max_objects_per_cluster <= 4;
+  // (one frame alone with a handful of tasks: the launch the split adds costs more than the compute units it frees --
+  //  0.688 against 0.675 ms per isolated frame; the objects are the same bits either way)
+  const bool two = split_on && split && split->hyp && tail.ticket && p.max_objects_per_cluster <= 4 &&
+                   (n_frames > 1 || (tail.grid > 0 ? tail.grid : 96) > 48);
 #define MH_POSE_LAUNCH(SPLIT_)                                                                                             \
   hipLaunchKernelGGL((pose_kernel<KIND, SPLIT_>), dim3((unsigned)std::max(1L, std::min((long)grid_cap, all_slots))),       \
                      dim3(POSE_THREADS), sizeof(PoseLds<KIND>), s, corr, depth, alpha, members, cl_model, cl_begin,        \
