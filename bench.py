@@ -292,10 +292,10 @@ def default_batch(args, sharded: bool) -> int:
     # sixteen frames per MATCH launch sequence (48 000 queries: three rounds of pass B workgroups that sweep 49 tiles each
     # instead of two rounds of 38 for eight frames -- fewer prologues and a fuller last query block per frame: +2.7% on
     # config 1, +1.6% on config 2); a batch of plain frames also shares the launches of its rest chain (one group /
-    # CLUSTER / POSE / POSE2 launch for all of them).  Frames with depth maps go frame after frame: four
-    # (round 4: frames with depth ATTRIBUTES share their launches like plain frames -- sixteen; frames that bring the depth
-    # map itself and run moped3d's front end on it still go frame after frame: four)
-    return 4 if args.moped3d_frontend else 16
+    # CLUSTER / POSE / POSE2 launch for all of them).  Round 4: frames with depth ATTRIBUTES share their launches like
+    # plain frames, and so do frames that bring the depth map itself and run moped3d's front end on it (a depth map per
+    # frame of the batch, DepthMaps): sixteen everywhere (front end: 5 270 / 5 920 / 6 290 frames/s at 4 / 8 / 16).
+    return 16
 
 
 class Job:

@@ -289,19 +289,22 @@ int ensure_linkage_scratch(mh_ctx* ctx, size_t floats) {
 }
 
 // Device buffers of the depth rules: patch map, per-(model, patch) counts (kept zero), keep flags.
-int ensure_rule_buffers(mh_ctx* ctx, int patches, int Q) {
+// (frames > 1: a merged batch -- every frame's patch map, counters and keep flags, frame after frame)
+int ensure_rule_buffers(mh_ctx* ctx, int patches, int Q, int frames = 1) {
   mh_ctx::DepthRuleState& rs = ctx->rules;
   if (patches > 4096) {
     ctx->err = "depth rules: more than 4096 patches (raise PatchSize)";
     return MH_ERR_CAPACITY;
   }
-  if (patches > rs.patches_cap) {
+  Q *= frames;
+  if (patches * frames > rs.patches_cap) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (rs.inv_size) MH_HIP(ctx, hipFree(rs.inv_size));
     rs.inv_size = nullptr;
-    MH_HIP(ctx, hipMalloc(&rs.inv_size, sizeof(double) * patches));
-    rs.patches_cap = patches;
+    MH_HIP(ctx, hipMalloc(&rs.inv_size, sizeof(double) * patches * frames));
+    rs.patches_cap = patches * frames;
   }
-  const size_t need = (size_t)std::max(ctx->n_models, 1) * patches;
+  const size_t need = (size_t)std::max(ctx->n_models, 1) * patches * frames;
   if (need > rs.cnt_cap) {
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (rs.cnt) MH_HIP(ctx, hipFree(rs.cnt));
@@ -402,18 +405,28 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     ctx->err = "frames with several images: the moped3d depth steps are single-camera";
     return MH_ERR_ARG;
   }
+  // a merged batch with a depth map per frame (mh_frame_set_depth_image_batch; merged_batch_ok has checked the count)
+  DepthMaps dmaps;
+  const DepthMaps* maps = nullptr;
+  if (batch_n > 1 && ctx->depth_img.img) {
+    for (int f = 0; f < batch_n; ++f) {
+      dmaps.img[f] = ctx->batch_img[f];
+      dmaps.fill[f] = ctx->batch_fill[f];
+    }
+    maps = &dmaps;
+  }
   // moped3d depth rules: patch maps of this frame's depth image, DEPTHFILTER on the features
   DepthRules rules;
   if (ctx->rules.on && ctx->depth_img.img) {
     mh_ctx::DepthRuleState& rs = ctx->rules;
     const int pw = (ctx->depth_img.w + rs.patch - 1) / rs.patch, ph = (ctx->depth_img.h + rs.patch - 1) / rs.patch;
-    int rc = ensure_rule_buffers(ctx, pw * ph, Q);
+    int rc = ensure_rule_buffers(ctx, pw * ph, Q, batch_n);
     if (rc) return rc;
     const bool filters = rs.feature_filter >= 0.f || rs.match_filter >= 0.f;
-    if (filters) launch_depth_patches(ctx->depth_img, rs.K, rs.patch, rs.inv_size, s);
+    if (filters) launch_depth_patches(ctx->depth_img, rs.K, rs.patch, rs.inv_size, s, maps, batch_n);
     if (rs.feature_filter >= 0.f) {
       launch_feature_density(q_uv_dev, Q, ctx->feat_count_dev, rs.patch, pw, ph, rs.inv_size, rs.feature_filter,
-                             rs.keep1, s);
+                             rs.keep1, s, batch_n);
       rules.keep1 = rs.keep1;
     }
     if (rs.match_filter >= 0.f) {
@@ -437,19 +450,21 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                ctx->q_depth ? ctx->q_depth + q0 : nullptr,   // (a batch's depth attributes lie frame after frame like its queries)
                fs->m_depth, ctx->depth_img, fs->counts, fs->n_slots, fs->best, s, rules,
                gathered ? ctx->exchange_stride : 0, gathered ? ctx->exchange_plane : 0, b1,
-               fs->slot == 0 ? ctx->exchange_tags : nullptr);
+               fs->slot == 0 ? ctx->exchange_tags : nullptr, maps);
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   const bool have_depth = ctx->q_depth || ctx->depth_img.img;
   if (ctx->linkage_on && have_depth && ctx->depth_img.img) {
     // moped3d: linkage over similarity matrices; 3 n^2 floats of scratch per model, n <= LK_CAP
+    // (a merged batch: every frame its own region)
     const size_t need = 3 * (size_t)std::min(fs->max_m, LK_CAP) * (size_t)fs->max_m;
-    int rc = ensure_linkage_scratch(ctx, need);
+    int rc = ensure_linkage_scratch(ctx, need * (size_t)std::max(1, batch_n));
     if (rc) return rc;
     launch_linkage_models(fs->m_corr, reinterpret_cast<const float*>(fs->m_depth), fs->model_off, nm, ctx->depth_img,
-                          ctx->linkage, ctx->lk_scratch, ctx->lk_scratch_floats, fs->ms_members, fs->ms_cl_start,
-                          fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count, fs->n_clusters,
-                          snap, fs->counts, fs->tickets + 0, s, ms_grid);
+                          ctx->linkage, ctx->lk_scratch, batch_n > 1 ? need : ctx->lk_scratch_floats, fs->ms_members,
+                          fs->ms_cl_start, fs->ms_ncl, fs->max_clusters, fs->cl_model, fs->cl_begin, fs->cl_count,
+                          fs->n_clusters, snap, fs->counts, fs->tickets + 0, s, ms_grid, b1, maps,
+                          fs->fb + 2 * MH_MAX_BATCH);
   } else if (multi) {
     // MeanShift per (model, image) in image order (CLUSTER_MEAN_SHIFT_CPU.hpp:189-195)
     launch_image_split(fs->m_corr, fs->m_q, fs->m_model, fs->model_off, nm, ctx->q_img + (size_t)ctx->batch_f * Q, ctx->n_images, fs->counts,
@@ -550,11 +565,16 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
 // Per-query depth ATTRIBUTES (mh_frame_set_depth: B Q entries, frame after frame like the queries) travel with a merged
 // batch where the caller says so (`attrs_ok`: mh_frame_enqueue_batch) -- group_kernel takes frame f's slice, the per-frame
 // arenas hold every frame's m_depth, pose_kernel<1 | 2> shifts its pointers like pose_kernel<0>.
-bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm, bool attrs_ok = false) {
+// A depth MAP per frame (mh_frame_set_depth_image_batch with as many maps as the batch has frames: `maps_for`), the depth
+// rules and the linkage clusterer travel with it too (round 4): depth_patch / feature_density / group / linkage_models
+// take frame f's map from a DepthMaps table and its rule buffers behind those of the frames before it.
+bool merged_batch_ok(const mh_ctx* ctx, const mh_frame_params* prm, bool attrs_ok = false, int maps_for = 0) {
   static const bool on = exp_int("MH_MERGE_BATCH", 1) != 0;
   static const bool fuse_filter = exp_int("MH_FUSE_FILTER", 1) != 0;
-  return on && fuse_filter && prm->run_stage2 && !ctx->timing && (attrs_ok || !ctx->q_depth) && !ctx->depth_img.img &&
-         !ctx->rules.on && !ctx->linkage_on && !(ctx->q_img && ctx->n_images > 1);
+  static const bool merge_maps = exp_int("MH_MERGE_MAPS", 1) != 0;
+  const bool maps_ok = merge_maps && attrs_ok && maps_for > 1 && ctx->batch_imgs == maps_for && ctx->depth_img.img;
+  return on && fuse_filter && prm->run_stage2 && !ctx->timing && (attrs_ok || !ctx->q_depth) &&
+         (maps_ok || (!ctx->depth_img.img && !ctx->rules.on && !ctx->linkage_on)) && !(ctx->q_img && ctx->n_images > 1);
 }
 
 int ensure_batch_arenas(mh_ctx* ctx, int B) {
@@ -1507,7 +1527,7 @@ int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
-  const bool merge = B > 1 && merged_batch_ok(ctx, prm, true);
+  const bool merge = B > 1 && merged_batch_ok(ctx, prm, true, B);
   int rc = prepare_frame(ctx, B * Q, Q, merge ? B : 1);   // (the arenas before any work is enqueued)
   if (rc) return rc;
   ctx->feat_count_dev = nullptr;

@@ -9,6 +9,8 @@
 //                     and on the model of its nearest neighbour.
 // Arithmetic follows the reference's expressions literally (float / double mix included); the
 // build has -ffp-contract=off.  The per-match parts live in group_kernel (group.hip).
+#include <algorithm>
+
 #include "steps.h"
 
 namespace mh {
@@ -36,10 +38,15 @@ __device__ __forceinline__ float eucl_dist(const float* a, const float* b) {
 // One workgroup per patch: minimum depth (:157-166, std::min semantics: NaN never wins), then
 // the patch's area at that depth (getArea :50-61, with the reference's `y1 = min(.., width)`)
 // and 1.0 / area as the double every feature of the patch adds to its density.
+// blockIdx.y = frame of a batch: its own depth map (DepthMaps), its own patch map behind the frames' before it.
 __global__ __launch_bounds__(DP_THREADS) void depth_patch_kernel(const float4* __restrict__ img, int w, int h,
                                                                  float k0, float k1, float k2, float k3, int patch,
-                                                                 int pw, double* __restrict__ inv_size) {
+                                                                 int pw, double* __restrict__ inv_size, DepthMaps maps) {
   __shared__ float red[DP_THREADS];
+  if (blockIdx.y) {
+    img = maps.img[blockIdx.y];
+    inv_size += (size_t)blockIdx.y * gridDim.x;
+  }
   const int p = blockIdx.x, px = p % pw, py = p / pw;
   const int x0 = px * patch, y0 = py * patch;
   const int x1 = min((px + 1) * patch, w), y1 = min((py + 1) * patch, h);
@@ -85,6 +92,11 @@ __global__ __launch_bounds__(1024) void feature_density_kernel(const float* __re
   __shared__ int cnt[DF_MAX_PATCHES];
   __shared__ float val[DF_MAX_PATCHES];
   const int P = pw * ph;
+  if (blockIdx.y) {   // frame of a batch: keypoints and flags frame after frame, the patch maps too
+    q_uv += 2 * (size_t)blockIdx.y * Q;
+    keep += (size_t)blockIdx.y * Q;
+    inv_size += (size_t)blockIdx.y * P;
+  }
   if (q_count) Q = min(Q, *q_count);
   for (int p = threadIdx.x; p < P; p += blockDim.x) cnt[p] = 0;
   __syncthreads();
@@ -100,17 +112,19 @@ __global__ __launch_bounds__(1024) void feature_density_kernel(const float* __re
 
 }  // namespace
 
-void launch_depth_patches(const DepthImage& dimg, const float K[4], int patch, double* inv_size, hipStream_t s) {
+void launch_depth_patches(const DepthImage& dimg, const float K[4], int patch, double* inv_size, hipStream_t s,
+                          const DepthMaps* maps, int n_frames) {
   const int pw = (dimg.w + patch - 1) / patch, ph = (dimg.h + patch - 1) / patch;
-  hipLaunchKernelGGL(depth_patch_kernel, dim3(pw * ph), dim3(DP_THREADS), 0, s, dimg.img, dimg.w, dimg.h, K[0], K[1],
-                     K[2], K[3], patch, pw, inv_size);
+  const bool batch = maps && n_frames > 1;
+  hipLaunchKernelGGL(depth_patch_kernel, dim3(pw * ph, batch ? n_frames : 1), dim3(DP_THREADS), 0, s, dimg.img, dimg.w,
+                     dimg.h, K[0], K[1], K[2], K[3], patch, pw, inv_size, batch ? *maps : DepthMaps());
 }
 
 void launch_feature_density(const float* q_uv, int Q, const int32_t* q_count, int patch, int pw, int ph,
-                            const double* inv_size, float filter, uint8_t* keep, hipStream_t s) {
+                            const double* inv_size, float filter, uint8_t* keep, hipStream_t s, int n_frames) {
   if (Q <= 0) return;
-  hipLaunchKernelGGL(feature_density_kernel, dim3(1), dim3(1024), 0, s, q_uv, Q, q_count, patch, pw, ph, inv_size,
-                     filter, keep);
+  hipLaunchKernelGGL(feature_density_kernel, dim3(1, std::max(1, n_frames)), dim3(1024), 0, s, q_uv, Q, q_count, patch, pw,
+                     ph, inv_size, filter, keep);
 }
 
 }  // namespace mh

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     int32_t* __restrict__ model_off, const mh_depth* __restrict__ q_depth,
     mh_depth* __restrict__ m_depth, DepthImage dimg, FrameCounts* counts, int32_t* __restrict__ n_slots,
     unsigned long long* __restrict__ best, DepthRules rules, int shard_stride, int plane_stride, FrameBatch fbx,
-    const int32_t* __restrict__ tags) {
+    const int32_t* __restrict__ tags, DepthMaps maps) {
   MH_TRACE_SCOPE(mh::TK_GROUP);
   if (blockIdx.y) {   // frame of a batch: its slice of the top-2 arrays / keypoints, its copy of the working arrays
     const unsigned long long a = blockIdx.y * fbx.arena;
@@ -95,6 +95,14 @@ __global__ __launch_bounds__(GROUP_THREADS) void group_kernel(
     m_model = frame_ptr(m_model, a); m_corr = frame_ptr(m_corr, a); m_rep = frame_ptr(m_rep, a);
     model_off = frame_ptr(model_off, a); m_depth = frame_ptr(m_depth, a); counts = frame_ptr(counts, a);
     n_slots = frame_ptr(n_slots, a); best = frame_ptr(best, a);
+    if (dimg.img) {   // a depth map per frame (DepthMaps), the frame's rule buffers behind those of the frames before it
+      dimg.img = maps.img[blockIdx.y];
+      dimg.fill = maps.fill[blockIdx.y];
+      const size_t P = (size_t)rules.pw * rules.ph;
+      if (rules.keep1) rules.keep1 += q0;
+      if (rules.inv_size) rules.inv_size += blockIdx.y * P;
+      if (rules.cnt) rules.cnt += blockIdx.y * P * n_models;
+    }
   }
   __shared__ int hist[GROUP_MAX_MODELS + 1];
   __shared__ int wave_cnt[GROUP_THREADS / 64];
@@ -472,12 +480,13 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int32_t* m_q, int32_t* m_model, mh_corr* m_corr, int32_t* m_rep,
                   int32_t* model_off, const mh_depth* q_depth, mh_depth* m_depth, const DepthImage& dimg,
                   FrameCounts* counts, int32_t* n_slots, unsigned long long* best, hipStream_t s,
-                  const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch, const int32_t* tags) {
+                  const DepthRules& rules, int shard_stride, int plane_stride, const FrameBatch* batch, const int32_t* tags,
+                  const DepthMaps* maps) {
   hipLaunchKernelGGL(group_kernel, dim3(1, batch ? batch->n : 1), dim3(GROUP_THREADS), 0, s, gathered, n_shards, idx1, d1, d2,
                      Q, ratio, q_uv, db_model, db_xyz, N, rmap, n_models, max_m, acc_q, acc_model,
                      m_q, m_model, m_corr, m_rep, model_off, q_depth, m_depth, dimg, counts, n_slots, best, rules,
                      shard_stride > 0 ? shard_stride : 3 * Q, plane_stride > 0 ? plane_stride : Q,
-                     batch ? *batch : FrameBatch(), gathered ? tags : nullptr);
+                     batch ? *batch : FrameBatch(), gathered ? tags : nullptr, (batch && maps) ? *maps : DepthMaps());
 }
 
 void launch_image_split(const mh_corr* m_corr, const int32_t* m_q, const int32_t* m_model, const int32_t* model_off,

@@ -15,6 +15,8 @@
 // oracle/linkage_oracle.cpp): per merge, a parallel arg-max over the candidate pairs in the
 // reference's scan order (first maximum wins), the average-linkage row update, the reversed
 // append of the absorbed cluster.
+#include <algorithm>
+
 #include "steps.h"
 
 namespace mh {
@@ -396,86 +398,115 @@ __device__ void linkage_body(LkLds& L, const mh_corr* __restrict__ corr, const f
   }
 }
 
-// Frame form: one workgroup per model over the frame's match lists; the model's scratch region
-// starts after the regions of the models before it.  Tail as in the mean-shift kernel.
+// Frame form: a few workgroups over the frame's (a batch's frames') match lists; a model's scratch region starts after
+// the regions of the models before it, a frame's after the frames' before it (`scratch_floats` each).  As in
+// meanshift_models_kernel: ONE row of workgroups for all frames of the launch, every workgroup walks the frames, lists
+// the models with more than MinPts matches and takes those whose number -- counted through the frames -- is its own
+// modulo the grid; the workgroup that finishes a frame's last model lays the frame's cluster table out.  Frame f of a
+// batch reads ITS depth map (maps.img[f]) and its copy of the working arrays (FrameBatch).
 __global__ __launch_bounds__(LK_THREADS) void linkage_models_kernel(
-    const mh_corr* __restrict__ corr, const float4* __restrict__ depth4, const int32_t* __restrict__ model_off,
-    int n_models, DepthImage dimg, LinkageParams P, float* __restrict__ scratch, size_t scratch_floats,
-    int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* __restrict__ cl_model,
-    int32_t* __restrict__ cl_begin, int32_t* __restrict__ cl_count, int32_t* __restrict__ n_clusters_out,
-    int32_t* __restrict__ snap, FrameCounts* counts, unsigned int* ticket) {
+    const mh_corr* __restrict__ corr0, const float4* __restrict__ depth40, const int32_t* __restrict__ model_off0,
+    int n_models, DepthImage dimg, LinkageParams P, float* __restrict__ scratch0, size_t scratch_floats,
+    int32_t* members0, int32_t* cl_start0, int32_t* ncl0, int max_clusters, int32_t* __restrict__ cl_model0,
+    int32_t* __restrict__ cl_begin0, int32_t* __restrict__ cl_count0, int32_t* __restrict__ n_clusters_out0,
+    int32_t* __restrict__ snap0, FrameCounts* counts0, unsigned int* ticket0, FrameBatch fbx, DepthMaps maps,
+    int32_t* __restrict__ feedback) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LkLds& L = *reinterpret_cast<LkLds*>(smem);
-  // A few workgroups share the models that have matches (as meanshift_models_kernel does: a workgroup of this kernel
-  // needs most of a compute unit's LDS, and one per model made every empty model wait for a CU to drain).
   __shared__ unsigned long long busy[LK_THREADS / 64];
-  int rank = 0;
-  for (int c0 = 0; c0 < n_models; c0 += LK_THREADS) {
-    {
-      const int mm = c0 + threadIdx.x;
-      int nn = mm < n_models ? model_off[mm + 1] - model_off[mm] : 0;
-      if (nn <= P.min_pts) {   // a cluster is only emitted with MORE than MinPts members (CLUSTER_LINKAGE_CPU.hpp:537)
-        if (mm < n_models && blockIdx.x == 0) ncl[mm] = 0;
-        nn = 0;
-      }
-      const unsigned long long bl = __ballot(nn > 0);
-      if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
+  const int G = (int)gridDim.x;
+  const int n_frames = fbx.n > 1 ? fbx.n : 1;
+  int rank = 0;   // models with work, counted through the frames of the launch
+  for (int f = 0; f < n_frames; ++f) {
+    const unsigned long long a = (unsigned long long)f * fbx.arena;
+    const mh_corr* corr = frame_ptr(corr0, a);
+    const float4* depth4 = frame_ptr(depth40, a);
+    const int32_t* model_off = frame_ptr(model_off0, a);
+    int32_t* members = frame_ptr(members0, a);
+    int32_t* cl_start = frame_ptr(cl_start0, a);
+    int32_t* ncl = frame_ptr(ncl0, a);
+    FrameCounts* counts = frame_ptr(counts0, a);
+    unsigned int* ticket = frame_ptr(ticket0, a);
+    float* scratch = scratch0 + (size_t)f * scratch_floats;
+    if (f) {
+      dimg.img = maps.img[f];
+      dimg.fill = maps.fill[f];
     }
-    __syncthreads();
-    for (int wd = 0; wd < LK_THREADS / 64; ++wd) {
-      for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank) {
-        if (rank % (int)gridDim.x != (int)blockIdx.x) continue;
-        const int m = c0 + wd * 64 + __builtin_ctzll(bits);
-        const int b = model_off[m];
-        int n = model_off[m + 1] - b;
-        size_t base = 0;   // floats before this model's region: 3 n'^2 per earlier model
-        for (int mm = 0; mm < m; ++mm) {
-          size_t k = (size_t)(model_off[mm + 1] - model_off[mm]);
-          if (k > LK_CAP) k = LK_CAP;
-          base += 3 * k * k;
-        }
-        if (n > LK_CAP) {
-          if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
-          n = LK_CAP;
-        }
-        __syncthreads();   // the previous model's LDS is done with
-        if (base + 3 * (size_t)n * n > scratch_floats) {
-          if (threadIdx.x == 0) {
-            atomicOr(&counts->error, ERR_MS_CAP);
-            ncl[m] = 0;
+    int n_busy = 0, mine = 0;
+    for (int c0 = 0; c0 < n_models; c0 += LK_THREADS) {
+      {
+        const int mm = c0 + threadIdx.x;
+        int nn = mm < n_models ? model_off[mm + 1] - model_off[mm] : 0;
+        if (nn <= P.min_pts) nn = 0;   // a cluster is only emitted with MORE than MinPts members (CLUSTER_LINKAGE_CPU.hpp:537)
+        const unsigned long long bl = __ballot(nn > 0);
+        if ((threadIdx.x & 63) == 0) busy[threadIdx.x >> 6] = bl;
+      }
+      __syncthreads();
+      for (int wd = 0; wd < LK_THREADS / 64; ++wd) {
+        for (unsigned long long bits = busy[wd]; bits; bits &= bits - 1ull, ++rank, ++n_busy) {
+          if (rank % G != (int)blockIdx.x) continue;
+          ++mine;
+          const int m = c0 + wd * 64 + __builtin_ctzll(bits);
+          const int b = model_off[m];
+          int n = model_off[m + 1] - b;
+          size_t base = 0;   // floats before this model's region: 3 n'^2 per earlier model
+          for (int mm = 0; mm < m; ++mm) {
+            size_t k = (size_t)(model_off[mm + 1] - model_off[mm]);
+            if (k > LK_CAP) k = LK_CAP;
+            base += 3 * k * k;
           }
-        } else {
-          float* A = scratch + base;
-          float* Dm = A + (size_t)n * n;
-          int32_t* mem = reinterpret_cast<int32_t*>(Dm + (size_t)n * n);
-          linkage_body(L, corr + b, depth4 + b, n, dimg, P, A, Dm, mem, members + b, b, cl_start + b + m, ncl + m, nullptr);
+          if (n > LK_CAP) {
+            if (threadIdx.x == 0) atomicOr(&counts->error, ERR_MS_CAP);
+            n = LK_CAP;
+          }
+          __syncthreads();   // the previous model's LDS is done with
+          if (base + 3 * (size_t)n * n > scratch_floats) {
+            if (threadIdx.x == 0) {
+              atomicOr(&counts->error, ERR_MS_CAP);
+              ncl[m] = 0;
+            }
+          } else {
+            float* A = scratch + base;
+            float* Dm = A + (size_t)n * n;
+            int32_t* mem = reinterpret_cast<int32_t*>(Dm + (size_t)n * n);
+            linkage_body(L, corr + b, depth4 + b, n, dimg, P, A, Dm, mem, members + b, b, cl_start + b + m, ncl + m, nullptr);
+          }
         }
       }
+      __syncthreads();   // (busy[] is rewritten for the next thousand)
     }
-    __syncthreads();   // (busy[] is rewritten for the next thousand)
-  }
-  if (!last_workgroup(ticket) || threadIdx.x != 0) return;
-  int k = 0;
-  for (int mm = 0; mm < n_models; ++mm) {
-    const int bb = model_off[mm];
-    const int32_t* st = cl_start + bb + mm;
-    const int nc = ncl[mm];
-    for (int c = 0; c < nc; ++c) {
-      if (k >= max_clusters) {
-        atomicOr(&counts->error, ERR_CLUSTER_CAP);
-        break;
+    bool last = false;
+    if (mine > 0) last = frame_work_done(ticket, (unsigned)mine, (unsigned)n_busy);
+    else if (n_busy == 0) last = (int)blockIdx.x == f % G;
+    if (!last || threadIdx.x != 0) continue;
+    if (feedback) feedback[f] = n_busy;   // what the next launches size their grids by
+    int32_t* cl_model = frame_ptr(cl_model0, a);
+    int32_t* cl_begin = frame_ptr(cl_begin0, a);
+    int32_t* cl_count = frame_ptr(cl_count0, a);
+    int k = 0;
+    for (int mm = 0; mm < n_models; ++mm) {
+      const int bb = model_off[mm];
+      const bool work = model_off[mm + 1] - bb > P.min_pts;
+      const int32_t* st = cl_start + bb + mm;
+      const int nc = work ? ncl[mm] : 0;   // (a model without work was never clustered)
+      if (!work) ncl[mm] = 0;
+      for (int c = 0; c < nc; ++c) {
+        if (k >= max_clusters) {
+          atomicOr(&counts->error, ERR_CLUSTER_CAP);
+          break;
+        }
+        cl_model[k] = mm;
+        cl_begin[k] = bb + st[c];
+        cl_count[k] = st[c + 1] - st[c];
+        ++k;
       }
-      cl_model[k] = mm;
-      cl_begin[k] = bb + st[c];
-      cl_count[k] = st[c + 1] - st[c];
-      ++k;
     }
-  }
-  counts->n_clusters = k;
-  *n_clusters_out = k;
-  if (snap) {
-    snap[0] = counts->n_matches;
-    snap[1] = k;
+    counts->n_clusters = k;
+    *frame_ptr(n_clusters_out0, a) = k;
+    if (snap0) {
+      snap0[4 * f] = counts->n_matches;
+      snap0[4 * f + 1] = k;
+    }
   }
 }
 
@@ -516,13 +547,16 @@ void launch_linkage_models(const mh_corr* corr, const float* depth4, const int32
                            const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                            int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                            int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid) {
+                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid, const FrameBatch* batch,
+                           const DepthMaps* maps, int32_t* feedback) {
   set_lds(linkage_models_kernel);
-  const int wgs = std::max(1, grid > 0 ? std::min(grid, n_models) : n_models);
+  const long n_frames = batch && batch->n > 1 ? batch->n : 1;
+  const long all = std::max(1L, (long)n_models * n_frames);
+  const int wgs = (int)std::max(1L, grid > 0 ? std::min((long)grid, all) : std::min(all, 256L));
   hipLaunchKernelGGL(linkage_models_kernel, dim3(wgs), dim3(LK_THREADS), sizeof(LkLds), s, corr,
                      reinterpret_cast<const float4*>(depth4), model_off, n_models, dimg, prm, scratch, scratch_floats,
                      members, cl_start, ncl, max_clusters, cl_model, cl_begin, cl_count, n_clusters_out, snap, counts,
-                     ticket);
+                     ticket, batch ? *batch : FrameBatch(), (maps && n_frames > 1) ? *maps : DepthMaps(), feedback);
 }
 
 void launch_linkage_batch(const mh_corr* corr, const float* depth4, const int32_t* off, int n_problems,

@@ -999,6 +999,8 @@ __device__ __forceinline__ void merge(Best& a, float ob1, float ob2, int oi1) { 
 // wave-uniform (LDS broadcast reads), the row comes straight from HBM / the Infinity Cache, 16 bytes per load.
 constexpr int RS_WAVES = 4;          // queries per workgroup
 constexpr int RS_MAXC = 1024;        // candidate rows a query may have before it is searched by brute force
+constexpr int RS_STAGE = 8;          // candidate rows staged through LDS (8 x 512 bytes = the candidate list's 4 KB)
+static_assert(RS_STAGE * DIM * 4 <= RS_MAXC * 4 && RS_STAGE % 2 == 0 && RS_STAGE <= 32, "staged rows live in the candidate list's LDS");
 
 __device__ __forceinline__ float exact_dist(const float* __restrict__ q_lds, const float* __restrict__ row, float nq, float dn) {
   // 64 bytes x 2 in flight per step: 48 VGPRs, ten wavefronts per SIMD.  (Round 3: the whole 512-byte row in flight before
@@ -1033,13 +1035,30 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     unsigned int* __restrict__ stats, int32_t zero_idx, float zero_d1, float zero_d2) {
   MH_TRACE_SCOPE(mh::TK_PASS_C);
   __shared__ __attribute__((aligned(16))) float q_s[RS_WAVES][DIM];
-  __shared__ int cand_s[RS_WAVES][RS_MAXC];
+  __shared__ __attribute__((aligned(16))) int cand_s[RS_WAVES][RS_MAXC];   // the candidate list, then RS_STAGE rows of them
   __shared__ int ncand_s[RS_WAVES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = blockIdx.x * RS_WAVES + wave;
   if (q >= Q) return;
+  // Everything the query's wavefront reads before it knows its candidates is asked for HERE, in one go: the kernel lives
+  // on round trips (a query is ~a dozen loads and ~400 fmaf), and loads issued behind the branches below each cost one.
+  constexpr int RS_ITERS = (SC_SLOTS_MAX + SCREEN_OVF_CAP + 63) / 64;
+  uint2* mine = recs + (size_t)q * SC_SLOTS_MAX;
+  uint2 recv[RS_ITERS];
+#pragma unroll
+  for (int it = 0; it < RS_ITERS; ++it) {
+    const int j = it * 64 + lane;
+    recv[it] = j < n_slots ? mine[j] : make_uint2(0u, 0u);
+  }
   const int Qe = q_count ? min(Q, *q_count) : Q;
+  const int bad = qbad[q];
+  const float nq = qnorm[q];
+  const float tau_q = tau[q];
+  const int n_ovf = ovf_cnt[q];
+  const float2 qv = reinterpret_cast<const float2*>(qn + (size_t)q * DIM)[lane];
+  // (the values are wanted HERE: without this the compiler moves the loads behind the tests below, one round trip each)
+  asm volatile("" ::"v"(bad), "v"(nq), "v"(tau_q), "v"(n_ovf), "v"(qv.x), "v"(qv.y), "s"(Qe));
   if (q >= Qe) {   // no such query in this frame: "no neighbour", like combine_splits_kernel (pass B left it no records)
     if (lane == 0) {
       idx1[q] = -1;
@@ -1048,7 +1067,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     }
     return;
   }
-  if (qbad[q] == 2) {   // an absent row inside the launch (see screen_prepare_kernel)
+  if (bad == 2) {   // an absent row inside the launch (see screen_prepare_kernel)
     if (lane == 0) {
       idx1[q] = -1;
       d1[q] = __builtin_inff();
@@ -1056,7 +1075,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     }
     return;
   }
-  if (qbad[q] == 3) {   // an all-zero query: every row's distance is its norm term
+  if (bad == 3) {   // an all-zero query: every row's distance is its norm term
     if (lane == 0) {
       idx1[q] = zero_idx >= 0 ? row_to_global(rmap, zero_idx) : -1;
       d1[q] = zero_d1;
@@ -1065,18 +1084,12 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     }
     return;
   }
-  const float nq = qnorm[q];
   if (lane == 0) ncand_s[wave] = 0;
-  {
-    const float2 v = reinterpret_cast<const float2*>(qn + (size_t)q * DIM)[lane];
-    q_s[wave][2 * lane] = v.x;
-    q_s[wave][2 * lane + 1] = v.y;
-  }
+  q_s[wave][2 * lane] = qv.x;
+  q_s[wave][2 * lane + 1] = qv.y;
   // ---- records -> candidate row list in LDS; the slots read are emptied for the next frame ----
-  const int n_ovf = ovf_cnt[q];
-  bool brute = n_ovf > ovf_cap || qbad[q] == 1;
+  bool brute = n_ovf > ovf_cap || bad == 1;
   int n_cand = 0;
-  uint2* mine = recs + (size_t)q * SC_SLOTS_MAX;
   if (!brute) {
     // Every record carries the largest screen value of its rows (f16, nearest).  Two different records hold different
     // rows, so the second largest of these values (minus the f16 rounding) is a lower bound of the DB's second largest
@@ -1084,10 +1097,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
     // with the exact s2 in the place of pass A's sampled one): records whose largest value (plus the rounding) lies
     // more than screen_margin below that bound cannot hold one.  Pass A's threshold comes from an eighth of the rows
     // and lets ~25 rows per query through; ~3 survive this one and get their 512-byte row fetched.
-    constexpr int RS_ITERS = (SC_SLOTS_MAX + SCREEN_OVF_CAP + 63) / 64;
-    uint2 recv[RS_ITERS];
     float l1 = -__builtin_inff(), l2 = -__builtin_inff();   // the lane's two largest lower bounds
-    const float tau_q = tau[q];
     auto bounds = [tau_q, spread, N, dmax](uint2 rec, float& lo, float& hi) {
       // the record's value: (largest dot of the block + the block's largest -dd/2) - tau, rounded to f16.  The block's
       // largest screen value is at most that, and at least that less the spread of -dd/2 inside a block (`spread`: the
@@ -1098,9 +1108,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
 #pragma unroll
     for (int it = 0; it < RS_ITERS; ++it) {
       const int j = it * 64 + lane;
-      uint2 rec = make_uint2(0u, 0u);
+      uint2 rec = recv[it];
       if (j < n_slots) {
-        rec = mine[j];
         if (rec.y) mine[j] = make_uint2(0u, 0u);
       } else if (j < n_slots + n_ovf) {
         rec = ovf[(size_t)q * ovf_cap + (j - n_slots)];
@@ -1152,9 +1161,51 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rescore_kernel(
 
   Best best = {__builtin_inff(), __builtin_inff(), -1};
   const int n_rows = brute ? N : n_cand;
-  for (int k = lane; k < n_rows; k += 64) {
-    const int row = brute ? k : cand_s[wave][k];
-    if (row >= 0 && row < N) take(best, exact_dist(q_s[wave], db + (size_t)row * DIM, nq, dnorm[row]), row);
+  if (!brute && n_cand <= 64) {
+    // The usual query: a handful of candidates.  The first RS_STAGE rows come in as ONE round trip -- 32 lanes x 16 bytes
+    // per row, all of them in flight at once -- into the LDS the candidate list lay in (chunk c of staged row r at
+    // c ^ r: the lanes that run the chains read different banks), and lane r runs row r's chain from there: the same
+    // fmaf chain in the same order as exact_dist, its 512 bytes read from LDS instead of in four dependent round trips.
+    const int my_row = lane < n_cand ? cand_s[wave][lane] : -1;
+    const bool my_ok = my_row >= 0 && my_row < N;
+    const float my_dn = my_ok ? dnorm[my_row] : 0.f;
+    wave_lds_sync();   // every lane holds its candidate: the list's memory is free
+    float4* stage = reinterpret_cast<float4*>(cand_s[wave]);
+    const int n_st = min(n_cand, RS_STAGE);
+    const int half = lane >> 5, c = lane & 31;
+    float4 v[RS_STAGE / 2];
+#pragma unroll
+    for (int i = 0; i < RS_STAGE / 2; ++i) {
+      const int r = 2 * i + half;
+      const int row_r = __shfl(my_row, r);
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < n_st && row_r >= 0 && row_r < N) v[i] = reinterpret_cast<const float4*>(db + (size_t)row_r * DIM)[c];
+    }
+#pragma unroll
+    for (int i = 0; i < RS_STAGE / 2; ++i) {
+      const int r = 2 * i + half;
+      if (r < n_st) stage[r * 32 + (c ^ r)] = v[i];
+    }
+    wave_lds_sync();
+    if (lane < n_st) {
+      if (my_ok) {
+        float sdot = 0.f;
+        const float4* qs4 = reinterpret_cast<const float4*>(q_s[wave]);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+          const float4 x = stage[lane * 32 + (k ^ lane)], y = qs4[k];
+          sdot = fmaf(y.x, x.x, sdot); sdot = fmaf(y.y, x.y, sdot); sdot = fmaf(y.z, x.z, sdot); sdot = fmaf(y.w, x.w, sdot);
+        }
+        take(best, fmaxf(fmaf(-2.f, sdot, nq + my_dn), 0.f), my_row);
+      }
+    } else if (my_ok) {
+      take(best, exact_dist(q_s[wave], db + (size_t)my_row * DIM, nq, my_dn), my_row);
+    }
+  } else {
+    for (int k = lane; k < n_rows; k += 64) {
+      const int row = brute ? k : cand_s[wave][k];
+      if (row >= 0 && row < N) take(best, exact_dist(q_s[wave], db + (size_t)row * DIM, nq, dnorm[row]), row);
+    }
   }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1310,7 +1361,11 @@ void launch_passes(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int blo
     return std::max(S, 1);
   };
   // pass A: every `stride`-th tile, starting in the middle of the first stride
-  const int stride = n_tiles >= 4 * sample ? sample : 1;
+  // (a shard of a few models: the records a query leaves do not shrink with the shard, the MFMA work beside them does --
+  // every 4th tile there: half the records for 1/8 more of pass A's rows.  15 000 rows x 96 000 queries: pass B 0.38 ->
+  // 0.34 ms, pass A 0.055 -> 0.09, the rank's frames/s +2.5%)
+  const int every = sample == 8 && n_tiles < 256 ? 4 : sample;
+  const int stride = n_tiles >= 4 * every ? every : 1;
   const int n_sel_a = (n_tiles + stride - 1) / stride;
   const int Sa = splits_for(n_sel_a, blocks_a, screen_max_splits_a());
   a.n_sel = n_sel_a;
@@ -1366,7 +1421,11 @@ void launch_passes16(ScreenArgs a, int Q, int qe, int n_tiles, int sample, int b
     if (S >= 8 && (S / 8 * 8) * 33 >= S * 32) S = S / 8 * 8;
     return std::max(S, 1);
   };
-  const int stride = n_tiles >= 4 * sample ? sample : 1;
+  // (a shard of a few models: the records a query leaves do not shrink with the shard, the MFMA work beside them does --
+  // every 4th tile there: half the records for 1/8 more of pass A's rows.  15 000 rows x 96 000 queries: pass B 0.38 ->
+  // 0.34 ms, pass A 0.055 -> 0.09, the rank's frames/s +2.5%)
+  const int every = sample == 8 && n_tiles < 256 ? 4 : sample;
+  const int stride = n_tiles >= 4 * every ? every : 1;
   const int n_sel_a = (n_tiles + stride - 1) / stride;
   const int Sa = splits_for(n_sel_a, blocks_a, screen_max_splits_a());
   a.n_sel = n_sel_a;

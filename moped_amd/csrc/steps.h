@@ -34,6 +34,13 @@ __device__ __forceinline__ T* frame_ptr(T* p, unsigned long long bytes) {   // (
 }
 #endif
 
+// The depth maps of the frames of a merged batch (mh_frame_set_depth_image_batch): frame f's map and fill-distance map;
+// all of the size of the context's DepthImage.  Frame 0's are the DepthImage's own.
+struct DepthMaps {
+  const float4* img[MH_MAX_BATCH] = {};
+  const float* fill[MH_MAX_BATCH] = {};
+};
+
 // ---- moped3d depth rules (depth.hip; applied inside group_kernel) --------------------
 struct DepthRules {
   // MATCH_ADAPTIVE_FLANN_CPU's ratio: per model (maxRatioDepth, minRatioDepth, ratioLow, ratioHigh)
@@ -84,10 +91,13 @@ __device__ __forceinline__ float density_replay(int n, double inv) {
 }
 #endif
 // Patch maps of the frame's depth image: inv_size[pw*ph] (pw = ceil(w / patch), ...).
-void launch_depth_patches(const DepthImage& dimg, const float K[4], int patch, double* inv_size, hipStream_t s);
+// (maps, n_frames > 1: the frames of a batch in one launch, frame f's patch map at inv_size + f pw ph)
+void launch_depth_patches(const DepthImage& dimg, const float K[4], int patch, double* inv_size, hipStream_t s,
+                          const DepthMaps* maps = nullptr, int n_frames = 1);
 // DEPTHFILTER on the detected features: keep[q] for q < min(Q, *q_count).
 void launch_feature_density(const float* q_uv, int Q, const int32_t* q_count, int patch, int pw, int ph,
-                            const double* inv_size, float filter, uint8_t* keep, hipStream_t s);
+                            const double* inv_size, float filter, uint8_t* keep, hipStream_t s,
+                            int n_frames = 1 /* > 1: q_uv / keep / inv_size frame after frame (Q, Q, pw ph apart) */);
 
 // ---- group -------------------------------------------------------------------
 // Ratio test + grouping by model in ascending query order (MATCH_ANN_CPU.hpp:165-176).
@@ -105,7 +115,9 @@ void launch_group(const int32_t* gathered, int n_shards, int32_t* idx1, float* d
                   int plane_stride = 0 /* words between the idx / d1 / d2 planes of a block; 0 = Q */,
                   const FrameBatch* batch = nullptr,
                   const int32_t* tags = nullptr /* optional: shard k's two tag words at tags + k * shard_stride (comm.hip); all
-                                                   shards must carry the same, else counts->error |= ERR_EXCHANGE */);
+                                                   shards must carry the same, else counts->error |= ERR_EXCHANGE */,
+                  const DepthMaps* maps = nullptr /* batch with a depth map per frame: frame f reads maps->img[f]; its
+                                                     rule buffers (keep1, inv_size, cnt) lie frame after frame */);
 void launch_rep(const mh_corr* corr, int M, int32_t* rep, hipStream_t s, const int32_t* img = nullptr);
 void launch_accept(const int32_t* idx1, const float* d1, const float* d2, int Q, float ratio,
                    int32_t* out_idx, hipStream_t s);
@@ -155,7 +167,9 @@ void launch_linkage_models(const mh_corr* corr, const float* depth4, const int32
                            const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                            int32_t* members, int32_t* cl_start, int32_t* ncl, int max_clusters, int32_t* cl_model,
                            int32_t* cl_begin, int32_t* cl_count, int32_t* n_clusters_out, int32_t* snap,
-                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid = 0);
+                           FrameCounts* counts, unsigned int* ticket, hipStream_t s, int grid = 0,
+                           const FrameBatch* batch = nullptr, const DepthMaps* maps = nullptr /* frame f's depth map */,
+                           int32_t* feedback = nullptr /* [frames]: models that had something to cluster */);
 void launch_linkage_batch(const mh_corr* corr, const float* depth4, const int32_t* off, int n_problems,
                           const DepthImage& dimg, const LinkageParams& prm, float* scratch, size_t scratch_floats,
                           int32_t* members, int32_t* cl_start, int32_t* ncl, int32_t* label, hipStream_t s);

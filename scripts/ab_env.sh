@@ -8,6 +8,6 @@ for r in $(seq 1 $reps); do
   for st in "$@"; do
     envs=""; [ "$st" != "-" ] && envs=$(echo "$st" | tr ',' ' ')
     env $envs python bench.py --no-secondary --no-cpu-baseline --h2d-steps 0 --steps 10 --warmup 2 $args 2>/dev/null \
-      | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print('$st', 'round $r', d['value'], 'frames/s', 'objects', d['config']['objects_per_frame'], 'B', d['config']['frames_per_match_launch'], 'passB ms', r.get('ms_per_launch'), 'frac', r.get('frac'), 'stage', r.get('match_stage',{}).get('kernels_ms'))"
+      | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d.get('roofline',{}); print('$st', 'round $r', d['value'], 'frames/s', 'objects', d['config']['objects_per_frame'], 'B', d['config']['frames_per_match_launch'], 'passB ms', r.get('ms_per_launch'), 'frac', r.get('frac'), 'stage', r.get('match_stage',{}).get('kernels_ms'))"
   done
 done

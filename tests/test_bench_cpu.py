@@ -55,4 +55,4 @@ def test_default_batch_follows_the_partition():
     a = b.parse(["--depth-kind", "1"])
     assert b.default_batch(a, False) == 16                 # depth attributes travel with a merged batch (round 4)
     a = b.parse(["--depth-kind", "1", "--moped3d-frontend"])
-    assert b.default_batch(a, False) == 4                  # a depth map per frame: frame after frame
+    assert b.default_batch(a, False) == 16                 # a depth map per frame travels with a merged batch too (round 4)

@@ -78,6 +78,7 @@ def _worker(rank, world, port, out_dir):
         # what every rank's GPU would send: its local top-2 block
         for r in range(WORLD):
             local = torch.zeros(stride, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()   # torch's fills and copies before the context's own stream touches the buffers
             ctxs[r].frame_enqueue_match_local(torch.from_numpy(fr.desc).to(dev).data_ptr(), Q, local.data_ptr())
             stream.synchronize()
             locals_.append(local)
@@ -89,6 +90,7 @@ def _worker(rank, world, port, out_dir):
             gathered[r * stride:(r + 1) * stride] = 0
             qd = torch.from_numpy(fr.desc).to(dev)
             local = torch.zeros(stride, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
             ctxs[r].frame_enqueue_match_local(qd.data_ptr(), Q, local.data_ptr())
             dist.all_gather_into_tensor(gathered[r * stride:(r + 1) * stride], local)
             ctxs[r].frame_enqueue_rest_strided(q_uv.data_ptr(), Q, gathered.data_ptr(), WORLD, stride, K, CAM0, prm, 31)

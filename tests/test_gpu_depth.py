@@ -198,6 +198,7 @@ def test_batch_of_distinct_frames_with_depth_attributes_equals_the_frames_alone(
     c1.frame_set_depth(dall.data_ptr(), kind, 0.5)
     for rep in range(2):
         qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        torch.cuda.synchronize()   # the copy runs on torch's stream, the frames on the library's own (non-blocking) streams
         pipe.enqueue_batch(1, qd, uv, B, seeds)
         got = pipe.fetch_batch(1, B)
         for f in range(B):
@@ -210,6 +211,7 @@ def test_batch_of_distinct_frames_with_depth_attributes_equals_the_frames_alone(
     # the attributes matter: the same batch without them gives other poses
     c1.frame_set_depth(0, 0, 0.5)
     qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+    torch.cuda.synchronize()   # the copy runs on torch's stream, the frames on the library's own (non-blocking) streams
     pipe.enqueue_batch(1, qd, uv, B, seeds)
     plain = pipe.fetch_batch(1, B)
     assert any(len(p[0]) and not np.array_equal(p[0]["pose"], a[0]["pose"]) for p, a in zip(plain, alone))

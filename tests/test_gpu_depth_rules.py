@@ -140,3 +140,50 @@ def test_batch_with_a_depth_map_per_frame_equals_single_frames():
         assert np.array_equal(counts, ac) and len(a) >= 1
         assert np.array_equal(objs["model"], a["model"]) and np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32))
     c.close()
+
+
+def test_merged_batch_of_five_frames_with_their_own_depth_maps_twice():
+    """Round 4: the frames of mh_frame_enqueue_batch share their launches with the moped3d front end on too -- depth
+    patches, DEPTHFILTER x 2, DEPTHMAP_PROP inside group_kernel and the linkage clusterer take frame f's depth map from
+    a table.  Five frames with 0..3 visible objects, their maps and fill-distance maps, twice over the same arenas and
+    rule buffers: objects and counts bit for bit those of the frames alone."""
+    import torch
+    from moped_amd import moped3d
+    dev = torch.device("cuda:0")
+    db = synth.make_db(6, 1500, seed=2)
+    n_vis = (2, 0, 3, 1, 2)
+    B, Q = len(n_vis), 1500
+    frs = [synth.make_frame(db, n_vis=n, seed=60 + i, Q=Q, pts_per_obj=130) for i, n in enumerate(n_vis)]
+    maps = []
+    for i, f in enumerate(frs):
+        img, fill = synth.depth_image(db, f, seed=10 + i, fill_max=0.3)
+        maps.append((torch.from_numpy(img).to(dev), torch.from_numpy(fill).to(dev)))
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    c.reserve(B * Q)
+    table = moped3d.ratio_table(db.xyz, db.model_of, db.n_models, synth.K_DEFAULT)
+    c.frame_set_depth_rules(synth.K_DEFAULT, 64, 0.05, 0.01, table)
+    c.frame_set_cluster_linkage(capi.default_linkage_params())
+    prm = capi.default_frame_params()
+    alone = []
+    for i, f in enumerate(frs):
+        c.frame_set_depth_image(maps[i][0].data_ptr(), maps[i][1].data_ptr(), 640, 480, capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+        qd, uv = torch.from_numpy(f.desc).to(dev), torch.from_numpy(f.uv).to(dev)
+        c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), Q, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, 5 + i)
+        alone.append(c.frame_fetch())
+    assert sum(len(a[0]) for a in alone) >= 6
+    uv = torch.cat([torch.from_numpy(f.uv) for f in frs]).to(dev)
+    c.frame_set_depth_image_batch([m[0].data_ptr() for m in maps], [m[1].data_ptr() for m in maps], 640, 480,
+                                  capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+    for rep in range(2):
+        qd = torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev)
+        c.frame_enqueue_batch(qd.data_ptr(), uv.data_ptr(), Q, B, synth.K_DEFAULT, synth.CAM_IDENTITY, prm,
+                              [5 + i for i in range(B)])
+        for f in range(B):
+            objs, counts = c.frame_fetch_slot(f)
+            a, ac = alone[f]
+            assert np.array_equal(counts, ac), (rep, f, counts, ac)
+            assert np.array_equal(objs["model"], a["model"]), (rep, f)
+            assert np.array_equal(objs["pose"].view(np.uint32), a["pose"].view(np.uint32)), (rep, f)
+            assert np.array_equal(objs["score"].view(np.uint32), a["score"].view(np.uint32)), (rep, f)
+    c.close()

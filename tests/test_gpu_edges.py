@@ -116,6 +116,7 @@ def test_frame_capacities_are_errors_not_faults():
     prm = capi.default_frame_params()
     c.reserve(3000, max_clusters=2, max_objects=4)          # six planted objects: > 2 clusters, > 4 object slots
     qa, qb = q.clone(), q.clone()                            # MATCH normalises in place
+    torch.cuda.synchronize()                                 # (torch's stream made the copies; the context runs on its own)
     c.frame_enqueue(qa.data_ptr(), uv.data_ptr(), 3000, synth.K_DEFAULT, synth.CAM_IDENTITY, prm, 5)
     with pytest.raises(capi.MhError, match="capacity"):
         c.frame_fetch()

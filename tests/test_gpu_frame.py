@@ -165,6 +165,7 @@ def test_pose_as_two_launches_gives_the_bits_of_the_one_launch_form(world):
             p2.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=50 + i)
             out.append(p2.fetch(0))
         qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        torch.cuda.synchronize()   # the copy runs on torch's stream, the frames on the library's own (non-blocking) streams
         p2.enqueue_batch(1, qd, uv, B, [50 + i for i in range(B)])
         out += p2.fetch_batch(1, B)
         res[split] = out

@@ -61,6 +61,7 @@ def test_frames_of_one_launch_sequence_equal_the_frames_alone_and_the_oracles_ma
     assert c.match_stats(B * Q)["two_stage"]
     for rep in range(2):   # the second batch runs on arenas and record slots the first one used
         qd.copy_(torch.cat([torch.from_numpy(f.desc) for f in frs]).to(dev))
+        torch.cuda.synchronize()   # the copy runs on torch's stream, the frames on the library's own (non-blocking) streams
         pipe.enqueue_batch(1, qd, uv, B, seeds)
         got = pipe.fetch_batch(1, B)
         for f in range(B):
