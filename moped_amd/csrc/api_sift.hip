@@ -8,7 +8,7 @@
 using namespace mh;
 
 struct SiftState {
-  int width = 0, height = 0, double_size = -1, cap = 0;
+  int width = 0, height = 0, double_size = -1, cap = 0, images = 1;
   SiftPlan plan;
   SiftBuffers B = {};
   uint8_t* gray = nullptr;       // staging for host-pointer calls
@@ -33,16 +33,19 @@ int alloc(mh_ctx* ctx, T*& p, size_t n) {
   return MH_OK;
 }
 
-int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
+// images > 1: room for a batch's images side by side (mh_frame_enqueue_image_batch: one launch per stage for all of them)
+int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap, int images = 1) {
   SiftState* st = ctx->sift;
   // internal keypoint room is never below 8192, so that a small output capacity still selects
   // the FIRST keypoints of the reference's list (which are the last ones generated)
   cap = std::max(cap, 8192);
-  if (st && st->width == width && st->height == height && st->double_size == double_size && st->cap >= cap)
+  if (st && st->width == width && st->height == height && st->double_size == double_size && st->cap >= cap &&
+      st->images >= images)
     return MH_OK;
   if (st) {
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     cap = std::max(cap, st->cap);
+    images = std::max(images, st->images);
     free_sift(st);
     ctx->sift = nullptr;
   }
@@ -52,6 +55,7 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
   st->height = height;
   st->double_size = double_size;
   st->cap = cap;
+  st->images = images;
   if (sift_plan(width, height, double_size, &st->plan) == 0) {
     ctx->err = "mh_sift: image too small (both sides must exceed 12 pixels after scaling)";
     free_sift(st);   // no half-built state: the next call with this geometry fails the same way
@@ -61,17 +65,19 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap) {
   size_t owner = 0;
   for (int o = 0; o < st->plan.n_octaves; ++o) owner += (size_t)st->plan.rows[o] * st->plan.cols[o];
   int rc = 0;
-  rc |= alloc(ctx, st->B.pyramid, st->plan.floats);
-  rc |= alloc(ctx, st->B.tmp, (size_t)st->plan.rows0 * st->plan.cols0);
-  rc |= alloc(ctx, st->B.owner, owner);
+  const size_t ni = (size_t)images;
+  rc |= alloc(ctx, st->B.pyramid, st->plan.floats * ni);
+  rc |= alloc(ctx, st->B.tmp, (size_t)st->plan.rows0 * st->plan.cols0 * ni);
+  rc |= alloc(ctx, st->B.owner, owner * ni);
   st->B.owner_elems = owner;
   st->B.cand_cap = 4 * cap;
   st->B.key_cap = cap;
-  rc |= alloc(ctx, st->B.cand, (size_t)st->B.cand_cap);
-  rc |= alloc(ctx, st->B.keys, (size_t)cap);
-  rc |= alloc(ctx, st->B.desc_tmp, (size_t)cap * 128);
-  rc |= alloc(ctx, st->B.geo_tmp, (size_t)cap * 4);
-  rc |= alloc(ctx, st->B.counters, 4);
+  st->B.images = images;
+  rc |= alloc(ctx, st->B.cand, (size_t)st->B.cand_cap * ni);
+  rc |= alloc(ctx, st->B.keys, (size_t)cap * ni);
+  rc |= alloc(ctx, st->B.desc_tmp, (size_t)cap * 128 * ni);
+  rc |= alloc(ctx, st->B.geo_tmp, (size_t)cap * 4 * ni);
+  rc |= alloc(ctx, st->B.counters, 4 * ni);
   rc |= alloc(ctx, st->gray, (size_t)width * height);
   rc |= alloc(ctx, st->desc, (size_t)cap * 128);
   rc |= alloc(ctx, st->xy, (size_t)cap * 2);
@@ -101,6 +107,19 @@ int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int d
               n_dev, ctx->stream);
   MH_HIP(ctx, hipGetLastError());
   if (n_dev_out) *n_dev_out = n_dev;
+  return MH_OK;
+}
+
+// n images of one size into the rows of a batch: image i's keypoints at desc_dev + i cap 128 / xy_dev + i cap 2, its count
+// in count_words[i]; one launch per stage for all of them.
+int sift_into_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, int n, int width, int height, int double_size, int cap,
+                    float* desc_dev, float* xy_dev, int32_t* count_words) {
+  int rc = ensure_sift(ctx, width, height, double_size ? 1 : 0, cap, n);
+  if (rc) return rc;
+  SiftState* st = ctx->sift;
+  launch_sift_batch(gray_dev, n, width, height, double_size ? 1 : 0, st->plan, st->B, cap, cap, desc_dev, xy_dev, nullptr,
+                    count_words, 1, ctx->stream);
+  MH_HIP(ctx, hipGetLastError());
   return MH_OK;
 }
 

@@ -1470,12 +1470,11 @@ int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, in
     MH_HIP(ctx, hipMemsetAsync(ctx->img_counts, 0, MH_MAX_BATCH * sizeof(int32_t), s));
   }
   // FEAT image by image into the batch's query rows (image f: rows f Q ..), every image's count in a word of its own
-  for (int f = 0; f < B; ++f) {
-    if ((rc = sift_into(ctx, gray_dev[f], width, height, double_size, Q, ctx->q_desc + (size_t)f * Q * DIM,
-                        ctx->q_uv + (size_t)f * Q * 2, nullptr, ctx->img_counts + f)))
-      return rc;
+  // (round 4: ONE launch per FEAT stage for all B images -- a frame's 26 dependent launches were what bounded this path)
+  if ((rc = sift_into_batch(ctx, gray_dev, B, width, height, double_size, Q, ctx->q_desc, ctx->q_uv, ctx->img_counts)))
+    return rc;
+  for (int f = 0; f < B; ++f)
     launch_normalize(ctx->q_desc + (size_t)f * Q * DIM, ctx->q_norm + (size_t)f * Q, Q, s, ctx->img_counts + f);
-  }
   MH_HIP(ctx, hipGetLastError());
   ctx->feat_count_dev = nullptr;
   stamp(ctx, 0);

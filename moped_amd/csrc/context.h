@@ -209,5 +209,7 @@ int delivery_begin(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char** 
 int delivery_end(mh_ctx* ctx, void* host_block, size_t bytes, unsigned char* dst_dev, int B, int max_objects, uint32_t tag);
 int sift_into(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size, int cap,
               float* desc_dev, float* xy_dev, int32_t** n_dev_out, int32_t* count_word = nullptr);
+int sift_into_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, int n, int width, int height, int double_size, int cap,
+                    float* desc_dev, float* xy_dev, int32_t* count_words);
 
 }  // namespace mh

@@ -1278,11 +1278,13 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
 // time that one wavefront refines.  The tasks of the batch are numbered through the frames like pose_kernel's; workgroup b
 // takes tasks 4 (round G + b) + wave in round `round`.  After every round the workgroup counts its finished tasks into
 // the frames' tickets; a frame whose last task that was is closed by this workgroup (pose_close_frame, all threads).
-constexpr int POSE_RCAP = 320;
+// (plain frames: 512 points -- 12 KB per wavefront, three workgroups per compute unit; the reference's own test frame has a
+// cluster of 330 matches, and a cluster that does not fit refines out of global scratch at a tenth of the speed: 1.4 ms)
+template <int KIND> struct RefineCap { static constexpr int value = KIND == 0 ? 512 : 320; };
 template <int KIND>
 struct RefineLds {
-  float pts[POSE_THREADS / 64][POSE_RCAP * PointStride<KIND>::value];
-  int list[POSE_THREADS / 64][POSE_RCAP];
+  float pts[POSE_THREADS / 64][RefineCap<KIND>::value * PointStride<KIND>::value];
+  int list[POSE_THREADS / 64][RefineCap<KIND>::value];
   int fr_tasks[MH_MAX_BATCH], fr_obj_base[MH_MAX_BATCH], fr_first[MH_MAX_BATCH + 1];
   int done_frame[POSE_THREADS / 64];
   int closed[POSE_THREADS / 64], n_closed;
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_REFINE_MIN_WAVES) void pose_refine
         // cluster writes the same values there; the inlier lists are per replica)
         float* pts = L.pts[wave];
         int* list = L.list[wave];
-        if (k > POSE_RCAP) {
+        if (k > RefineCap<KIND>::value) {
           pts = frame_ptr(sp.pts, fa) + (size_t)begin * PS;
           list = frame_ptr(sp.list, fa) + (size_t)(replica & 3) * sp.max_m + begin;
         }
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_REFINE_MIN_WAVES) void pose_refine
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (k > POSE_RCAP) __threadfence();   // (global scratch written by other lanes of this wavefront)
+        if (k > RefineCap<KIND>::value) __threadfence();   // (global scratch written by other lanes of this wavefront)
         float R[9], t[3];
         for (int i = 0; i < 9; ++i) R[i] = hyp[slot].pose[i];
         for (int i = 0; i < 3; ++i) t[i] = hyp[slot].pose[9 + i];

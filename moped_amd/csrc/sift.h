@@ -35,6 +35,19 @@ struct SiftKey {            // one (extremum, orientation peak)
   float fsize, frow, fcol, ori;
 };
 
+// The images of a batch through ONE launch per stage (blockIdx.y / z = image): image i's working arrays lie `*_step`
+// elements behind image i - 1's (SiftBuffers holds room for `images` of them), its outputs `out_step` keypoints and
+// `n_out_step` count words behind.
+struct SiftBatch {
+  unsigned long long pyr_step = 0, own_step = 0, tmp_step = 0;   // floats / words
+  int cand_step = 0, key_step = 0;                               // candidates / keys (counters: 4 words per image)
+  int out_step = 0, n_out_step = 0;
+  int n = 1;
+};
+struct SiftImages {
+  const uint8_t* gray[MH_MAX_BATCH];
+};
+
 struct SiftPlan {
   int n_octaves;
   int rows0, cols0;
@@ -55,6 +68,7 @@ struct SiftBuffers {
   float* desc_tmp;          // [key_cap][128] in generation order
   float* geo_tmp;           // [key_cap][4]
   int32_t* counters;        // [4]: candidates, keys, overflow flag, -
+  int images;               // every array above holds this many images' worth, one after the other
 };
 
 // Octave sizes of GetKeypoints' loop (:344-348).  Returns the number of octaves.
@@ -66,5 +80,10 @@ int sift_plan(int width, int height, int double_size, SiftPlan* plan);
 void launch_sift(const uint8_t* gray, int width, int height, int double_size, const SiftPlan& plan,
                  const SiftBuffers& B, int out_cap, float* desc_out, float* xy_out, float* scale_ori_out,
                  int32_t* n_out, hipStream_t s);
+// The same for n <= B.images images of one size in ONE launch per stage: image i's keypoints at desc_out + i out_step
+// 128 (xy_out, scale_ori_out: + i out_step 2), its count at n_out + i n_out_step; out_cap <= out_step.
+void launch_sift_batch(const uint8_t* const* gray, int n, int width, int height, int double_size, const SiftPlan& plan,
+                       const SiftBuffers& B, int out_cap, int out_step, float* desc_out, float* xy_out,
+                       float* scale_ori_out, int32_t* n_out, int n_out_step, hipStream_t s);
 
 }  // namespace mh

@@ -39,11 +39,16 @@ constexpr float kInitSigma = 1.6f;    // :109
 // FEAT_SIFT_CPU.hpp:91 (pixel * 1./255. in double) and SiftDoubleSize (:363-380).
 __device__ __forceinline__ float to_unit(uint8_t g) { return (float)((double)(float)g * 1. / 255.); }
 
+// blockIdx.z = image of a batch (SiftImages: its pixels; its output `out_step` floats behind the image's before it)
 __global__ void prepare_kernel(const uint8_t* __restrict__ gray, int w, int h, int double_size,
-                               float* __restrict__ out, int orows, int ocols) {
+                               float* __restrict__ out, int orows, int ocols, SiftImages imgs, size_t out_step) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= ocols || r >= orows) return;
+  if (blockIdx.z) {
+    gray = imgs.gray[blockIdx.z];
+    out += blockIdx.z * out_step;
+  }
   if (!double_size) {
     out[(size_t)r * ocols + c] = to_unit(gray[(size_t)r * w + c]);
     return;
@@ -172,6 +177,7 @@ struct BlurJob {
   float* dog;
   float* half_dst;   // level 0 of the job's octave when `half`
   int rows, cols, src_cols, half, taps, tiles_x, tile_begin;
+  size_t src_step, pyr_step;   // images of a batch (blockIdx.y): floats from an image's source / pyramid to the next one's
 };
 struct BlurJobs {
   BlurJob j[2];
@@ -275,7 +281,13 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
   __shared__ __attribute__((aligned(16))) float row_s[(BT_Y + 2 * BT_MAXW) * BT_X];
   const int tid = threadIdx.x;
   const int jn = (J.n > 1 && (int)blockIdx.x >= J.j[1].tile_begin) ? 1 : 0;
-  const BlurJob& job = J.j[jn];
+  BlurJob job = J.j[jn];
+  if (blockIdx.y) {   // image of a batch
+    job.src += blockIdx.y * job.src_step;
+    job.dst += blockIdx.y * job.pyr_step;
+    if (job.dog) job.dog += blockIdx.y * job.pyr_step;
+    if (job.half_dst) job.half_dst += blockIdx.y * job.pyr_step;
+  }
   const Taps& t = J.t[job.taps];
   const int rows = job.rows, cols = job.cols;
   const int tile = blockIdx.x - job.tile_begin;
@@ -332,10 +344,13 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
 }
 
 // HalfImageSize (:390-408)
-__global__ void half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols) {
+__global__ void half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols,
+                            size_t pyr_step) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= cols || r >= rows) return;
+  src += blockIdx.z * pyr_step;   // image of a batch
+  dst += blockIdx.z * pyr_step;
   dst[(size_t)r * cols + c] = src[(size_t)(2 * r) * scols + 2 * c];
 }
 
@@ -351,7 +366,8 @@ struct Taps5 {
 // image, above / below the row-blurred one), so the tap loops read straight through without clamping an index per
 // tap; the others run the clamped loops.
 constexpr int SO_PAD = 12, SO_CAP = 6912;
-__global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int o_first, Taps5 T) {
+__global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int o_first, Taps5 T, size_t pyr_step) {
+  const size_t off = blockIdx.x * pyr_step;   // one workgroup per image of a batch
   __shared__ float cur[SO_CAP];   // image i - 1 of the octave: [px], or [rows][cols + 2 SO_PAD]
   __shared__ float tmp[SO_CAP];   // its row-blurred version:   [px], or [rows + 2 SO_PAD][cols]
   const int tid = threadIdx.x;
@@ -375,11 +391,11 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
       if (c == cols - 1)
         for (int h = 0; h < SO_PAD; ++h) row[SO_PAD + cols + h] = v;
     };
-    const float* src0 = O.gaus[0];
+    const float* src0 = O.gaus[0] + off;
     if (o > o_first) {   // HalfImageSize (:390-408) of the previous octave's image `kScales`
       const SiftOctave& V = P.oct[o - 1];
-      const float* src = V.gaus[kScales];
-      float* dst = O.gaus[0];
+      const float* src = V.gaus[kScales] + off;
+      float* dst = O.gaus[0] + off;
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
         const float v = src[(size_t)(2 * r) * V.cols + 2 * c];
@@ -418,8 +434,8 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
         }
       }
       __syncthreads();
-      float* dst = O.gaus[i];
-      float* dog = O.dog[i - 1];
+      float* dst = O.gaus[i] + off;
+      float* dog = O.dog[i - 1] + off;
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
         float a = 0.f;
@@ -464,7 +480,8 @@ __device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index,
   return b < G.begin[G.n];
 }
 
-__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G) {
+__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G, size_t pyr_step) {
+  const size_t off = blockIdx.y * pyr_step;   // image of a batch
   int o, index, bx, by;
   if (!sift_tile(G, o, index, bx, by)) return;
   const SiftOctave& O = P.oct[o];
@@ -472,7 +489,7 @@ __global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G) {
   const int j = bx * blockDim.x + threadIdx.x;
   const int i = by * blockDim.y + threadIdx.y;
   if (j >= cols || i >= rows) return;
-  const float* im = O.gaus[index];
+  const float* im = O.gaus[index] + off;
   const float* p = im + (size_t)i * cols;
   float dc, dr;
   if (j == 0) dc = __fmul_rn(2.0f, __fsub_rn(p[1], p[0]));
@@ -482,8 +499,8 @@ __global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G) {
   else if (i == rows - 1) dr = __fmul_rn(2.0f, __fsub_rn(p[-cols + j], p[j]));
   else dr = __fsub_rn(p[-cols + j], p[cols + j]);
   const size_t at = (size_t)i * cols + j;
-  O.grad[index - 1][at] = sqrtf(__fadd_rn(__fmul_rn(dc, dc), __fmul_rn(dr, dr)));
-  O.ori[index - 1][at] = atan2f(dr, dc);
+  (O.grad[index - 1] + off)[at] = sqrtf(__fadd_rn(__fmul_rn(dc, dc), __fmul_rn(dr, dr)));
+  (O.ori[index - 1] + off)[at] = atan2f(dr, dc);
 }
 
 // ---- detection ------------------------------------------------------------------------------
@@ -568,7 +585,11 @@ __device__ float fit_quadratic(float* X, const float* p0, const float* p1, const
 // its FINAL pixel with atomicMin(generation key): the reference's s_MaxMinArray gives that
 // pixel to the first survivor in (scale index, row, column) order.
 __global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restrict__ cand, int32_t* __restrict__ n_cand,
-                              int cap, int32_t* __restrict__ overflow) {
+                              int cap, int32_t* __restrict__ overflow, SiftBatch Bt) {
+  const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch: its pyramid, owner map, candidates, counters
+  cand += (size_t)blockIdx.y * Bt.cand_step;
+  n_cand += 4 * blockIdx.y;
+  overflow += 4 * blockIdx.y;
   int o, index, bx, by;
   if (!sift_tile(G, o, index, bx, by)) return;
   const SiftOctave& O = P.oct[o];
@@ -577,10 +598,10 @@ __global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restri
   const int r = 5 + by * blockDim.y + threadIdx.y;
   if (c >= cols - 5 || r >= rows - 5) return;
   const float peak_thresh = 0.04f / (float)kScales;
-  const float* d1 = O.dog[index];
+  const float* d1 = O.dog[index] + off;
   const float v = d1[(size_t)r * cols + c];
   if (!(fabsf(v) > __fmul_rn(peak_thresh, 0.8f))) return;
-  const float *d0 = O.dog[index - 1], *d2 = O.dog[index + 1];
+  const float *d0 = O.dog[index - 1] + off, *d2 = O.dog[index + 1] + off;
   if (!local_extremum(v, d1, cols, r, c) || !local_extremum(v, d0, cols, r, c) ||
       !local_extremum(v, d2, cols, r, c) || !not_on_edge(d1, cols, r, c))
     return;
@@ -602,7 +623,7 @@ __global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restri
   }
   if (!(fabsf(X[0]) <= 1.5f && fabsf(X[1]) <= 1.5f && fabsf(X[2]) <= 1.5f && fabsf(val) >= peak_thresh)) return;
   const unsigned key = (unsigned)(index - 1) * (unsigned)(rows * cols) + (unsigned)(r * cols + c);
-  atomicMin(&O.owner[(size_t)rr * cols + cc], key);
+  atomicMin(&(O.owner + blockIdx.y * Bt.own_step)[(size_t)rr * cols + cc], key);
   const int at = atomicAdd(n_cand, 1);
   if (at >= cap) {
     *overflow = 1;
@@ -627,17 +648,23 @@ __global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restri
 __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCandidate* __restrict__ cand,
                                                     const int32_t* __restrict__ n_cand, int cand_cap,
                                                     SiftKey* __restrict__ keys, int32_t* __restrict__ n_keys,
-                                                    int key_cap, int32_t* __restrict__ overflow) {
+                                                    int key_cap, int32_t* __restrict__ overflow, SiftBatch Bt) {
   const int lane = threadIdx.x;
+  const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
+  cand += (size_t)blockIdx.y * Bt.cand_step;
+  keys += (size_t)blockIdx.y * Bt.key_step;
+  n_cand += 4 * blockIdx.y;
+  n_keys += 4 * blockIdx.y;
+  overflow += 4 * blockIdx.y;
   int n = *n_cand;
   if (n > cand_cap) n = cand_cap;
   for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
     const SiftCandidate k = cand[ci];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
-    if (O.owner[(size_t)k.r * cols + k.c] != k.key) continue;  // another extremum got this pixel first
-    const float* grad = O.grad[k.index - 1];
-    const float* orim = O.ori[k.index - 1];
+    if ((O.owner + blockIdx.y * Bt.own_step)[(size_t)k.r * cols + k.c] != k.key) continue;  // another extremum got this pixel first
+    const float* grad = O.grad[k.index - 1] + off;
+    const float* orim = O.ori[k.index - 1] + off;
     const float fSize = __fmul_rn(kInitSigma, powf(2.0f, __fdiv_rn(__fadd_rn((float)k.index, k.x0), (float)kScales)));
     const float frow = __fadd_rn((float)k.r, k.x1), fcol = __fadd_rn((float)k.c, k.x2);
     const int rowstart = (int)__fadd_rn(frow, 0.5f), colstart = (int)__fadd_rn(fcol, 0.5f);
@@ -781,7 +808,13 @@ struct DescLds {
 __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
                                                       const int32_t* __restrict__ n_keys, int key_cap,
                                                       float* __restrict__ desc_out /* [key][128] */,
-                                                      float* __restrict__ geo_out /* [key][4] col,row,scale,ori */) {
+                                                      float* __restrict__ geo_out /* [key][4] col,row,scale,ori */,
+                                                      SiftBatch Bt) {
+  const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
+  keys += (size_t)blockIdx.y * Bt.key_step;
+  n_keys += 4 * blockIdx.y;
+  desc_out += (size_t)blockIdx.y * Bt.key_step * 128;
+  geo_out += (size_t)blockIdx.y * Bt.key_step * 4;
   __shared__ DescLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int n = *n_keys;
@@ -796,8 +829,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
     const SiftKey k = keys[ki];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
-    const float* grad = O.grad[k.index - 1];
-    const float* orim = O.ori[k.index - 1];
+    const float* grad = O.grad[k.index - 1] + off;
+    const float* orim = O.ori[k.index - 1] + off;
     const float fSize = k.fsize, frow = k.frow, fcol = k.fcol, ang = k.ori;
     const int rowstart = (int)__fadd_rn(frow, 0.5f), colstart = (int)__fadd_rn(fcol, 0.5f);
     const float sinang = sinf(ang), cosang = cosf(ang);
@@ -956,7 +989,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
 __global__ void order_kernel(const SiftKey* __restrict__ keys, const int32_t* __restrict__ n_keys, int key_cap,
                              const float* __restrict__ desc_in, const float* __restrict__ geo_in, int out_cap,
                              float* __restrict__ desc_out, float* __restrict__ xy_out,
-                             float* __restrict__ scale_ori_out, int32_t* __restrict__ n_out) {
+                             float* __restrict__ scale_ori_out, int32_t* __restrict__ n_out, SiftBatch Bt) {
+  if (blockIdx.y) {   // image of a batch: its keys, its rows of the outputs (out_step keypoints apart), its count word
+    keys += (size_t)blockIdx.y * Bt.key_step;
+    n_keys += 4 * blockIdx.y;
+    desc_in += (size_t)blockIdx.y * Bt.key_step * 128;
+    geo_in += (size_t)blockIdx.y * Bt.key_step * 4;
+    desc_out += (size_t)blockIdx.y * Bt.out_step * 128;
+    xy_out += (size_t)blockIdx.y * Bt.out_step * 2;
+    if (scale_ori_out) scale_ori_out += (size_t)blockIdx.y * Bt.out_step * 2;
+    n_out += (size_t)blockIdx.y * Bt.n_out_step;
+  }
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n < out_cap ? n : out_cap;
@@ -1030,9 +1073,25 @@ int sift_plan(int width, int height, int double_size, SiftPlan* plan) {
   return plan->n_octaves;
 }
 
-void launch_sift(const uint8_t* gray, int width, int height, int double_size, const SiftPlan& plan,
-                 const SiftBuffers& B, int out_cap, float* desc_out, float* xy_out, float* scale_ori_out,
-                 int32_t* n_out, hipStream_t s) {
+namespace {
+
+// launch_sift / launch_sift_batch: n images (n = 1: `grays` holds the one) in one launch per stage
+void launch_sift_images(const uint8_t* const* grays, int n, int width, int height, int double_size, const SiftPlan& plan,
+                        const SiftBuffers& B, int out_cap, int out_step, float* desc_out, float* xy_out,
+                        float* scale_ori_out, int32_t* n_out, int n_out_step, hipStream_t s) {
+  const uint8_t* const gray = grays[0];
+  SiftBatch Bt;
+  Bt.pyr_step = plan.floats;
+  Bt.own_step = B.owner_elems;
+  Bt.tmp_step = (size_t)plan.rows0 * plan.cols0;
+  Bt.cand_step = B.cand_cap;
+  Bt.key_step = B.key_cap;
+  Bt.out_step = out_step;
+  Bt.n_out_step = n_out_step;
+  Bt.n = n;
+  SiftImages imgs;
+  for (int i = 0; i < MH_MAX_BATCH; ++i) imgs.gray[i] = grays[i < n ? i : 0];
+  const unsigned un = (unsigned)n;
   SiftPyramid P;
   memset(&P, 0, sizeof P);
   P.n_octaves = plan.n_octaves;
@@ -1051,19 +1110,19 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
     O.owner = own;
     own += px;
   }
-  hipMemsetAsync(B.owner, 0xFF, B.owner_elems * sizeof(unsigned int), s);
-  hipMemsetAsync(B.counters, 0, 4 * sizeof(int32_t), s);
+  hipMemsetAsync(B.owner, 0xFF, B.owner_elems * sizeof(unsigned int) * n, s);
+  hipMemsetAsync(B.counters, 0, 4 * sizeof(int32_t) * n, s);
 
   const SiftOctave& O0 = P.oct[0];
   const dim3 tb(256);
-  auto grid_for = [](int rows, int cols) { return dim3((cols + 255) / 256, rows); };
+  auto grid_for = [un](int rows, int cols) { return dim3((cols + 255) / 256, rows, un); };
   const float fnew = double_size ? 1.0f : 0.5f;
   const bool init_blur = kInitSigma > fnew;   // :325-327
   const Taps t0 = init_blur ? make_taps(sqrtf(kInitSigma * kInitSigma - fnew * fnew)) : Taps{};
   const bool init_fused = init_blur && (t0.n >> 1) <= BT_MAXW;
   // the prepared image goes to the scratch image when the fused blur can write octave 0's first level from there
   hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
-                     init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols);
+                     init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols, imgs, init_fused ? Bt.tmp_step : Bt.pyr_step);
   if (init_fused) {
     BlurJobs J;
     J.n = 1;
@@ -1078,9 +1137,11 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
     b.taps = 0;
     b.tiles_x = (O0.cols + BT_X - 1) / BT_X;
     b.tile_begin = 0;
+    b.src_step = Bt.tmp_step;
+    b.pyr_step = Bt.pyr_step;
     J.j[1] = b;
     J.t[0] = J.t[1] = t0;
-    hipLaunchKernelGGL(blur_jobs_kernel, dim3(b.tiles_x * ((O0.rows + BT_Y - 1) / BT_Y)), dim3(BT_THREADS), 0, s, J);
+    hipLaunchKernelGGL(blur_jobs_kernel, dim3(b.tiles_x * ((O0.rows + BT_Y - 1) / BT_Y), un), dim3(BT_THREADS), 0, s, J);
   } else if (init_blur) {   // in place through the scratch image
     hipLaunchKernelGGL(blur_rows_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, O0.gaus[0], B.tmp, O0.rows, O0.cols, t0);
     hipLaunchKernelGGL(blur_cols_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, B.tmp, O0.gaus[0], O0.rows, O0.cols, t0,
@@ -1117,6 +1178,7 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
       b.taps = i - 1;
       b.tiles_x = (O.cols + BT_X - 1) / BT_X;
       b.tile_begin = 0;
+      b.src_step = b.pyr_step = Bt.pyr_step;
       if (i == 1 && o > 0) {
         b.src = P.oct[o - 1].gaus[kScales];
         b.src_cols = P.oct[o - 1].cols;
@@ -1148,7 +1210,7 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
         J.j[1] = a;
         J.t[1] = J.t[0];
       }
-      hipLaunchKernelGGL(blur_jobs_kernel, dim3(total), dim3(BT_THREADS), 0, s, J);
+      hipLaunchKernelGGL(blur_jobs_kernel, dim3(total, un), dim3(BT_THREADS), 0, s, J);
     };
     for (int o = 0; o < o_small; ++o) {
       // levels 1 (unless it went out with the previous octave's level kScales + 1), 2 .. kScales on their own
@@ -1168,7 +1230,7 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
         const SiftOctave& O = P.oct[o];
         const SiftOctave& N = P.oct[o + 1];
         hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
-                           N.gaus[0], N.rows, N.cols);
+                           N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
       }
     }
   } else
@@ -1189,11 +1251,11 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
     if (o + 1 < plan.n_octaves) {
       const SiftOctave& N = P.oct[o + 1];
       hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
-                         N.gaus[0], N.rows, N.cols);
+                         N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
     }
   }
   if (o_small < plan.n_octaves)
-    hipLaunchKernelGGL(small_octaves_kernel, dim3(1), dim3(1024), 0, s, P, o_small, T5);
+    hipLaunchKernelGGL(small_octaves_kernel, dim3(un), dim3(1024), 0, s, P, o_small, T5, (size_t)Bt.pyr_step);
   const dim3 tb2(64, 4);
   SiftGrid G;
   G.n = plan.n_octaves * kScales;
@@ -1203,16 +1265,55 @@ void launch_sift(const uint8_t* gray, int width, int height, int double_size, co
     for (int i = 0; i < kScales; ++i)
       G.begin[o * kScales + i + 1] = G.begin[o * kScales + i] + G.tiles_x[o] * ((plan.rows[o] + 3) / 4);
   }
-  const dim3 g2(G.begin[G.n]);
-  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G);
-  hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, G, B.cand, B.counters + 0, B.cand_cap, B.counters + 2);
-  hipLaunchKernelGGL(orient_kernel, dim3(4096), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
-                     (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2);
-  hipLaunchKernelGGL(describe_kernel, dim3(2048), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
-                     (const int32_t*)(B.counters + 1), B.key_cap, B.desc_tmp, B.geo_tmp);
-  hipLaunchKernelGGL(order_kernel, dim3(1024), dim3(64), 0, s, (const SiftKey*)B.keys,
+  const dim3 g2(G.begin[G.n], un);
+  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G, (size_t)Bt.pyr_step);
+  hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, G, B.cand, B.counters + 0, B.cand_cap, B.counters + 2, Bt);
+  // (the per-key kernels loop over the keys: a batch's images share the chip, fewer workgroups per image)
+  const unsigned per = n > 4 ? 4 : 1;
+  hipLaunchKernelGGL(orient_kernel, dim3(4096 / per, un), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
+                     (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2, Bt);
+  hipLaunchKernelGGL(describe_kernel, dim3(2048 / per, un), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
+                     (const int32_t*)(B.counters + 1), B.key_cap, B.desc_tmp, B.geo_tmp, Bt);
+  hipLaunchKernelGGL(order_kernel, dim3(1024 / per, un), dim3(64), 0, s, (const SiftKey*)B.keys,
                      (const int32_t*)(B.counters + 1), B.key_cap, (const float*)B.desc_tmp, (const float*)B.geo_tmp,
-                     out_cap, desc_out, xy_out, scale_ori_out, n_out);
+                     out_cap, desc_out, xy_out, scale_ori_out, n_out, Bt);
+}
+
+}  // namespace
+
+void launch_sift(const uint8_t* gray, int width, int height, int double_size, const SiftPlan& plan,
+                 const SiftBuffers& B, int out_cap, float* desc_out, float* xy_out, float* scale_ori_out,
+                 int32_t* n_out, hipStream_t s) {
+  launch_sift_images(&gray, 1, width, height, double_size, plan, B, out_cap, out_cap, desc_out, xy_out, scale_ori_out,
+                     n_out, 1, s);
+}
+
+void launch_sift_batch(const uint8_t* const* gray, int n, int width, int height, int double_size, const SiftPlan& plan,
+                       const SiftBuffers& B, int out_cap, int out_step, float* desc_out, float* xy_out,
+                       float* scale_ori_out, int32_t* n_out, int n_out_step, hipStream_t s) {
+  if (n <= 0) return;
+  // the tile blur takes every level of the shipped constants; kernels it does not take go image after image
+  const float fnew = double_size ? 1.0f : 0.5f;
+  bool tiles = !(kInitSigma > fnew) || (make_taps(sqrtf(kInitSigma * kInitSigma - fnew * fnew)).n >> 1) <= BT_MAXW;
+  {
+    const float fwidth = powf(2.0f, 1.0f / (float)kScales);
+    const float fincsigma = sqrtf(fwidth * fwidth - 1.0f);
+    float sigma = kInitSigma;
+    for (int i = 1; i < kScales + 3; ++i) {
+      tiles = tiles && (make_taps(fincsigma * sigma).n >> 1) <= BT_MAXW;
+      sigma *= fwidth;
+    }
+  }
+  if (n == 1 || n > B.images || !tiles) {
+    for (int i = 0; i < n; ++i)
+      launch_sift_images(gray + i, 1, width, height, double_size, plan, B, out_cap, out_step,
+                         desc_out + (size_t)i * out_step * 128, xy_out + (size_t)i * out_step * 2,
+                         scale_ori_out ? scale_ori_out + (size_t)i * out_step * 2 : nullptr, n_out + (size_t)i * n_out_step,
+                         n_out_step, s);
+    return;
+  }
+  launch_sift_images(gray, n, width, height, double_size, plan, B, out_cap, out_step, desc_out, xy_out, scale_ori_out,
+                     n_out, n_out_step, s);
 }
 
 }  // namespace mh

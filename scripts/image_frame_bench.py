@@ -23,6 +23,8 @@ xyz = np.stack([(xy[:, 0] - K[2]) / K[0] * z, (xy[:, 1] - K[3]) / K[1] * z, np.f
 all_desc = c0.normalize(np.concatenate([db.desc, desc]))
 all_xyz = np.concatenate([db.xyz, xyz])
 model_of = np.concatenate([db.model_of, np.full(len(xy), models, np.int32)])
+if os.environ.get("IFB_NO_OBJECT"):   # the frame's object is not in the DB: FEAT + MATCH alone (nothing to cluster or pose)
+    all_desc[len(db.desc):] = c0.normalize(np.random.default_rng(5).standard_normal(desc.shape).astype(np.float32))
 c0.close()
 ctxs, streams = [], []
 for i in range(depth):
