@@ -18,67 +18,106 @@ __device__ __forceinline__ int best_obj(unsigned long long k) {
 }
 
 // LDS of one FILTER workgroup
+constexpr int FL_SLOTS = 256;   // object slots whose model / list / score / cluster size wait in LDS (more: read from global)
 struct FilterLds {
-  double term_s[FT];
-  float score_s;
+  double term_s[FT];            // 64 per wavefront
   int cnt_s, kept_s;
   DevCam cams_s[MH_MAX_IMAGES];   // several images: every match is projected through its own image's camera
+  int model_s[FL_SLOTS], b_s[FL_SLOTS], n_s[FL_SLOTS], cl_s[FL_SLOTS];   // n_s < 0: the slot holds no object
+  float score_s[FL_SLOTS];
 };
 
-// F1 for the object slots first, first + stride, ... < n_slots (every thread of the workgroup calls it)
+__device__ __forceinline__ void filter_wave_sync() {   // LDS written by lanes of this wavefront, read by others of it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The slots' model, list and (with_scores) score into LDS: one round trip for all of them instead of a chain of four
+// dependent loads per slot inside the loops below (all threads; ends with a barrier).
+__device__ __forceinline__ void filter_load_slots(FilterLds& S, const FilterBuffers& fb, int n_slots, bool with_scores) {
+  for (int o = threadIdx.x; o < n_slots && o < FL_SLOTS; o += FT) {
+    const bool v = fb.obj_valid[o] != 0;
+    const int m = v ? fb.obj_model[o] : 0;
+    const int b = fb.model_off[m];
+    S.model_s[o] = m;
+    S.b_s[o] = b;
+    S.n_s[o] = v ? fb.model_off[m + 1] - b : -1;
+    if (with_scores) S.score_s[o] = v ? fb.obj_score[o] : 0.f;
+  }
+  __syncthreads();
+}
+// (slot o's list: from LDS, or -- slots past FL_SLOTS -- from the arrays)
+__device__ __forceinline__ bool filter_slot(const FilterLds& S, const FilterBuffers& fb, int o, int& m, int& b, int& n) {
+  if (o < FL_SLOTS) {
+    m = S.model_s[o];
+    b = S.b_s[o];
+    n = S.n_s[o];
+    return n >= 0;
+  }
+  if (!fb.obj_valid[o]) return false;
+  m = fb.obj_model[o];
+  b = fb.model_off[m];
+  n = fb.model_off[m + 1] - b;
+  return true;
+}
+
+// F1 for the object slots first, first + stride, ... < n_slots (every thread of the workgroup calls it).  One WAVEFRONT
+// per object, four objects at a time: 64 matches per step, their quotients into the wavefront's 64 LDS words, lane 0
+// adds them in list order (the reference's Float += double chain; adding 0. leaves a float unchanged); no workgroup
+// barrier inside.  (Round 4: the whole workgroup per object, slot after slot with four barriers and four dependent
+// loads each, was 85-100 us of one synchronous frame's 670 -- the closing workgroup of a POSE launch runs this.)
 __device__ __forceinline__ void filter_score(FilterLds& S, const FilterBuffers& fb, const DevCam& cam, float feature_distance,
                                              int n_slots, int first, int stride) {
-  double (&term_s)[FT] = S.term_s;
-  float& score_s = S.score_s;
   DevCam (&cams_s)[MH_MAX_IMAGES] = S.cams_s;
-
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool multi = fb.m_img != nullptr;
-  if (multi) {
+  if (multi)
     for (int i = tid; i < fb.n_images * (int)(sizeof(DevCam) / 4); i += FT)
       reinterpret_cast<float*>(cams_s)[i] = reinterpret_cast<const float*>(fb.cams)[i];
-    __syncthreads();
-  }
+  filter_load_slots(S, fb, n_slots, false);
   auto cam_of = [&](int match) -> const DevCam& { return multi ? cams_s[fb.m_img[match]] : cam; };
+  const int tw = 64 * wave;   // the wavefront's 64 words of term_s
   // ---- F1 ----
-  for (int o = first; o < n_slots; o += stride) {
-    __syncthreads();
-    if (!fb.obj_valid[o]) continue;
-    const int m = fb.obj_model[o];
-    const int b = fb.model_off[m];
-    const int n = fb.model_off[m + 1] - b;
+  for (int o = first + stride * wave; o < n_slots; o += stride * (FT / 64)) {
+    int m, b, n;
+    if (!filter_slot(S, fb, o, m, b, n)) continue;
     TM T;
     tm_from_pose(T, fb.obj_pose + 7 * (size_t)o, fb.obj_pose + 7 * (size_t)o + 4);
-    float score = 0.f;  // tid 0 only
-    for (int base = 0; base < n; base += FT) {
-      const int i = base + tid;
+    float score = 0.f;          // lane 0 only
+    unsigned inl_bits = 0u;     // this lane's in-cluster flags of the first 32 steps
+    for (int base = 0, step = 0; base < n; base += 64, ++step) {
+      const int i = base + lane;
       float e = __builtin_inff();
       if (i < n) {
         const mh_corr c = fb.corr[b + i];
         e = reproj_err2(T.r, T.t, cam_of(b + i), c.x, c.y, c.z, c.u, c.v);
       }
-      // score += 1./(err+1.) over the in-cluster matches, in list order: the quotients in parallel, the
-      // Float += double chain by one thread (adding 0. leaves a float unchanged)
-      term_s[tid] = e < feature_distance ? 1. / ((double)e + 1.) : 0.;
-      __syncthreads();
-      if (tid == 0) {
-        const int cnt = min(FT, n - base);
-        for (int j = 0; j < cnt; ++j) score = (float)((double)score + term_s[j]);
+      const bool in = e < feature_distance;
+      if (in && step < 32) inl_bits |= 1u << step;
+      S.term_s[tw + lane] = in ? 1. / ((double)e + 1.) : 0.;
+      filter_wave_sync();
+      if (lane == 0) {
+        const int cnt = min(64, n - base);
+        for (int j = 0; j < cnt; ++j) score = (float)((double)score + S.term_s[tw + j]);
       }
-      __syncthreads();
+      filter_wave_sync();
     }
-    if (tid == 0) {
-      score_s = score;
-      fb.obj_score[o] = score;
-    }
-    __syncthreads();
-    score = score_s;
+    score = __shfl(score, 0);
+    if (lane == 0) fb.obj_score[o] = score;
     if (!(score > 0.f)) continue;
     const unsigned long long key = pack_best(score, o);
-    for (int i = tid; i < n; i += FT) {
-      const mh_corr c = fb.corr[b + i];
-      if (reproj_err2(T.r, T.t, cam_of(b + i), c.x, c.y, c.z, c.u, c.v) < feature_distance)
-        atomicMax(&fb.best[fb.m_rep[b + i]], key);
+    for (int base = 0, step = 0; base < n; base += 64, ++step) {
+      const int i = base + lane;
+      if (i >= n) continue;
+      bool in;
+      if (step < 32) {
+        in = (inl_bits >> step) & 1u;
+      } else {
+        const mh_corr c = fb.corr[b + i];
+        in = reproj_err2(T.r, T.t, cam_of(b + i), c.x, c.y, c.z, c.u, c.v) < feature_distance;
+      }
+      if (in) atomicMax(&fb.best[fb.m_rep[b + i]], key);
     }
   }
 }
@@ -87,24 +126,20 @@ __device__ __forceinline__ void filter_score(FilterLds& S, const FilterBuffers& 
 __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers& fb, int min_points, float min_score, int n_slots,
                                               int32_t* n_slots_dev, int32_t* n_clusters_dev, FrameCounts* counts,
                                               const FilterTail& tail) {
-  int& cnt_s = S.cnt_s;
   int& kept_s = S.kept_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  filter_load_slots(S, fb, n_slots, true);   // (the scores: other workgroups may have written them)
 
-  // ---- F2: keypoints each object owns ----
-  for (int o = 0; o < n_slots; ++o) {
-    if (tid == 0) cnt_s = 0;
-    __syncthreads();
-    if (fb.obj_valid[o]) {
-      const int m = fb.obj_model[o];
-      const int b = fb.model_off[m];
-      const int n = fb.model_off[m + 1] - b;
-      int mine = 0;
-      for (int i = tid; i < n; i += FT) mine += (best_obj(fb.best[fb.m_rep[b + i]]) == o);
-      if (mine) atomicAdd(&cnt_s, mine);
+  // ---- F2: keypoints each object owns (one wavefront per object) ----
+  for (int o = wave; o < n_slots; o += FT / 64) {
+    int m, b, n, mine = 0;
+    if (filter_slot(S, fb, o, m, b, n))
+      for (int i = lane; i < n; i += 64) mine += (best_obj(fb.best[fb.m_rep[b + i]]) == o);
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) {
+      fb.obj_clsize[o] = mine;
+      if (o < FL_SLOTS) S.cl_s[o] = mine;
     }
-    __syncthreads();
-    if (tid == 0) fb.obj_clsize[o] = cnt_s;
   }
   __syncthreads();
 
@@ -114,21 +149,36 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
   if (tid == 0) {
     int k = 0, w = 0;
     for (int o = 0; o < n_slots; ++o) {
-      fb.obj_score_raw[o] = fb.obj_valid[o] ? fb.obj_score[o] : 0.f;
-      if (!fb.obj_valid[o]) continue;
-      const int sz = fb.obj_clsize[o];
-      if (sz < min_points || fb.obj_score[o] < min_score) continue;
+      // (explicit branches: `cond ? lds : global` makes one generic pointer of the two, and this compiler's cast of an
+      // LDS address to a generic one does not assemble)
+      bool valid;
+      float score;
+      int sz, model;
+      if (o < FL_SLOTS) {
+        valid = S.n_s[o] >= 0;
+        score = S.score_s[o];
+        sz = S.cl_s[o];
+        model = S.model_s[o];
+      } else {
+        valid = fb.obj_valid[o] != 0;
+        score = valid ? fb.obj_score[o] : 0.f;
+        sz = fb.obj_clsize[o];
+        model = fb.obj_model[o];
+      }
+      fb.obj_score_raw[o] = score;
+      if (!valid) continue;
+      if (sz < min_points || score < min_score) continue;
       if (k >= fb.max_clusters) {
         atomicOr(&counts->error, ERR_CLUSTER_CAP);
         break;
       }
       old_of[k] = o;
-      fb.obj_model[k] = fb.obj_model[o];
+      fb.obj_model[k] = model;
       for (int j = 0; j < 7; ++j) fb.obj_pose[7 * k + j] = fb.obj_pose[7 * o + j];
-      fb.obj_score[k] = fb.obj_score[o];
+      fb.obj_score[k] = score;
       fb.obj_npts[k] = sz;
       fb.obj_valid[k] = 1;
-      fb.cl_model[k] = fb.obj_model[k];
+      fb.cl_model[k] = model;
       fb.cl_begin[k] = w;
       fb.cl_count[k] = sz;
       w += sz;
@@ -146,9 +196,15 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
   // ---- F4: ordered member list of each kept object, one wavefront per object ----
   for (int r = wave; r < kept; r += FT / 64) {
     const int o = old_of[r];
-    const int m = fb.obj_model[r];
-    const int b = fb.model_off[m];
-    const int n = fb.model_off[m + 1] - b;
+    int m, b, n;
+    if (o < FL_SLOTS) {
+      b = S.b_s[o];
+      n = S.n_s[o];
+    } else {
+      m = fb.obj_model[r];
+      b = fb.model_off[m];
+      n = fb.model_off[m + 1] - b;
+    }
     int w = fb.cl_begin[r];
     for (int base = 0; base < n; base += 64) {
       const int i = base + lane;
