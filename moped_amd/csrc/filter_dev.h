@@ -25,6 +25,7 @@ struct FilterLds {
   DevCam cams_s[MH_MAX_IMAGES];   // several images: every match is projected through its own image's camera
   int model_s[FL_SLOTS], b_s[FL_SLOTS], n_s[FL_SLOTS], cl_s[FL_SLOTS];   // n_s < 0: the slot holds no object
   float score_s[FL_SLOTS];
+  int vlist_s[FL_SLOTS];        // the slots (below FL_SLOTS) that hold an object, in no particular order: cnt_s of them
 };
 
 __device__ __forceinline__ void filter_wave_sync() {   // LDS written by lanes of this wavefront, read by others of it
@@ -35,7 +36,11 @@ __device__ __forceinline__ void filter_wave_sync() {   // LDS written by lanes o
 
 // The slots' model, list and (with_scores) score into LDS: one round trip for all of them instead of a chain of four
 // dependent loads per slot inside the loops below (all threads; ends with a barrier).
+// An object holds one of four replicas' slots of a cluster at most times: the loops below walk the LIST of slots with an
+// object (vlist_s), not the slots.
 __device__ __forceinline__ void filter_load_slots(FilterLds& S, const FilterBuffers& fb, int n_slots, bool with_scores) {
+  if (threadIdx.x == 0) S.cnt_s = 0;
+  __syncthreads();
   for (int o = threadIdx.x; o < n_slots && o < FL_SLOTS; o += FT) {
     const bool v = fb.obj_valid[o] != 0;
     const int m = v ? fb.obj_model[o] : 0;
@@ -43,7 +48,14 @@ __device__ __forceinline__ void filter_load_slots(FilterLds& S, const FilterBuff
     S.model_s[o] = m;
     S.b_s[o] = b;
     S.n_s[o] = v ? fb.model_off[m + 1] - b : -1;
-    if (with_scores) S.score_s[o] = v ? fb.obj_score[o] : 0.f;
+    if (v) S.vlist_s[atomicAdd(&S.cnt_s, 1)] = o;
+    if (with_scores) {
+      S.score_s[o] = v ? fb.obj_score[o] : 0.f;
+      if (!v) {   // F2's answer for a slot without an object
+        S.cl_s[o] = 0;
+        fb.obj_clsize[o] = 0;
+      }
+    }
   }
   __syncthreads();
 }
@@ -79,7 +91,10 @@ __device__ __forceinline__ void filter_score(FilterLds& S, const FilterBuffers& 
   auto cam_of = [&](int match) -> const DevCam& { return multi ? cams_s[fb.m_img[match]] : cam; };
   const int tw = 64 * wave;   // the wavefront's 64 words of term_s
   // ---- F1 ----
-  for (int o = first + stride * wave; o < n_slots; o += stride * (FT / 64)) {
+  const int n_listed = S.cnt_s, n_low = min(n_slots, FL_SLOTS);
+  // the listed slots, then (more than FL_SLOTS slots) the rest slot by slot
+  for (int idx = first + stride * wave; idx < n_listed + (n_slots - n_low); idx += stride * (FT / 64)) {
+    const int o = idx < n_listed ? S.vlist_s[idx] : n_low + (idx - n_listed);
     int m, b, n;
     if (!filter_slot(S, fb, o, m, b, n)) continue;
     TM T;
@@ -131,7 +146,9 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
   filter_load_slots(S, fb, n_slots, true);   // (the scores: other workgroups may have written them)
 
   // ---- F2: keypoints each object owns (one wavefront per object) ----
-  for (int o = wave; o < n_slots; o += FT / 64) {
+  const int n_listed = S.cnt_s, n_low = min(n_slots, FL_SLOTS);
+  for (int idx = wave; idx < n_listed + (n_slots - n_low); idx += FT / 64) {
+    const int o = idx < n_listed ? S.vlist_s[idx] : n_low + (idx - n_listed);
     int m, b, n, mine = 0;
     if (filter_slot(S, fb, o, m, b, n))
       for (int i = lane; i < n; i += 64) mine += (best_obj(fb.best[fb.m_rep[b + i]]) == o);
