@@ -364,7 +364,8 @@ int mh_frame_set_depth(mh_ctx* ctx, const mh_depth* q_depth_dev, int kind, float
 int mh_frame_set_depth_image(mh_ctx* ctx, const float* depth_xyzn_dev, const float* fill_distance_dev,
                              int width, int height, int kind, float alpha, float cauchy_scale);
 /* One depth map (and distance map) per frame of the batches enqueued from now on (mh_frame_enqueue_batch with
- * B = n_frames): pointer arrays of n_frames <= MH_MAX_BATCH device images of the same size. */
+ * B = n_frames): pointer arrays of n_frames <= MH_MAX_BATCH device images of the same size.  The batch's frames share
+ * their launches (round 4): every frame's map must stay valid until the batch's results are fetched. */
 int mh_frame_set_depth_image_batch(mh_ctx* ctx, const float* const* depth_xyzn_dev, const float* const* fill_distance_dev,
                                    int n_frames, int width, int height, int kind, float alpha, float cauchy_scale);
 /* The same for hosts that hold the maps in host memory (the STEP plugins): copies them into

@@ -99,6 +99,10 @@ if has latency; then
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/sft -- python3 $root/scripts/single_frame_timeline.py run 20 2 > /tmp/sft.log 2>&1
     python3 $root/scripts/single_frame_timeline.py report /tmp/sft 2>&1 | grep -v amdgpu.ids
     cd $root
+    if [ -f moped_amd/libmoped_hip_trace.so ]; then
+      echo "# trace build: the workgroups of CLUSTER / POSE / POSE2 of one synchronous frame (scripts/single_frame_trace.py)"
+      python3 scripts/single_frame_trace.py 20 2 20 2>&1 | grep -v amdgpu.ids
+    fi
     if [ -f moped_amd/libmoped_hip_poseprof.so ]; then
       echo "# POSE_PROF build (cycles of thread 0 of the tasks that refine an object; scripts/pose_prof.py)"
       MH_LIB_PATH=$root/moped_amd/libmoped_hip_poseprof.so python3 scripts/pose_prof.py 2>&1 | grep -v amdgpu.ids
@@ -117,6 +121,7 @@ if has feat; then
   cd $root
   timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 > $out/r04_image_frame_bench.txt 2>&1
   timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 8 >> $out/r04_image_frame_bench.txt 2>&1
+  timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 16 >> $out/r04_image_frame_bench.txt 2>&1
   cat $out/r04_sift_size_probe.txt; grep -v amdgpu $out/r04_image_frame_bench.txt | grep "image->"
 fi
 if has stress; then
@@ -124,6 +129,7 @@ if has stress; then
   timeout -k 10 600 python3 tests/tools/depth_rules_stress.py 800 > $out/r04_depth_rules_stress.txt 2>&1; tail -1 $out/r04_depth_rules_stress.txt
   timeout -k 10 400 python3 scripts/screen_stress.py 200 11 > $out/r04_screen_stress.txt 2>&1; tail -1 $out/r04_screen_stress.txt
   timeout -k 10 600 python3 tests/tools/shard_stress.py 200 3 > $out/r04_shard_stress.txt 2>&1; tail -1 $out/r04_shard_stress.txt
+  timeout -k 10 400 python3 tests/tools/depth_batch_stress.py 300 > $out/r04_depth_batch_stress.txt 2>&1; tail -1 $out/r04_depth_batch_stress.txt
 fi
 if has misc; then
   { for i in 1 2; do moped_amd/host/mfma_rate 2>/dev/null; done; } > $out/r04_mfma_shapes_rate.txt 2>&1
