@@ -177,3 +177,29 @@ def test_pose_as_two_launches_gives_the_bits_of_the_one_launch_form(world):
         n_obj += len(o1)
     assert n_obj >= 2 * 30 and len(res[1][B][0]) == 1     # the 420-point object is found (its cluster does not fit the cache)
     p2.close()
+
+
+def test_frame_with_more_object_slots_than_filter_keeps_in_lds():
+    """72 visible objects: >= 288 (cluster, replica) object slots after POSE, more than the 256 whose model / list / score
+    the fused FILTER tail holds in LDS (csrc/filter_dev.h, FL_SLOTS) -- the slots past them take the path that reads the
+    arrays.  Same objects as the oracle pipeline, scores within its 5%, every planted object found."""
+    import torch
+    from moped_amd.pipeline import FramePipeline, ShardedDB
+    db = synth.make_db(80, 400, seed=5)
+    fr = synth.make_frame(db, n_vis=72, seed=9, Q=6000, pts_per_obj=60)
+    Q = len(fr.desc)
+    dev = torch.device("cuda:0")
+    pipe = FramePipeline(0, ShardedDB(db.desc, db.xyz, db.model_of, db.n_models), depth=1, max_queries=Q)
+    pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=21)
+    objs, counts = pipe.fetch(0)
+    pipe.close()
+    assert counts[2] > 256          # object slots in use after POSE
+    idx, d1, d2 = orclib.match_2nn(orclib.normalize(db.desc), orclib.normalize(fr.desc))
+    om, op, osc, oc, _ = orclib.frame_rest_inliers(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0,
+                                                   n_threads=4, seed=9)
+    assert counts[0] == oc[0] and counts[1] == oc[1]
+    assert sorted(objs["model"].tolist()) == sorted(om.tolist())
+    assert set(fr.visible.tolist()) <= set(objs["model"].tolist())
+    for m, sc in zip(om, osc):
+        g = objs[objs["model"] == m][0]
+        assert abs(g["score"] - sc) <= 0.05 * sc, (m, g["score"], sc)
