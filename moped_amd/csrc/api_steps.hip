@@ -11,6 +11,8 @@ using namespace mh;
 
 // Device buffers of one frame.  Match records are kept sorted by (model, query):
 // matches[model] of the reference is the slice [model_off[m], model_off[m+1]).
+constexpr int FETCH_PIN_OBJECTS = 32;   // objects that come with a frame's head in mh_frame_fetch's first copy
+
 struct FrameState {
   int max_m = 0, max_clusters = 0, max_objects = 0, n_models_cap = 0;
   // The working arrays below (counts .. tickets) are carved out of ONE allocation of MH_MAX_BATCH equal arenas: the
@@ -60,6 +62,16 @@ struct FrameState {
   // any synchronisation: a guess is all it is -- when the next launches are sized: [0][f] (cluster, replica) tasks of POSE
   // in frame f of the batch, [1][f] of POSE2, [2][f] models that CLUSTER had to cluster.
   int32_t* fb = nullptr;
+  // mh_frame_fetch[_slot]: where the frame's head, counters and first objects land -- pinned, so that the copies are
+  // enqueued together and one synchronisation ends them (into pageable memory every one of them blocks: four round
+  // trips, ~40 us of one synchronous frame's 550)
+  struct FetchPin {
+    int32_t head[4];
+    mh_object objects[FETCH_PIN_OBJECTS];
+    int32_t snap[4];
+    FrameCounts fc;
+    int32_t n_feat;
+  }* fetch_pin = nullptr;
   // the fused FILTER / FILTER2 steps' arguments on the device + what the host last stored there (FilterFuse, steps.h)
   FilterFuseArgs* fuse_dev = nullptr;   // [2]
   FilterFuseArgs fuse_shadow[2];
@@ -81,6 +93,7 @@ void free_fs(FrameState* fs) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (fs->fb) hipHostFree(fs->fb);
+  if (fs->fetch_pin) hipHostFree(fs->fetch_pin);
   delete fs;
 }
 
@@ -188,6 +201,7 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   if (!rc) {
     if (hipHostMalloc(&fs->fb, 3 * MH_MAX_BATCH * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
     else std::memset(fs->fb, 0xFF, 3 * MH_MAX_BATCH * sizeof(int32_t));   // -1 = nothing known yet
+    if (hipHostMalloc(&fs->fetch_pin, sizeof(*fs->fetch_pin), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
   }
   if (rc) {   // a half-built state must not look valid to the next call
     free_fs(fs);
@@ -1597,27 +1611,35 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   FrameState* fs = ctx->fs;
-  int32_t head[4];
-  MH_HIP(ctx, hipMemcpyAsync(head, fs->result, sizeof head, hipMemcpyDeviceToHost, ctx->stream));
-  int32_t snap[4] = {0, 0, 0, 0};
-  FrameCounts fc;
-  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(&fc, fs->counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-  int32_t n_feat = -1;
+  FrameState::FetchPin& pin = *fs->fetch_pin;
+  const size_t first = std::min(fs->result_bytes, sizeof pin.head + sizeof pin.objects);   // head + the first objects: one copy
+  MH_HIP(ctx, hipMemcpyAsync(pin.head, fs->result, first, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(pin.snap, fs->snap, sizeof pin.snap, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(&pin.fc, fs->counts, sizeof pin.fc, hipMemcpyDeviceToHost, ctx->stream));
+  pin.n_feat = -1;
   if (ctx->feat_count_dev)
-    MH_HIP(ctx, hipMemcpyAsync(&n_feat, ctx->feat_count_dev, sizeof n_feat, hipMemcpyDeviceToHost, ctx->stream));
+    MH_HIP(ctx, hipMemcpyAsync(&pin.n_feat, ctx->feat_count_dev, sizeof pin.n_feat, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t* head = pin.head;
+  const int32_t* snap = pin.snap;
+  const FrameCounts fc = pin.fc;
+  const int32_t n_feat = pin.n_feat;
   if (n_feat >= 0) ctx->feat_expected = ctx->feat_last = n_feat;
   const int n = head[0];
   *n_objects = n;
-  if (counts) std::memcpy(counts, snap, sizeof snap);
+  if (counts) std::memcpy(counts, snap, 4 * sizeof(int32_t));
   // clusters x 4 replicas (POSE), kept objects x 4 (POSE2), + 50 % head room, in steps of 8
   const int tasks = 4 * std::max(snap[1], snap[3]);
   fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
   fs->ms_grid = std::min(32, std::max(4, snap[1] + 2));   // (a model with matches and no cluster still takes a turn: the workgroups loop)
   const int take = n < max_objects ? n : max_objects;
-  if (take > 0 && objects_host)
-    MH_HIP(ctx, hipMemcpy(objects_host, fs->result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
+  if (take > 0 && objects_host) {
+    const int have = std::min(take, FETCH_PIN_OBJECTS);
+    std::memcpy(objects_host, pin.objects, sizeof(mh_object) * (size_t)have);
+    if (take > have)
+      MH_HIP(ctx, hipMemcpy(objects_host + have, fs->result + 16 + sizeof(mh_object) * (size_t)have,
+                            sizeof(mh_object) * (size_t)(take - have), hipMemcpyDeviceToHost));
+  }
   if (fc.error) {
     ctx->err = (fc.error & ERR_EXCHANGE)
                    ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
@@ -1697,19 +1719,26 @@ int mh_frame_fetch_slot(mh_ctx* ctx, int slot, mh_object* objects_host, int max_
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   FrameState* fs = ctx->fs;
   const unsigned char* result = fs->result + (size_t)slot * fs->result_bytes;
-  int32_t head[4];
-  int32_t snap[4] = {0, 0, 0, 0};
-  MH_HIP(ctx, hipMemcpyAsync(head, result, sizeof head, hipMemcpyDeviceToHost, ctx->stream));
-  MH_HIP(ctx, hipMemcpyAsync(snap, fs->snap + 4 * slot, sizeof snap, hipMemcpyDeviceToHost, ctx->stream));
+  FrameState::FetchPin& pin = *fs->fetch_pin;
+  const size_t first = std::min(fs->result_bytes, sizeof pin.head + sizeof pin.objects);
+  MH_HIP(ctx, hipMemcpyAsync(pin.head, result, first, hipMemcpyDeviceToHost, ctx->stream));
+  MH_HIP(ctx, hipMemcpyAsync(pin.snap, fs->snap + 4 * slot, sizeof pin.snap, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t* head = pin.head;
+  const int32_t* snap = pin.snap;
   *n_objects = head[0];
-  if (counts) std::memcpy(counts, snap, sizeof snap);
+  if (counts) std::memcpy(counts, snap, 4 * sizeof(int32_t));
   const int tasks = 4 * std::max(snap[1], snap[3]);
   fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
   fs->ms_grid = std::min(32, std::max(4, snap[1] + 2));   // (a model with matches and no cluster still takes a turn: the workgroups loop)
   const int take = head[0] < max_objects ? head[0] : max_objects;
-  if (take > 0 && objects_host)
-    MH_HIP(ctx, hipMemcpy(objects_host, result + 16, sizeof(mh_object) * (size_t)take, hipMemcpyDeviceToHost));
+  if (take > 0 && objects_host) {
+    const int have = std::min(take, FETCH_PIN_OBJECTS);
+    std::memcpy(objects_host, pin.objects, sizeof(mh_object) * (size_t)have);
+    if (take > have)
+      MH_HIP(ctx, hipMemcpy(objects_host + have, result + 16 + sizeof(mh_object) * (size_t)have,
+                            sizeof(mh_object) * (size_t)(take - have), hipMemcpyDeviceToHost));
+  }
   if (head[1]) {
     ctx->err = (head[1] & ERR_EXCHANGE)
                    ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
