@@ -336,6 +336,20 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
 int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
                       const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back,
                       mh_object* objects_host, int max_objects, int32_t* n_objects, int32_t* counts);
+/* The same in two halves, for a host that has work of its own to do while the frame runs (FRAME_RESIDENT_HIP copies the
+ * normalised descriptors back into FrameData::detectedFeatures meanwhile): mh_frame_run_host_begin uploads and enqueues
+ * the frame and returns; mh_frame_wait_descriptors returns when q_desc_host holds the normalised descriptors (write_back
+ * was set; they are through right after the frame's first kernel); mh_frame_fetch ends the frame as usual.  The host
+ * buffers must stay untouched by the caller until mh_frame_wait_descriptors (q_desc_host) / mh_frame_fetch (the others). */
+int mh_frame_run_host_begin(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
+                            const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back);
+int mh_frame_wait_descriptors(mh_ctx* ctx);
+/* Page-locked host memory for the buffers a host hands to mh_frame_run_host (and to the other host-pointer entry points):
+ * from pageable memory the frame's 1.5 MB of descriptors cross PCIe through the driver's staging copies (~0.1 ms each
+ * way), from here at the link's rate and asynchronously.  FRAME_RESIDENT_HIP packs FrameData::detectedFeatures
+ * (src/util.hpp:70-79) straight into such a block.  mh_host_free(NULL) is a no-op. */
+int mh_host_alloc(mh_ctx* ctx, size_t bytes, void** out);
+int mh_host_free(mh_ctx* ctx, void* p);
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):

@@ -112,7 +112,7 @@ EXPORTS = [
     "mh_pose_kernel_info", "mh_db_upload_blocks", "mh_frame_fetch_matches_slot",
     "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch", "mh_frame_run_host",
     "mh_frame_block_stride", "mh_frame_fetch_batch_async", "mh_frame_fetch_previous_async", "mh_frame_fetch_wait",
-    "mh_frame_fetch_query",
+    "mh_frame_fetch_query", "mh_host_alloc", "mh_host_free", "mh_frame_run_host_begin", "mh_frame_wait_descriptors",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -270,6 +270,8 @@ def load():
     L.mh_frame_fetch_batch_async.argtypes = [vp, i32, i32, vp, C.c_uint32]
     L.mh_frame_fetch_previous_async.argtypes = [vp, i32, vp, C.c_uint32]
     L.mh_frame_fetch_wait.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mh_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.mh_host_free.argtypes = [vp, vp]
     L.mh_frame_fetch_query.argtypes = [vp]
     _lib = L
     return L

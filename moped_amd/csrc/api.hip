@@ -205,6 +205,8 @@ void mh_destroy(mh_ctx* ctx) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->wb_ev) hipEventDestroy(ctx->wb_ev);
+  if (ctx->wb_stream) hipStreamDestroy(ctx->wb_stream);
   if (ctx->ev_made)
     for (auto& e : ctx->ev) hipEventDestroy(e);
   for (auto& set : ctx->mev)

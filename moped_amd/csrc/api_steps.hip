@@ -1400,6 +1400,7 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   ctx->feat_count_dev = nullptr;
   stamp(ctx, 0);
   launch_normalize(q_desc_dev, ctx->q_norm, Q, ctx->stream);
+  if (ctx->wb_want && ctx->wb_ev) hipEventRecord(ctx->wb_ev, ctx->stream);   // (mh_frame_run_host copies them back from here)
   if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2)) return rc_m;
   stamp(ctx, 1);
   return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
@@ -1409,10 +1410,23 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
 // loop body of MopedPimpl::processImages (src/moped.cpp:183-191: MATCH .. FILTER2 one after the other on one FrameData)
 // as ONE call -- two uploads, one stream-ordered chain of launches, one synchronisation -- instead of six steps with the
 // frame's lists crossing PCIe between them (FRAME_RESIDENT_HIP, moped_amd/host).
-int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
-                      const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back,
-                      mh_object* objects_host, int max_objects, int32_t* n_objects, int32_t* counts) {
-  if (!ctx || Q <= 0 || !q_desc_host || !q_uv_host || !cams || n_images < 1 || n_images > MH_MAX_IMAGES || !prm || !n_objects ||
+int mh_host_alloc(mh_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0) return MH_ERR_ARG;
+  *out = nullptr;
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  MH_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return MH_OK;
+}
+
+int mh_host_free(mh_ctx* ctx, void* p) {
+  if (!ctx) return MH_ERR_ARG;
+  if (p) MH_HIP(ctx, hipHostFree(p));
+  return MH_OK;
+}
+
+int mh_frame_run_host_begin(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
+                            const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back) {
+  if (!ctx || Q <= 0 || !q_desc_host || !q_uv_host || !cams || n_images < 1 || n_images > MH_MAX_IMAGES || !prm ||
       (n_images > 1 && !q_image_host)) {
     if (ctx) ctx->err = "mh_frame_run_host: bad argument";
     return MH_ERR_ARG;
@@ -1437,10 +1451,47 @@ int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, c
   } else if (ctx->q_img) {
     if ((rc = mh_frame_set_images(ctx, nullptr, nullptr, 0))) return rc;
   }
-  if ((rc = mh_frame_enqueue(ctx, ctx->q_desc, ctx->q_uv, Q, &cams[0], prm, seed))) return rc;
-  if (write_back)   // the reference normalises the frame's descriptors in place (MATCH_ANN_CPU.hpp:157)
-    MH_HIP(ctx, hipMemcpyAsync(q_desc_host, ctx->q_desc, (size_t)Q * DIM * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  return mh_frame_fetch(ctx, objects_host, max_objects, n_objects, counts);
+  // the reference normalises the frame's descriptors in place (MATCH_ANN_CPU.hpp:157): the copy back starts as soon as
+  // normalize_kernel is through -- on a stream of its own, beside the frame's other kernels; behind them on the frame's
+  // stream it was another ~0.13 ms at the end of every frame
+  if (write_back && !ctx->wb_stream) {
+    MH_HIP(ctx, hipStreamCreateWithFlags(&ctx->wb_stream, hipStreamNonBlocking));
+    MH_HIP(ctx, hipEventCreateWithFlags(&ctx->wb_ev, hipEventDisableTiming));
+  }
+  ctx->wb_want = write_back != 0;
+  rc = mh_frame_enqueue(ctx, ctx->q_desc, ctx->q_uv, Q, &cams[0], prm, seed);
+  ctx->wb_want = false;
+  if (rc) return rc;
+  if (write_back) {
+    MH_HIP(ctx, hipStreamWaitEvent(ctx->wb_stream, ctx->wb_ev, 0));
+    MH_HIP(ctx, hipMemcpyAsync(q_desc_host, ctx->q_desc, (size_t)Q * DIM * sizeof(float), hipMemcpyDeviceToHost, ctx->wb_stream));
+  }
+  ctx->wb_pending = write_back != 0;
+  return MH_OK;
+}
+
+int mh_frame_wait_descriptors(mh_ctx* ctx) {
+  if (!ctx) return MH_ERR_ARG;
+  if (ctx->wb_pending) {
+    MH_HIP(ctx, hipSetDevice(ctx->device));
+    MH_HIP(ctx, hipStreamSynchronize(ctx->wb_stream));   // (the next frame's upload overwrites q_desc)
+    ctx->wb_pending = false;
+  }
+  return MH_OK;
+}
+
+int mh_frame_run_host(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, const int32_t* q_image_host, int Q,
+                      const mh_cam* cams, int n_images, const mh_frame_params* prm, uint64_t seed, int write_back,
+                      mh_object* objects_host, int max_objects, int32_t* n_objects, int32_t* counts) {
+  if (!n_objects) {
+    if (ctx) ctx->err = "mh_frame_run_host: bad argument";
+    return MH_ERR_ARG;
+  }
+  int rc = mh_frame_run_host_begin(ctx, q_desc_host, q_uv_host, q_image_host, Q, cams, n_images, prm, seed, write_back);
+  if (rc) return rc;
+  rc = mh_frame_fetch(ctx, objects_host, max_objects, n_objects, counts);
+  const int rc_wb = mh_frame_wait_descriptors(ctx);
+  return rc ? rc : rc_wb;
 }
 
 int mh_frame_enqueue_image(mh_ctx* ctx, const uint8_t* gray_dev, int width, int height, int double_size,

@@ -93,6 +93,12 @@ struct mh_ctx {
   size_t scratch_cap = 0;
   void* pinned = nullptr;
   size_t pinned_cap = 0;
+  // mh_frame_run_host's write-back of the normalised descriptors: a stream of its own behind an event recorded right
+  // after normalize_kernel, so that the 1.5 MB copy runs beside MATCH .. FILTER2 instead of after them
+  hipStream_t wb_stream = nullptr;
+  hipEvent_t wb_ev = nullptr;
+  bool wb_want = false;   // the frame being enqueued records wb_ev after its normalisation
+  bool wb_pending = false;   // a write-back is in flight on wb_stream (mh_frame_wait_descriptors)
 
   // frame state (group / cluster / pose / filter); defined in frame.h
   struct FrameState* fs = nullptr;

@@ -26,8 +26,30 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
   bool skipCalculation;
   unsigned long frameCounter;
   int FillMatches;
-  vector<float> packed, uv;
-  vector<int32_t> imageOf, matchQuery, matchModel;
+  // the frame's descriptors / keypoints / image indices as the C ABI takes them: ONE page-locked block (mh_host_alloc),
+  // grown when a frame has more features -- packing into pageable vectors cost the frame two staged 1.5 MB copies
+  void* pinBlock;
+  size_t pinBytes;
+  float *packed, *uv;
+  int32_t* imageOf;
+  vector<int32_t> matchQuery, matchModel;
+
+  bool pinFor(mh_ctx* ctx, int Q) {
+    const size_t need = (size_t)Q * (MH_DESC_DIM + 2) * sizeof(float) + (size_t)Q * sizeof(int32_t);
+    if (need > pinBytes) {
+      if (pinBlock) mh_host_free(ctx, pinBlock);
+      pinBlock = NULL;
+      pinBytes = 0;
+      const size_t want = need + need / 4;
+      if (mh_host_alloc(ctx, want, &pinBlock) != MH_OK) return false;
+      pinBytes = want;
+    }
+    const size_t cap = pinBytes / ((MH_DESC_DIM + 2) * sizeof(float) + sizeof(int32_t));
+    packed = (float*)pinBlock;
+    uv = packed + cap * MH_DESC_DIM;
+    imageOf = (int32_t*)(uv + cap * 2);
+    return true;
+  }
 
   void Update() {
     skipCalculation = true;
@@ -70,7 +92,8 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
                      int MinPoints1, Float FeatureDistance1, Float MinScore1,                                // FILTER
                      int NHyp2, int MaxObj2, int NPtsAlign2, int MinNPts2, Float ErrorThreshold2,            // POSE2
                      int MinPoints2, Float FeatureDistance2, Float MinScore2)                                // FILTER2
-      : DescriptorSize(DescriptorSize), DescriptorType(DescriptorType), skipCalculation(true), frameCounter(0), FillMatches(0) {
+      : DescriptorSize(DescriptorSize), DescriptorType(DescriptorType), skipCalculation(true), frameCounter(0), FillMatches(0),
+        pinBlock(NULL), pinBytes(0), packed(NULL), uv(NULL), imageOf(NULL) {
     mh_frame_default_params(&prm);
     prm.ratio = (float)Ratio;
     prm.ms_radius = (float)Radius;
@@ -162,27 +185,30 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
                 << MH_MAX_IMAGES << " supported): frame skipped" << std::endl;
       return;
     }
-    packed.resize((size_t)Q * MH_DESC_DIM);
-    uv.resize((size_t)Q * 2);
-    imageOf.resize(Q);
+    mh_ctx* ctx = HipSession::get();
+    if (!pinFor(ctx, Q)) { HipSession::warn("mh_host_alloc"); return; }
     for (int i = 0; i < Q; ++i) {
       for (int j = 0; j < MH_DESC_DIM; ++j) packed[(size_t)i * MH_DESC_DIM + j] = feats[i].descriptor[j];
       uv[2 * i] = feats[i].coord2D[0];
       uv[2 * i + 1] = feats[i].coord2D[1];
       imageOf[i] = local[feats[i].imageIdx];
     }
-    mh_ctx* ctx = HipSession::get();
     vector<mh_object> out(256);
     int32_t n = 0, counts[4];
-    int rc = mh_frame_run_host(ctx, &packed[0], &uv[0], &imageOf[0], Q, &cams[0], (int)cams.size(), &prm,
-                               (uint64_t)frameCounter * 2654435761ul + _alg, 1, &out[0], (int)out.size(), &n, counts);
+    // upload + the whole chain of launches; the normalised descriptors are back right after the frame's first kernel and go
+    // into detectedFeatures (MATCH_ANN_CPU.hpp:157 normalises them in place) WHILE the device clusters and poses
+    int rc = mh_frame_run_host_begin(ctx, &packed[0], &uv[0], &imageOf[0], Q, &cams[0], (int)cams.size(), &prm,
+                                     (uint64_t)frameCounter * 2654435761ul + _alg, 1);
+    if (rc == MH_OK) rc = mh_frame_wait_descriptors(ctx);
+    if (rc != MH_OK) { HipSession::warn("mh_frame_run_host_begin"); return; }
+    for (int i = 0; i < Q; ++i)
+      for (int j = 0; j < MH_DESC_DIM; ++j) feats[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
+    rc = mh_frame_fetch(ctx, &out[0], (int)out.size(), &n, counts);
     if (rc == MH_OK && n > (int)out.size()) {   // more objects than the first guess: fetch again into a block that holds them
       out.resize(n);
       rc = mh_frame_fetch(ctx, &out[0], (int)out.size(), &n, counts);
     }
-    if (rc != MH_OK) { HipSession::warn("mh_frame_run_host"); return; }
-    for (int i = 0; i < Q; ++i)
-      for (int j = 0; j < MH_DESC_DIM; ++j) feats[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
+    if (rc != MH_OK) { HipSession::warn("mh_frame_fetch"); return; }
     if (FillMatches) {
       // frameData.matches as MATCH_ANN_CPU::process leaves it (MATCH_ANN_CPU.hpp:165-176): per model, in ascending
       // query order, {imageIdx, coord2D, coord3D of the nearest model point} -- from the device's lists of the frame
