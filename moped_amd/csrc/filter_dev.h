@@ -137,6 +137,55 @@ __device__ __forceinline__ void filter_score(FilterLds& S, const FilterBuffers& 
   }
 }
 
+// F1 of ONE object by the wavefront that has just refined it (fused FILTER, round 4's end): the closing workgroup of the
+// launch then starts at F2 -- with ten objects in a frame their F1s were 40 us of its tail, one after the other; here they
+// run where the objects are made, on as many compute units.  Same arithmetic as filter_score: 64 matches per step, the
+// quotients added in list order (every lane runs the chain on the lanes' values, read lane by lane), the claims by
+// atomic max.  `quat` / `trans`: the pose as obj_pose holds it (all lanes); fb: the frame's buffers (arena applied).
+__device__ __forceinline__ void filter_score_wave(const FilterBuffers& fb, const DevCam& cam, float feature_distance, int o,
+                                                  int m, const float* quat, const float* trans, int lane) {
+  const bool multi = fb.m_img != nullptr;
+  const int b = fb.model_off[m];
+  const int n = fb.model_off[m + 1] - b;
+  TM T;
+  tm_from_pose(T, quat, trans);
+  float score = 0.f;
+  unsigned inl_bits = 0u;
+  for (int base = 0, step = 0; base < n; base += 64, ++step) {
+    const int i = base + lane;
+    float e = __builtin_inff();
+    if (i < n) {
+      const mh_corr c = fb.corr[b + i];
+      e = reproj_err2(T.r, T.t, multi ? fb.cams[fb.m_img[b + i]] : cam, c.x, c.y, c.z, c.u, c.v);
+    }
+    const bool in = e < feature_distance;
+    if (in && step < 32) inl_bits |= 1u << step;
+    const double term = in ? 1. / ((double)e + 1.) : 0.;
+    const unsigned lo = (unsigned)__double_as_longlong(term), hi = (unsigned)((unsigned long long)__double_as_longlong(term) >> 32);
+    const int cnt = min(64, n - base);
+    for (int j = 0; j < cnt; ++j) {
+      const unsigned long long bits = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, j);
+      score = (float)((double)score + __longlong_as_double((long long)bits));
+    }
+  }
+  if (lane == 0) fb.obj_score[o] = score;
+  if (!(score > 0.f)) return;
+  const unsigned long long key = pack_best(score, o);
+  for (int base = 0, step = 0; base < n; base += 64, ++step) {
+    const int i = base + lane;
+    if (i >= n) continue;
+    bool in;
+    if (step < 32) {
+      in = (inl_bits >> step) & 1u;
+    } else {
+      const mh_corr c = fb.corr[b + i];
+      in = reproj_err2(T.r, T.t, multi ? fb.cams[fb.m_img[b + i]] : cam, c.x, c.y, c.z, c.u, c.v) < feature_distance;
+    }
+    if (in) atomicMax(&fb.best[fb.m_rep[b + i]], key);
+  }
+}
+
 // F2..F4 (+ the result block) by ONE workgroup, after every object has been scored
 __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers& fb, int min_points, float min_score, int n_slots,
                                               int32_t* n_slots_dev, int32_t* n_clusters_dev, FrameCounts* counts,

@@ -722,7 +722,7 @@ template <int KIND>
 __device__ void pose_refine(const float* pts, int* list, const int k, float* R, float* t, const bool near_miss,
                             const DevCam* cams, const mh_pose_params& prm, const float alpha, const int lane, const int slot,
                             float* __restrict__ obj_pose, int32_t* __restrict__ obj_ninl, float* __restrict__ obj_err,
-                            int32_t* obj_valid PR_PROF_PARAMS) {
+                            int32_t* obj_valid, const FilterFuseArgs* __restrict__ fuse, const unsigned long long fa PR_PROF_PARAMS) {
   constexpr int PS = PointStride<KIND>::value;
   // The inliers of a pose, in point order, into list; `same` = the list already held exactly these points.
   auto collect = [&](bool& same) {
@@ -791,9 +791,9 @@ __device__ void pose_refine(const float* pts, int* list, const int k, float* R, 
     }
   }
   PP_T(5);
+  float q[4];
+  rot_to_quat(R, q);
   if (lane == 0) {
-    float q[4];
-    rot_to_quat(R, q);
     float* o = obj_pose + 7 * (size_t)slot;
     o[0] = q[0];
     o[1] = q[1];
@@ -805,6 +805,18 @@ __device__ void pose_refine(const float* pts, int* list, const int k, float* R, 
     obj_ninl[slot] = n_inl;
     obj_err[slot] = err;
     obj_valid[slot] = 1;
+  }
+  if (fuse) {
+    // fused FILTER: the new object's F1 (score + keypoint claims, filter_dev.h) here, by the wavefront that made it -- the
+    // frame's closing workgroup starts at F2
+    FilterBuffers fb = fuse->fb;
+    fb.corr = frame_ptr(fb.corr, fa);
+    fb.m_rep = frame_ptr(fb.m_rep, fa);
+    fb.model_off = frame_ptr(fb.model_off, fa);
+    fb.obj_score = frame_ptr(fb.obj_score, fa);
+    fb.best = frame_ptr(fb.best, fa);
+    const int model = frame_ptr(fb.obj_model, fa)[slot];
+    filter_score_wave(fb, cams[0], fuse->feature_distance, slot, model, q, t, lane);
   }
 }
 #ifdef POSE_PROF   // (back to the task-level form for pose_task below)
@@ -842,7 +854,7 @@ __device__ void pose_task(
     const int obj_base, int max_objects,
     int32_t* __restrict__ obj_model0, float* __restrict__ obj_pose0, int32_t* __restrict__ obj_ninl0,
     float* __restrict__ obj_err0, int32_t* __restrict__ obj_cluster0, int32_t* obj_valid0,
-    FrameCounts* counts0, PoseHyp* hyp_out0) {
+    FrameCounts* counts0, PoseHyp* hyp_out0, const FilterFuseArgs* __restrict__ fuse) {
   PoseHyp* hyp_out = frame_ptr(hyp_out0, fa);
   const mh_corr* __restrict__ corr = frame_ptr(corr0, fa);
   const float4* __restrict__ depth = frame_ptr(depth0, fa);
@@ -1143,14 +1155,15 @@ __device__ void pose_task(
   for (int i = 0; i < 3; ++i) t[i] = L.best_pose[9 + i];
 #ifdef POSE_PROF
   pose_refine<KIND>(L.pts, L.list, k, R, t, near_miss, cams, prm, alpha, lane, slot, obj_pose, obj_ninl, obj_err, obj_valid,
-                    pp_loc, &t_prof);
+                    fuse, fa, pp_loc, &t_prof);
   if (threadIdx.x == 0 && obj_valid[slot]) {
     for (int i = 0; i < 6; ++i) atomicAdd(&g_pose_prof[i], pp_loc[i]);
     atomicAdd(&g_pose_prof[7], 1ull);
     pp_end.done = true;
   }
 #else
-  pose_refine<KIND>(L.pts, L.list, k, R, t, near_miss, cams, prm, alpha, lane, slot, obj_pose, obj_ninl, obj_err, obj_valid);
+  pose_refine<KIND>(L.pts, L.list, k, R, t, near_miss, cams, prm, alpha, lane, slot, obj_pose, obj_ninl, obj_err, obj_valid,
+                    fuse, fa);
 #endif
 }
 
@@ -1207,8 +1220,7 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
     ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
     __shared__ FilterLds FS;
     __syncthreads();
-    filter_score(FS, ffb, cam, fuse_args->feature_distance, n_slots, 0, 1);
-    __syncthreads();
+    // (F1 -- every object's score and its claims -- was run by the wavefront that refined the object: pose_refine)
     filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
                   frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
     __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)
@@ -1260,7 +1272,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     for (int task = first; task < n_tasks; task += G) {
       pose_task<KIND, SPLIT>(L, task / R_, task % R_, a, corr0, depth0, alpha, members0, cl_model0, cl_begin0, cl_count0, cam,
                       cam_table, img_of0, n_images, prm, seed, obj_base, max_objects, obj_model0, obj_pose0, obj_ninl0,
-                      obj_err0, obj_cluster0, obj_valid0, counts0, hyp0);
+                      obj_err0, obj_cluster0, obj_valid0, counts0, hyp0, SPLIT ? nullptr : fuse_args);
       __syncthreads();  // LDS is reused by the next task
       if (ticket && frame_work_done(ticket, 1u, (unsigned)n_tasks)) last = true;
     }
@@ -1393,10 +1405,10 @@ __global__ __launch_bounds__(POSE_THREADS, MH_REFINE_MIN_WAVES) void pose_refine
         for (int i = 0; i < 3; ++i) t[i] = hyp[slot].pose[9 + i];
 #ifdef POSE_PROF
         pose_refine<KIND>(pts, list, k, R, t, hyp[slot].flags & 1, cams, prm, alpha, lane, slot, frame_ptr(obj_pose0, fa),
-                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa), nullptr, nullptr);
+                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa), fuse_args, fa, nullptr, nullptr);
 #else
         pose_refine<KIND>(pts, list, k, R, t, hyp[slot].flags & 1, cams, prm, alpha, lane, slot, frame_ptr(obj_pose0, fa),
-                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa));
+                          frame_ptr(obj_ninl0, fa), frame_ptr(obj_err0, fa), frame_ptr(obj_valid0, fa), fuse_args, fa);
 #endif
       }
     }
