@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from moped_amd import synth, capi
 from moped_amd.pipeline import FramePipeline, ShardedDB
