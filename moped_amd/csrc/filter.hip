@@ -11,7 +11,9 @@
 //  F3  one thread: erase objects with too few points or too low a score, keep list
 //      order, build the rewritten cluster table (:150-160)
 //  F4  per kept object: ordered member list
-// One launch: F1 in every workgroup, F2..F4 in the last workgroup to finish.
+// One launch: F1 in every workgroup (one wavefront per object), F2..F4 in the last workgroup to finish.  The frame paths
+// do not launch this kernel: their FILTER is fused into the POSE launch before it -- every object's F1 by the wavefront
+// that refined it (filter_score_wave), F2..F4 by the workgroup that closes the frame (pose.hip, pose_close_frame).
 #include <cstdlib>
 
 #include "filter_dev.h"
