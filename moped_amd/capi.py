@@ -174,6 +174,7 @@ def load():
     L.mh_frame_enqueue.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params), C.c_uint64]
     L.mh_frame_run_host.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), i32, C.POINTER(mh_frame_params), C.c_uint64, i32,
                                     vp, i32, C.POINTER(C.c_int32), vp]
+    L.mh_frame_run_host_begin.argtypes = [vp, vp, vp, vp, i32, C.POINTER(mh_cam), i32, C.POINTER(mh_frame_params), C.c_uint64, i32]
     L.mh_sift_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_sift_extract_dev.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.mh_frame_enqueue_image.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(mh_cam), C.POINTER(mh_frame_params),
@@ -272,6 +273,7 @@ def load():
     L.mh_frame_fetch_wait.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mh_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mh_host_free.argtypes = [vp, vp]
+    L.mh_frame_wait_descriptors.argtypes = [vp]
     L.mh_frame_fetch_query.argtypes = [vp]
     _lib = L
     return L
@@ -829,6 +831,32 @@ class Context:
                                           arr, len(Ks), C.byref(params), C.c_uint64(int(seed)), int(bool(write_back)),
                                           _ptr(objs), max_objects, C.byref(n), _ptr(counts)), "mh_frame_run_host")
         return objs[:min(n.value, max_objects)].copy(), counts
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory from the library (mh_host_alloc) as a uint8 array; host_free(array) releases it."""
+        p = C.c_void_p()
+        self._ck(self.L.mh_host_alloc(self.h, C.c_size_t(int(nbytes)), C.byref(p)), "mh_host_alloc")
+        a = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p.value))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        self._ck(self.L.mh_host_free(self.h, C.c_void_p(self._pinned.pop(a.ctypes.data))), "mh_host_free")
+
+    def frame_run_host_begin(self, q_desc, q_uv, Ks, cams, params: mh_frame_params, seed=1, q_image=None, write_back=True):
+        """mh_frame_run_host in halves: upload + enqueue (returns at once); then frame_wait_descriptors(), frame_fetch().
+        The arrays must stay alive and untouched until then."""
+        assert q_desc.dtype == np.float32 and q_desc.flags.c_contiguous and q_desc.shape[1] == 128
+        assert q_uv.dtype == np.float32 and q_uv.flags.c_contiguous
+        arr = make_cams(Ks, cams)
+        self._rh_keep = (q_desc, q_uv, q_image, arr)
+        self._ck(self.L.mh_frame_run_host_begin(self.h, _ptr(q_desc), _ptr(q_uv), None if q_image is None else _ptr(q_image),
+                                                q_desc.shape[0], arr, len(Ks), C.byref(params), C.c_uint64(int(seed)),
+                                                int(bool(write_back))), "mh_frame_run_host_begin")
+
+    def frame_wait_descriptors(self):
+        self._ck(self.L.mh_frame_wait_descriptors(self.h), "mh_frame_wait_descriptors")
 
     def frame_enqueue_image(self, gray_ptr, w, h, double_size, max_keypoints, K, cam, params: mh_frame_params,
                             seed=1, _cam_struct=None):

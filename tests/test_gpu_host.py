@@ -254,3 +254,35 @@ def test_frame_resident_plugin_publishes_every_constant_and_fills_matches_on_req
     assert outs["resident"][1] == 0                                   # sized, left empty (the default)
     assert outs["filled"][1] == outs["steps"][1] > 100                # what MATCH_BRUTE_HIP put there step by step
     assert outs["filled"][2] == outs["resident"][2] and len(outs["filled"][2]) == 2
+
+
+@pytest.mark.gpu
+def test_run_host_in_halves_from_page_locked_memory_equals_the_one_call():
+    """mh_host_alloc + mh_frame_run_host_begin / mh_frame_wait_descriptors / mh_frame_fetch (what FRAME_RESIDENT_HIP calls
+    since the end of round 4): the descriptors come back normalised as soon as the wait returns, the objects are those
+    of mh_frame_run_host -- bit for bit, three frames in a row through the same page-locked block."""
+    from moped_amd import capi
+    db = synth.make_db(6, 2000)
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    prm = capi.default_frame_params()
+    Q = 1500
+    block = c.host_alloc(Q * (128 + 2) * 4)
+    desc = block[:Q * 128 * 4].view(np.float32).reshape(Q, 128)
+    uv = block[Q * 128 * 4:].view(np.float32).reshape(Q, 2)
+    for i in range(3):
+        fr = synth.make_frame(db, n_vis=2, seed=40 + i, Q=Q, pts_per_obj=120)
+        plain = fr.desc.copy()
+        want, wcounts = c.frame_run_host(plain, fr.uv, [K], [CAM0], prm, 77 + i)
+        desc[:] = fr.desc
+        uv[:] = fr.uv
+        c.frame_run_host_begin(desc, uv, [K], [CAM0], prm, 77 + i)
+        c.frame_wait_descriptors()
+        assert np.array_equal(desc.view(np.uint32), plain.view(np.uint32))     # normalised, before the frame is fetched
+        objs, counts = c.frame_fetch()
+        assert len(want) == 2 and np.array_equal(counts, wcounts)
+        assert np.array_equal(objs["model"], want["model"])
+        assert np.array_equal(objs["pose"].view(np.uint32), want["pose"].view(np.uint32))
+        assert np.array_equal(objs["score"].view(np.uint32), want["score"].view(np.uint32))
+    c.host_free(block)
+    c.close()
