@@ -17,6 +17,10 @@
 #pragma once
 #include "hip_session.hpp"
 
+#ifndef MH_PACK_THREADS
+#define MH_PACK_THREADS 8   // threads of the loops that pack / unpack the frame's descriptors (OpenMP builds)
+#endif
+
 namespace MopedNS {
 
 class FRAME_RESIDENT_HIP : public MopedAlg {
@@ -187,6 +191,9 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
     }
     mh_ctx* ctx = HipSession::get();
     if (!pinFor(ctx, Q)) { HipSession::warn("mh_host_alloc"); return; }
+    // (3 000 features = 3 000 separately allocated descriptors: ~0.1 ms on one thread -- the reference's steps use OpenMP
+    //  for their own loops over the features, MATCH_ANN_CPU.hpp:160)
+    #pragma omp parallel for num_threads(MH_PACK_THREADS) schedule(static)
     for (int i = 0; i < Q; ++i) {
       for (int j = 0; j < MH_DESC_DIM; ++j) packed[(size_t)i * MH_DESC_DIM + j] = feats[i].descriptor[j];
       uv[2 * i] = feats[i].coord2D[0];
@@ -201,6 +208,7 @@ class FRAME_RESIDENT_HIP : public MopedAlg {
                                      (uint64_t)frameCounter * 2654435761ul + _alg, 1);
     if (rc == MH_OK) rc = mh_frame_wait_descriptors(ctx);
     if (rc != MH_OK) { HipSession::warn("mh_frame_run_host_begin"); return; }
+    #pragma omp parallel for num_threads(MH_PACK_THREADS) schedule(static)
     for (int i = 0; i < Q; ++i)
       for (int j = 0; j < MH_DESC_DIM; ++j) feats[i].descriptor[j] = packed[(size_t)i * MH_DESC_DIM + j];
     rc = mh_frame_fetch(ctx, &out[0], (int)out.size(), &n, counts);
