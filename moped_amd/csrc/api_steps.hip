@@ -72,6 +72,10 @@ struct FrameState {
     FrameCounts fc;
     int32_t n_feat;
   }* fetch_pin = nullptr;
+  // one frame alone: the closing workgroup of FILTER2 writes the frame's head, counters and objects HERE itself
+  // (page-locked, device-writable): mh_frame_fetch then synchronises and reads -- no copy at all
+  FrameHostBlock* host_block = nullptr;
+  bool host_armed = false;   // the frame enqueued last writes host_block (a batch, a frame without FILTER2: no)
   // the fused FILTER / FILTER2 steps' arguments on the device + what the host last stored there (FilterFuse, steps.h)
   FilterFuseArgs* fuse_dev = nullptr;   // [2]
   FilterFuseArgs fuse_shadow[2];
@@ -94,6 +98,7 @@ void free_fs(FrameState* fs) {
     if (p) hipFree(p);
   if (fs->fb) hipHostFree(fs->fb);
   if (fs->fetch_pin) hipHostFree(fs->fetch_pin);
+  if (fs->host_block) hipHostFree(fs->host_block);
   delete fs;
 }
 
@@ -202,6 +207,8 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
     if (hipHostMalloc(&fs->fb, 3 * MH_MAX_BATCH * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
     else std::memset(fs->fb, 0xFF, 3 * MH_MAX_BATCH * sizeof(int32_t));   // -1 = nothing known yet
     if (hipHostMalloc(&fs->fetch_pin, sizeof(*fs->fetch_pin), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
+    if (hipHostMalloc(&fs->host_block, sizeof(*fs->host_block), hipHostMallocDefault) != hipSuccess) rc = MH_ERR_HIP;
+    else std::memset(fs->host_block, 0, sizeof(*fs->host_block));
   }
   if (rc) {   // a half-built state must not look valid to the next call
     free_fs(fs);
@@ -513,7 +520,11 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     fb.n_images = ctx->n_images;
   }
   const bool fused = fuse_filter && prm->run_stage2 && !ctx->timing;   // (stage timing wants the steps apart)
-  const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid}, ft2{fs->tickets + 4, nullptr, result, grid};
+  // (one frame alone in result slot 0: FILTER2's tail also writes the host's block, mh_frame_fetch reads it without a copy)
+  fs->host_armed = batch_n == 1 && fs->slot == 0 && prm->run_stage2 && fs->host_block;
+  if (fs->host_armed) fs->host_block->seq = 0u;
+  const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid, nullptr, nullptr},
+      ft2{fs->tickets + 4, nullptr, result, grid, fs->host_armed ? fs->host_block : nullptr, fs->host_armed ? snap : nullptr};
   FilterFuse ff1, ff2;
   ff1.fb = ff2.fb = &fb;
   ff1.tail = &ft1;
@@ -1349,7 +1360,7 @@ int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image
     fb.n_images = n_images;
   }
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
-                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0}, s);
+                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0, nullptr, nullptr}, s);
   MH_HIP(ctx, hipGetLastError());
   // results: everything the host needs in ONE pinned block, copied behind the kernel, one synchronisation (five
   // blocking copies after it cost the step 0.1 ms: profiles/r02_host_step_timing.txt)
@@ -1663,6 +1674,36 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   FrameState* fs = ctx->fs;
   FrameState::FetchPin& pin = *fs->fetch_pin;
+  if (fs->host_armed && !ctx->feat_count_dev) {
+    // the frame's FILTER2 wrote the host's block itself: wait for the stream, read
+    MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const FrameHostBlock& h = *fs->host_block;
+    if (h.seq == 1u) {
+      const int n = h.head[0];
+      *n_objects = n;
+      if (counts) std::memcpy(counts, h.snap, 4 * sizeof(int32_t));
+      const int tasks = 4 * std::max(h.snap[1], h.snap[3]);
+      fs->task_grid = std::min(96, std::max(16, (tasks + tasks / 2 + 7) / 8 * 8));
+      fs->ms_grid = std::min(32, std::max(4, h.snap[1] + 2));
+      const int take = n < max_objects ? n : max_objects;
+      if (take > 0 && objects_host) {
+        const int have = std::min(take, FRAME_HOST_OBJECTS);
+        std::memcpy(objects_host, h.objects, sizeof(mh_object) * (size_t)have);
+        if (take > have)
+          MH_HIP(ctx, hipMemcpy(objects_host + have, fs->result + 16 + sizeof(mh_object) * (size_t)have,
+                                sizeof(mh_object) * (size_t)(take - have), hipMemcpyDeviceToHost));
+      }
+      if (h.error) {
+        ctx->err = (h.error & ERR_EXCHANGE)
+                       ? std::string("frame exchange: the ranks' blocks carry different sequence numbers / seeds -- the ranks issued "
+                                     "their collectives in different orders (every rank must enqueue its slots in the same order)")
+                       : "frame: capacity exceeded (flags " + std::to_string(h.error) + ")";
+        return MH_ERR_CAPACITY;
+      }
+      return MH_OK;
+    }
+    // (the tail did not run -- a launch failed: the copies below report what there is)
+  }
   const size_t first = std::min(fs->result_bytes, sizeof pin.head + sizeof pin.objects);   // head + the first objects: one copy
   MH_HIP(ctx, hipMemcpyAsync(pin.head, fs->result, first, hipMemcpyDeviceToHost, ctx->stream));
   MH_HIP(ctx, hipMemcpyAsync(pin.snap, fs->snap, sizeof pin.snap, hipMemcpyDeviceToHost, ctx->stream));

@@ -298,6 +298,17 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
     }
     reinterpret_cast<int32_t*>(tail.result)[0] = kept;
     reinterpret_cast<int32_t*>(tail.result)[1] = counts->error;   // sticky capacity flags of this frame
+    if (tail.host) {   // one frame alone: the same straight into the host's page-locked block (no copies at fetch)
+      FrameHostBlock* h = tail.host;
+      h->head[0] = kept;
+      h->head[1] = counts->error;
+      h->head[2] = h->head[3] = 0;
+      for (int r = 0; r < kept && r < FRAME_HOST_OBJECTS; ++r) h->objects[r] = out[r];
+      for (int i = 0; i < 4; ++i) h->snap[i] = tail.snap_all ? tail.snap_all[i] : 0;
+      h->error = counts->error;
+      __threadfence_system();
+      h->seq = 1u;
+    }
   }
 }
 

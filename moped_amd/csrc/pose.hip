@@ -1217,6 +1217,7 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
     FilterTail ftail = fuse_args->tail;
     ftail.ticket = frame_ptr(ftail.ticket, a);
     if (ftail.snap_kept) ftail.snap_kept += 4 * f;
+    if (ftail.snap_all) ftail.snap_all += 4 * f;
     ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
     __shared__ FilterLds FS;
     __syncthreads();

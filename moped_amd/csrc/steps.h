@@ -283,6 +283,18 @@ struct FilterTail {
   int32_t* snap_kept;       // optional: number of kept objects
   unsigned char* result;    // optional: packed result block {int32 n; int32 pad[3]; mh_object[]}
   int grid;                 // workgroups to launch (0 = default cap)
+  // optional (with `result`): the frame's head, counters and first objects ALSO into host memory the device can write
+  // (FrameHostBlock in page-locked memory, one frame alone) -- mh_frame_fetch then needs a synchronisation and no copy
+  struct FrameHostBlock* host = nullptr;
+  const int32_t* snap_all = nullptr;   // the frame's four counters (snap[0..3]) for the host block
+};
+constexpr int FRAME_HOST_OBJECTS = 32;
+struct FrameHostBlock {
+  int32_t head[4];                       // n objects, error flags, -, -  (as the result block's)
+  mh_object objects[FRAME_HOST_OBJECTS];
+  int32_t snap[4];
+  int32_t error;                         // FrameCounts::error
+  volatile uint32_t seq;                 // 0 written by the host at enqueue, 1 by the kernel after everything above
 };
 // The fused FILTER step's arguments as the POSE kernel reads them: from device memory, at the one place that needs them
 // (the closing workgroup of a frame), instead of ~70 scalar registers' worth of kernel arguments held -- and spilled --
