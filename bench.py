@@ -12,12 +12,18 @@ N > 1 = one process per GPU.  Started under torch.distributed.run the ranks are 
 launcher's; started as plain `python bench.py --gpus N` this process starts the N
 ranks itself (a child torch.distributed.run, BEFORE anything here touches the GPU)
 and relays rank 0's line -- `n_gpus` is always the number of ranks that ran.  The
-default partition at N > 1 is BASELINE.json north_star's: the model database is
-sharded by model over the ranks and every batch of frames does the one all-gather
-of SURVEY.md 8(e) over RCCL (total work fixed: "strong" scaling).  Two secondary
-measurements ride in the same line: `replicated_frames` (DB replicated, frames
-split, no collective: SURVEY 8(e)'s alternative) and `sharded_200_models`
-(BASELINE configs[3]: the 200-model DB sharded N ways).  Rank 0 prints ONE JSON line.
+partition at N > 1 is BASELINE.json north_star's -- the model database sharded by
+model, one all-gather of SURVEY.md 8(e) per batch of frames over RCCL -- as a
+models x frames GRID: G model shards x R frame groups (G R = N).  The G ranks of a
+frame group hold the whole DB between them and exchange over communicators of their
+own; the R groups work on different frames and never talk.  R = 1 is pure model
+sharding (total work fixed: "strong" scaling), G = 1 pure frame splitting;
+`--parallelism auto` takes the largest G whose projected rate (committed per-rank
+loads, profiles/per_rank_load.json) reaches 0.75 N times the single GPU's, else the
+best G >= 2 (20 models at N = 8: 2 x 4; 200 models: 8 x 1).  Secondary measurements
+ride in the same line: `pure_model_shard` (when auto took R > 1), `replicated_frames`
+(DB replicated, frames split, no collective) and `sharded_200_models` (BASELINE
+configs[3]: the 200-model DB sharded N ways).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -73,10 +79,14 @@ def parse(argv=None):
                     help="with --moped3d-frontend: the sensor's depth map arrives with holes (z < 0 on ~12%% of the pixels) and "
                          "moped3d's DEPTHFILL step (DEPTH_FILL_EXACT_CPU(8, false), config.hpp:39) runs on the device for every "
                          "frame inside the timed region: a 4.9 MB working copy, the fill, the distance map")
-    ap.add_argument("--parallelism", choices=("auto", "models", "frames"), default="auto",
-                    help="N > 1: 'models' (the north-star design, and what 'auto' means) shards the DB by model with one "
+    ap.add_argument("--parallelism", choices=("auto", "models", "frames", "grid"), default="auto",
+                    help="N > 1: 'models' (the north-star design) shards the DB by model over all N ranks with one "
                          "all-gather per batch of frames; 'frames' replicates the DB and gives every rank its own frames (no "
-                         "exchange: SURVEY 8(e)'s alternative for DBs too small to shard)")
+                         "exchange: SURVEY 8(e)'s alternative for DBs too small to shard); 'grid' = G model shards x R frame "
+                         "groups (--grid, or the table's choice); 'auto' = the grid the committed per-rank loads project "
+                         "fastest under the rule in choose_partition (pure model sharding wherever that reaches 0.75 N)")
+    ap.add_argument("--grid", default="",
+                    help="'GxR' for --parallelism grid: G model shards per frame group x R frame groups, G R = the ranks")
     ap.add_argument("--assign", choices=("block", "round-robin"), default="round-robin",
                     help="model -> rank assignment of a sharded DB: round-robin (rank r owns models r, r + N, ...; SURVEY 8(e): spreads the "
                          "visible models' POSE work over the ranks) or contiguous blocks")
@@ -256,11 +266,68 @@ def cpu_baseline(db, frames, args):
     }
 
 
-def choose_parallelism(n_models: int, world: int) -> str:
-    """What `--parallelism auto` runs: north_star's partition -- the model database sharded over the ranks, one
-    all-gather per batch of frames -- for every DB and every N (a small DB scales badly that way and the line says
-    so; `replicated_frames` beside it is the partition that suits such a DB).  DESIGN.md 5."""
-    return "models"
+PER_RANK_LOAD = os.path.join(ROOT, "profiles", "per_rank_load.json")
+
+
+def per_rank_us(models_per_rank: float, table=None) -> float:
+    """Microseconds per frame of ONE rank that owns `models_per_rank` models (5 000 points each; one of them visible
+    in a frame), from the committed measurements (profiles/per_rank_load.json: bench.py --models m --n-vis 1
+    --force-exchange on one MI355X, i.e. behind the real exchange entry points at world 1), piecewise linear in
+    between, the last segment's slope beyond."""
+    if table is None:
+        with open(PER_RANK_LOAD) as f:
+            table = json.load(f)["frames_per_s_by_models_per_rank"]
+    pts = sorted((float(m), 1e6 / float(v)) for m, v in table.items())
+    if models_per_rank <= pts[0][0]:
+        return pts[0][1]
+    for (m0, u0), (m1, u1) in zip(pts, pts[1:]):
+        if models_per_rank <= m1:
+            return u0 + (u1 - u0) * (models_per_rank - m0) / (m1 - m0)
+    (m0, u0), (m1, u1) = pts[-2], pts[-1]
+    return u1 + (u1 - u0) / (m1 - m0) * (models_per_rank - m1)
+
+
+def projected_speedup(n_models: int, G: int, R: int, table=None) -> float:
+    """R frame groups, each at the rate of a rank that owns n_models / G models, over the single GPU's rate."""
+    return R * per_rank_us(n_models, table) / per_rank_us(n_models / G, table)
+
+
+def choose_partition(n_models: int, world: int, parallelism: str = "auto", grid: str = "", table=None):
+    """(G, R): G model shards per frame group x R frame groups, G R = world.
+    'models' -> (world, 1): north_star's partition as it is written.  'frames' -> (1, world).  'grid' -> --grid, else
+    like 'auto'.  'auto': model sharding stays the design (G >= 2 whenever world >= 2); a rank's cost per frame does not
+    shrink with its shard below ~20 us (every rank still screens every query), so a small DB sharded 8 ways
+    projects 2.7-2.9x where north_star asks >= 6x.  Rule: the LARGEST G dividing world whose projection reaches 0.75
+    world; none does -> the G >= 2 with the best projection.  (20 models: 2 x 4 at N = 8, 2 x 2 at 4; 200 models: 8 x 1.)"""
+    if world <= 1:
+        return 1, 1
+    if parallelism == "models":
+        return world, 1
+    if parallelism == "frames":
+        return 1, world
+    if grid:
+        G, R = (int(x) for x in grid.lower().split("x"))
+        if G < 1 or R < 1 or G * R != world:
+            raise SystemExit(f"bench.py: --grid {grid} does not multiply to the {world} ranks that run")
+        return G, R
+    cands = [g for g in range(world, 1, -1) if world % g == 0 and g <= max(n_models, 2)]
+    proj = {g: projected_speedup(n_models, g, world // g, table) for g in cands}
+    for g in cands:   # descending
+        if proj[g] >= 0.75 * world:
+            return g, world // g
+    g = max(cands, key=lambda k: proj[k])
+    return g, world // g
+
+
+def partition_label(G: int, R: int) -> str:
+    world = G * R
+    if world <= 1:
+        return "single GPU"
+    if R == 1:
+        return f"model-shard x{world}"
+    if G == 1:
+        return f"frame-parallel x{world} (DB replicated)"
+    return f"grid: {G} model shards x {R} frame groups"
 
 
 def parse_lane(text: str):
@@ -271,15 +338,16 @@ def parse_lane(text: str):
     return (v[0], v[1] if len(v) > 1 else 2, bool(v[2]) if len(v) > 2 else False)
 
 
-def scaling_label(parallelism: str, world: int) -> str:
-    """The contract's `scaling` key: nothing scales at N = 1; model sharding keeps the total work fixed; frame
-    splitting keeps the per-GPU work fixed."""
-    if world <= 1:
+def scaling_label(G: int, R: int) -> str:
+    """The contract's `scaling` key: nothing scales at N = 1; pure model sharding (R = 1) keeps the total work fixed;
+    frame groups each bring their own frames -- the job's frames grow with R ("weak": with G = 1 the per-GPU work is
+    fixed outright, in a grid each rank's share of a frame is 1/G of the single GPU's)."""
+    if G * R <= 1:
         return "n/a"
-    return "weak" if parallelism == "frames" else "strong"
+    return "strong" if R == 1 else "weak"
 
 
-def default_batch(args, sharded: bool) -> int:
+def default_batch(args, sharded: bool, shards: int = 0) -> int:
     from moped_amd import capi
     if args.batch > 0:
         return min(args.batch, capi.MAX_BATCH)
@@ -288,7 +356,7 @@ def default_batch(args, sharded: bool) -> int:
     if sharded:
         # a shard of a few thousand rows does not fill the chip for one frame's queries, and every launch of the rest
         # chain is shared by the frames of a batch: as many as the library takes
-        return capi.MAX_BATCH if args.models // max(args.gpus, 1) < 25 else 16
+        return capi.MAX_BATCH if args.models // max(shards or args.gpus, 1) < 25 else 16
     # sixteen frames per MATCH launch sequence (48 000 queries: three rounds of pass B workgroups that sweep 49 tiles each
     # instead of two rounds of 38 for eight frames -- fewer prologues and a fuller last query block per frame: +2.7% on
     # config 1, +1.6% on config 2); a batch of plain frames also shares the launches of its rest chain (one group /

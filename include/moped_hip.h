@@ -218,7 +218,8 @@ typedef struct {
   int n_pts_align;         /* distinct 2-D points a cluster needs (5 POSE / 6 POSE2) */
   int min_n_pts_object;    /* a hypothesis needs MORE inliers than this (6 / 8) */
   float error_threshold;   /* squared pixel error of an inlier (10 / 5) */
-  int lm_iters_l2;         /* LM iterations on plain pixel residuals */
+  int lm_iters_l2;         /* LM iterations on plain residuals (default 2: a warm start; with depth residuals,
+                              depth_kind 1 / 2, values 1..9 are raised to 10; 0 = no plain phase) */
   int lm_iters_l4;         /* then on the reference's squared residuals */
 } mh_pose_params;
 

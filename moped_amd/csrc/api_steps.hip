@@ -76,6 +76,7 @@ struct FrameState {
   // (page-locked, device-writable): mh_frame_fetch then synchronises and reads -- no copy at all
   FrameHostBlock* host_block = nullptr;
   bool host_armed = false;   // the frame enqueued last writes host_block (a batch, a frame without FILTER2: no)
+  uint32_t host_seq_expect = 0;   // armed enqueues so far = what host_block->seq reads once the last of them is through
   // the fused FILTER / FILTER2 steps' arguments on the device + what the host last stored there (FilterFuse, steps.h)
   FilterFuseArgs* fuse_dev = nullptr;   // [2]
   FilterFuseArgs fuse_shadow[2];
@@ -217,6 +218,8 @@ int ensure_fs(mh_ctx* ctx, int max_m, int max_clusters, int max_objects, int n_m
   }
   // every frame's tickets, claim table (best), obj_valid / obj_score / obj_npts start at zero
   MH_HIP(ctx, hipMemsetAsync(fs->arena, 0, fs->arena_bytes * n_arenas, ctx->stream));
+  fs->host_seq_expect = 0;   // (tickets[7], the device's count of host-block writes, is zero again)
+  fs->host_armed = false;
   return MH_OK;
 }
 
@@ -522,9 +525,10 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   const bool fused = fuse_filter && prm->run_stage2 && !ctx->timing;   // (stage timing wants the steps apart)
   // (one frame alone in result slot 0: FILTER2's tail also writes the host's block, mh_frame_fetch reads it without a copy)
   fs->host_armed = batch_n == 1 && fs->slot == 0 && prm->run_stage2 && fs->host_block;
-  if (fs->host_armed) fs->host_block->seq = 0u;
-  const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid, nullptr, nullptr},
-      ft2{fs->tickets + 4, nullptr, result, grid, fs->host_armed ? fs->host_block : nullptr, fs->host_armed ? snap : nullptr};
+  if (fs->host_armed) ++fs->host_seq_expect;
+  const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid, nullptr, nullptr, nullptr},
+      ft2{fs->tickets + 4, nullptr, result, grid, fs->host_armed ? fs->host_block : nullptr, fs->host_armed ? snap : nullptr,
+          fs->host_armed ? fs->tickets + 7 : nullptr};
   FilterFuse ff1, ff2;
   ff1.fb = ff2.fb = &fb;
   ff1.tail = &ft1;
@@ -1129,6 +1133,10 @@ int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, con
 
 int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {
   if (!ctx) return MH_ERR_ARG;
+  if (prm && (prm->linkage_type < 0 || prm->linkage_type > 2)) {   // (before anything of the context changes)
+    ctx->err = "mh_frame_set_cluster_linkage: linkage_type must be 0 (minimum), 1 (average) or 2 (maximum)";
+    return MH_ERR_ARG;
+  }
   ctx->linkage_on = prm != nullptr;
   if (prm) {
     ctx->linkage.cutoff = prm->cutoff;
@@ -1136,7 +1144,6 @@ int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {
     ctx->linkage.use3d_filter = prm->use3d_filter;
     ctx->linkage.sigma2d = prm->sigma2d;
     ctx->linkage.sigma3d = prm->sigma3d;
-    if (prm->linkage_type < 0 || prm->linkage_type > 2) return MH_ERR_ARG;
     ctx->linkage.linkage_type = prm->linkage_type;
   }
   return MH_OK;
@@ -1147,6 +1154,10 @@ int mh_cluster_linkage(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* de
                        int32_t* n_clusters) {
   if (!ctx || n_problems < 0 || !prm || (n_problems > 0 && (!off || !n_clusters))) {
     if (ctx) ctx->err = "mh_cluster_linkage: bad argument";
+    return MH_ERR_ARG;
+  }
+  if (prm->linkage_type < 0 || prm->linkage_type > 2) {   // (before any upload is enqueued)
+    ctx->err = "mh_cluster_linkage: linkage_type must be 0 (minimum), 1 (average) or 2 (maximum)";
     return MH_ERR_ARG;
   }
   if (n_problems == 0) return MH_OK;
@@ -1203,7 +1214,6 @@ int mh_cluster_linkage(mh_ctx* ctx, const mh_corr* corr_host, const mh_depth* de
   lp.use3d_filter = prm->use3d_filter;
   lp.sigma2d = prm->sigma2d;
   lp.sigma3d = prm->sigma3d;
-  if (prm->linkage_type < 0 || prm->linkage_type > 2) return MH_ERR_ARG;
   lp.linkage_type = prm->linkage_type;
   launch_linkage_batch(d_corr, d_depth, d_off, n_problems, ctx->depth_img, lp, ctx->lk_scratch, ctx->lk_scratch_floats,
                        d_members, d_start, d_ncl, d_label, s);
@@ -1360,7 +1370,7 @@ int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image
     fb.n_images = n_images;
   }
   launch_filter(fb, make_devcam(*cam), min_points, feature_distance, min_score, fs->n_slots,
-                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0, nullptr, nullptr}, s);
+                fs->n_clusters, fs->counts, FilterTail{fs->tickets + 5, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, s);
   MH_HIP(ctx, hipGetLastError());
   // results: everything the host needs in ONE pinned block, copied behind the kernel, one synchronisation (five
   // blocking copies after it cost the step 0.1 ms: profiles/r02_host_step_timing.txt)
@@ -1444,6 +1454,13 @@ int mh_frame_run_host_begin(mh_ctx* ctx, float* q_desc_host, const float* q_uv_h
   }
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
+  // A write-back of the frame before may still be copying q_desc out on wb_stream (the caller skipped
+  // mh_frame_wait_descriptors, or a call failed behind its copy): this frame's upload overwrites that buffer and
+  // ensure_frame_buffers may free it -- wait for the stream whatever wb_pending says (nothing in flight: no cost).
+  if (ctx->wb_stream) {
+    MH_HIP(ctx, hipStreamSynchronize(ctx->wb_stream));
+    ctx->wb_pending = false;
+  }
   int rc = ensure_frame_buffers(ctx, Q);
   if (rc) return rc;
   MH_HIP(ctx, hipMemcpyAsync(ctx->q_desc, q_desc_host, (size_t)Q * DIM * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -1475,9 +1492,9 @@ int mh_frame_run_host_begin(mh_ctx* ctx, float* q_desc_host, const float* q_uv_h
   if (rc) return rc;
   if (write_back) {
     MH_HIP(ctx, hipStreamWaitEvent(ctx->wb_stream, ctx->wb_ev, 0));
+    ctx->wb_pending = true;   // (set before the copy: an error below must not hide a copy that did start)
     MH_HIP(ctx, hipMemcpyAsync(q_desc_host, ctx->q_desc, (size_t)Q * DIM * sizeof(float), hipMemcpyDeviceToHost, ctx->wb_stream));
   }
-  ctx->wb_pending = write_back != 0;
   return MH_OK;
 }
 
@@ -1678,7 +1695,9 @@ int mh_frame_fetch(mh_ctx* ctx, mh_object* objects_host, int max_objects, int32_
     // the frame's FILTER2 wrote the host's block itself: wait for the stream, read
     MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const FrameHostBlock& h = *fs->host_block;
-    if (h.seq == 1u) {
+    const uint32_t seq = h.seq;
+    if (seq != fs->host_seq_expect) fs->host_seq_expect = seq;   // (stale block: the stream is idle, the device's count is final -- resynchronise)
+    else {
       const int n = h.head[0];
       *n_objects = n;
       if (counts) std::memcpy(counts, h.snap, 4 * sizeof(int32_t));

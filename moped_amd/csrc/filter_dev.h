@@ -298,7 +298,7 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
     }
     reinterpret_cast<int32_t*>(tail.result)[0] = kept;
     reinterpret_cast<int32_t*>(tail.result)[1] = counts->error;   // sticky capacity flags of this frame
-    if (tail.host) {   // one frame alone: the same straight into the host's page-locked block (no copies at fetch)
+    if (tail.host && tail.host_seq) {   // one frame alone: the same straight into the host's page-locked block (no copies at fetch)
       FrameHostBlock* h = tail.host;
       h->head[0] = kept;
       h->head[1] = counts->error;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
       for (int i = 0; i < 4; ++i) h->snap[i] = tail.snap_all ? tail.snap_all[i] : 0;
       h->error = counts->error;
       __threadfence_system();
-      h->seq = 1u;
+      h->seq = atomicAdd(tail.host_seq, 1u) + 1u;
     }
   }
 }

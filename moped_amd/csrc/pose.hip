@@ -751,7 +751,11 @@ __device__ void pose_refine(const float* pts, int* list, const int k, float* R, 
   int n_inl = collect(same);
   PP_T(3);
   const bool repass = prm.lm_iters_l2 >= 0;   // (launch_pose: MH_POSE_REPASS=0 hands the cap over negated = one pass, for A/B runs)
-  const int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
+  int iters_l2 = prm.lm_iters_l2 >= 0 ? prm.lm_iters_l2 : -prm.lm_iters_l2;
+  // The 2-iteration default of the plain phase is a warm start for a squared-residual phase that takes Newton steps
+  // (LM_HS, RES 0 / 3).  The depth classes' second phase is plain Gauss-Newton at tol 1e-6: their first phase keeps the
+  // ten iterations it had before that default came; 0 still means "no plain phase".
+  if ((KIND == 1 || KIND == 2) && iters_l2 > 0 && iters_l2 < 10) iters_l2 = 10;
   if (near_miss) {
     lm_refine<KIND>(R, t, cams, pts, list, n_inl, alpha, 0, 10, lane);   // (to convergence: the count is taken under this pose)
     n_inl = collect(same);
@@ -1204,8 +1208,8 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
   int32_t* n_slots_dev = frame_ptr(tail0.n_slots, a);
   if (threadIdx.x == 0) *n_slots_dev = n_slots;
   if (fuse_args) {
-    // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores all objects, then
-    // F2..F4 and (FILTER2) the result block -- the same code the stand-alone kernel runs on several workgroups
+    // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores the objects the frame
+    // held before the launch, then F2..F4 and (FILTER2) the result block
     FilterBuffers ffb = fuse_args->fb;
     ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
     ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
@@ -1221,7 +1225,22 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
     ftail.result = frame_ptr(ftail.result, (unsigned long long)f * fbx.result_bytes);
     __shared__ FilterLds FS;
     __syncthreads();
-    // (F1 -- every object's score and its claims -- was run by the wavefront that refined the object: pose_refine)
+    // F1 -- an object's score and its claims -- of THIS launch's objects was run by the wavefront that refined each of
+    // them (pose_refine).  The objects the frame already held (FILTER2: the POSE objects FILTER kept, slots
+    // [0, obj_base)) compete with their re-estimates like the reference's list does (POSE2 appends to
+    // frameData.objects, ...REPROJECTION_CPU.hpp:299; FILTER_PROJECTION_CPU.hpp:96 scores every object): their F1 here,
+    // one wavefront per object, before the owners are counted.
+    if (obj_base > 0) {
+      const int lane = threadIdx.x & 63;
+      const int n_old = obj_base < n_slots ? obj_base : n_slots;
+      for (int o = threadIdx.x >> 6; o < n_old; o += POSE_THREADS / 64) {
+        if (!ffb.obj_valid[o]) continue;   // (wave-uniform)
+        filter_score_wave(ffb, cam, fuse_args->feature_distance, o, ffb.obj_model[o], ffb.obj_pose + 7 * (size_t)o,
+                          ffb.obj_pose + 7 * (size_t)o + 4, lane);
+      }
+      __threadfence();
+      __syncthreads();
+    }
     filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
                   frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
     __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)

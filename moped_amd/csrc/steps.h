@@ -287,6 +287,7 @@ struct FilterTail {
   // (FrameHostBlock in page-locked memory, one frame alone) -- mh_frame_fetch then needs a synchronisation and no copy
   struct FrameHostBlock* host = nullptr;
   const int32_t* snap_all = nullptr;   // the frame's four counters (snap[0..3]) for the host block
+  unsigned int* host_seq = nullptr;    // with `host`: device word counting the tails that wrote the block (FrameHostBlock::seq)
 };
 constexpr int FRAME_HOST_OBJECTS = 32;
 struct FrameHostBlock {
@@ -294,7 +295,10 @@ struct FrameHostBlock {
   mh_object objects[FRAME_HOST_OBJECTS];
   int32_t snap[4];
   int32_t error;                         // FrameCounts::error
-  volatile uint32_t seq;                 // 0 written by the host at enqueue, 1 by the kernel after everything above
+  // Written by the kernel after everything above: the number of FILTER2 tails that have written this block so far (a
+  // device counter).  The host counts its armed enqueues; a block whose seq is not that count is a stale one -- a frame
+  // whose launches failed, or were replayed without frame_rest -- and mh_frame_fetch falls back to the copies.
+  volatile uint32_t seq;
 };
 // The fused FILTER step's arguments as the POSE kernel reads them: from device memory, at the one place that needs them
 // (the closing workgroup of a frame), instead of ~70 scalar registers' worth of kernel arguments held -- and spilled --

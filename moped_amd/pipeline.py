@@ -79,7 +79,8 @@ class FramePipeline:
 
     def __init__(self, device: int, db: ShardedDB, depth: int = 1, max_queries: int = 4096,
                  params: capi.mh_frame_params | None = None, K=None, cam=None, group=None,
-                 force_exchange: bool = False, n_comms: int = 4, batch: int = 1, lane: "tuple | None" = None):
+                 force_exchange: bool = False, n_comms: int = 4, batch: int = 1, lane: "tuple | None" = None,
+                 id_leader: "int | None" = None):
         from . import synth
         self.dev = torch.device(f"cuda:{device}")
         torch.cuda.set_device(self.dev)
@@ -88,6 +89,12 @@ class FramePipeline:
         self.K = synth.K_DEFAULT if K is None else K
         self.cam = synth.CAM_IDENTITY if cam is None else cam
         self.group = group
+        # A models x frames grid (bench.py --parallelism grid): this pipeline's communicators span the db.world ranks of ONE
+        # frame group.  `id_leader` = the rank (of the default process group) that is shard 0 of this rank's frame group: the
+        # RCCL ids then travel by ONE all_gather_object over the default group per communicator, which every rank of the
+        # job joins -- no torch-side NCCL communicator per frame group.  `group` (a gloo subgroup of the frame group's ranks)
+        # carries the host transport of the rehearsal instead.
+        self.id_leader = id_leader
         self.world = db.world
         self.ctxs, self.streams = [], []
         normalized = None
@@ -135,8 +142,13 @@ class FramePipeline:
         comms = []
         for _ in range(n):
             ids = [capi.comm_unique_id() if self.db.rank == 0 else None]
-            if self.world > 1:
-                dist.broadcast_object_list(ids, src=0, group=self.group)
+            if self.id_leader is not None and inited:
+                every = [None] * dist.get_world_size()
+                dist.all_gather_object(every, ids[0])
+                ids[0] = every[self.id_leader]
+            elif self.world > 1:
+                src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+                dist.broadcast_object_list(ids, src=src, group=self.group)
             comms.append(capi.Comm.create(self.ctxs[0], ids[0], self.db.rank, self.world))
         return comms
 

@@ -203,3 +203,43 @@ def test_frame_with_more_object_slots_than_filter_keeps_in_lds():
     for m, sc in zip(om, osc):
         g = objs[objs["model"] == m][0]
         assert abs(g["score"] - sc) <= 0.05 * sc, (m, g["score"], sc)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3, 4])
+def test_pose_survivor_stays_when_pose2_finds_nothing(world, seed):
+    """Eight clean matches per object: POSE finds it (8 > MinNPtsObject 6), FILTER keeps it, POSE2 cannot succeed (it needs
+    MORE than 8 inliers) -- the reference's list still holds the POSE object (POSE2 appends, ...REPROJECTION_CPU.hpp:299)
+    and FILTER2 scores every object (FILTER_PROJECTION_CPU.hpp:96): 8 >= MinPoints 7, score ~7.8 >= 3, it stays.
+    The fused FILTER2 tail must score those kept slots too (it erased them): fused == stand-alone FILTER
+    launches (stage timing keeps the steps apart) == oracle, alone and in a batch."""
+    db, dbn, pipe, torch = world
+    dev = torch.device("cuda:0")
+    fr = synth.make_frame(db, n_vis=2, seed=seed, pts_per_obj=8, outlier_frac=0.0, pix_noise=0.2)
+    idx, d1, d2 = orclib.match_2nn(dbn, orclib.normalize(fr.desc))
+    om, op, osc, oc, _ = orclib.frame_rest_inliers(fr.uv, idx, d1, d2, db.model_of, db.xyz, db.n_models, K, CAM0,
+                                                   n_threads=1, seed=seed)
+    assert len(om) >= 1 and oc[3] == len(om)
+    res = []
+    c = pipe.ctxs[0]
+    for timing in (False, True):
+        c.enable_timing(timing)
+        pipe.enqueue(0, torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev), seed=seed + 5)
+        res.append(pipe.fetch(0))
+    c.enable_timing(False)
+    (fo, fc), (uo, uc) = res
+    assert np.array_equal(fc, uc) and fc[0] == oc[0] and fc[1] == oc[1]
+    assert sorted(fo["model"].tolist()) == sorted(uo["model"].tolist()) == sorted(om.tolist())
+    assert np.array_equal(fo["pose"].view(np.uint32), uo["pose"].view(np.uint32))
+    assert np.array_equal(fo["score"].view(np.uint32), uo["score"].view(np.uint32))
+    for m, sc in zip(om, osc):
+        g = fo[fo["model"] == m][0]
+        assert abs(g["score"] - sc) <= 0.05 * sc and g["n_points"] >= 7
+    # the same frame twice in a merged batch (the refine launch closes the frames)
+    qd = torch.cat([torch.from_numpy(fr.desc)] * 2).to(dev)
+    uv = torch.cat([torch.from_numpy(fr.uv)] * 2).to(dev)
+    pipe.ctxs[1].reserve(2 * 3000)
+    pipe.enqueue_batch(1, qd, uv, 2, [seed + 5, seed + 5])
+    for objs, counts in pipe.fetch_batch(1, 2):
+        assert np.array_equal(counts, fc) and np.array_equal(objs["model"], fo["model"])
+        assert np.array_equal(objs["pose"].view(np.uint32), fo["pose"].view(np.uint32))
+        assert np.array_equal(objs["score"].view(np.uint32), fo["score"].view(np.uint32))
