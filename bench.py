@@ -369,13 +369,20 @@ def default_batch(args, sharded: bool, shards: int = 0) -> int:
 class Job:
     """One partition of one workload on this rank: the pipeline, the resident inputs, the step loop."""
 
-    def __init__(self, args, env, db, n_models_total, by_frames, sharded, batch, frames_per_step, seeds_base=0):
+    def __init__(self, args, env, db, n_models_total, by_frames, sharded, batch, frames_per_step, seeds_base=0, part=None):
+        """part = (G, R): G model shards per frame group x R frame groups (G R = the ranks; rank = r G + g).  Default: what
+        by_frames / sharded said before the grid existed -- (1, world) / (world, 1)."""
         import torch
         from moped_amd import capi, synth
         from moped_amd.pipeline import FramePipeline, ShardedDB
         self.args, self.env, self.db = args, env, db
         self.by_frames, self.sharded, self.B = by_frames, sharded, batch
         rank, world, dev = env["rank"], env["world"], env["dev"]
+        if part is None:
+            part = (1, world) if by_frames else (world, 1)
+        self.G, self.R = G, R = part
+        assert G * R == world or (world == 1 and G == 1 and R == 1), (G, R, world)
+        self.shard_rank, self.frame_group = rank % G, rank // G
         Q = args.queries
         n_frames = max(frames_per_step, 1)
         n_pool = max(1, min(args.frame_pool, n_frames))
@@ -387,12 +394,12 @@ class Job:
             n_pool = max(1, min(n_pool, n_frames))
         self.n_frames, self.n_pool = n_frames, n_pool
         self.seeds_base = seeds_base
-        if by_frames:   # every rank holds the whole DB and works on its own frames
-            if rank:
-                self.seeds_base = seeds_base + 1000 * rank
+        # every frame group works on its own frames (group 0: the single GPU's); its G ranks hold the DB between them
+        self.seeds_base = seeds_base + 1000 * self.frame_group
+        if G == 1:
             self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, 0, 1)
         else:
-            self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, rank, world, assign=args.assign)
+            self.shard = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, self.shard_rank, G, assign=args.assign)
         params = capi.default_frame_params()
         if args.no_adaptive:
             params.pose1.n_hypotheses = -abs(params.pose1.n_hypotheses)
@@ -413,9 +420,14 @@ class Job:
             params.f2_min_points, params.f2_feature_distance, params.f2_min_score = 8, 8192.0, 1e-4
         self.params = params
         free0, _ = torch.cuda.mem_get_info(dev)
+        # a grid's frame groups exchange among their own G ranks: RCCL ids from the group's shard 0 (id_leader), or -- the
+        # rehearsal on one GPU -- the host transport over the group's gloo subgroup
+        grid = G > 1 and R > 1
         self.pipe = FramePipeline(env["local_rank"], self.shard, depth=args.depth, max_queries=Q * B, params=params,
                                   force_exchange=args.force_exchange and sharded, n_comms=args.comms, batch=B,
-                                  lane=parse_lane(args.lane))
+                                  lane=parse_lane(args.lane),
+                                  group=env["subgroups"](G)[self.frame_group] if grid and env.get("rehearse") else None,
+                                  id_leader=self.frame_group * G if grid and not env.get("rehearse") else None)
         torch.cuda.synchronize(dev)
         self.hbm_pipeline_mb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20   # the DB (one copy, shared by all slots) + every slot's frame buffers
         self.work = [torch.empty((Q, 128), dtype=torch.float32, device=dev) for _ in range(args.depth)]
@@ -671,7 +683,7 @@ class Job:
         return dt, t_issue
 
     def total_frames(self, steps):
-        return steps * self.n_frames * (self.env["world"] if self.by_frames else 1)
+        return steps * self.n_frames * self.R
 
     def detections_per_frame(self):
         """Objects per frame over EVERY frame of the last timed region, as delivered to the host inside it."""
@@ -727,10 +739,11 @@ def main():
     args.gpus = world                    # n_gpus = the ranks that run, whatever --gpus said
     wd = args.watchdog if args.watchdog >= 0 else (900 if world > 1 else 0)
     arm_watchdog(wd)   # a collective that never completes must end the job with a stack, not hold the node; re-armed per leg
-    if args.parallelism == "auto":
-        args.parallelism = choose_parallelism(args.models, world)
-    by_frames = args.parallelism == "frames" and not args.force_exchange
-    sharded = (world > 1 and not by_frames) or args.force_exchange
+    G, R = choose_partition(args.models, world, args.parallelism, args.grid)
+    if args.force_exchange and world == 1:
+        G, R = 1, 1
+    by_frames = G == 1 and world > 1 and not args.force_exchange
+    sharded = G > 1 or args.force_exchange
     depth_given = args.depth > 0
     if args.depth <= 0:
         args.depth = 16
@@ -749,7 +762,7 @@ def main():
     import torch
     import torch.distributed as dist
     from moped_amd import capi, synth
-    B = default_batch(args, sharded)
+    B = default_batch(args, sharded, G)
 
     # MH_BENCH_REHEARSE=1: the N > 1 code paths on a one-GPU box -- all ranks on cuda:0, gloo for the timing contract's
     # barrier / max (RCCL refuses two ranks on one device); with a sharded DB the frames' exchange then runs over the
@@ -767,11 +780,20 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    env = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev, "red_dev": red_dev}
+    _subgroups = {}
+
+    def subgroups(g):
+        """The gloo subgroups of a G = g grid (rehearsal: the host transport's all-gather runs over them), made once:
+        every rank creates every group, in the same order."""
+        if g not in _subgroups:
+            _subgroups[g] = [dist.new_group(list(range(r * g, (r + 1) * g)), backend="gloo") for r in range(world // g)]
+        return _subgroups[g]
+    env = {"rank": rank, "local_rank": local_rank, "world": world, "dev": dev, "red_dev": red_dev, "rehearse": rehearse,
+           "subgroups": subgroups}
 
     Q = args.queries
     db = synth.make_db(args.models, 5000)
-    job = Job(args, env, db, args.models, by_frames, sharded, B, args.frames_per_step)
+    job = Job(args, env, db, args.models, by_frames, sharded, B, args.frames_per_step, part=(G, R))
     pipe, params = job.pipe, job.params
     if B > 1 and not depth_given and args.depth == 16:
         job.calibrate_slots()
@@ -794,7 +816,7 @@ def main():
         "metric": "detections/sec (frames/s) 640x480 ~3k SIFT vs N models",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-        "higher_is_better": True, "scaling": scaling_label(args.parallelism, world), "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling_label(G, R), "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "dtype_detail": "every delivered result is fp32 arithmetic (bit-identical to the exact f32 kernels and the oracle); "
                         "the screen that decides which rows get it multiplies in f16 on the matrix pipe with a proved margin",
@@ -811,8 +833,17 @@ def main():
                    "host_issue_seconds": round(t_issue, 3),
                    "frames_in_flight": (job.active_slots if B > 1 else args.depth) * B, "frames_per_match_launch": B,
                    "lane": args.lane or None,
-                   "parallelism": (f"frame-parallel x{world} (DB replicated)" if by_frames and world > 1 else
-                                   f"model-shard x{world}" if world > 1 else "single GPU"),
+                   "parallelism": partition_label(G, R),
+                   "partition": {"model_shards": G, "frame_groups": R,
+                                 "models_per_rank": -(-args.models // G),
+                                 "chosen_by": (args.parallelism if args.parallelism != "auto" else
+                                               "auto: largest G whose projection from profiles/per_rank_load.json reaches 0.75 N, "
+                                               "else the best G >= 2"),
+                                 "projected_speedup": (None if world == 1 or not os.path.exists(PER_RANK_LOAD) else
+                                                       round(projected_speedup(args.models, G, R), 2)),
+                                 "communicators": (None if G == 1 else
+                                                   f"{R} disjoint sets of {args.comms if not rehearse else 1} communicator(s), one set per "
+                                                   f"frame group, each over the group's {G} ranks (ranks r G .. r G + G - 1)")},
                    "model_assignment": (args.assign if sharded else None),
                    "ranks_launched_by": os.environ.get("MH_BENCH_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "none"),
                    "exchange": comm_info,
@@ -934,12 +965,30 @@ def main():
     # ---- secondary partitions / workloads in the same line (all ranks take part) ----
     if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
         sec_steps = max(1, args.secondary_steps)
-        if world > 1 and not by_frames:
+        if world > 1 and G > 1 and R > 1:
+            # the north star's partition as it is written -- every rank a shard, ONE frame stream -- beside the grid
             job.close()
+            arm_watchdog(wd)
+            a1 = argparse.Namespace(**vars(args))
+            a1.parallelism = "models"
+            j1 = Job(a1, env, db, args.models, False, True, default_batch(a1, True, world), args.frames_per_step, part=(world, 1))
+            dt1, _ = j1.timed(sec_steps, 1)
+            det1 = j1.detections_per_frame()
+            out["pure_model_shard"] = {"value": round(j1.total_frames(sec_steps) / dt1, 2), "unit": "frames/s", "steps": sec_steps,
+                                       "parallelism": partition_label(world, 1), "scaling": "strong",
+                                       "models_per_rank": -(-args.models // world), "objects_per_frame": det1,
+                                       "objects_detail": j1.detections_detail,
+                                       "note": "north_star's partition with no frame groups: the DB sharded over all ranks, one "
+                                               "all-gather per batch over all of them; a reported figure, not `value`"}
+            j1.close()
+            job = None
+        if world > 1 and not by_frames:
+            if job is not None:
+                job.close()
             arm_watchdog(wd)
             a2 = argparse.Namespace(**vars(args))
             a2.parallelism = "frames"
-            j2 = Job(a2, env, db, args.models, True, False, default_batch(a2, False), args.frames_per_step)
+            j2 = Job(a2, env, db, args.models, True, False, default_batch(a2, False), args.frames_per_step, part=(1, world))
             dt2, _ = j2.timed(sec_steps, 1)
             det2 = j2.detections_per_frame()
             out["replicated_frames"] = {"value": round(j2.total_frames(sec_steps) / dt2, 2), "unit": "frames/s", "steps": sec_steps,
@@ -958,7 +1007,7 @@ def main():
             a3.models, a3.parallelism = 200, "models"
             db200 = synth.make_db(200, 5000)
             sh3 = world > 1
-            j3 = Job(a3, env, db200, 200, False, sh3, default_batch(a3, sh3), 256)
+            j3 = Job(a3, env, db200, 200, False, sh3, default_batch(a3, sh3, world), 256, part=(world, 1))
             dt3, _ = j3.timed(sec_steps, 1)
             det3 = j3.detections_per_frame()
             out["sharded_200_models"] = {"value": round(j3.total_frames(sec_steps) / dt3, 2), "unit": "frames/s", "steps": sec_steps,

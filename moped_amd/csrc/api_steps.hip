@@ -355,10 +355,15 @@ void stamp(mh_ctx* ctx, int i) {
 // exchange-1 blocks ([n_shards][3][Q]) to merge first.
 // batch_n > 1: the batch_n frames of a batch together, one launch per stage (FrameBatch, steps.h; the caller has checked
 // merged_batch_ok) -- q_uv_dev / the top-2 arrays name frame 0's, fs->slot is 0, batch_seeds the frames' seeds.
+// stage_lo .. stage_hi (mh_step_*: the six slots one call each on a frame that stays on the device): only the stages
+// 0 MATCH's tail (ratio test + lists), 1 CLUSTER, 2 POSE, 3 FILTER, 4 POSE2, 5 FILTER2 in that range are launched, FILTER
+// as launches of its own; everything else of the frame's state is left as the stage before wrote it.
 int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathered, int n_shards,
                const mh_cam* cam, const mh_frame_params* prm, uint64_t seed, const uint64_t* batch_seeds = nullptr,
-               int batch_n = 1) {
+               int batch_n = 1, int stage_lo = 0, int stage_hi = 5) {
   FrameState* fs = ctx->fs;
+  const bool stepped = stage_lo != 0 || stage_hi != 5;
+  auto runs = [&](int stage) { return stage >= stage_lo && stage <= stage_hi; };
   FrameBatch fb1, fb2;
   const FrameBatch *b1 = nullptr, *b2 = nullptr;
   if (batch_n > 1) {
@@ -441,7 +446,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   }
   // moped3d depth rules: patch maps of this frame's depth image, DEPTHFILTER on the features
   DepthRules rules;
-  if (ctx->rules.on && ctx->depth_img.img) {
+  if (ctx->rules.on && ctx->depth_img.img && runs(0)) {
     mh_ctx::DepthRuleState& rs = ctx->rules;
     const int pw = (ctx->depth_img.w + rs.patch - 1) / rs.patch, ph = (ctx->depth_img.h + rs.patch - 1) / rs.patch;
     int rc = ensure_rule_buffers(ctx, pw * ph, Q, batch_n);
@@ -468,6 +473,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   }
   // MATCH tail: (shard merge,) ratio test + per-model lists; resets the frame's counters
   const int q0 = gathered ? 0 : ctx->batch_q0;   // frame of a batch matched in one launch: its slice of the top-2 arrays
+  if (runs(0))
   launch_group(gathered, n_shards, ctx->nn_idx + q0, ctx->nn_d1 + q0, ctx->nn_d2 + q0, Q, prm->ratio, q_uv_dev,
                ctx->db_model, ctx->db_xyz, ctx->N, ctx->rmap, nm, fs->max_m, fs->acc_q,
                fs->acc_model, fs->m_q, fs->m_model, fs->m_corr, fs->m_rep, fs->model_off,
@@ -478,7 +484,8 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   stamp(ctx, 2);
   // CLUSTER (+ flat cluster table, snap[0..1])
   const bool have_depth = ctx->q_depth || ctx->depth_img.img;
-  if (ctx->linkage_on && have_depth && ctx->depth_img.img) {
+  if (!runs(1)) {
+  } else if (ctx->linkage_on && have_depth && ctx->depth_img.img) {
     // moped3d: linkage over similarity matrices; 3 n^2 floats of scratch per model, n <= LK_CAP
     // (a merged batch: every frame its own region)
     const size_t need = 3 * (size_t)std::min(fs->max_m, LK_CAP) * (size_t)fs->max_m;
@@ -522,9 +529,9 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
     fb.cams = ctx->cams_dev;
     fb.n_images = ctx->n_images;
   }
-  const bool fused = fuse_filter && prm->run_stage2 && !ctx->timing;   // (stage timing wants the steps apart)
+  const bool fused = fuse_filter && prm->run_stage2 && !ctx->timing && !stepped;   // (stage timing wants the steps apart)
   // (one frame alone in result slot 0: FILTER2's tail also writes the host's block, mh_frame_fetch reads it without a copy)
-  fs->host_armed = batch_n == 1 && fs->slot == 0 && prm->run_stage2 && fs->host_block;
+  fs->host_armed = batch_n == 1 && fs->slot == 0 && prm->run_stage2 && fs->host_block && !stepped;
   if (fs->host_armed) ++fs->host_seq_expect;
   const FilterTail ft1{fs->tickets + 2, snap + 3, nullptr, grid, nullptr, nullptr, nullptr},
       ft2{fs->tickets + 4, nullptr, result, grid, fs->host_armed ? fs->host_block : nullptr, fs->host_armed ? snap : nullptr,
@@ -552,6 +559,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   split.pts = fs->rf_pts;
   split.list = fs->rf_list;
   split.max_m = fs->max_m;
+  if (runs(2))
   launch_pose(multi ? fs->mi_corr : fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->ms_members, fs->cl_model,
               fs->cl_begin, fs->cl_count, fs->n_clusters, fs->max_clusters, dc, prm->pose1, seed, fs->n_slots,
               fs->max_objects, fs->obj_model, fs->obj_pose, fs->obj_ninl, fs->obj_err, fs->obj_cluster,
@@ -560,11 +568,12 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   stamp(ctx, 4);
   if (prm->run_stage2) {
     // FILTER (snap[3] = objects kept)
-    if (!fused)
+    if (!fused && runs(3))
       launch_filter(fb, dc, prm->f1_min_points, prm->f1_feature_distance, prm->f1_min_score,
                     fs->n_slots, fs->n_clusters2, fs->counts, ft1, s);
     stamp(ctx, 5);
     // POSE2 on the rewritten clusters, objects appended after the kept ones
+    if (runs(4))
     launch_pose(fs->m_corr, depth4, ctx->depth_kind, ctx->depth_alpha, fs->new_members, fs->cl_model,
                 fs->cl_begin, fs->cl_count, fs->n_clusters2, fs->max_clusters, dc, prm->pose2,
                 seed ^ 0x5DEECE66Dull, fs->n_slots, fs->max_objects, fs->obj_model, fs->obj_pose,
@@ -573,7 +582,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
                 &split);
     stamp(ctx, 6);
     // FILTER2 (+ the frame's result block)
-    if (!fused)
+    if (!fused && runs(5))
       launch_filter(fb, dc, prm->f2_min_points, prm->f2_feature_distance, prm->f2_min_score,
                     fs->n_slots, fs->n_clusters, fs->counts, ft2, s);
     stamp(ctx, 7);

@@ -71,10 +71,35 @@ def test_frames_partition_is_an_option():
 def test_four_ranks_with_every_leg_of_the_default_run():
     """The line exactly as the driver asks for it -- roofline, POSE figures, secondary partitions -- with four ranks: every
     leg that only rank 0 runs must be free of collectives (round 3: the POSE measurement enqueued a sharded batch on rank
-    0 alone and the job hung in its all-gather; the two-rank tests had run with --no-roofline)."""
+    0 alone and the job hung in its all-gather; the two-rank tests had run with --no-roofline).  Round 5: `auto` takes
+    the models x frames grid the committed per-rank loads project fastest -- 2 model shards x 2 frame groups for the
+    20-model DB at N = 4, each frame group exchanging among its own two ranks -- and the pure sharding of the north
+    star rides along as `pure_model_shard`."""
     d = _run(["--frames-per-step", "128", "--secondary-steps", "1"], gpus=4, roofline=True)
-    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x4"
-    assert d["config"]["model_assignment"] == "round-robin" and d["config"]["exchange"]["world"] == 4
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["parallelism"] == "grid: 2 model shards x 2 frame groups"
+    part = d["config"]["partition"]
+    assert part["model_shards"] == 2 and part["frame_groups"] == 2 and part["models_per_rank"] == 10
+    assert part["projected_speedup"] >= 3.0
+    assert d["config"]["model_assignment"] == "round-robin" and d["config"]["exchange"]["world"] == 2   # a frame group's ranks
     assert d["config"]["objects_per_frame"] == 2.0 and "suspect" not in d
+    # both frame groups' frames were delivered and counted: 2 groups x 2 steps x frames_per_step
+    det = d["config"]["objects_detail"]
+    assert det["frames_missing_a_planted_object"] == 0
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
+    pm = d["pure_model_shard"]
+    assert pm["parallelism"] == "model-shard x4" and pm["models_per_rank"] == 5 and pm["objects_per_frame"] == 2.0
     assert d["replicated_frames"]["objects_per_frame"] == 2.0 and d["sharded_200_models"]["models_per_rank"] == 50
+
+
+def test_four_ranks_pure_model_sharding_is_still_an_option():
+    d = _run(["--parallelism", "models", "--frames-per-step", "64", "--no-secondary"], gpus=4)
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["parallelism"] == "model-shard x4"
+    assert d["config"]["exchange"]["world"] == 4 and d["config"]["objects_per_frame"] == 2.0 and "suspect" not in d
+
+
+def test_explicit_grid_under_the_drivers_launcher():
+    d = _run(["--parallelism", "grid", "--grid", "2x2", "--models", "50", "--frames-per-step", "32", "--no-secondary"], gpus=4,
+             launcher=True, port=29871 + os.getpid() % 100)
+    assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "grid: 2 model shards x 2 frame groups"
+    assert d["config"]["partition"]["models_per_rank"] == 25 and d["config"]["exchange"]["world"] == 2
+    assert d["config"]["objects_per_frame"] == 2.0 and "suspect" not in d

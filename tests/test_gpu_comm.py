@@ -219,3 +219,82 @@ def test_ranks_that_disagree_on_the_frame_fail_loudly(scene):
     out = _two_ranks_as_threads(db, fr, [[7], [8]])
     assert all(isinstance(o, capi.MhError) for o in out), out
     assert "different orders" in str(out[0])
+
+
+def test_grid_two_shards_by_two_frame_groups_as_threads(scene):
+    """bench.py --parallelism grid on one device: 4 ranks = 2 model shards x 2 frame groups (rank = r G + g), each frame
+    group with a communicator of its own over its two ranks (here: the host transport, one board per group) and its own
+    frame; the groups run concurrently and never exchange.  Every rank's gathered objects are the single-context result
+    of ITS group's frame, bit for bit, with the round-robin model assignment bench.py uses."""
+    import threading
+    import torch
+    from moped_amd.pipeline import ShardedDB
+    db, fr_a, _ = scene
+    fr_b = synth.make_frame(db, n_vis=2, seed=11, Q=Q, pts_per_obj=120)
+    frames = [fr_a, fr_b]
+    dev = torch.device("cuda:0")
+    G, R = 2, 2
+    want = []
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    c.reserve(Q)
+    for r, fr in enumerate(frames):
+        qd, uv = torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev)
+        c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), Q, synth.K_DEFAULT, synth.CAM_IDENTITY, capi.default_frame_params(), 20 + r)
+        want.append(c.frame_fetch()[0])
+    c.close()
+    assert len(want[0]) >= 3 and len(want[1]) >= 2
+    assert sorted(want[0]["model"].tolist()) != sorted(want[1]["model"].tolist())   # the groups see different objects
+
+    boards = [{"n": 0, "round": 0, "blocks": [None] * G, "cv": threading.Condition()} for _ in range(R)]
+
+    def allgather_for(r, g):
+        board = boards[r]
+        cv = board["cv"]
+
+        def fn(blob):
+            with cv:
+                my_round = board["round"]
+                board["blocks"][g] = blob
+                board["n"] += 1
+                if board["n"] == G:
+                    board["out"] = b"".join(board["blocks"])
+                    board["n"] = 0
+                    board["round"] += 1
+                    cv.notify_all()
+                else:
+                    cv.wait_for(lambda: board["round"] != my_round, timeout=60)
+                return board["out"]
+        return fn
+
+    out = [None] * (G * R)
+
+    def run(rank):
+        r, g = rank // G, rank % G
+        try:
+            c = capi.Context(0)
+            sh = ShardedDB(db.desc, db.xyz, db.model_of, db.n_models, g, G, assign="round-robin")
+            sh.upload(c, c.normalize(sh.desc))
+            c.reserve_batch(Q, 2)
+            comm = capi.Comm.create_host(c, g, G, allgather_for(r, g))
+            assert comm.info()[:2] == (g, G)
+            fr = frames[r]
+            qd = torch.from_numpy(np.concatenate([fr.desc] * 2)).to(dev)
+            uv = torch.from_numpy(np.concatenate([fr.uv] * 2)).to(dev)
+            c.frame_enqueue_sharded_batch(comm, qd.data_ptr(), uv.data_ptr(), Q, 2, synth.K_DEFAULT, synth.CAM_IDENTITY,
+                                          capi.default_frame_params(), [20 + r, 20 + r])
+            c.frame_fetch_slot(0)
+            out[rank] = [c.frame_gather_objects(comm, f) for f in (0, 1)]
+            comm.close()
+            c.close()
+        except Exception as e:   # pragma: no cover - reported by the assertion below
+            out[rank] = e
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(G * R)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    for rank, o in enumerate(out):
+        assert isinstance(o, list), (rank, o)
+        for f in (0, 1):
+            assert _same(o[f], want[rank // G]), (rank, f)
