@@ -351,6 +351,51 @@ int mh_frame_wait_descriptors(mh_ctx* ctx);
  * (src/util.hpp:70-79) straight into such a block.  mh_host_free(NULL) is a no-op. */
 int mh_host_alloc(mh_ctx* ctx, size_t bytes, void** out);
 int mh_host_free(mh_ctx* ctx, void* p);
+
+/* ---- the six slots one call each, the frame resident between them (the per-step plugins' hand-over) ----------------
+ * The reference runs its steps strictly one after the other on one FrameData (src/moped.cpp:183-191, the step list of
+ * src/config.hpp:83-120); every step's contract is what it leaves in FrameData for the next (src/util.hpp:68-110).  These
+ * entry points keep that contract -- each returns what its slot writes into FrameData -- but the step that follows does
+ * not upload it again: the frame's match lists, clusters and objects stay in the context's working arrays and each
+ * call launches only its own slot's kernels behind the previous call's.  Order: mh_step_match, mh_step_match_fetch,
+ * mh_step_cluster, mh_step_pose(1), mh_step_filter(1), mh_step_pose(2), mh_step_filter(2).  A call out of that order, or
+ * after any other call that uses the context's frame arrays (mh_frame_*, mh_filter*, mh_pose_ransac*), is refused with
+ * MH_ERR_ARG -- the plugin then takes the upload path of its slot (mh_normalize_match / mh_meanshift_batch /
+ * mh_pose_ransac_images / mh_filter_images), which is always valid.  One camera per frame.  Objects are bit for bit
+ * those of mh_frame_run_host with the same constants and seeds (POSE: seed, POSE2: seed ^ 0x5DEECE66D there).
+ *
+ * mh_step_match: MATCH_ANN_CPU::process (src/match/MATCH_ANN_CPU.hpp:136-178) -- uploads the frame's features
+ * (q_desc_host [Q][128] raw, q_uv_host [Q][2]; page-locked memory from mh_host_alloc crosses PCIe asynchronously),
+ * normalises (:157), searches, applies the ratio test and leaves matches[model] (:165-176) on the device; returns
+ * without waiting.  write_back: the normalised descriptors come back into q_desc_host on a stream of their own
+ * (mh_frame_wait_descriptors).  mh_step_match_fetch waits and returns the lists: model_off_host[n_models + 1],
+ * match (model_off[m] + k) = k-th element of matches[m] = {query index, {u, v, x, y, z}}; cap >= Q always suffices. */
+int mh_step_match(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, int Q, const mh_cam* cam, float ratio,
+                  int write_back);
+int mh_step_match_fetch(mh_ctx* ctx, int32_t* model_off_host, int32_t* match_query, mh_corr* match_pts, int cap,
+                        int32_t* n_matches);
+/* CLUSTER_MEAN_SHIFT_CPU::process (src/cluster/CLUSTER_MEAN_SHIFT_CPU.hpp:182-199) on the resident lists: cluster c
+ * belongs to model cl_model_host[c] and holds members_host[cl_off_host[c] .. cl_off_host[c + 1]) = indices into
+ * matches[model], in the reference's emission and member order; clusters in (model, emission) order. */
+int mh_step_cluster(mh_ctx* ctx, float radius, float merge, int min_pts, int max_iter, int32_t* cl_model_host,
+                    int32_t* cl_off_host /* cap_clusters + 1 */, int32_t* members_host, int cap_clusters, int cap_members,
+                    int32_t* n_clusters);
+/* POSE_RANSAC_LM_DIFF_REPROJECTION_CPU::process (src/pose/...REPROJECTION_CPU.hpp:264-307) on the resident clusters
+ * (which = 1: CLUSTER's; 2: the clusters FILTER rewrote): the objects this step APPENDS to FrameData::objects (:299), in
+ * task order. */
+typedef struct {
+  int32_t model;
+  float pose[7];   /* qx qy qz qw tx ty tz */
+} mh_step_object;
+int mh_step_pose(mh_ctx* ctx, int which, const mh_pose_params* prm, uint64_t seed, mh_step_object* out, int cap,
+                 int32_t* n_out);
+/* FILTER_PROJECTION_CPU::process (src/filter/FILTER_PROJECTION_CPU.hpp:80-162) on the resident objects (which = 1:
+ * FILTER, 2: FILTER2).  n_objects = length of the host's object list (checked against the device's).  Outputs as
+ * mh_filter_images, indexed by LIST position: score[i], keep[i]; kept object k was list element out_order[k] and now
+ * owns cl_members[cl_off[k] .. cl_off[k + 1]) = indices into its model's match list. */
+int mh_step_filter(mh_ctx* ctx, int which, int min_points, float feature_distance, float min_score, int n_objects,
+                   float* score, uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off /* n_objects + 1 */,
+                   int cap_members, int32_t* n_kept);
 int mh_frame_enqueue_batch(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int Q, int B, const mh_cam* cam,
                            const mh_frame_params* prm, const uint64_t* seeds);
 /* Frames with several images (FrameData::images; every DetectedFeature carries its imageIdx, src/util.hpp:70-79):

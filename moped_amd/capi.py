@@ -61,6 +61,7 @@ class mh_times(C.Structure):
 
 CORR_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4")])
 OBJECT_DTYPE = np.dtype([("model", "<i4"), ("pose", "<f4", (7,)), ("score", "<f4"), ("n_points", "<i4")])
+STEP_OBJECT_DTYPE = np.dtype([("model", "<i4"), ("pose", "<f4", (7,))])   # mh_step_object
 DEPTH_DTYPE = np.dtype([("wx", "<f4"), ("wy", "<f4"), ("wz", "<f4"), ("w", "<f4")])
 DEPTH_BACKPROJECTION, DEPTH_REPROJECTION = 1, 2
 POSE_OUT_DTYPE = np.dtype([("pose", "<f4", (7,)), ("cluster", "<i4"), ("n_inliers", "<i4"), ("err", "<f4")])
@@ -113,6 +114,7 @@ EXPORTS = [
     "mh_screen_values", "mh_screen_record_value", "mh_screen_record_bounds", "mh_reserve_batch", "mh_frame_run_host",
     "mh_frame_block_stride", "mh_frame_fetch_batch_async", "mh_frame_fetch_previous_async", "mh_frame_fetch_wait",
     "mh_frame_fetch_query", "mh_host_alloc", "mh_host_free", "mh_frame_run_host_begin", "mh_frame_wait_descriptors",
+    "mh_step_match", "mh_step_match_fetch", "mh_step_cluster", "mh_step_pose", "mh_step_filter",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -274,6 +276,11 @@ def load():
     L.mh_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mh_host_free.argtypes = [vp, vp]
     L.mh_frame_wait_descriptors.argtypes = [vp]
+    L.mh_step_match.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, i32]
+    L.mh_step_match_fetch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_step_cluster.argtypes = [vp, f32, f32, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_int32)]
+    L.mh_step_pose.argtypes = [vp, i32, C.POINTER(mh_pose_params), C.c_uint64, vp, i32, C.POINTER(C.c_int32)]
+    L.mh_step_filter.argtypes = [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_fetch_query.argtypes = [vp]
     _lib = L
     return L
@@ -857,6 +864,61 @@ class Context:
 
     def frame_wait_descriptors(self):
         self._ck(self.L.mh_frame_wait_descriptors(self.h), "mh_frame_wait_descriptors")
+
+    # ---- the six slots one call each on a frame that stays on the device (mh_step_*: the per-step plugins' hand-over) ----
+    def step_match(self, q_desc, q_uv, K, cam, ratio=0.8, write_back=True):
+        """MATCH: upload, normalise, search, ratio test, per-model lists on the device -> (model_off [n_models + 1],
+        match_query [M], match_pts [M] CORR_DTYPE).  q_desc is normalised in place if write_back."""
+        assert q_desc.dtype == np.float32 and q_desc.flags.c_contiguous and q_desc.shape[1] == 128
+        uv = np.ascontiguousarray(q_uv, np.float32)
+        Q = q_desc.shape[0]
+        c = make_cam(K, cam)
+        self._ck(self.L.mh_step_match(self.h, _ptr(q_desc), _ptr(uv), Q, C.byref(c), C.c_float(ratio), int(bool(write_back))),
+                 "mh_step_match")
+        if write_back:
+            self.frame_wait_descriptors()
+        nn_, nm_ = C.c_int(0), C.c_int(0)
+        self._ck(self.L.mh_db_size(self.h, C.byref(nn_), C.byref(nm_)), "mh_db_size")
+        nm = nm_.value
+        off = np.zeros(nm + 1, np.int32)
+        mq = np.zeros(Q, np.int32)
+        pts = np.zeros(Q, CORR_DTYPE)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_step_match_fetch(self.h, _ptr(off), _ptr(mq), _ptr(pts), Q, C.byref(n)), "mh_step_match_fetch")
+        return off, mq[:n.value].copy(), pts[:n.value].copy()
+
+    def step_cluster(self, radius=200.0, merge=20.0, min_pts=7, max_iter=100, cap_clusters=1024, cap_members=1 << 16):
+        """CLUSTER on the resident lists -> (cl_model [n], cl_off [n + 1], members [cl_off[n]]: indices into matches[model])."""
+        cm = np.zeros(cap_clusters, np.int32)
+        co = np.zeros(cap_clusters + 1, np.int32)
+        mem = np.zeros(cap_members, np.int32)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_step_cluster(self.h, C.c_float(radius), C.c_float(merge), int(min_pts), int(max_iter), _ptr(cm), _ptr(co),
+                                        _ptr(mem), cap_clusters, cap_members, C.byref(n)), "mh_step_cluster")
+        return cm[:n.value].copy(), co[:n.value + 1].copy(), mem[:co[n.value]].copy()
+
+    def step_pose(self, which, prm: mh_pose_params, seed, cap=4096):
+        """POSE (which = 1) / POSE2 (2) on the resident clusters -> the objects the step appends (STEP_OBJECT_DTYPE)."""
+        out = np.zeros(cap, STEP_OBJECT_DTYPE)
+        n = C.c_int32(0)
+        self._ck(self.L.mh_step_pose(self.h, int(which), C.byref(prm), C.c_uint64(int(seed)), _ptr(out), cap, C.byref(n)),
+                 "mh_step_pose")
+        return out[:n.value].copy()
+
+    def step_filter(self, which, min_points, feature_distance, min_score, n_objects, cap_members=1 << 16):
+        """FILTER (1) / FILTER2 (2) on the resident objects -> (score [n_objects], keep [n_objects], out_order [kept],
+        cl_off [kept + 1], members)."""
+        score = np.zeros(max(n_objects, 1), np.float32)
+        keep = np.zeros(max(n_objects, 1), np.uint8)
+        order = np.zeros(max(n_objects, 1), np.int32)
+        co = np.zeros(n_objects + 1, np.int32)
+        mem = np.zeros(cap_members, np.int32)
+        kept = C.c_int32(0)
+        self._ck(self.L.mh_step_filter(self.h, int(which), int(min_points), C.c_float(feature_distance), C.c_float(min_score),
+                                       int(n_objects), _ptr(score), _ptr(keep), _ptr(order), _ptr(mem), _ptr(co), cap_members,
+                                       C.byref(kept)), "mh_step_filter")
+        k = kept.value
+        return score[:n_objects].copy(), keep[:n_objects].copy(), order[:k].copy(), co[:k + 1].copy(), mem[:co[k]].copy()
 
     def frame_enqueue_image(self, gray_ptr, w, h, double_size, max_keypoints, K, cam, params: mh_frame_params,
                             seed=1, _cam_struct=None):

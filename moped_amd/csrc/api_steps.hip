@@ -364,6 +364,7 @@ int frame_rest(mh_ctx* ctx, const float* q_uv_dev, int Q, const int32_t* gathere
   FrameState* fs = ctx->fs;
   const bool stepped = stage_lo != 0 || stage_hi != 5;
   auto runs = [&](int stage) { return stage >= stage_lo && stage <= stage_hi; };
+  if (!stepped) ctx->step.done = -1;   // (a whole frame overwrites whatever a stepped frame left in the arrays)
   FrameBatch fb1, fb2;
   const FrameBatch *b1 = nullptr, *b2 = nullptr;
   if (batch_n > 1) {
@@ -957,6 +958,7 @@ static int pose_ransac_impl(mh_ctx* ctx, const mh_corr* corr_host, const mh_dept
   const int R_ = prm->max_objects_per_cluster > 0 ? prm->max_objects_per_cluster : 1;
   const int total = cluster_off[n_clusters];
   const int n_obj = n_clusters * R_;
+  ctx->step.done = -1;   // (the frame's working arrays are this call's now)
   int rc = ensure_fs(ctx, std::max(total, 1), n_clusters, n_obj, std::max(ctx->n_models, 1));
   if (rc) return rc;
   FrameState* fs = ctx->fs;
@@ -1347,6 +1349,7 @@ int mh_filter_images(mh_ctx* ctx, const mh_corr* corr_host, const int32_t* image
   MH_HIP(ctx, hipSetDevice(ctx->device));
   if (int rc_stream = mh::use_stream(ctx)) return rc_stream;
   const int M = model_off[n_models];
+  ctx->step.done = -1;   // (the frame's working arrays are this call's now)
   int rc = ensure_fs(ctx, std::max(M, 1), std::max(n_obj, 1), std::max(n_obj, 1), n_models);
   if (rc) return rc;
   FrameState* fs = ctx->fs;
@@ -1433,7 +1436,8 @@ int mh_frame_enqueue(mh_ctx* ctx, float* q_desc_dev, const float* q_uv_dev, int 
   if (ctx->wb_want && ctx->wb_ev) hipEventRecord(ctx->wb_ev, ctx->stream);   // (mh_frame_run_host copies them back from here)
   if (int rc_m = ctx_match(ctx, q_desc_dev, ctx->q_norm, Q, ctx->nn_idx, ctx->nn_d1, ctx->nn_d2)) return rc_m;
   stamp(ctx, 1);
-  return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed);
+  ctx->step.done = -1;   // (whatever a stepped frame left on the device is overwritten from here on)
+  return frame_rest(ctx, q_uv_dev, Q, nullptr, 0, cam, prm, seed, nullptr, 1, ctx->stage_lo, ctx->stage_hi);
 }
 
 // The whole frame for a host that holds its features in HOST memory and wants the objects back before it goes on: the
@@ -1982,6 +1986,322 @@ int mh_timing(mh_ctx* ctx, mh_times* out) {
   hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[8]);
   out->total_ms = tot;
   return MH_OK;
+}
+
+// ---- the frame's six slots ONE CALL EACH on a frame that stays on the device between them -----------------------------
+// The per-step plugins' hand-over (moped_amd/host/hip_session.hpp, HipHandover): MATCH leaves the frame's lists in the
+// context's working arrays, CLUSTER clusters them where they lie, POSE poses those clusters, FILTER filters those
+// objects ... -- every call launches its slot's kernels behind the previous call's (frame_rest with a stage range),
+// copies what the slot's contract says the host's FrameData must hold into page-locked memory, and waits once.  What
+// the steps uploaded again and again before (the match list three times, the objects twice, ~25 small copies per
+// FILTER) stays where it is.  ctx->step says where the resident frame stands; a call out of order, or after anything
+// else has used the context's working arrays, is refused (MH_ERR_ARG) and the plugin takes its upload path.
+}  // extern "C"
+namespace {
+
+int step_refuse(mh_ctx* ctx, const char* who) {
+  ctx->err = std::string(who) + ": the resident frame is not at the stage before this one (the steps must run in pipeline "
+             "order on one frame; any other call that uses the frame's working arrays ends the hand-over)";
+  return MH_ERR_ARG;
+}
+
+int step_flags(mh_ctx* ctx, const FrameCounts& fc, const char* who) {
+  if (!fc.error) return MH_OK;
+  ctx->step.done = -1;
+  ctx->err = std::string(who) + ": capacity exceeded (flags " + std::to_string(fc.error) + ")";
+  return MH_ERR_CAPACITY;
+}
+
+// (the words of a stage's results, one after the other in the context's page-locked block)
+struct PinCursor {
+  unsigned char* base;
+  size_t off = 0;
+  template <typename T> T* take(size_t n) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += (n * sizeof(T) + 15) & ~(size_t)15;
+    return p;
+  }
+};
+
+}  // namespace
+extern "C" {
+
+int mh_step_match(mh_ctx* ctx, float* q_desc_host, const float* q_uv_host, int Q, const mh_cam* cam, float ratio,
+                  int write_back) {
+  if (!ctx || Q <= 0 || !q_desc_host || !q_uv_host || !cam) {
+    if (ctx) ctx->err = "mh_step_match: bad argument";
+    return MH_ERR_ARG;
+  }
+  mh_frame_params p;
+  mh_frame_default_params(&p);
+  p.ratio = ratio;
+  ctx->stage_lo = ctx->stage_hi = 0;
+  const int rc = mh_frame_run_host_begin(ctx, q_desc_host, q_uv_host, nullptr, Q, cam, 1, &p, 0, write_back);
+  ctx->stage_lo = 0;
+  ctx->stage_hi = 5;
+  if (rc) return rc;
+  mh_ctx::StepState& st = ctx->step;
+  st.done = 0;
+  st.Q = Q;
+  st.M = -1;   // (known once mh_step_match_fetch has run)
+  st.n_clusters = st.n_slots = 0;
+  st.cam = *cam;
+  st.valid.clear();
+  st.valid_model.clear();
+  return MH_OK;
+}
+
+int mh_step_match_fetch(mh_ctx* ctx, int32_t* model_off_host, int32_t* match_query, mh_corr* match_pts, int cap,
+                        int32_t* n_matches) {
+  if (!ctx || !n_matches || cap < 0 || (cap > 0 && (!match_query || !match_pts))) return MH_ERR_ARG;
+  *n_matches = 0;
+  if (!ctx->fs || ctx->step.done != 0) return step_refuse(ctx, "mh_step_match_fetch");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  mh_ctx::StepState& st = ctx->step;
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  const int nm = ctx->n_models, take = std::min(st.Q, fs->max_m);   // (a frame accepts at most one match per query)
+  if (int rc = ensure_pinned(ctx, 64 + (size_t)(nm + 1 + take) * 4 + (size_t)take * sizeof(mh_corr) + 64)) return rc;
+  PinCursor pc{static_cast<unsigned char*>(ctx->pinned)};
+  FrameCounts* fc = pc.take<FrameCounts>(1);
+  int32_t* off = pc.take<int32_t>(nm + 1);
+  int32_t* mq = pc.take<int32_t>(take);
+  mh_corr* mc = pc.take<mh_corr>(take);
+  MH_HIP(ctx, hipMemcpyAsync(fc, fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(off, fs->model_off, (size_t)(nm + 1) * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(mq, fs->m_q, (size_t)take * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(mc, fs->m_corr, (size_t)take * sizeof(mh_corr), hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  if (int rc = step_flags(ctx, *fc, "mh_step_match_fetch")) return rc;
+  const int M = off[nm];
+  if (M < 0 || M > take) {
+    st.done = -1;
+    ctx->err = "mh_step_match_fetch: inconsistent match count";
+    return MH_ERR_HIP;
+  }
+  st.M = M;
+  st.model_off.assign(off, off + nm + 1);
+  *n_matches = M;
+  if (model_off_host) std::memcpy(model_off_host, off, (size_t)(nm + 1) * 4);
+  const int give = std::min(M, cap);
+  if (give > 0) {
+    std::memcpy(match_query, mq, (size_t)give * 4);
+    std::memcpy(match_pts, mc, (size_t)give * sizeof(mh_corr));
+  }
+  return MH_OK;
+}
+
+int mh_step_cluster(mh_ctx* ctx, float radius, float merge, int min_pts, int max_iter, int32_t* cl_model_host,
+                    int32_t* cl_off_host, int32_t* members_host, int cap_clusters, int cap_members, int32_t* n_clusters) {
+  if (!ctx || !n_clusters || cap_clusters < 0 || cap_members < 0) return MH_ERR_ARG;
+  *n_clusters = 0;
+  mh_ctx::StepState& st = ctx->step;
+  if (!ctx->fs || st.done != 0 || st.M < 0) return step_refuse(ctx, "mh_step_cluster");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  mh_frame_params p;
+  mh_frame_default_params(&p);
+  p.ms_radius = radius;
+  p.ms_merge = merge;
+  p.ms_min_pts = min_pts;
+  p.ms_max_iter = max_iter;
+  if (int rc = frame_rest(ctx, ctx->q_uv, st.Q, nullptr, 0, &st.cam, &p, 0, nullptr, 1, 1, 1)) {
+    st.done = -1;
+    return rc;
+  }
+  const int M = st.M, tab = std::min(fs->max_clusters, std::max(M, 1));
+  if (int rc = ensure_pinned(ctx, 256 + (size_t)(3 * tab + std::max(M, 1)) * 4)) return rc;
+  PinCursor pc{static_cast<unsigned char*>(ctx->pinned)};
+  FrameCounts* fc = pc.take<FrameCounts>(1);
+  int32_t* ncl = pc.take<int32_t>(1);
+  int32_t* cm = pc.take<int32_t>(tab);
+  int32_t* cb = pc.take<int32_t>(tab);
+  int32_t* cc = pc.take<int32_t>(tab);
+  int32_t* mem = pc.take<int32_t>(std::max(M, 1));
+  MH_HIP(ctx, hipMemcpyAsync(fc, fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(ncl, fs->n_clusters, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(cm, fs->cl_model, (size_t)tab * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(cb, fs->cl_begin, (size_t)tab * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(cc, fs->cl_count, (size_t)tab * 4, hipMemcpyDeviceToHost, s));
+  if (M > 0) MH_HIP(ctx, hipMemcpyAsync(mem, fs->ms_members, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  if (int rc = step_flags(ctx, *fc, "mh_step_cluster")) return rc;
+  const int n = *ncl;
+  if (n < 0 || n > tab) {
+    st.done = -1;
+    ctx->err = "mh_step_cluster: inconsistent cluster count";
+    return MH_ERR_HIP;
+  }
+  *n_clusters = n;
+  int w = 0;
+  for (int c = 0; c < n; ++c) {
+    const int model = cm[c], b = st.model_off[model];
+    if (c < cap_clusters) {
+      if (cl_model_host) cl_model_host[c] = model;
+      if (cl_off_host) cl_off_host[c] = w;
+    }
+    for (int j = 0; j < cc[c]; ++j, ++w)
+      if (members_host && w < cap_members) members_host[w] = mem[cb[c] + j] - b;   // index inside the model's match list
+  }
+  if (cl_off_host && n <= cap_clusters) cl_off_host[n] = w;
+  st.n_clusters = n;
+  st.done = 1;
+  return (n > cap_clusters || w > cap_members) ? MH_ERR_CAPACITY : MH_OK;
+}
+
+int mh_step_pose(mh_ctx* ctx, int which, const mh_pose_params* prm, uint64_t seed, mh_step_object* out, int cap,
+                 int32_t* n_out) {
+  if (!ctx || !prm || !n_out || cap < 0 || (cap > 0 && !out) || (which != 1 && which != 2) ||
+      prm->max_objects_per_cluster < 1)
+    return MH_ERR_ARG;
+  *n_out = 0;
+  mh_ctx::StepState& st = ctx->step;
+  if (!ctx->fs || st.done != (which == 1 ? 1 : 3)) return step_refuse(ctx, "mh_step_pose");
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  const int stage = which == 1 ? 2 : 4;
+  const int base = which == 1 ? 0 : st.n_slots, n_new = st.n_clusters * prm->max_objects_per_cluster;
+  if (base + n_new > fs->max_objects) {
+    ctx->err = "mh_step_pose: more (cluster, replica) tasks than object slots reserved";
+    return MH_ERR_CAPACITY;
+  }
+  mh_frame_params p;
+  mh_frame_default_params(&p);
+  (which == 1 ? p.pose1 : p.pose2) = *prm;
+  // (frame_rest keys POSE2's random streams with seed ^ 0x5DEECE66D: undone here, the caller's seed is the stage's)
+  if (int rc = frame_rest(ctx, ctx->q_uv, st.Q, nullptr, 0, &st.cam, &p, which == 1 ? seed : seed ^ 0x5DEECE66Dull, nullptr, 1,
+                          stage, stage)) {
+    st.done = -1;
+    return rc;
+  }
+  if (int rc = ensure_pinned(ctx, 256 + (size_t)std::max(n_new, 1) * (4 + 4 + 28))) return rc;
+  PinCursor pc{static_cast<unsigned char*>(ctx->pinned)};
+  FrameCounts* fc = pc.take<FrameCounts>(1);
+  int32_t* valid = pc.take<int32_t>(std::max(n_new, 1));
+  int32_t* model = pc.take<int32_t>(std::max(n_new, 1));
+  float* pose = pc.take<float>((size_t)7 * std::max(n_new, 1));
+  MH_HIP(ctx, hipMemcpyAsync(fc, fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, s));
+  if (n_new > 0) {
+    MH_HIP(ctx, hipMemcpyAsync(valid, fs->obj_valid + base, (size_t)n_new * 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(ctx, hipMemcpyAsync(model, fs->obj_model + base, (size_t)n_new * 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(ctx, hipMemcpyAsync(pose, fs->obj_pose + (size_t)7 * base, (size_t)n_new * 28, hipMemcpyDeviceToHost, s));
+  }
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  if (int rc = step_flags(ctx, *fc, "mh_step_pose")) return rc;
+  if (which == 1) {
+    st.valid.clear();
+    st.valid_model.clear();
+  }
+  int k = 0;
+  for (int o = 0; o < n_new; ++o) {
+    if (!valid[o]) continue;
+    st.valid.push_back(base + o);
+    st.valid_model.push_back(model[o]);
+    if (k < cap) {
+      out[k].model = model[o];
+      std::memcpy(out[k].pose, pose + (size_t)7 * o, 28);
+    }
+    ++k;
+  }
+  *n_out = k;
+  st.n_slots = base + n_new;
+  st.done = stage;
+  return k > cap ? MH_ERR_CAPACITY : MH_OK;
+}
+
+int mh_step_filter(mh_ctx* ctx, int which, int min_points, float feature_distance, float min_score, int n_objects,
+                   float* score, uint8_t* keep, int32_t* out_order, int32_t* cl_members, int32_t* cl_off, int cap_members,
+                   int32_t* n_kept) {
+  if (!ctx || !n_kept || n_objects < 0 || cap_members < 0 || (which != 1 && which != 2)) return MH_ERR_ARG;
+  *n_kept = 0;
+  if (cl_off) cl_off[0] = 0;
+  mh_ctx::StepState& st = ctx->step;
+  if (!ctx->fs || st.done != (which == 1 ? 2 : 4)) return step_refuse(ctx, "mh_step_filter");
+  if (n_objects != (int)st.valid.size()) {
+    st.done = -1;
+    ctx->err = "mh_step_filter: the host's object list is not the one the device holds";
+    return MH_ERR_ARG;
+  }
+  MH_HIP(ctx, hipSetDevice(ctx->device));
+  FrameState* fs = ctx->fs;
+  hipStream_t s = ctx->stream;
+  const int stage = which == 1 ? 3 : 5;
+  mh_frame_params p;
+  mh_frame_default_params(&p);
+  if (which == 1) {
+    p.f1_min_points = min_points;
+    p.f1_feature_distance = feature_distance;
+    p.f1_min_score = min_score;
+  } else {
+    p.f2_min_points = min_points;
+    p.f2_feature_distance = feature_distance;
+    p.f2_min_score = min_score;
+  }
+  if (int rc = frame_rest(ctx, ctx->q_uv, st.Q, nullptr, 0, &st.cam, &p, 0, nullptr, 1, stage, stage)) {
+    st.done = -1;
+    return rc;
+  }
+  const int nb = std::max(st.n_slots, 1), tab = std::min(nb, fs->max_clusters), M = std::max(st.M, 1);
+  if (int rc = ensure_pinned(ctx, 512 + (size_t)(2 * nb + 2 * tab + M) * 4)) return rc;
+  PinCursor pc{static_cast<unsigned char*>(ctx->pinned)};
+  FrameCounts* fc = pc.take<FrameCounts>(1);
+  int32_t* kept_p = pc.take<int32_t>(1);
+  float* sc = pc.take<float>(nb);
+  int32_t* old_of = pc.take<int32_t>(nb);
+  int32_t* cb = pc.take<int32_t>(tab);
+  int32_t* cc = pc.take<int32_t>(tab);
+  int32_t* mem = pc.take<int32_t>(M);
+  MH_HIP(ctx, hipMemcpyAsync(fc, fs->counts, sizeof(FrameCounts), hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(kept_p, fs->n_slots, 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(sc, fs->obj_score_raw, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(old_of, fs->obj_clsize + fs->max_objects, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(cb, fs->cl_begin, (size_t)tab * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipMemcpyAsync(cc, fs->cl_count, (size_t)tab * 4, hipMemcpyDeviceToHost, s));
+  if (st.M > 0) MH_HIP(ctx, hipMemcpyAsync(mem, fs->new_members, (size_t)st.M * 4, hipMemcpyDeviceToHost, s));
+  MH_HIP(ctx, hipStreamSynchronize(s));
+  if (int rc = step_flags(ctx, *fc, "mh_step_filter")) return rc;
+  const int kept = *kept_p;
+  if (kept < 0 || kept > n_objects || kept > tab) {
+    st.done = -1;
+    ctx->err = "mh_step_filter: inconsistent object count";
+    return MH_ERR_HIP;
+  }
+  for (int i = 0; i < n_objects; ++i) {
+    if (score) score[i] = sc[st.valid[i]];
+    if (keep) keep[i] = 0;
+  }
+  std::vector<int32_t> new_model(kept);
+  int w = 0;
+  bool over = false;
+  for (int k = 0; k < kept; ++k) {
+    // kept object k sat in slot old_of[k]: the slots that held an object are in ascending order = the host's list order
+    const int i = (int)(std::lower_bound(st.valid.begin(), st.valid.end(), old_of[k]) - st.valid.begin());
+    if (i >= n_objects || st.valid[i] != old_of[k]) {
+      st.done = -1;
+      ctx->err = "mh_step_filter: a kept object does not come from a slot that held one";
+      return MH_ERR_HIP;
+    }
+    const int model = st.valid_model[i], b = st.model_off[model];
+    new_model[k] = model;
+    if (keep) keep[i] = 1;
+    if (out_order) out_order[k] = i;
+    if (cl_off) cl_off[k] = w;
+    for (int j = 0; j < cc[k]; ++j, ++w) {
+      if (w >= cap_members) over = true;
+      else if (cl_members) cl_members[w] = mem[cb[k] + j] - b;
+    }
+  }
+  if (cl_off) cl_off[kept] = w;
+  *n_kept = kept;
+  st.valid.resize(kept);
+  for (int k = 0; k < kept; ++k) st.valid[k] = k;   // FILTER compacts the kept objects to slots 0 .. kept - 1, in order
+  st.valid_model.swap(new_model);
+  st.n_slots = kept;
+  st.n_clusters = kept;
+  st.done = stage;
+  return over ? MH_ERR_CAPACITY : MH_OK;
 }
 
 }  // extern "C"

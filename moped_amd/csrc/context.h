@@ -100,6 +100,20 @@ struct mh_ctx {
   bool wb_want = false;   // the frame being enqueued records wb_ev after its normalisation
   bool wb_pending = false;   // a write-back is in flight on wb_stream (mh_frame_wait_descriptors)
 
+  // mh_step_*: the frame's six slots one call each.  stage_lo / stage_hi: what the next frame_rest launches (0 .. 5 =
+  // everything); step: where the resident frame stands and what the host needs to know to read its results back.
+  int stage_lo = 0, stage_hi = 5;
+  struct StepState {
+    int done = -1;          // last stage run on the resident frame (-1: none / invalidated)
+    int Q = 0, M = 0;       // queries, accepted matches
+    int n_clusters = 0;     // clusters POSE / POSE2 will work on (CLUSTER's, then FILTER's)
+    int n_slots = 0;        // object slots in use
+    mh_cam cam;
+    std::vector<int32_t> model_off;   // host copy of the per-model offsets into the match list
+    std::vector<int32_t> valid;       // slots that hold an object, ascending = the host's list order
+    std::vector<int32_t> valid_model; // ... and the model of each
+  } step;
+
   // frame state (group / cluster / pose / filter); defined in frame.h
   struct FrameState* fs = nullptr;
   struct SiftState* sift = nullptr;   // pyramid + keypoint buffers of the SIFT extractor (api_sift.hip)

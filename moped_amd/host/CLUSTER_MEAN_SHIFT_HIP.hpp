@@ -29,9 +29,41 @@ class CLUSTER_MEAN_SHIFT_HIP : public MopedAlg {
   }
   void setConfig(map<string, string>&) {}
 
+  // CLUSTER on the lists MATCH_BRUTE_HIP left on the device (HipHandover); false = not taken
+  bool processResident(FrameData& frameData, mh_ctx* ctx) {
+    HipHandover& ho = HipHandover::get();
+    if (!ho.at(0, frameData) || frameData.matches.size() != models->size()) return false;
+    for (size_t m = 0; m < frameData.clusters.size(); ++m)
+      if (!frameData.clusters[m].empty()) return false;
+    if (ho.matchesTag != HipHandover::tagMatches(frameData)) return false;   // a step in between changed the lists
+    size_t total = 0;
+    for (size_t m = 0; m < frameData.matches.size(); ++m) total += frameData.matches[m].size();
+    const int cap = (int)total + 1;
+    vector<int32_t> clModel(cap), clOff(cap + 1), members(cap);
+    int32_t ncl = 0;
+    if (mh_step_cluster(ctx, Radius, Merge, MinPts, MaxIterations, &clModel[0], &clOff[0], &members[0], cap, cap, &ncl) != MH_OK) {
+      HipSession::warn("mh_step_cluster");
+      return false;
+    }
+    for (int c = 0; c < ncl; ++c) {
+      vector<FrameData::Cluster>& dst = frameData.clusters[clModel[c]];
+      dst.resize(dst.size() + 1);
+      for (int j = clOff[c]; j < clOff[c + 1]; ++j) dst.back().push_back(members[j]);
+    }
+    ho.stage = 1;
+    ++ho.taken;
+    ho.clustersTag = HipHandover::tagClusters(frameData);
+    return true;
+  }
+
   void process(FrameData& frameData) {
     frameData.clusters.resize(models->size());
     mh_ctx* ctx = HipSession::get();
+    if (processResident(frameData, ctx)) {
+      if (_stepName == "CLUSTER") frameData.oldClusters = frameData.clusters;
+      return;
+    }
+    HipHandover::get().drop();
     // every (model, image) point set of the frame goes to the device in ONE call
     vector<float> pts;
     vector<int> matchIdx;

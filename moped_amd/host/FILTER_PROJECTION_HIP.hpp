@@ -34,9 +34,58 @@ class FILTER_PROJECTION_HIP : public MopedAlg {
   }
   void setConfig(map<string, string>&) {}
 
+  // FILTER / FILTER2 on the objects POSE_RANSAC_P3P_HIP left on the device (HipHandover); false = not taken
+  bool processResident(FrameData& frameData) {
+    HipHandover& ho = HipHandover::get();
+    const int which = ho.at(2, frameData) ? 1 : ho.at(4, frameData) ? 2 : 0;
+    if (!which) return false;
+    if (ho.matchesTag != HipHandover::tagMatches(frameData) || ho.objectsTag != HipHandover::tagObjects(frameData)) return false;
+    const int nm = (int)models->size();
+    // the device's objects are the list's, in list order
+    vector<list<SP_Object>::iterator> its;
+    vector<int> objModel;
+    for (list<SP_Object>::iterator it = frameData.objects->begin(); it != frameData.objects->end(); ++it) {
+      int m = 0;
+      while (m < nm && (*models)[m].get() != (*it)->model.get()) ++m;
+      if (m == nm) return false;
+      its.push_back(it);
+      objModel.push_back(m);
+    }
+    const int nobj = (int)its.size();
+    size_t total = 0;
+    for (int m = 0; m < nm; ++m) total += frameData.matches[m].size();
+    vector<float> score(nobj + 1);
+    vector<uint8_t> keep(nobj + 1);
+    vector<int32_t> order(nobj + 1), members(total + 1), cloff(nobj + 1);
+    int32_t kept = 0;
+    if (mh_step_filter(HipSession::get(), which, MinPoints, FeatureDistance, MinScore, nobj, &score[0], &keep[0], &order[0],
+                       &members[0], &cloff[0], (int)total + 1, &kept) != MH_OK) {
+      HipSession::warn("mh_step_filter");
+      return false;
+    }
+    frameData.clusters.clear();
+    frameData.clusters.resize(nm);
+    for (int o = 0; o < nobj; ++o) (*its[o])->score = score[o];
+    for (int k = 0; k < kept; ++k) {
+      const int o = order[k];
+      vector<FrameData::Cluster>& dst = frameData.clusters[objModel[o]];
+      dst.resize(dst.size() + 1);
+      for (int j = cloff[k]; j < cloff[k + 1]; ++j) dst.back().push_back(members[j]);
+    }
+    for (int o = 0; o < nobj; ++o)
+      if (!keep[o]) frameData.objects->erase(its[o]);
+    ho.stage = which == 1 ? 3 : 5;
+    ++ho.taken;
+    ho.clustersTag = HipHandover::tagClusters(frameData);
+    ho.objectsTag = HipHandover::tagObjects(frameData);
+    return true;
+  }
+
   void process(FrameData& frameData) {
     vector<vector<FrameData::Match> >& matches = frameData.matches;
     if (matches.size() < models->size()) return;  // the reference's sanity check (:85-87)
+    if (processResident(frameData)) return;
+    HipHandover::get().drop();
     const int nm = (int)models->size();
     const HipCameraTable table(frameData);
     if (!table.ok) return;

@@ -37,6 +37,40 @@ class POSE_RANSAC_P3P_HIP : public MopedAlg {
   }
   void setConfig(map<string, string>&) {}
 
+  // POSE / POSE2 on the clusters the HIP step before left on the device (HipHandover): after CLUSTER_MEAN_SHIFT_HIP the
+  // first stage, after FILTER_PROJECTION_HIP the second (its random streams keyed like the one-call frame's:
+  // mh_frame_run_host, seed ^ 0x5DEECE66D).  false = not taken.
+  bool processResident(FrameData& frameData, mh_ctx* ctx, const mh_pose_params& prm, uint64_t seed) {
+    HipHandover& ho = HipHandover::get();
+    int which = 0;
+    if (ho.at(1, frameData) && frameData.objects->empty()) which = 1;
+    else if (ho.at(3, frameData) && ho.objectsTag == HipHandover::tagObjects(frameData)) which = 2;
+    if (!which || MaxObjectsPerCluster < 1) return false;
+    if (ho.matchesTag != HipHandover::tagMatches(frameData) || ho.clustersTag != HipHandover::tagClusters(frameData)) return false;
+    size_t ncl = 0;
+    for (size_t m = 0; m < frameData.clusters.size(); ++m) ncl += frameData.clusters[m].size();
+    const int cap = (int)ncl * MaxObjectsPerCluster + 1;
+    vector<mh_step_object> out(cap);
+    int32_t nout = 0;
+    if (mh_step_pose(ctx, which, &prm, which == 1 ? seed : seed ^ 0x5DEECE66Dull, &out[0], cap, &nout) != MH_OK) {
+      HipSession::warn("mh_step_pose");
+      return false;
+    }
+    for (int o = 0; o < nout; ++o) {
+      if (out[o].model < 0 || out[o].model >= (int)models->size()) continue;
+      SP_Object obj(new Object);
+      frameData.objects->push_back(obj);
+      obj->pose.rotation.init(out[o].pose[0], out[o].pose[1], out[o].pose[2], out[o].pose[3]);
+      obj->pose.translation.init(out[o].pose[4], out[o].pose[5], out[o].pose[6]);
+      obj->model = (*models)[out[o].model];
+      obj->score = 0;
+    }
+    ho.stage = which == 1 ? 2 : 4;
+    ++ho.taken;
+    ho.objectsTag = HipHandover::tagObjects(frameData);
+    return true;
+  }
+
   void process(FrameData& frameData) {
     mh_ctx* ctx = HipSession::get();
     ++frameCounter;
@@ -48,6 +82,11 @@ class POSE_RANSAC_P3P_HIP : public MopedAlg {
     prm.error_threshold = ErrorThreshold;
     prm.lm_iters_l2 = 2;
     prm.lm_iters_l4 = 10;
+    if (processResident(frameData, ctx, prm, (uint64_t)frameCounter * 2654435761ul + _alg)) {
+      if (_stepName == "POSE") frameData.oldObjects = *frameData.objects;
+      return;
+    }
+    HipHandover::get().drop();
     // every cluster of the frame in ONE launch, in the reference's task order (model, cluster) (:275-303); each
     // correspondence carries its own image (LmData::image, :228-237): CLUSTER's clusters live in one image,
     // FILTER's (the input of POSE2) mix images

@@ -5,7 +5,9 @@
 #pragma once
 #include <moped_hip.h>
 
+#include <cstdlib>
 #include <iostream>
+#include <list>
 #include <map>
 #include <sstream>
 #include <string>
@@ -35,6 +37,79 @@ class HipSession {
     if (ctx_) mh_destroy(ctx_);
   }
   mh_ctx* ctx_;
+};
+
+// The hand-over between consecutive HIP steps of one frame (mh_step_*, include/moped_hip.h): a HIP step that finds
+// FrameData as the HIP step before it left it -- same frame object, and the lists it is about to read hash to what that
+// step wrote -- runs on the device-resident copy instead of uploading them again.  Anything else (a CPU step in between
+// that touched the lists, a frame with several cameras, lists that were not empty before MATCH, MH_STEP_HANDOVER=0)
+// takes the upload path of the slot, which is always valid; so does a refusal by the library (the context's frame
+// arrays were used by another call).  One instance per process, like the context.
+struct HipHandover {
+  int stage;                 // -1: nothing resident; 0 MATCH .. 5 FILTER2 = the last slot that ran on the resident frame
+  const void* frame;         // the FrameData it belongs to
+  unsigned long long matchesTag, clustersTag, objectsTag;
+  unsigned long taken;       // steps that ran on the resident frame so far (tests, moped_hip_test)
+
+  static HipHandover& get() {
+    static HipHandover h;
+    return h;
+  }
+  static bool enabled() {
+    static const int on = (std::getenv("MH_STEP_HANDOVER") && std::getenv("MH_STEP_HANDOVER")[0] == '0') ? 0 : 1;
+    return on != 0;
+  }
+  void drop() { stage = -1; frame = 0; }
+
+  // FNV-1a over the bytes a step reads
+  static unsigned long long mix(unsigned long long h, const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+  }
+  static unsigned long long tagMatches(const FrameData& fd) {
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t m = 0; m < fd.matches.size(); ++m) {
+      const size_t n = fd.matches[m].size();
+      h = mix(h, &n, sizeof n);
+      for (size_t k = 0; k < n; ++k) {
+        const FrameData::Match& x = fd.matches[m][k];
+        const float v[5] = {(float)x.coord2D[0], (float)x.coord2D[1], (float)x.coord3D[0], (float)x.coord3D[1], (float)x.coord3D[2]};
+        h = mix(h, &x.imageIdx, sizeof x.imageIdx);
+        h = mix(h, v, sizeof v);
+      }
+    }
+    return h;
+  }
+  static unsigned long long tagClusters(const FrameData& fd) {
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t m = 0; m < fd.clusters.size(); ++m) {
+      const size_t n = fd.clusters[m].size();
+      h = mix(h, &n, sizeof n);
+      for (size_t c = 0; c < n; ++c) {
+        const size_t sz = fd.clusters[m][c].size();
+        h = mix(h, &sz, sizeof sz);
+        for (FrameData::Cluster::const_iterator it = fd.clusters[m][c].begin(); it != fd.clusters[m][c].end(); ++it) h = mix(h, &*it, sizeof(int));
+      }
+    }
+    return h;
+  }
+  static unsigned long long tagObjects(const FrameData& fd) {
+    unsigned long long h = 1469598103934665603ull;
+    for (list<SP_Object>::const_iterator it = fd.objects->begin(); it != fd.objects->end(); ++it) {
+      const void* model = (*it)->model.get();
+      float v[7];
+      for (int i = 0; i < 4; ++i) v[i] = (float)(*it)->pose.rotation[i];
+      for (int i = 0; i < 3; ++i) v[4 + i] = (float)(*it)->pose.translation[i];
+      h = mix(h, &model, sizeof model);
+      h = mix(h, v, sizeof v);
+    }
+    return h;
+  }
+  bool at(int wanted, const FrameData& fd) const { return enabled() && stage == wanted && frame == (const void*)&fd; }
+
+ private:
+  HipHandover() : stage(-1), frame(0), matchesTag(0), clustersTag(0), objectsTag(0), taken(0) {}
 };
 
 // The cameras of a frame for the *_images entry points.  The reference projects every match through

@@ -410,6 +410,7 @@ int main(int argc, char** argv) {
     }
   }
   const int timed = repeats > 1 ? repeats - 1 : 1;
+  std::printf("HANDOVER_STEPS %lu FRAMES %d\n", HipHandover::get().taken, repeats);   // steps that ran on the device-resident frame
   for (map<string, double>::iterator t = total.begin(); t != total.end(); ++t)
     std::printf("TIME %s %.6f\n", t->first.c_str(), t->second / timed);
   for (list<SP_Object>::iterator o = objects.begin(); o != objects.end(); ++o)

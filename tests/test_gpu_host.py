@@ -286,3 +286,37 @@ def test_run_host_in_halves_from_page_locked_memory_equals_the_one_call():
         assert np.array_equal(objs["score"].view(np.uint32), want["score"].view(np.uint32))
     c.host_free(block)
     c.close()
+
+
+@pytest.mark.gpu
+def test_six_hip_steps_hand_the_frame_over_on_the_device(tmp_path):
+    """MATCH_BRUTE_HIP -> CLUSTER_MEAN_SHIFT_HIP -> POSE -> FILTER -> POSE2 -> FILTER2 wired as six steps
+    (src/config.hpp:83-120): every step finds FrameData as the HIP step before left it and runs on the device-resident
+    frame (mh_step_*, HipHandover) -- six hand-overs per frame, and the frame's objects are bit for bit those of the six
+    slots as ONE step (FRAME_RESIDENT_HIP -> mh_frame_run_host): same kernels on the same lists with the same random
+    streams.  With MH_STEP_HANDOVER=0 every step takes its upload path: same models, poses within the bar."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_scene
+    subprocess.check_call(["make", "-s", "-C", HOST, "moped_hip_test"])
+    db = synth.make_db(10, 3000)
+    fr = synth.make_frame(db, n_vis=4, seed=12, Q=3000)
+    scene = str(tmp_path / "scene.bin")
+    dump_scene.dump(scene, db, fr)
+    exe = os.path.join(HOST, "moped_hip_test")
+
+    def run(args, env=None):
+        out = subprocess.check_output([exe] + args, text=True, env=dict(os.environ, **(env or {})))
+        objs = [l for l in out.splitlines() if l.startswith("OBJ ")]
+        head = {l.split()[0]: l.split()[1:] for l in out.splitlines() if not l.startswith(("OBJ", "TIME"))}
+        return objs, head
+    stepped, h1 = run([scene, "3"])
+    resident, _ = run(["--resident", scene, "3"])
+    upload, h0 = run([scene, "3"], {"MH_STEP_HANDOVER": "0"})
+    assert h1["HANDOVER_STEPS"][0] == "18" and h0["HANDOVER_STEPS"][0] == "0"      # 6 steps x 3 frames / none
+    assert len(stepped) >= 4 and stepped == resident                                 # printed to 1e-6: the same objects
+    assert h1["MATCHES"] == h0["MATCHES"]                                            # matches, clusters, objects after POSE counts
+    assert sorted(l.split()[1] for l in upload) == sorted(l.split()[1] for l in stepped)
+    for a in upload:
+        b = [l for l in stepped if l.split()[1] == a.split()[1]][0]
+        pa, pb = np.array(a.split()[2:9], float), np.array(b.split()[2:9], float)
+        assert np.abs(pa[:3] - pb[:3]).max() < 3e-3 and min(np.abs(pa[3:] - pb[3:]).max(), np.abs(pa[3:] + pb[3:]).max()) < 2e-2
