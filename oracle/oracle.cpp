@@ -706,8 +706,18 @@ int orc_optimize_camera(float pose7[7], const float* uv, const float* xyz, int n
   return ret;
 }
 
-int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const float cam[7],
-               const orc_pose_params* prm, float pose7[7]) {
+// libc rand() like the reference (:83, :184), or a stream a test injects (orc_set_rand: tests/test_witness_cpu.py drives the
+// RANSAC skeleton with streams that force ties between the points' random keys).
+static int (*g_rand_fn)(void) = NULL;
+static inline int orc_rand_() { return g_rand_fn ? g_rand_fn() : rand(); }
+void orc_set_rand(int (*fn)(void)) { g_rand_fn = fn; }
+
+// addr (optional, NULL = position order): the points' rank by ADDRESS.  randSample sorts pair<Float, LmData*> (:81-84), so
+// two points whose (Float)rand() keys are equal come out in pointer order -- &lmData[model][match] (:287-288): ascending
+// match index, not the position inside the cluster.  Keys collide in ~1 sample in 1 500 at 150 points (a 31-bit rand() in
+// a 24-bit mantissa).
+int orc_ransac_addr(const float* uv, const float* xyz, const int32_t* addr, int k, const float K[4], const float cam[7],
+                    const orc_pose_params* prm, float pose7[7]) {
   Camera c;
   camera_init(c, K, cam);
   std::vector<float> suv, sxyz;
@@ -715,15 +725,15 @@ int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const
   for (int it = 0; it < prm->max_ransac_tests; it++) {
     // randSample (:76-98): a random float key per point, sort, take from the
     // front skipping points whose 2-D coordinate was already taken.
-    std::vector<std::pair<float, int> > keyed(k);
-    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)rand(), i);
+    std::vector<std::pair<float, std::pair<int, int> > > keyed(k);
+    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)orc_rand_(), std::make_pair(addr ? addr[i] : i, i));
     std::sort(keyed.begin(), keyed.end());
     std::map<std::pair<float, float>, int> used;
     suv.clear();
     sxyz.clear();
     size_t pos = 0;
     while ((int)used.size() < prm->n_pts_align && pos < keyed.size()) {
-      int i = keyed[pos++].second;
+      int i = keyed[pos++].second.second;
       std::pair<float, float> key(uv[2 * i], uv[2 * i + 1]);
       if (!used[key]++) {
         suv.push_back(uv[2 * i]);
@@ -735,7 +745,8 @@ int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const
     }
     if ((int)used.size() != prm->n_pts_align) return 0;
     // initPose (:182-186)
-    for (int j = 0; j < 4; j++) pose7[j] = (float)((rand() & 255) / 256.);
+    // (the reference draws the four inside ONE call's argument list, :184: their order is the compiler's; here x, y, z, w)
+    for (int j = 0; j < 4; j++) pose7[j] = (float)((orc_rand_() & 255) / 256.);
     pose7[4] = 0.f;
     pose7[5] = 0.f;
     pose7[6] = 0.5f;
@@ -759,6 +770,11 @@ int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const
     }
   }
   return 0;
+}
+
+int orc_ransac(const float* uv, const float* xyz, int k, const float K[4], const float cam[7],
+               const orc_pose_params* prm, float pose7[7]) {
+  return orc_ransac_addr(uv, xyz, NULL, k, K, cam, prm, pose7);
 }
 
 // ---- moped3d depth variants (A14) -------------------------------------------------
@@ -810,7 +826,7 @@ int orc_ransac_depth(int mode, const float* uv, const float* xyz, const float* w
   std::vector<float> suv, sxyz, sw3, sww;
   for (int it = 0; it < prm->max_ransac_tests; it++) {
     std::vector<std::pair<float, int> > keyed(k);
-    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)rand(), i);
+    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)orc_rand_(), i);
     std::sort(keyed.begin(), keyed.end());
     std::map<std::pair<float, float>, int> used;
     pick.clear();
@@ -821,7 +837,7 @@ int orc_ransac_depth(int mode, const float* uv, const float* xyz, const float* w
       if (!used[key]++) pick.push_back(i);
     }
     if ((int)used.size() != prm->n_pts_align) return 0;
-    for (int j = 0; j < 4; j++) pose7[j] = (float)((rand() & 255) / 256.);
+    for (int j = 0; j < 4; j++) pose7[j] = (float)((orc_rand_() & 255) / 256.);
     float sum[3] = {0, 0, 0};
     for (size_t j = 0; j < pick.size(); j++)
       for (int x = 0; x < 3; x++) sum[x] += world[3 * pick[j] + x];
@@ -1008,7 +1024,7 @@ int orc_frame_rest_inliers(const float* q_uv, const int32_t* idx1, const float* 
         cxyz[3 * i + 2] = xyz[3 * g + 2];
       }
       found[t].model = m;
-      ok[t] = (char)orc_ransac(&cuv[0], &cxyz[0], (int)cl.size(), K, cam, &pp, found[t].pose);
+      ok[t] = (char)orc_ransac_addr(&cuv[0], &cxyz[0], &cl[0], (int)cl.size(), K, cam, &pp, found[t].pose);   // (cl: match indices = address order)
     }
     for (size_t t = 0; t < tasks.size(); t++)
       if (ok[t]) objects.push_back(found[t]);  // task order (the 1-thread order of :294-303)
@@ -1148,7 +1164,7 @@ int orc_ransac_images(const float* uv, const float* xyz, const int32_t* img, int
   std::vector<uint8_t> inl(k);
   for (int it = 0; it < prm->max_ransac_tests; it++) {
     std::vector<std::pair<float, int> > keyed(k);
-    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)rand(), i);
+    for (int i = 0; i < k; i++) keyed[i] = std::make_pair((float)orc_rand_(), i);
     std::sort(keyed.begin(), keyed.end());
     std::map<std::pair<int, std::pair<float, float> >, int> used;   // (image, coord2D) (:79)
     suv.clear();
@@ -1166,7 +1182,7 @@ int orc_ransac_images(const float* uv, const float* xyz, const int32_t* img, int
       }
     }
     if ((int)used.size() != prm->n_pts_align) return 0;
-    for (int j = 0; j < 4; j++) pose7[j] = (float)((rand() & 255) / 256.);
+    for (int j = 0; j < 4; j++) pose7[j] = (float)((orc_rand_() & 255) / 256.);
     pose7[4] = 0.f;
     pose7[5] = 0.f;
     pose7[6] = 0.5f;

@@ -116,6 +116,13 @@ typedef struct {
  * min_n_pts_object inliers was found, else 0. */
 int orc_ransac(const float* uv, const float* xyz, int k, const float K[4],
                const float cam[7], const orc_pose_params* prm, float pose7[7]);
+/* The same with the points' rank by address (randSample sorts pair<Float, LmData*>, :81-84: equal keys come out in
+ * pointer order = ascending match index, :287-288); addr == NULL: position order.  orc_frame_rest passes the clusters'
+ * match indices. */
+int orc_ransac_addr(const float* uv, const float* xyz, const int32_t* addr, int k, const float K[4],
+                    const float cam[7], const orc_pose_params* prm, float pose7[7]);
+/* rand() of the RANSAC skeletons: libc's (fn == NULL, the default) or a stream a test injects. */
+void orc_set_rand(int (*fn)(void));
 
 /* A14 moped3d depth variants.  mode 1 = POSE_RANSAC_LM_DIFF_BACKPROJECTION_DEPTH_CPU
  * (moped3d/libmoped/src/pose/...BACKPROJECTION_DEPTH_CPU.hpp:108-190; 2 residuals per
