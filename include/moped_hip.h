@@ -495,6 +495,11 @@ typedef struct mh_linkage_params {
 } mh_linkage_params;
 /* CLUSTER of the following frames: linkage with *prm, or mean shift again when prm == NULL. */
 int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm);
+/* The clusterer's scratch is three n x n similarity matrices per (model, frame) problem (CLUSTER_LINKAGE_CPU.hpp:573-704
+ * keeps the same three as vector<vector<Float>>): sized for the worst case of what the context has reserved -- 3 x 1024 x
+ * max matches floats per frame of a batch, 37 MB at 3 000 -- and bounded: a frame or batch that would need more than
+ * `bytes` (0 = the default, 4 GiB) fails with MH_ERR_CAPACITY before anything is allocated or launched. */
+int mh_set_linkage_scratch_limit(mh_ctx* ctx, size_t bytes);
 /* The step on its own, n_problems point sets (one per model) in one call: corr_host / depth_host
  * = the matches (image point + model point / camera-frame point from the depth map), problem p =
  * rows [off[p], off[p+1]).  label[i] = cluster of row i within its problem or -1; order (optional)

@@ -115,6 +115,7 @@ EXPORTS = [
     "mh_frame_block_stride", "mh_frame_fetch_batch_async", "mh_frame_fetch_previous_async", "mh_frame_fetch_wait",
     "mh_frame_fetch_query", "mh_host_alloc", "mh_host_free", "mh_frame_run_host_begin", "mh_frame_wait_descriptors",
     "mh_step_match", "mh_step_match_fetch", "mh_step_cluster", "mh_step_pose", "mh_step_filter",
+    "mh_set_linkage_scratch_limit",
 ]
 COMM_ID_BYTES = 128      # MH_COMM_ID_BYTES
 EX2_OBJECTS = 62         # MH_EX2_OBJECTS
@@ -276,6 +277,7 @@ def load():
     L.mh_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mh_host_free.argtypes = [vp, vp]
     L.mh_frame_wait_descriptors.argtypes = [vp]
+    L.mh_set_linkage_scratch_limit.argtypes = [vp, C.c_size_t]
     L.mh_step_match.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, i32]
     L.mh_step_match_fetch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_step_cluster.argtypes = [vp, f32, f32, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_int32)]
@@ -937,6 +939,10 @@ class Context:
         sd = (C.c_uint64 * B)(*[int(x) for x in seeds])
         self._ck(self.L.mh_frame_enqueue_image_batch(self.h, g, B, w, h, int(double_size), max_keypoints, C.byref(c),
                                                      C.byref(params), sd), "mh_frame_enqueue_image_batch")
+
+    def set_linkage_scratch_limit(self, nbytes):
+        """Bound of the linkage clusterer's similarity-matrix scratch for this context (0: the default, 4 GiB)."""
+        self._ck(self.L.mh_set_linkage_scratch_limit(self.h, C.c_size_t(int(nbytes))), "mh_set_linkage_scratch_limit")
 
     def frame_set_cluster_linkage(self, params: "mh_linkage_params | None"):
         """CLUSTER of the next frames: moped3d's linkage clusterer (None: mean shift again)."""

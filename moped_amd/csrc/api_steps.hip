@@ -303,6 +303,15 @@ __global__ void pack_result_kernel(unsigned char* result, const int32_t* n_slots
 
 int ensure_linkage_scratch(mh_ctx* ctx, size_t floats) {
   if (floats <= ctx->lk_scratch_floats) return MH_OK;
+  // 3 n^2 floats per (model, frame) problem: 37 MB per frame at 3 000 matches, 0.6 GB for a batch of 16 -- and it grows
+  // with the square of what a caller reserves.  Bounded per context (mh_set_linkage_scratch_limit, default 4 GiB)
+  // with an error the caller can act on instead of an allocation that takes the device's memory from the other slots.
+  if (floats * sizeof(float) > ctx->lk_scratch_limit) {
+    ctx->err = "linkage clusterer: " + std::to_string(floats * sizeof(float) >> 20) + " MiB of similarity-matrix scratch asked for, the "
+               "context's limit is " + std::to_string(ctx->lk_scratch_limit >> 20) + " MiB (fewer frames per batch, fewer queries "
+               "reserved, or mh_set_linkage_scratch_limit)";
+    return MH_ERR_CAPACITY;
+  }
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->lk_scratch) MH_HIP(ctx, hipFree(ctx->lk_scratch));
   ctx->lk_scratch = nullptr;
@@ -1140,6 +1149,12 @@ int mh_frame_set_depth_image_host(mh_ctx* ctx, const float* depth_xyzn_host, con
   MH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host maps may change after the call
   return mh_frame_set_depth_image(ctx, ctx->own_depth, fill_distance_host ? ctx->own_fill : nullptr, width, height, kind,
                                   alpha, cauchy_scale);
+}
+
+int mh_set_linkage_scratch_limit(mh_ctx* ctx, size_t bytes) {
+  if (!ctx) return MH_ERR_ARG;
+  ctx->lk_scratch_limit = bytes ? bytes : (size_t)4 << 30;
+  return MH_OK;
 }
 
 int mh_frame_set_cluster_linkage(mh_ctx* ctx, const mh_linkage_params* prm) {

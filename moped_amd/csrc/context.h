@@ -180,6 +180,7 @@ struct mh_ctx {
   float* lk_scratch = nullptr;
   unsigned char* df_buf = nullptr; // mh_depth_fill: [status words | downscaled depths | downscaled distances]
   size_t lk_scratch_floats = 0;
+  size_t lk_scratch_limit = (size_t)4 << 30;   // bytes; mh_set_linkage_scratch_limit
 
   // mh_frame_fetch_batch_async / mh_frame_fetch_previous_async: delivery of a batch's objects into the caller's pinned block
   struct Delivery {

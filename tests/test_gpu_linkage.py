@@ -122,3 +122,28 @@ def test_linkage_larger_sets_use_the_global_matrix(scene, n):
         prm = capi.mh_linkage_params(cutoff, min_pts, 2, -1.0, -1.0)
         (clusters, _), = s["c"].cluster_linkage([(uv, mx, world)], prm)
         _same(clusters, orclib.cluster_linkage(uv, mx, world, s["img"], s["fill"], cutoff=cutoff, min_pts=min_pts))
+
+
+def test_linkage_scratch_is_bounded_per_context(scene):
+    """The clusterer's three n x n matrices per (model, frame) problem are sized for the worst case of what the context
+    reserved (37 MB per frame at 3 000 matches, 0.6 GB per 16-frame batch): a context refuses, with an error
+    that says what to change, to take more than its limit (mh_set_linkage_scratch_limit) -- before allocating or
+    launching anything -- and runs the same frame once the limit allows it."""
+    s = scene
+    torch, dev, fr, db = s["torch"], s["dev"], s["fr"], s["db"]
+    c = capi.Context(0)
+    c.db_upload(c.normalize(db.desc), db.model_of, db.xyz, db.n_models)
+    c.reserve(1600)
+    d_img, d_fill = s["keep"]
+    c.frame_set_depth_image(d_img.data_ptr(), d_fill.data_ptr(), 640, 480, capi.DEPTH_BACKPROJECTION, 0.5, 0.1)
+    c.frame_set_cluster_linkage(capi.default_linkage_params())
+    qd, uv = torch.from_numpy(fr.desc).to(dev), torch.from_numpy(fr.uv).to(dev)
+    c.set_linkage_scratch_limit(1 << 20)
+    with pytest.raises(capi.MhError, match="limit is 1 MiB"):
+        c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), 1600, K, CAM0, capi.default_frame_params(), 3)
+    c.set_linkage_scratch_limit(0)      # the default again
+    qd = torch.from_numpy(fr.desc).to(dev)
+    c.frame_enqueue(qd.data_ptr(), uv.data_ptr(), 1600, K, CAM0, capi.default_frame_params(), 3)
+    objs, counts = c.frame_fetch()
+    assert len(objs) >= 1 and set(objs["model"].tolist()) <= set(fr.visible.tolist())
+    c.close()
