@@ -18,6 +18,7 @@ bad = 0
 scores = 0
 spread = 0
 marginal = 0
+sensitive = 0
 done = 0
 t0 = time.perf_counter()
 while done < scenes:
@@ -126,6 +127,38 @@ while done < scenes:
                               f"{prm.pose1.error_threshold} px^2 of the planted pose", flush=True)
                         marginal += 1
                         w = []
+            # The mirror image: an object only the DEVICE reports that is a planted, visible object with MORE than
+            # MinNPtsObject correspondences of one cluster within POSE's threshold of its planted pose, found at a pose
+            # inside the bar -- the reference's own acceptance rule (:204) holds for it, but its 600 draws of five points
+            # rarely all land on the few good ones of a cluster of clutter (seed 1, scene 120: 7 good among 44 -- a chance
+            # of (7/44)^5 per draw, 6% per replica; the 4 x 1024 three-point samples here meet it almost surely).
+            # Reported as `sensitive`, not failed.
+            if w and len(w) == 1 and w[0].startswith("models "):
+                dev_m, orc_m = sorted(first["model"].tolist()), sorted(om.tolist())
+                extra = [m for m in set(dev_m) if dev_m.count(m) > orc_m.count(m)]
+                if extra and not [m for m in set(orc_m) if orc_m.count(m) > dev_m.count(m)]:
+                    mq_, mm_ = pipe.ctxs[0].frame_fetch_matches()
+                    ok_all, notes = True, []
+                    for m in extra:
+                        if m not in fr.visible.tolist() or dev_m.count(m) != 1:
+                            ok_all = False
+                            break
+                        acc_ = mq_[mm_ == m]
+                        pl_ = fr.poses[list(fr.visible).index(m)]
+                        e2_ = ((orclib.project(pl_, db.xyz[idx[acc_]], K, CAM0) - fr.uv[acc_]) ** 2).sum(1)
+                        cls_, _ = pipe.ctxs[0].meanshift(np.ascontiguousarray(fr.uv[acc_]))
+                        good_ = [(int((e2_[np.asarray(c_)] < prm.pose1.error_threshold).sum()), len(c_)) for c_ in cls_]
+                        g_ = first[first["model"] == m][0]
+                        rows_ = np.nonzero((fr.src_point >= 0) & ~fr.is_outlier)[0]
+                        rows_ = rows_[db.model_of[fr.src_point[rows_]] == m]
+                        e_dev = float(np.sqrt(((orclib.project(g_["pose"], db.xyz[fr.src_point[rows_]], K, CAM0) - fr.uv[rows_]) ** 2).sum(1)).mean()) if len(rows_) else 9e9
+                        if max([g for g, _ in good_] + [0]) <= prm.pose1.min_n_pts_object or e_dev > 1.0:
+                            ok_all = False
+                        notes.append(f"model {m}: clusters (good, size) {good_}, device pose {e_dev:.2f} px off the planted points")
+                    if ok_all:
+                        print(f"sensitive scene {done}: " + w[0] + " -- " + "; ".join(notes), flush=True)
+                        sensitive += 1
+                        w = []
             # what is left after reseeding both sides: a different model set or a pose outside the bar is a mismatch;
             # a FILTER2 score that differs by more than 5% while the pose is inside the bar is reported and counted,
             # not failed -- FILTER's arithmetic is bit-exact for equal poses (tests/test_gpu_steps.py), the score follows
@@ -210,5 +243,6 @@ while done < scenes:
     print(f"{done} scenes, {bad} mismatches, {time.perf_counter() - t0:.0f} s", flush=True)
 print(f"{done} scenes, {bad} mismatches ({spread} object-level differences inside the seed-to-seed spread of the oracle or of the device; "
       f"{scores} scenes with an object whose FILTER2 score differs by more than 5% at a pose inside the 1 px bar; "
-      f"{marginal} scenes with an object only the oracle reports that has no cluster of more than MinNPtsObject points within the threshold of its planted pose)")
+      f"{marginal} scenes with an object only the oracle reports that has no cluster of more than MinNPtsObject points within the threshold of its planted pose; "
+      f"{sensitive} scenes with a planted object only the device reports, at a pose inside the bar, that meets the reference's acceptance rule)")
 sys.exit(1 if bad else 0)
