@@ -145,9 +145,9 @@ def arm_watchdog(seconds: int):
     """(Re-)arm the hang watchdog for the leg that starts now: a rank still inside it after `seconds` dumps every
     thread's stack and exits with an error.  Per leg, not per job: a long --steps or a slow host must not be killed for
     the sum of its legs."""
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()   # (seconds <= 0: off -- a timer armed for an earlier leg must not outlive it)
     if seconds > 0:
-        import faulthandler
-        faulthandler.cancel_dump_traceback_later()
         faulthandler.dump_traceback_later(seconds, exit=True)
 
 
@@ -806,7 +806,7 @@ def main():
     pipe, params = job.pipe, job.params
     if B > 1 and not depth_given and args.depth == 16:
         job.calibrate_slots()
-    arm_watchdog(wd + 2 * args.steps)
+    arm_watchdog(wd + 2 * args.steps if wd > 0 else 0)   # (wd = 0 is "off", not "2 s per step": the N = 1 default)
     dt, t_issue = job.timed(args.steps, args.warmup)
     fps = job.total_frames(args.steps) / dt    # every one of these frames' objects reached the host inside dt (checked below)
     det_per_frame = job.detections_per_frame()

@@ -277,12 +277,13 @@ def load():
     L.mh_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.mh_host_free.argtypes = [vp, vp]
     L.mh_frame_wait_descriptors.argtypes = [vp]
-    L.mh_set_linkage_scratch_limit.argtypes = [vp, C.c_size_t]
-    L.mh_step_match.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, i32]
-    L.mh_step_match_fetch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
-    L.mh_step_cluster.argtypes = [vp, f32, f32, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_int32)]
-    L.mh_step_pose.argtypes = [vp, i32, C.POINTER(mh_pose_params), C.c_uint64, vp, i32, C.POINTER(C.c_int32)]
-    L.mh_step_filter.argtypes = [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
+    if hasattr(L, "mh_step_match"):   # (absent only in an older build named by MH_LIB_PATH for an A/B run)
+        L.mh_set_linkage_scratch_limit.argtypes = [vp, C.c_size_t]
+        L.mh_step_match.argtypes = [vp, vp, vp, i32, C.POINTER(mh_cam), f32, i32]
+        L.mh_step_match_fetch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
+        L.mh_step_cluster.argtypes = [vp, f32, f32, i32, i32, vp, vp, vp, i32, i32, C.POINTER(C.c_int32)]
+        L.mh_step_pose.argtypes = [vp, i32, C.POINTER(mh_pose_params), C.c_uint64, vp, i32, C.POINTER(C.c_int32)]
+        L.mh_step_filter.argtypes = [vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_int32)]
     L.mh_frame_fetch_query.argtypes = [vp]
     _lib = L
     return L

@@ -1064,7 +1064,7 @@ __device__ void pose_refine(const float* pts, int* list, const int k, float* R, 
     const int nt = collect(same, 0.5f);
     bool kept = false;
     if (nt > prm.min_n_pts_object) {
-      lm_refine<KIND>(R, t, cams, pts, list, nt, alpha, 0, iters_l2, lane);
+      // (from the minimiser over the full set: the squared-residual phase alone, two to three Newton steps -- no warm start)
       err = lm_refine<KIND>(R, t, cams, pts, list, nt, alpha, 1, prm.lm_iters_l4, lane);
       const int nf = collect(same);
       if (nf > prm.min_n_pts_object) {
@@ -1538,6 +1538,47 @@ constexpr int POSE_GRID = 160;
 
 // What the workgroup that finishes a frame's LAST task does (all POSE_THREADS threads): the object-slot count past this
 // launch's slots, the count of valid objects, the feedback word -- and, fused FILTER, the step that follows.
+// The frame's buffers as the fused FILTER step sees them (arena of frame f applied)
+__device__ __forceinline__ FilterBuffers fused_filter_buffers(const FilterFuseArgs* __restrict__ fuse_args, const unsigned long long a) {
+  FilterBuffers ffb = fuse_args->fb;
+  ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
+  ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
+  ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
+  ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
+  ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
+  ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
+  ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
+  return ffb;
+}
+
+// F1 -- score and keypoint claims -- of the objects a frame held BEFORE the launch (FILTER2: the POSE objects FILTER kept,
+// slots [0, obj_base)): they compete with their re-estimates like the reference's list does (POSE2 appends to
+// frameData.objects, ...REPROJECTION_CPU.hpp:299; FILTER_PROJECTION_CPU.hpp:96 scores every object).  Dealt over the
+// launch's workgroups at their START, four slots per workgroup (one wavefront each): slot o belongs to workgroup
+// (o / 4) mod G.  Returns how many slots this workgroup took.  (Round 5, first form: the closing workgroup did them all
+// at the end -- ten kept objects were three rounds of ~10 us behind everything else, 0.74 -> 0.77 ms for a frame alone.)
+__device__ __forceinline__ int pose_kept_f1(const FilterFuseArgs* __restrict__ fuse_args, const unsigned long long a, const int obj_base,
+                                            const int max_objects, const DevCam& cam) {
+  const int n_old = obj_base < max_objects ? obj_base : max_objects;
+  const int G = (int)gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = POSE_THREADS / 64;
+  int mine = 0;
+  FilterBuffers ffb;
+  bool have = false;
+  for (int o0 = (int)blockIdx.x * NW; o0 < n_old; o0 += G * NW) {
+    if (!have) {
+      ffb = fused_filter_buffers(fuse_args, a);
+      have = true;
+    }
+    mine += min(NW, n_old - o0);
+    const int o = o0 + wave;
+    if (o < n_old && ffb.obj_valid[o])   // (wave-uniform)
+      filter_score_wave(ffb, cam, fuse_args->feature_distance, o, ffb.obj_model[o], ffb.obj_pose + 7 * (size_t)o,
+                        ffb.obj_pose + 7 * (size_t)o + 4, lane);
+  }
+  return mine;
+}
+
 __device__ void pose_close_frame(const int f, const unsigned long long a, const int n_tasks, const int obj_base,
                                  const int max_objects, int32_t* obj_valid0, FrameCounts* counts0, const PoseTail& tail0,
                                  const FilterFuseArgs* __restrict__ fuse_args, const DevCam& cam, const FrameBatch& fbx) {
@@ -1564,14 +1605,7 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
   if (fuse_args) {
     // the frame's FILTER step, here instead of in a launch of its own: this workgroup scores the objects the frame
     // held before the launch, then F2..F4 and (FILTER2) the result block
-    FilterBuffers ffb = fuse_args->fb;
-    ffb.corr = frame_ptr(ffb.corr, a); ffb.m_rep = frame_ptr(ffb.m_rep, a); ffb.model_off = frame_ptr(ffb.model_off, a);
-    ffb.obj_model = frame_ptr(ffb.obj_model, a); ffb.obj_pose = frame_ptr(ffb.obj_pose, a);
-    ffb.obj_score = frame_ptr(ffb.obj_score, a); ffb.obj_score_raw = frame_ptr(ffb.obj_score_raw, a);
-    ffb.obj_valid = frame_ptr(ffb.obj_valid, a); ffb.obj_npts = frame_ptr(ffb.obj_npts, a);
-    ffb.best = frame_ptr(ffb.best, a); ffb.obj_clsize = frame_ptr(ffb.obj_clsize, a);
-    ffb.new_members = frame_ptr(ffb.new_members, a); ffb.cl_model = frame_ptr(ffb.cl_model, a);
-    ffb.cl_begin = frame_ptr(ffb.cl_begin, a); ffb.cl_count = frame_ptr(ffb.cl_count, a);
+    FilterBuffers ffb = fused_filter_buffers(fuse_args, a);
     FilterTail ftail = fuse_args->tail;
     ftail.ticket = frame_ptr(ftail.ticket, a);
     if (ftail.snap_kept) ftail.snap_kept += 4 * f;
@@ -1580,21 +1614,8 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
     __shared__ FilterLds FS;
     __syncthreads();
     // F1 -- an object's score and its claims -- of THIS launch's objects was run by the wavefront that refined each of
-    // them (pose_refine).  The objects the frame already held (FILTER2: the POSE objects FILTER kept, slots
-    // [0, obj_base)) compete with their re-estimates like the reference's list does (POSE2 appends to
-    // frameData.objects, ...REPROJECTION_CPU.hpp:299; FILTER_PROJECTION_CPU.hpp:96 scores every object): their F1 here,
-    // one wavefront per object, before the owners are counted.
-    if (obj_base > 0) {
-      const int lane = threadIdx.x & 63;
-      const int n_old = obj_base < n_slots ? obj_base : n_slots;
-      for (int o = threadIdx.x >> 6; o < n_old; o += POSE_THREADS / 64) {
-        if (!ffb.obj_valid[o]) continue;   // (wave-uniform)
-        filter_score_wave(ffb, cam, fuse_args->feature_distance, o, ffb.obj_model[o], ffb.obj_pose + 7 * (size_t)o,
-                          ffb.obj_pose + 7 * (size_t)o + 4, lane);
-      }
-      __threadfence();
-      __syncthreads();
-    }
+    // them (pose_refine), that of the objects the frame already held by the launch's workgroups at their start
+    // (pose_kept_f1): every one of them is counted in the frame's ticket, or ran in the launch before this one.
     filter_finish(FS, ffb, fuse_args->min_points, fuse_args->min_score, n_slots, n_slots_dev,
                   frame_ptr(fuse_args->n_clusters_dev, a), frame_ptr(counts0, a), ftail);
     __syncthreads();   // (FS and the task's LDS are reused by this workgroup's next frame)
@@ -1641,6 +1662,13 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
     const int n_tasks = fr_tasks[f];
     const int obj_base = fr_obj_base[f];
     bool last = false;
+    // fused FILTER2: the kept objects' F1s, dealt over the workgroups (a split launch: the refine kernel closes the
+    // frames after this kernel has ended; one launch: they count in the frame's ticket like tasks)
+    const int n_kept = (fuse_args && n_tasks > 0) ? (obj_base < max_objects ? obj_base : max_objects) : 0;
+    if (n_kept > 0) {
+      const int took = pose_kept_f1(fuse_args, a, obj_base, max_objects, cam);
+      if (ticket && took > 0 && frame_work_done(ticket, (unsigned)took, (unsigned)(n_tasks + n_kept))) last = true;
+    }
     int first = ((int)blockIdx.x - rank_base) % G;
     if (first < 0) first += G;
     for (int task = first; task < n_tasks; task += G) {
@@ -1648,7 +1676,7 @@ __global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
                       cam_table, img_of0, n_images, prm, seed, obj_base, max_objects, obj_model0, obj_pose0, obj_ninl0,
                       obj_err0, obj_cluster0, obj_valid0, counts0, hyp0, SPLIT ? nullptr : fuse_args);
       __syncthreads();  // LDS is reused by the next task
-      if (ticket && frame_work_done(ticket, 1u, (unsigned)n_tasks)) last = true;
+      if (ticket && frame_work_done(ticket, 1u, (unsigned)(n_tasks + n_kept))) last = true;
     }
     rank_base = (rank_base + n_tasks) % G;
     if (ticket && n_tasks == 0) last = (int)blockIdx.x == f % G;   // nobody has a task here: one workgroup still closes the frame
