@@ -2130,6 +2130,10 @@ int mh_step_match_fetch(mh_ctx* ctx, int32_t* model_off_host, int32_t* match_que
     std::memcpy(match_query, mq, (size_t)give * 4);
     std::memcpy(match_pts, mc, (size_t)give * sizeof(mh_corr));
   }
+  if (M > cap) {   // (the first `cap` are written, the resident frame stays valid: a larger buffer can fetch again)
+    ctx->err = "mh_step_match_fetch: more matches than the caller's buffers hold (cap >= Q always suffices)";
+    return MH_ERR_CAPACITY;
+  }
   return MH_OK;
 }
 

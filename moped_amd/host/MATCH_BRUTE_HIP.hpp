@@ -163,6 +163,7 @@ class MATCH_BRUTE_HIP : public MopedAlg {
   void setConfig(map<string, string>&) {}  // a no-op in the reference as well
 
   void process(FrameData& frameData) {
+    HipHandover::get().drop();   // MATCH begins a frame: whatever is resident belongs to an earlier one
     if (configUpdated) Update();
     if (skipCalculation) return;
     vector<FrameData::DetectedFeature>& corresp = frameData.detectedFeatures[DescriptorType];
@@ -171,7 +172,6 @@ class MATCH_BRUTE_HIP : public MopedAlg {
     matches.resize(models->size());
     const int Q = (int)corresp.size();
     mh_ctx* ctx = HipSession::get();
-    HipHandover::get().drop();   // (whatever is resident belongs to an earlier frame)
     if (processResident(frameData, corresp, ctx)) return;
     // the upload path: norm() + the search in one call, the nearest rows back, the lists built here
     float* buf = pinFor(ctx, Q) ? pinDesc : (packed.resize((size_t)Q * MH_DESC_DIM), &packed[0]);

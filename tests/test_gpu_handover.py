@@ -105,3 +105,25 @@ def test_a_call_out_of_order_or_after_another_use_of_the_frame_arrays_is_refused
     # ... and the next stepped frame is fine again
     r = _stepped(c, fr, prm, 9)
     assert len(r["f2"][2]) >= 2
+
+
+def test_match_fetch_into_buffers_that_are_too_small_says_so_and_can_be_repeated(world):
+    import ctypes as C
+    db, c = world
+    fr = synth.make_frame(db, n_vis=2, seed=6)
+    desc = fr.desc.copy()
+    cam = capi.make_cam(K, CAM0)
+    uv = np.ascontiguousarray(fr.uv, np.float32)
+    assert c.L.mh_step_match(c.h, desc.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p), len(desc), C.byref(cam),
+                             C.c_float(0.8), 0) == 0
+    off = np.zeros(db.n_models + 1, np.int32)
+    mq, pts, n = np.zeros(4, np.int32), np.zeros(4, capi.CORR_DTYPE), C.c_int32(0)
+    rc = c.L.mh_step_match_fetch(c.h, off.ctypes.data_as(C.c_void_p), mq.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), 4,
+                                 C.byref(n))
+    assert rc == -3 and n.value > 4 and b"cap >= Q" in c.L.mh_last_error(c.h)      # MH_ERR_CAPACITY, the count is reported
+    mq2, pts2 = np.zeros(n.value, np.int32), np.zeros(n.value, capi.CORR_DTYPE)
+    rc = c.L.mh_step_match_fetch(c.h, off.ctypes.data_as(C.c_void_p), mq2.ctypes.data_as(C.c_void_p), pts2.ctypes.data_as(C.c_void_p),
+                                 n.value, C.byref(n))
+    assert rc == 0 and np.array_equal(mq2[:4], mq) and off[-1] == n.value
+    cm, co, mem = c.step_cluster()                                                    # the resident frame went on being valid
+    assert len(cm) >= 2
