@@ -55,6 +55,10 @@ constexpr int POSE_THREADS = MH_POSE_THREADS;
 #ifndef MH_POSE_MIN_WAVES
 #define MH_POSE_MIN_WAVES 2
 #endif
+// ... and of the hypothesis-only instantiation of a split launch (no LM code: 176 registers since round 5)
+#ifndef MH_POSE_SPLIT_WAVES
+#define MH_POSE_SPLIT_WAVES 2
+#endif
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
@@ -1623,7 +1627,7 @@ __device__ void pose_close_frame(const int f, const unsigned long long a, const 
 }
 
 template <int KIND, bool SPLIT>
-__global__ __launch_bounds__(POSE_THREADS, MH_POSE_MIN_WAVES) void pose_kernel(
+__global__ __launch_bounds__(POSE_THREADS, SPLIT ? MH_POSE_SPLIT_WAVES : MH_POSE_MIN_WAVES) void pose_kernel(
     const mh_corr* __restrict__ corr0, const float4* __restrict__ depth0, float alpha,
     const int32_t* __restrict__ members0,
     const int32_t* __restrict__ cl_model0, const int32_t* __restrict__ cl_begin0,
