@@ -1594,8 +1594,7 @@ int mh_frame_enqueue_image_batch(mh_ctx* ctx, const uint8_t* const* gray_dev, in
   // (round 4: ONE launch per FEAT stage for all B images -- a frame's 26 dependent launches were what bounded this path)
   if ((rc = sift_into_batch(ctx, gray_dev, B, width, height, double_size, Q, ctx->q_desc, ctx->q_uv, ctx->img_counts)))
     return rc;
-  for (int f = 0; f < B; ++f)
-    launch_normalize(ctx->q_desc + (size_t)f * Q * DIM, ctx->q_norm + (size_t)f * Q, Q, s, ctx->img_counts + f);
+  launch_normalize_batch(ctx->q_desc, ctx->q_norm, Q, B, s, ctx->img_counts);   // (one launch: blockIdx.y = image)
   MH_HIP(ctx, hipGetLastError());
   ctx->feat_count_dev = nullptr;
   stamp(ctx, 0);

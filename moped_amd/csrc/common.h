@@ -152,6 +152,7 @@ __device__ __forceinline__ int32_t row_to_local(const RowMap& m, int32_t gi, int
 // A1: normalise rows in place + norm term of the normalised rows.
 // n_dev (optional): device-side row count, rows [min(n, *n_dev), n) are left alone.
 void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s, const int32_t* n_dev = nullptr);
+void launch_normalize_batch(float* desc, float* norm_out, int n, int B, hipStream_t s, const int32_t* n_dev);
 // dot(d,d) chain for every DB row.
 void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s);
 // Scratch (in Top2 units) the match kernel needs for Q queries.

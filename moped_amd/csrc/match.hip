@@ -59,6 +59,11 @@ __global__ __launch_bounds__(NORM_THREADS) void normalize_kernel(float* __restri
   __shared__ float tile[NORM_ROWS * NORM_STRIDE];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * NORM_ROWS;
+  if (blockIdx.y) {   // image of a batch: its n rows, its count word
+    desc += (size_t)blockIdx.y * n * DIM;
+    norm_out += (size_t)blockIdx.y * n;
+    n_dev += blockIdx.y;
+  }
   if (n_dev) n = min(n, *n_dev);   // row count known only on the device (features extracted there)
   const int rows = min(NORM_ROWS, n - (int)row0);
   if (rows <= 0) return;
@@ -435,6 +440,13 @@ void launch_normalize(float* desc, float* norm_out, int n, hipStream_t s, const 
   if (n <= 0) return;
   const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
   hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks), dim3(NORM_THREADS), 0, s, desc, norm_out, n, n_dev);
+}
+
+// B images' rows in one launch: image f's descriptors n rows behind image f - 1's, its count in n_dev[f]
+void launch_normalize_batch(float* desc, float* norm_out, int n, int B, hipStream_t s, const int32_t* n_dev) {
+  if (n <= 0 || B <= 0) return;
+  const int blocks = (n + NORM_ROWS - 1) / NORM_ROWS;
+  hipLaunchKernelGGL(normalize_kernel<true>, dim3(blocks, B), dim3(NORM_THREADS), 0, s, desc, norm_out, n, n_dev);
 }
 
 void launch_row_norms(const float* desc, float* norm_out, int n, hipStream_t s) {

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "sift.h"
+#include "sift_rows.h"
 
 namespace mh {
 
@@ -41,7 +42,10 @@ __device__ __forceinline__ float to_unit(uint8_t g) { return (float)((double)(fl
 
 // blockIdx.z = image of a batch (SiftImages: its pixels; its output `out_step` floats behind the image's before it)
 __global__ void prepare_kernel(const uint8_t* __restrict__ gray, int w, int h, int double_size,
-                               float* __restrict__ out, int orows, int ocols, SiftImages imgs, size_t out_step) {
+                               float* __restrict__ out, int orows, int ocols, SiftImages imgs, size_t out_step,
+                               int32_t* __restrict__ counters) {
+  // the image's counters (candidates, keys, overflow, -) start at zero: the first kernel of the chain clears them
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) counters[4 * blockIdx.z + threadIdx.x] = 0;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   if (c >= ocols || r >= orows) return;
@@ -198,20 +202,43 @@ __device__ __forceinline__ void blur_tile_fixed(const BlurJob& job, const float*
   static_assert((IN_H & 1) == 0 && IN_H * IN_WP <= (BT_Y + 2 * BT_MAXW) * (BT_X + 2 * BT_MAXW), "tile buffer");
   const int rows = job.rows, cols = job.cols;
   const int step = job.half ? 2 : 1;
-  // staging: 16 x 16 threads over rows x columns (replicated edges; a `half` job reads every second row and column
-  // of the previous octave and writes its own pixels out as level 0)
-  for (int yy = tid >> 4; yy < IN_H; yy += 16) {
-    const int yu = r0 - W + yy;
-    const int y = yu < 0 ? 0 : (yu >= rows ? rows - 1 : yu);
-    const float* srow = job.src + (size_t)(step * y) * job.src_cols;
-    float* drow = in_s + (yy >> 1) * (2 * IN_WP) + (yy & 1);
-    for (int xx = tid & 15; xx < IN_W; xx += 16) {
-      const int xu = c0 - W + xx;
-      const int x = xu < 0 ? 0 : (xu >= cols ? cols - 1 : xu);
-      const float v = srow[step * x];
-      drow[2 * xx] = v;
-      if (job.half && yu == y && xu == x && yy >= W && yy < W + BT_Y && xx >= W && xx < W + BT_X)
-        job.half_dst[(size_t)y * cols + x] = v;
+  // staging: 8 x 32 threads over rows x columns (replicated edges; a `half` job reads every second row and column
+  // of the previous octave and writes its own pixels out as level 0).  ALL of a thread's pixels are requested before
+  // the first one is used: written as one loop (load, store to LDS, next) every pixel was a round trip to L2 of its
+  // own -- up to 24 in a row, most of a level's 12 us.
+  {
+    constexpr int NY = (IN_H + 7) / 8, NX = (IN_W + 31) / 32;
+    float v[NY][NX];
+#pragma unroll
+    for (int iy = 0; iy < NY; ++iy) {
+      const int yy = (tid >> 5) + 8 * iy;
+      const int yu = r0 - W + yy;
+      const int y = yu < 0 ? 0 : (yu >= rows ? rows - 1 : yu);
+      const float* srow = job.src + (size_t)(step * y) * job.src_cols;
+#pragma unroll
+      for (int ix = 0; ix < NX; ++ix) {
+        const int xx = (tid & 31) + 32 * ix;
+        const int xu = c0 - W + xx;
+        const int x = xu < 0 ? 0 : (xu >= cols ? cols - 1 : xu);
+        v[iy][ix] = (yy < IN_H && xx < IN_W) ? srow[step * x] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int iy = 0; iy < NY; ++iy) {
+      const int yy = (tid >> 5) + 8 * iy;
+      const int yu = r0 - W + yy;
+      const int y = yu < 0 ? 0 : (yu >= rows ? rows - 1 : yu);
+      float* drow = in_s + (yy >> 1) * (2 * IN_WP) + (yy & 1);
+#pragma unroll
+      for (int ix = 0; ix < NX; ++ix) {
+        const int xx = (tid & 31) + 32 * ix;
+        if (yy >= IN_H || xx >= IN_W) continue;
+        const int xu = c0 - W + xx;
+        const int x = xu < 0 ? 0 : (xu >= cols ? cols - 1 : xu);
+        drow[2 * xx] = v[iy][ix];
+        if (job.half && yu == y && xu == x && yy >= W && yy < W + BT_Y && xx >= W && xx < W + BT_X)
+          job.half_dst[(size_t)y * cols + x] = v[iy][ix];
+      }
     }
   }
   __syncthreads();
@@ -366,13 +393,67 @@ struct Taps5 {
 // image, above / below the row-blurred one), so the tap loops read straight through without clamping an index per
 // tap; the others run the clamped loops.
 constexpr int SO_PAD = 12, SO_CAP = 6912;
+__device__ __forceinline__ void so_put_padded(float* cur, int cs, int cols, int r, int c, float v) {
+  float* row = cur + r * cs;
+  row[SO_PAD + c] = v;
+  if (c == 0)
+    for (int h = 0; h < SO_PAD; ++h) row[h] = v;
+  if (c == cols - 1)
+    for (int h = 0; h < SO_PAD; ++h) row[SO_PAD + cols + h] = v;
+}
+// One level of a padded octave with the tap count known at compile time: the taps sit in registers and the tap loops are
+// unrolled, N independent LDS reads in flight in front of the chain of products and sums (ascending taps, like
+// ConvHorizontal / ConvVertical).  The loop over a run-time tap count below did one scalar load of the tap from the
+// kernel's arguments and one LDS read per tap, each waited for: 88 us per image for ~800 taps per thread.
+template <int N>
+__device__ __forceinline__ void so_level_padded(float* cur, float* tmp, const float* __restrict__ tk, int rows, int cols,
+                                                float* __restrict__ dst, float* __restrict__ dog, int tid) {
+  constexpr int W = N / 2;
+  const int px = rows * cols, cs = cols + 2 * SO_PAD;
+  float k[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) k[j] = tk[j];
+  for (int e = tid; e < px; e += 1024) {
+    const int r = e / cols, c = e - r * cols;
+    const float* row = cur + r * cs + SO_PAD + c - W;
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = row[j];
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) a = __fadd_rn(a, __fmul_rn(v[j], k[j]));
+    tmp[(r + SO_PAD) * cols + c] = a;
+    if (r == 0)
+      for (int h = 0; h < SO_PAD; ++h) tmp[h * cols + c] = a;
+    if (r == rows - 1)
+      for (int h = 0; h < SO_PAD; ++h) tmp[(rows + SO_PAD + h) * cols + c] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < px; e += 1024) {
+    const int r = e / cols, c = e - r * cols;
+    const float* col = tmp + (r + SO_PAD - W) * cols + c;
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = col[j * cols];
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) a = __fadd_rn(a, __fmul_rn(v[j], k[j]));
+    const float old = cur[r * cs + SO_PAD + c];
+    dst[e] = a;
+    dog[e] = __fsub_rn(old, a);
+    so_put_padded(cur, cs, cols, r, c, a);   // source of the next level (nobody reads cur in this phase but the owner of a pixel)
+  }
+  __syncthreads();
+}
 __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int o_first, Taps5 T, size_t pyr_step) {
   const size_t off = blockIdx.x * pyr_step;   // one workgroup per image of a batch
   __shared__ float cur[SO_CAP];   // image i - 1 of the octave: [px], or [rows][cols + 2 SO_PAD]
   __shared__ float tmp[SO_CAP];   // its row-blurred version:   [px], or [rows + 2 SO_PAD][cols]
+  __shared__ float taps_s[kScales + 2][MAX_TAPS];
   const int tid = threadIdx.x;
   int wmax = 0;
   for (int i = 0; i < kScales + 2; ++i) wmax = max(wmax, T.t[i].n >> 1);
+  if (tid < (kScales + 2) * MAX_TAPS) taps_s[tid / MAX_TAPS][tid % MAX_TAPS] = T.t[tid / MAX_TAPS].k[tid % MAX_TAPS];
   for (int o = o_first; o < P.n_octaves; ++o) {
     const SiftOctave& O = P.oct[o];
     const int rows = O.rows, cols = O.cols, px = rows * cols;
@@ -384,12 +465,7 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
         cur[r * cols + c] = v;
         return;
       }
-      float* row = cur + r * cs;
-      row[SO_PAD + c] = v;
-      if (c == 0)
-        for (int h = 0; h < SO_PAD; ++h) row[h] = v;
-      if (c == cols - 1)
-        for (int h = 0; h < SO_PAD; ++h) row[SO_PAD + cols + h] = v;
+      so_put_padded(cur, cs, cols, r, c, v);
     };
     const float* src0 = O.gaus[0] + off;
     if (o > o_first) {   // HalfImageSize (:390-408) of the previous octave's image `kScales`
@@ -410,14 +486,29 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
     }
     __syncthreads();
     for (int i = 1; i < kScales + 3; ++i) {
-      const Taps& t = T.t[i - 1];
-      const int w = t.n >> 1;
+      const int tn = T.t[i - 1].n;
+      const float* tk = taps_s[i - 1];
+      const int w = tn >> 1;
+      float* dst = O.gaus[i] + off;
+      float* dog = O.dog[i - 1] + off;
+      if (padded) {   // the tap counts of the shipped constants
+        bool done = true;
+        switch (tn) {
+          case 11: so_level_padded<11>(cur, tmp, tk, rows, cols, dst, dog, tid); break;
+          case 13: so_level_padded<13>(cur, tmp, tk, rows, cols, dst, dog, tid); break;
+          case 17: so_level_padded<17>(cur, tmp, tk, rows, cols, dst, dog, tid); break;
+          case 21: so_level_padded<21>(cur, tmp, tk, rows, cols, dst, dog, tid); break;
+          case 25: so_level_padded<25>(cur, tmp, tk, rows, cols, dst, dog, tid); break;
+          default: done = false; break;
+        }
+        if (done) continue;
+      }
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
         float a = 0.f;
         if (padded) {
           const float* row = cur + r * cs + SO_PAD + c - w;
-          for (int j = 0; j < t.n; ++j) a = __fadd_rn(a, __fmul_rn(row[j], t.k[j]));
+          for (int j = 0; j < tn; ++j) a = __fadd_rn(a, __fmul_rn(row[j], tk[j]));
           tmp[(r + SO_PAD) * cols + c] = a;
           if (r == 0)
             for (int h = 0; h < SO_PAD; ++h) tmp[h * cols + c] = a;
@@ -425,28 +516,26 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
             for (int h = 0; h < SO_PAD; ++h) tmp[(rows + SO_PAD + h) * cols + c] = a;
         } else {
           const float* row = cur + r * cols;
-          for (int j = 0; j < t.n; ++j) {
+          for (int j = 0; j < tn; ++j) {
             int x = c + j - w;
             x = x < 0 ? 0 : (x >= cols ? cols - 1 : x);
-            a = __fadd_rn(a, __fmul_rn(row[x], t.k[j]));
+            a = __fadd_rn(a, __fmul_rn(row[x], tk[j]));
           }
           tmp[e] = a;
         }
       }
       __syncthreads();
-      float* dst = O.gaus[i] + off;
-      float* dog = O.dog[i - 1] + off;
       for (int e = tid; e < px; e += 1024) {
         const int r = e / cols, c = e - r * cols;
         float a = 0.f;
         if (padded) {
           const float* col = tmp + (r + SO_PAD - w) * cols + c;
-          for (int j = 0; j < t.n; ++j) a = __fadd_rn(a, __fmul_rn(col[j * cols], t.k[j]));
+          for (int j = 0; j < tn; ++j) a = __fadd_rn(a, __fmul_rn(col[j * cols], tk[j]));
         } else {
-          for (int j = 0; j < t.n; ++j) {
+          for (int j = 0; j < tn; ++j) {
             int y = r + j - w;
             y = y < 0 ? 0 : (y >= rows ? rows - 1 : y);
-            a = __fadd_rn(a, __fmul_rn(tmp[y * cols + c], t.k[j]));
+            a = __fadd_rn(a, __fmul_rn(tmp[y * cols + c], tk[j]));
           }
         }
         const float old = padded ? cur[r * cs + SO_PAD + c] : cur[e];
@@ -471,7 +560,7 @@ struct SiftGrid {
 __device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index, int& bx, int& by) {
   const int b = blockIdx.x;
   int z = 0;
-  while (z + 1 < G.n && b >= G.begin[z + 1]) ++z;
+  while (z + 1 < G.n && b >= G.begin[z + 1]) ++z;   // (most blocks belong to the first slices: one or two steps)
   o = z / kScales;
   index = 1 + z % kScales;
   const int t = b - G.begin[z];
@@ -480,8 +569,8 @@ __device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index,
   return b < G.begin[G.n];
 }
 
-__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G, size_t pyr_step) {
-  const size_t off = blockIdx.y * pyr_step;   // image of a batch
+__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G, SiftBatch Bt) {
+  const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
   int o, index, bx, by;
   if (!sift_tile(G, o, index, bx, by)) return;
   const SiftOctave& O = P.oct[o];
@@ -501,29 +590,10 @@ __global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G, size_t pyr_step) {
   const size_t at = (size_t)i * cols + j;
   (O.grad[index - 1] + off)[at] = sqrtf(__fadd_rn(__fmul_rn(dc, dc), __fmul_rn(dr, dr)));
   (O.ori[index - 1] + off)[at] = atan2f(dr, dc);
+  if (index == 1) (O.owner + blockIdx.y * Bt.own_step)[at] = 0xFFFFFFFFu;   // nobody owns the pixel yet (detect_kernel)
 }
 
 // ---- detection ------------------------------------------------------------------------------
-__device__ __forceinline__ bool local_extremum(float v, const float* d, int cols, int r, int c) {
-  for (int rr = r - 1; rr <= r + 1; ++rr) {
-    const float* p = d + (size_t)rr * cols + c - 1;
-    if (v > 0 ? (p[0] > v || p[1] > v || p[2] > v) : (v > p[0] || v > p[1] || v > p[2])) return false;
-  }
-  return true;
-}
-
-__device__ __forceinline__ bool not_on_edge(const float* d, int cols, int r, int c) {  // :1149-1162
-  const float* p = d + (size_t)r * cols;
-  const float f1 = __fadd_rn(__fsub_rn(p[-cols + c], __fmul_rn(p[c], 2.f)), p[cols + c]);
-  const float f2 = __fadd_rn(__fsub_rn(p[c - 1], __fmul_rn(p[c], 2.f)), p[c + 1]);
-  const float f3 = __fsub_rn(p[cols + c + 1], p[cols + c - 1]);
-  const float f4 = __fsub_rn(p[-cols + c + 1], p[-cols + c - 1]);
-  const float f5 = __fmul_rn(__fsub_rn(f3, f4), 0.25f);
-  const float f6 = __fsub_rn(__fmul_rn(f1, f2), __fmul_rn(f5, f5));
-  const float f8 = __fadd_rn(f1, f2);
-  return __fmul_rn(__fmul_rn(f6, 11.f), 11.f) > __fmul_rn(__fmul_rn(f8, f8), 10.f);
-}
-
 __device__ void solve3(float* Y, float* H) {  // SolveLinearSystem (:1235-1272), dim = 3
   int best = 0;
 #pragma unroll
@@ -584,61 +654,131 @@ __device__ float fit_quadratic(float* X, const float* p0, const float* p1, const
 // FindMaxMin's scan (:925-940) + InterpKeyPoint (:1164-1206).  A surviving extremum claims
 // its FINAL pixel with atomicMin(generation key): the reference's s_MaxMinArray gives that
 // pixel to the first survivor in (scale index, row, column) order.
-__global__ void detect_kernel(SiftPyramid P, SiftGrid G, SiftCandidate* __restrict__ cand, int32_t* __restrict__ n_cand,
-                              int cap, int32_t* __restrict__ overflow, SiftBatch Bt) {
+// A workgroup takes a 64 x 8 tile of an octave through ALL THREE scale indices: the five DoG levels' tiles (with a ring of
+// one pixel) are staged in LDS first -- every pixel requested before the first is used -- and the threshold, the 27-point
+// extremum test and the edge test read LDS.  (One pixel of one index per thread straight from global memory, as until
+// round 5, paid for the extremum test row by row: up to nine dependent trips to L2 per level, 54 - 90 us per image, and
+// read every level's tile three times.)  The few survivors (~3 000 per image) run the quadratic fit from global memory: it
+// walks up to five pixels away.
+constexpr int DT_X = 64, DT_Y = 8, DT_W = DT_X + 2, DT_H = DT_Y + 2, DT_THREADS = 256;
+struct DetectGrid {
+  int begin[SIFT_MAX_OCTAVES + 1];   // first block of octave o
+  int tiles_x[SIFT_MAX_OCTAVES];
+  int n;
+};
+__global__ __launch_bounds__(DT_THREADS) void detect_kernel(SiftPyramid P, DetectGrid G, SiftCandidate* __restrict__ cand,
+                                                            int32_t* __restrict__ n_cand, int cap,
+                                                            int32_t* __restrict__ overflow, SiftBatch Bt) {
   const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch: its pyramid, owner map, candidates, counters
   cand += (size_t)blockIdx.y * Bt.cand_step;
   n_cand += 4 * blockIdx.y;
   overflow += 4 * blockIdx.y;
-  int o, index, bx, by;
-  if (!sift_tile(G, o, index, bx, by)) return;
+  const int b = blockIdx.x;
+  if (b >= G.begin[G.n]) return;
+  int o = 0;
+  while (o + 1 < G.n && b >= G.begin[o + 1]) ++o;
   const SiftOctave& O = P.oct[o];
   const int rows = O.rows, cols = O.cols;
-  const int c = 5 + bx * blockDim.x + threadIdx.x;
-  const int r = 5 + by * blockDim.y + threadIdx.y;
-  if (c >= cols - 5 || r >= rows - 5) return;
-  const float peak_thresh = 0.04f / (float)kScales;
-  const float* d1 = O.dog[index] + off;
-  const float v = d1[(size_t)r * cols + c];
-  if (!(fabsf(v) > __fmul_rn(peak_thresh, 0.8f))) return;
-  const float *d0 = O.dog[index - 1] + off, *d2 = O.dog[index + 1] + off;
-  if (!local_extremum(v, d1, cols, r, c) || !local_extremum(v, d0, cols, r, c) ||
-      !local_extremum(v, d2, cols, r, c) || !not_on_edge(d1, cols, r, c))
-    return;
-  int rr = r, cc = c;
-  float X[3], val;
-  for (int steps = 5;; --steps) {
-    val = fit_quadratic(X, d0, d1, d2, cols, rr, cc);
-    int nr = rr, nc = cc;
-    if (X[1] > 0.6f && rr < rows - 3) nr++;
-    if (X[1] < -0.6f && rr > 3) nr--;
-    if (X[2] > 0.6f && cc < cols - 3) nc++;
-    if (X[2] < -0.6f && cc > 3) nc--;
-    if (steps > 0 && (nr != rr || nc != cc)) {
-      rr = nr;
-      cc = nc;
-      continue;
+  const int t = b - G.begin[o];
+  const int c0 = 5 + (t % G.tiles_x[o]) * DT_X, r0 = 5 + (t / G.tiles_x[o]) * DT_Y;
+  __shared__ float S[kScales + 2][DT_H][DT_W + 1];
+  const int tid = threadIdx.x;
+  {
+    constexpr int PER = ((kScales + 2) * DT_H * DT_W + DT_THREADS - 1) / DT_THREADS;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + i * DT_THREADS;
+      const int l = e / (DT_H * DT_W), rem = e - l * (DT_H * DT_W);
+      const int yy = rem / DT_W, xx = rem - yy * DT_W;
+      // (the ring of a tile that ends at the scanned region's border lies inside the image; beyond it nobody looks)
+      const int y = min(r0 - 1 + yy, rows - 1), x = min(c0 - 1 + xx, cols - 1);
+      v[i] = l < kScales + 2 ? (O.dog[l] + off)[(size_t)y * cols + x] : 0.f;
     }
-    break;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + i * DT_THREADS;
+      const int l = e / (DT_H * DT_W), rem = e - l * (DT_H * DT_W);
+      const int yy = rem / DT_W, xx = rem - yy * DT_W;
+      if (l < kScales + 2) S[l][yy][xx] = v[i];
+    }
   }
-  if (!(fabsf(X[0]) <= 1.5f && fabsf(X[1]) <= 1.5f && fabsf(X[2]) <= 1.5f && fabsf(val) >= peak_thresh)) return;
-  const unsigned key = (unsigned)(index - 1) * (unsigned)(rows * cols) + (unsigned)(r * cols + c);
-  atomicMin(&(O.owner + blockIdx.y * Bt.own_step)[(size_t)rr * cols + cc], key);
-  const int at = atomicAdd(n_cand, 1);
-  if (at >= cap) {
-    *overflow = 1;
-    return;
+  __syncthreads();
+  const float peak_thresh = 0.04f / (float)kScales;
+  const int x = tid & (DT_X - 1);
+  const int c = c0 + x;
+  if (c >= cols - 5) return;
+#pragma unroll
+  for (int index = 1; index <= kScales; ++index) {
+#pragma unroll
+    for (int k = 0; k < DT_Y / (DT_THREADS / DT_X); ++k) {
+      const int y = (tid / DT_X) + k * (DT_THREADS / DT_X);
+      const int r = r0 + y;
+      if (r >= rows - 5) continue;
+      const float v = S[index][y + 1][x + 1];
+      if (!(fabsf(v) > __fmul_rn(peak_thresh, 0.8f))) continue;
+      // local_extremum on the level, the one below and the one above: no neighbour beyond v on v's side
+      float hi = v, lo = v;
+#pragma unroll
+      for (int l = index - 1; l <= index + 1; ++l)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float p = S[l][y + dy][x + dx];
+            hi = fmaxf(hi, p);
+            lo = fminf(lo, p);
+          }
+      if (v > 0 ? hi > v : v > lo) continue;
+      {   // not on an edge (:1149-1162)
+        const float(*p)[DT_W + 1] = S[index];
+        const int yy = y + 1, xx = x + 1;
+        const float f1 = __fadd_rn(__fsub_rn(p[yy - 1][xx], __fmul_rn(p[yy][xx], 2.f)), p[yy + 1][xx]);
+        const float f2 = __fadd_rn(__fsub_rn(p[yy][xx - 1], __fmul_rn(p[yy][xx], 2.f)), p[yy][xx + 1]);
+        const float f3 = __fsub_rn(p[yy + 1][xx + 1], p[yy + 1][xx - 1]);
+        const float f4 = __fsub_rn(p[yy - 1][xx + 1], p[yy - 1][xx - 1]);
+        const float f5 = __fmul_rn(__fsub_rn(f3, f4), 0.25f);
+        const float f6 = __fsub_rn(__fmul_rn(f1, f2), __fmul_rn(f5, f5));
+        const float f8 = __fadd_rn(f1, f2);
+        if (!(__fmul_rn(__fmul_rn(f6, 11.f), 11.f) > __fmul_rn(__fmul_rn(f8, f8), 10.f))) continue;
+      }
+      const float *d0 = O.dog[index - 1] + off, *d1 = O.dog[index] + off, *d2 = O.dog[index + 1] + off;
+      int rr = r, cc = c;
+      float X[3], val;
+      for (int steps = 5;; --steps) {
+        val = fit_quadratic(X, d0, d1, d2, cols, rr, cc);
+        int nr = rr, nc = cc;
+        if (X[1] > 0.6f && rr < rows - 3) nr++;
+        if (X[1] < -0.6f && rr > 3) nr--;
+        if (X[2] > 0.6f && cc < cols - 3) nc++;
+        if (X[2] < -0.6f && cc > 3) nc--;
+        if (steps > 0 && (nr != rr || nc != cc)) {
+          rr = nr;
+          cc = nc;
+          continue;
+        }
+        break;
+      }
+      if (!(fabsf(X[0]) <= 1.5f && fabsf(X[1]) <= 1.5f && fabsf(X[2]) <= 1.5f && fabsf(val) >= peak_thresh)) continue;
+      const unsigned key = (unsigned)(index - 1) * (unsigned)(rows * cols) + (unsigned)(r * cols + c);
+      atomicMin(&(O.owner + blockIdx.y * Bt.own_step)[(size_t)rr * cols + cc], key);
+      const int at = atomicAdd(n_cand, 1);
+      if (at >= cap) {
+        *overflow = 1;
+        continue;
+      }
+      SiftCandidate q;
+      q.octave = o;
+      q.index = index;
+      q.key = key;
+      q.r = rr;
+      q.c = cc;
+      q.x0 = X[0];
+      q.x1 = X[1];
+      q.x2 = X[2];
+      cand[at] = q;
+    }
   }
-  SiftCandidate k;
-  k.octave = o;
-  k.index = index;
-  k.key = key;
-  k.r = rr;
-  k.c = cc;
-  k.x0 = X[0];
-  k.x1 = X[1];
-  k.x2 = X[2];
-  cand[at] = k;
 }
 
 // ---- orientation (AssignOriHist, :1274-1382) ---------------------------------------------------
@@ -749,7 +889,7 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
       const unsigned long long pm = __ballot(is_peak);
       if (pm != 0ull) {
         int at0 = 0;
-        if (lane == 0) at0 = atomicAdd(n_keys, __popcll(pm));   // slots in any order: order_kernel sorts by q.order
+        if (lane == 0) at0 = atomicAdd(n_keys, __popcll(pm));   // slots in any order: rank_kernel places by q.order
         at0 = __builtin_amdgcn_readfirstlane(at0);
         if (is_peak) {
           const int at = at0 + __popcll(pm & ((1ull << lane) - 1ull));
@@ -780,43 +920,129 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
   }
 }
 
+// ---- order: the reference's list = generation order reversed (every key is pushed on the
+// front of a linked list, :1432, :944-952) -------------------------------------------------------
+// A key's place in the list = the number of keys generated after it.  64 keys per workgroup of 16 wavefronts, the other
+// keys' generation words staged through LDS and every wavefront comparing a sixteenth of them with its lane's key (all
+// lanes read the same words: a broadcast).  (Until round 5 one workgroup per key walked all keys in global memory and
+// then copied the key's descriptor to its place: 49 us at 3 240 keys; now describe_kernel writes each descriptor where
+// it belongs.)
+constexpr int RK_KEYS = 64, RK_SEGS = 16, RK_TILE = 4096;
+__global__ __launch_bounds__(RK_KEYS* RK_SEGS) void rank_kernel(const SiftKey* __restrict__ keys,
+                                                                const int32_t* __restrict__ n_keys, int key_cap, int out_cap,
+                                                                int32_t* __restrict__ rank, int32_t* __restrict__ n_out,
+                                                                SiftBatch Bt) {
+  keys += (size_t)blockIdx.y * Bt.key_step;   // image of a batch
+  n_keys += 4 * blockIdx.y;
+  rank += (size_t)blockIdx.y * Bt.key_step;
+  n_out += (size_t)blockIdx.y * Bt.n_out_step;
+  int n = *n_keys;
+  if (n > key_cap) n = key_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n < out_cap ? n : out_cap;
+  __shared__ __attribute__((aligned(16))) unsigned long long tile[RK_TILE];
+  __shared__ int cnt_s[RK_SEGS][RK_KEYS];
+  const int lane = threadIdx.x & (RK_KEYS - 1), seg = threadIdx.x / RK_KEYS;
+  for (int base = blockIdx.x * RK_KEYS; base < n; base += gridDim.x * RK_KEYS) {
+    const int i = base + lane;
+    const unsigned long long mine = i < n ? keys[i].order : ~0ull;
+    int c = 0;
+    for (int t0 = 0; t0 < n; t0 += RK_TILE) {
+      const int m = min(RK_TILE, n - t0);
+      __syncthreads();
+      for (int j = threadIdx.x; j < RK_TILE; j += RK_KEYS * RK_SEGS) tile[j] = j < m ? keys[t0 + j].order : 0ull;   // (0: greater than nothing)
+      __syncthreads();
+      // wavefront `seg` takes the words 8 seg .. 8 seg + 7 of every 128: eight independent reads per step
+      for (int j = 8 * seg; j < m; j += 8 * RK_SEGS) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(tile + j);
+        const ulonglong2 a = q[0], b = q[1], d = q[2], e = q[3];
+        c += (int)(a.x > mine) + (int)(a.y > mine) + (int)(b.x > mine) + (int)(b.y > mine) + (int)(d.x > mine) +
+             (int)(d.y > mine) + (int)(e.x > mine) + (int)(e.y > mine);   // keys are distinct
+      }
+    }
+    cnt_s[seg][lane] = c;
+    __syncthreads();
+    if (seg == 0 && i < n) {
+      int r = 0;
+#pragma unroll
+      for (int g = 0; g < RK_SEGS; ++g) r += cnt_s[g][lane];
+      rank[i] = r;
+    }
+  }
+}
+
 // ---- descriptor (MakeKeypointSample / KeySample / AddSample / PlaceInIndex, :1424-1668) ---------
-// One 256-thread workgroup per key.  The reference adds a sample's (up to eight) contributions to the descriptor
-// entries it touches one sample after the other in raster order; the 128 entries are independent of each other, so
-// what has to be kept is the ORDER OF THE ADDITIONS PER ENTRY (a chain of only ~S/16 additions), not the walk over all
-// S samples.  The window is taken in chunks of 256 raster-ordered samples:
-//   A. four wavefronts, 64 samples each, one per lane: the sample's weight, bilinear fractions and first row / column
-//      / orientation bin (the arithmetic of KeySample / PlaceInIndex).  A sample feeds entry (cell, bin) when it
-//      touches the cell (rows nr, nr + 1, columns nc, nc + 1) AND the bin is its own or the next one -- two
-//      independent conditions, so 16 cell ballots + 8 bin ballots describe all 128 lists of the wavefront:
-//      list (cell, bin) = lanes in cmask[cell] & bmask[bin], in lane = raster order.  Their sizes (two lists per
-//      lane, a wave prefix sum) give every list its place in the wavefront's value array; every sample then writes
-//      its up to eight products -- the reference's cg (1 - of) / cg of -- at offset + rank;
+// One workgroup of DESC_WAVES wavefronts per key.  The reference adds a sample's (up to eight) contributions to the
+// descriptor entries it touches one sample after the other in raster order; the 128 entries are independent of each
+// other, so what has to be kept is the ORDER OF THE ADDITIONS PER ENTRY (a chain of only ~S/16 additions), not the walk
+// over all S samples:
+//   0. the window's rows: KeySample keeps a sample only inside the rotated 5 x 5-cell square (rx, cx in (-0.9999,
+//      3.9999)) -- half of the window's square.  Lane = row computes a CONSERVATIVE column interval (desc_row_interval:
+//      the two linear conditions solved with a margin of 0.01 and a column on each side, tests/test_sift_rows_cpu.py),
+//      a prefix sum over the rows numbers the samples inside the intervals in raster order, and the workgroup takes
+//      them 64 DESC_WAVES at a time (every lane walks a row cursor of its own); the exact tests still run per sample;
+//   A. every wavefront 64 samples, one per lane: weight, bilinear fractions, first row / column / orientation bin (the
+//      arithmetic of KeySample / PlaceInIndex).  A sample feeds entry (cell, bin) when it touches the cell's row AND its
+//      column AND the bin is its own or the next one -- three independent conditions, so 4 + 4 + 8 ballots describe all
+//      128 lists of the wavefront: list (cell, bin) = lanes in rmask[cell / 4] & xmask[cell % 4] & bmask[bin], in lane
+//      = raster order.  Their sizes (two lists per lane, a wave prefix sum) give every list its place in the wavefront's
+//      value array; every sample writes its up to eight products -- the reference's cg (1 - of) / cg of -- at offset +
+//      rank;
 //   B. thread E < 128 owns entry E = 8 cell + bin and adds its list's values, wavefront after wavefront: the same
 //      products in the same order as the serial code, and nothing else (no entry is visited that is not added).
-// History (per 640x480 frame): every wavefront folding all samples of its key with readlanes, eight wavefronts sharing
-// a key when keys are few 0.28 ms; per-cell lists that four lanes per cell filter by bin 0.14; this 0.0x.
-constexpr int DESC_WAVES = 4;
+// The lists are double-buffered -- step i + 1's A runs beside step i's B, ONE workgroup barrier per step -- and a
+// sample's gradient / orientation values are requested a step before they are used.  The descriptor goes straight to
+// its place in the reference's list order (rank_kernel).
+// History (per 640x480 frame of ~600 keys): every wavefront folding all samples of its key with readlanes 0.28 ms;
+// per-cell lists that four lanes per cell filter by bin 0.14; 256 samples per step out of the window's whole square, 24
+// ballots, two barriers per step 0.1 (197 us at 3 240 keys); one wavefront per key with the interval walk: slower (225
+// us: ~2 us per step of dependent LDS / permute latency and three wavefronts per SIMD to hide it); this: DESIGN.md 7.
+// inclusive prefix sum over the 64 lanes in six DPP additions (rows of 16: shifts by 1, 2, 4, 8; then lane 15 of rows 0 / 2
+// onto rows 1 / 3 and lane 31 onto rows 2, 3) -- __shfl_up goes through the LDS crossbar, ~100 cycles a step
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  int s = x;
+  s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);   // row_shr:1
+  s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);   // row_shr:2
+  s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);   // row_shr:4
+  s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);   // row_shr:8
+  s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+  return s;
+}
+#ifndef MH_DESC_WAVES
+#define MH_DESC_WAVES 4
+#endif
+#ifndef MH_DESC_B
+#define MH_DESC_B 0
+#endif
+#ifndef MH_DESC_MINW
+#define MH_DESC_MINW 1
+#endif
+constexpr int DESC_WAVES = MH_DESC_WAVES, DESC_MAX_SIDE = 128;
 struct DescLds {
-  unsigned long long cmask[DESC_WAVES][16];
-  unsigned long long bmask[DESC_WAVES][8];
-  uint16_t off[DESC_WAVES][130];     // list (cell, bin) of the wavefront = val[off[8 cell + bin] .. off[8 cell + bin + 1])
-  float val[DESC_WAVES][512];
-  float d[128];
+  unsigned long long mask[2][DESC_WAVES][16];   // 0..3 rows of cells, 4..7 columns of cells, 8..15 bins
+  uint16_t off[2][DESC_WAVES][132];             // list (cell, bin) of the wavefront = val[off[8 cell + bin] .. off[8 cell + bin + 1])
+  float val[2][DESC_WAVES][512];
+  int rowbeg[DESC_MAX_SIDE + 1];                // samples in front of window row i
+  short rowlo[DESC_MAX_SIDE];                   // first column (window coordinates) of row i's interval
+  float sq[128];
   float scal;
 };
-__global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
+__global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
                                                       const int32_t* __restrict__ n_keys, int key_cap,
-                                                      float* __restrict__ desc_out /* [key][128] */,
-                                                      float* __restrict__ geo_out /* [key][4] col,row,scale,ori */,
+                                                      const int32_t* __restrict__ rank, int out_cap,
+                                                      float* __restrict__ desc_out /* [place][128] */,
+                                                      float* __restrict__ xy_out /* [place][2] col,row */,
+                                                      float* __restrict__ scale_ori_out /* [place][2] or null */,
                                                       SiftBatch Bt) {
   const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
   keys += (size_t)blockIdx.y * Bt.key_step;
   n_keys += 4 * blockIdx.y;
-  desc_out += (size_t)blockIdx.y * Bt.key_step * 128;
-  geo_out += (size_t)blockIdx.y * Bt.key_step * 4;
+  rank += (size_t)blockIdx.y * Bt.key_step;
+  desc_out += (size_t)blockIdx.y * Bt.out_step * 128;
+  xy_out += (size_t)blockIdx.y * Bt.out_step * 2;
+  if (scale_ori_out) scale_ori_out += (size_t)blockIdx.y * Bt.out_step * 2;
   __shared__ DescLds L;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -839,192 +1065,244 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void describe_kernel(SiftPyramid P
     const int win = (int)__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(frealsize, kSqrt2), 5.0f), 0.5f), 0.5f);
     const float fsr = __fmul_rn(sinang, firealsize), fcr = __fmul_rn(cosang, firealsize);
     const float fdrr = __fmul_rn(-fdrow, firealsize), fdcr = __fmul_rn(-fdcol, firealsize);
-    const int side = 2 * win + 1, total = side * side;
-    float acc = 0.f;
-    for (int chunk = 0; chunk < total; chunk += 64 * DESC_WAVES) {
-      // ---- A ----
-      {
-        const int s = chunk + tid;
-        bool ok = false;
-        float mag = 0.f, rf = 0.f, cf = 0.f, of = 0.f;
-        int nr = 0, nc = 0, nb = 0;
-        if (s < total) {
-          const int row = s / side - win, col = s % side - win;
-          const float fr = (float)row, fc = (float)col;
-          const float rpos = __fadd_rn(__fadd_rn(__fmul_rn(fsr, fc), __fmul_rn(fcr, fr)), fdrr);
-          const float cpos = __fadd_rn(__fsub_rn(__fmul_rn(fcr, fc), __fmul_rn(fsr, fr)), fdcr);
-          const float rx = __fadd_rn(rpos, 2.0f - 0.5f), cx = __fadd_rn(cpos, 2.0f - 0.5f);
-          const int r = rowstart + row, c = colstart + col;
-          if (rx > -0.9999f && rx < 3.9999f && cx > -0.9999f && cx < 3.9999f && r >= 0 && r < rows && c >= 0 &&
-              c < cols) {
-            ok = true;
-            const float e = expf(__fmul_rn(-0.125f, __fadd_rn(__fmul_rn(rpos, rpos), __fmul_rn(cpos, cpos))));
-            mag = __fmul_rn(grad[(size_t)r * cols + c], e);
-            float o = __fsub_rn(orim[(size_t)r * cols + c], ang);
-            while (o > 2 * kPi) o = __fsub_rn(o, 2 * kPi);
-            while (o < 0) o = __fadd_rn(o, 2 * kPi);
-            const float oribin = __fmul_rn(o, 8.0f / (2 * (float)kPi));   // PlaceInIndex
-            nr = rx < 0 ? (int)__fsub_rn(rx, 1.f) : (int)rx;
-            rf = __fsub_rn(rx, (float)nr);
-            nc = cx < 0 ? (int)__fsub_rn(cx, 1.f) : (int)cx;
-            cf = __fsub_rn(cx, (float)nc);
-            const int no = oribin < 0 ? (int)__fsub_rn(oribin, 1.f) : (int)oribin;
-            of = __fsub_rn(oribin, (float)no);
-            nb = no & 7;   // the bins wrap: orientation 2 pi falls into bin 8 = bin 0
+    const int side = 2 * win + 1;
+    // ---- 0: the rows' intervals (a window of more than DESC_MAX_SIDE rows -- none with the shipped constants: side <= 97
+    // -- is walked whole, a sample's row and column by division)
+    const bool compact = side <= DESC_MAX_SIDE;
+    int total = side * side;
+    if (compact) {
+      if (wave == 0) {
+        int sum = 0;
+        for (int base = 0; base < side; base += 64) {
+          const int rr = base + lane;
+          int lo = 0, len = 0;
+          if (rr < side) {
+            int hi;
+            desc_row_interval(fsr, fcr, fdrr, fdcr, rr - win, win, rowstart, colstart, rows, cols, lo, hi);
+            len = hi - lo + 1;
           }
+          const int incl = wave_incl_scan(len);
+          if (rr < side) {
+            L.rowbeg[rr] = sum + incl - len;
+            L.rowlo[rr] = (short)lo;
+          }
+          sum += __builtin_amdgcn_readlane(incl, 63);
         }
-        // the 24 masks of this wavefront: cell c in lane c, bin b in lane 16 + b
+        if (lane == 0) L.rowbeg[side] = sum;
+      }
+      __syncthreads();
+      total = L.rowbeg[side];
+    }
+    int rho = 0;   // the lane's row cursor
+    // sample t of the walk: its window row / column, and its two values when its pixel exists
+    struct Sample {
+      bool have;
+      int row, col;
+      float g, o;
+    };
+    auto fetch = [&](int t) -> Sample {
+      Sample q{false, 0, 0, 0.f, 0.f};
+      if (t >= total) return q;
+      if (compact) {
+        while (t >= L.rowbeg[rho + 1]) ++rho;
+        q.row = rho - win;
+        q.col = (int)L.rowlo[rho] + (t - L.rowbeg[rho]);
+      } else {
+        q.row = t / side - win;
+        q.col = t % side - win;
+      }
+      const int r = rowstart + q.row, c = colstart + q.col;
+      if (r >= 0 && r < rows && c >= 0 && c < cols) {
+        q.have = true;
+        q.g = grad[(size_t)r * cols + c];
+        q.o = orim[(size_t)r * cols + c];
+      }
+      return q;
+    };
+    // ---- A: the wavefront's 64 samples into its lists of buffer `buf`
+    auto phase_a = [&](const Sample& q, int buf) {
+      unsigned long long* const mask = L.mask[buf][wave];
+      uint16_t* const offs = L.off[buf][wave];
+      float* const val = L.val[buf][wave];
+      bool ok = false;
+      float mag = 0.f, rf = 0.f, cf = 0.f, of = 0.f;
+      int nr = 0, nc = 0, nb = 0;
+      if (q.have) {
+        const float fr = (float)q.row, fc = (float)q.col;
+        const float rpos = __fadd_rn(__fadd_rn(__fmul_rn(fsr, fc), __fmul_rn(fcr, fr)), fdrr);
+        const float cpos = __fadd_rn(__fsub_rn(__fmul_rn(fcr, fc), __fmul_rn(fsr, fr)), fdcr);
+        const float rx = __fadd_rn(rpos, 2.0f - 0.5f), cx = __fadd_rn(cpos, 2.0f - 0.5f);
+        if (rx > -0.9999f && rx < 3.9999f && cx > -0.9999f && cx < 3.9999f) {
+          ok = true;
+          const float e = expf(__fmul_rn(-0.125f, __fadd_rn(__fmul_rn(rpos, rpos), __fmul_rn(cpos, cpos))));
+          mag = __fmul_rn(q.g, e);
+          float oo = __fsub_rn(q.o, ang);
+          while (oo > 2 * kPi) oo = __fsub_rn(oo, 2 * kPi);
+          while (oo < 0) oo = __fadd_rn(oo, 2 * kPi);
+          const float oribin = __fmul_rn(oo, 8.0f / (2 * (float)kPi));   // PlaceInIndex
+          nr = rx < 0 ? (int)__fsub_rn(rx, 1.f) : (int)rx;
+          rf = __fsub_rn(rx, (float)nr);
+          nc = cx < 0 ? (int)__fsub_rn(cx, 1.f) : (int)cx;
+          cf = __fsub_rn(cx, (float)nc);
+          const int no = oribin < 0 ? (int)__fsub_rn(oribin, 1.f) : (int)oribin;
+          of = __fsub_rn(oribin, (float)no);
+          nb = no & 7;   // the bins wrap: orientation 2 pi falls into bin 8 = bin 0
+        }
+      }
+      // the 16 masks: rows of cells in lanes 0..3, columns in 4..7, bins in 8..15
+      {
+        const int nrk = ok ? nr : -100, nck = ok ? nc : -100;
         unsigned long long keep = 0ull;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const int r_ = c >> 2, c_ = c & 3;
-          const unsigned long long m = __ballot(ok && (nr == r_ - 1 || nr == r_) && (nc == c_ - 1 || nc == c_));
-          if (lane == c) keep = m;
+        for (int i = 0; i < 4; ++i) {
+          const unsigned long long m = __ballot((unsigned)(i - nrk) < 2u);   // nr == i - 1 or nr == i
+          if (lane == i) keep = m;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned long long m = __ballot((unsigned)(i - nck) < 2u);
+          if (lane == 4 + i) keep = m;
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-          const unsigned long long m = __ballot(ok && (nb == b || ((nb + 1) & 7) == b));
-          if (lane == 16 + b) keep = m;
+          const unsigned long long m = __ballot(ok && (unsigned)((b - nb) & 7) < 2u);   // nb == b or nb + 1 == b (mod 8)
+          if (lane == 8 + b) keep = m;
         }
-        if (lane < 16) L.cmask[wave][lane] = keep;
-        else if (lane < 24) L.bmask[wave][lane - 16] = keep;
-        wave_sync();
-        // sizes of lists 2 lane, 2 lane + 1 (cell lane / 4, bins 2 (lane % 4), + 1) and their places
-        {
-          const unsigned long long cm = L.cmask[wave][lane >> 2];
-          const int c0 = __popcll(cm & L.bmask[wave][2 * (lane & 3)]);
-          const int c1 = __popcll(cm & L.bmask[wave][2 * (lane & 3) + 1]);
-          int incl = c0 + c1;
+        if (lane < 16) mask[lane] = keep;
+      }
+      wave_sync();
+      // sizes of lists 2 lane, 2 lane + 1 (cell lane / 4, bins 2 (lane % 4), + 1) and their places
+      {
+        const int cell = lane >> 2;
+        const unsigned long long cm = mask[cell >> 2] & mask[4 + (cell & 3)];
+        const int c0 = __popcll(cm & mask[8 + 2 * (lane & 3)]);
+        const int c1 = __popcll(cm & mask[9 + 2 * (lane & 3)]);
+        const int incl = wave_incl_scan(c0 + c1);
+        const int excl = incl - (c0 + c1);
+        offs[2 * lane] = (uint16_t)excl;
+        offs[2 * lane + 1] = (uint16_t)(excl + c0);
+        if (lane == 63) offs[128] = (uint16_t)incl;
+      }
+      wave_sync();
+      if (ok) {
+        const float rg0 = __fmul_rn(mag, __fsub_rn(1.f, rf)), rg1 = __fmul_rn(mag, rf);   // rows nr, nr + 1
+        const float cfm = __fsub_rn(1.f, cf), ofm = __fsub_rn(1.f, of);
+        const int b1 = (nb + 1) & 7;
+        const unsigned long long bm0 = mask[8 + nb] & lt, bm1 = mask[8 + b1] & lt;
 #pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-          }
-          const int excl = incl - (c0 + c1);
-          L.off[wave][2 * lane] = (uint16_t)excl;
-          L.off[wave][2 * lane + 1] = (uint16_t)(excl + c0);
-          if (lane == 63) L.off[wave][128] = (uint16_t)incl;
-        }
-        wave_sync();
-        if (ok) {
-          const float rg0 = __fmul_rn(mag, __fsub_rn(1.f, rf)), rg1 = __fmul_rn(mag, rf);   // rows nr, nr + 1
-          const float cfm = __fsub_rn(1.f, cf), ofm = __fsub_rn(1.f, of);
-          const int b1 = (nb + 1) & 7;
-          const unsigned long long bm0 = L.bmask[wave][nb] & lt, bm1 = L.bmask[wave][b1] & lt;
+        for (int i = 0; i < 2; ++i) {
+          const int r_ = nr + i;
+          if ((unsigned)r_ >= 4u) continue;
+          const unsigned long long rm = mask[r_];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int r_ = nr + i;
-            if ((unsigned)r_ >= 4u) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int c_ = nc + j;
-              if ((unsigned)c_ >= 4u) continue;
-              const int cell = 4 * r_ + c_;
-              const float rg = i == 0 ? rg0 : rg1;
-              const float cg = j == 0 ? __fmul_rn(rg, cfm) : __fmul_rn(rg, cf);
-              const unsigned long long cm = L.cmask[wave][cell];
-              L.val[wave][L.off[wave][8 * cell + nb] + __popcll(cm & bm0)] = __fmul_rn(cg, ofm);
-              L.val[wave][L.off[wave][8 * cell + b1] + __popcll(cm & bm1)] = __fmul_rn(cg, of);
-            }
+          for (int j = 0; j < 2; ++j) {
+            const int c_ = nc + j;
+            if ((unsigned)c_ >= 4u) continue;
+            const int cell = 4 * r_ + c_;
+            const float rg = i == 0 ? rg0 : rg1;
+            const float cg = j == 0 ? __fmul_rn(rg, cfm) : __fmul_rn(rg, cf);
+            const unsigned long long cm = rm & mask[4 + c_];
+            val[offs[8 * cell + nb] + __popcll(cm & bm0)] = __fmul_rn(cg, ofm);
+            val[offs[8 * cell + b1] + __popcll(cm & bm1)] = __fmul_rn(cg, of);
           }
         }
       }
-      __syncthreads();
+    };
+    const int per_step = 64 * DESC_WAVES;
+    const int n_steps = (total + per_step - 1) / per_step;
+    // step i's sample of this lane: t = i per_step + tid (raster order over the wavefronts, then the lanes)
+    Sample cur = fetch(tid), nxt = fetch(per_step + tid);
+    float acc = 0.f;
+    if (n_steps > 0) phase_a(cur, 0);
+    for (int i = 0; i < n_steps; ++i) {
+      __syncthreads();   // step i's lists are written, step i - 1's are read: step i + 1 may overwrite those
+      if (i + 1 < n_steps) {
+        cur = nxt;
+        nxt = fetch((i + 2) * per_step + tid);
+      }
       // ---- B ----
       if (tid < 128) {
+        const int buf = i & 1;
+        int e0[DESC_WAVES], e1[DESC_WAVES];   // every wavefront's list bounds first: one trip to LDS, not one per list
 #pragma unroll
         for (int w = 0; w < DESC_WAVES; ++w) {
-          const int e0 = L.off[w][tid], e1 = L.off[w][tid + 1];
-          const float* v = L.val[w];
-          for (int e = e0; e < e1; e += 4) {
+          e0[w] = L.off[buf][w][tid];
+          e1[w] = L.off[buf][w][tid + 1];
+        }
+#if MH_DESC_B > 0
+        // the first MH_DESC_B values of every list requested before the first addition
+        float x[DESC_WAVES][MH_DESC_B];
+#pragma unroll
+        for (int w = 0; w < DESC_WAVES; ++w)
+#pragma unroll
+          for (int j = 0; j < MH_DESC_B; ++j) x[w][j] = L.val[buf][w][min(e0[w] + j, 511)];
+#pragma unroll
+        for (int w = 0; w < DESC_WAVES; ++w) {
+#pragma unroll
+          for (int j = 0; j < MH_DESC_B; ++j)
+            if (e0[w] + j < e1[w]) acc = __fadd_rn(acc, x[w][j]);
+          for (int e = e0[w] + MH_DESC_B; e < e1[w]; ++e) acc = __fadd_rn(acc, L.val[buf][w][e]);
+        }
+#else
+#pragma unroll
+        for (int w = 0; w < DESC_WAVES; ++w) {
+          const float* v = L.val[buf][w];
+          for (int e = e0[w]; e < e1[w]; e += 4) {
             // four at a time: the loads do not depend on the running sum (reads past the list's end stay inside val)
             float x[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = v[min(e + j, 511)];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (e + j < e1) acc = __fadd_rn(acc, x[j]);
+              if (e + j < e1[w]) acc = __fadd_rn(acc, x[j]);
           }
         }
+#endif
       }
-      __syncthreads();   // the lists are rewritten by the next chunk
+      if (i + 1 < n_steps) phase_a(cur, (i + 1) & 1);
     }
-    if (tid < 128) L.d[tid] = acc;
-    __syncthreads();
-    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527)
+    // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527); the squares are summed in the
+    // entries' order by one thread
+    float d = acc;
     for (int pass = 0; pass < 2; ++pass) {
+      if (tid < 128) L.sq[tid] = __fmul_rn(d, d);
+      __syncthreads();
       if (tid == 0) {
         float a = 0.f;
-        for (int i = 0; i < 128; ++i) a = __fadd_rn(a, __fmul_rn(L.d[i], L.d[i]));
+        const float4* q = reinterpret_cast<const float4*>(L.sq);
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const float4 v = q[i];
+          a = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(a, v.x), v.y), v.z), v.w);
+        }
         L.scal = __fdiv_rn(1.f, sqrtf(a));
       }
       __syncthreads();
       bool clamp = false;
       if (tid < 128) {
-        float v = __fmul_rn(L.d[tid], L.scal);
-        if (pass == 0 && v > 0.2f) {
-          v = 0.2f;
+        d = __fmul_rn(d, L.scal);
+        if (pass == 0 && d > 0.2f) {
+          d = 0.2f;
           clamp = true;
         }
-        L.d[tid] = v;
       }
       const int any = __syncthreads_or(clamp ? 1 : 0);
       if (!any) break;
     }
-    if (tid < 128) desc_out[(size_t)ki * 128 + tid] = L.d[tid];
-    if (tid == 0) {
-      const float fscale = O.fscale;
-      float* g = geo_out + (size_t)ki * 4;
-      g[0] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
-      g[1] = __fmul_rn(fscale, frow);
-      g[2] = __fmul_rn(fscale, fSize);
-      g[3] = ang;
-    }
-    __syncthreads();
-  }
-}
-
-// ---- order: the reference's list = generation order reversed (every key is pushed on the
-// front of a linked list, :1432, :944-952) -------------------------------------------------------
-__global__ void order_kernel(const SiftKey* __restrict__ keys, const int32_t* __restrict__ n_keys, int key_cap,
-                             const float* __restrict__ desc_in, const float* __restrict__ geo_in, int out_cap,
-                             float* __restrict__ desc_out, float* __restrict__ xy_out,
-                             float* __restrict__ scale_ori_out, int32_t* __restrict__ n_out, SiftBatch Bt) {
-  if (blockIdx.y) {   // image of a batch: its keys, its rows of the outputs (out_step keypoints apart), its count word
-    keys += (size_t)blockIdx.y * Bt.key_step;
-    n_keys += 4 * blockIdx.y;
-    desc_in += (size_t)blockIdx.y * Bt.key_step * 128;
-    geo_in += (size_t)blockIdx.y * Bt.key_step * 4;
-    desc_out += (size_t)blockIdx.y * Bt.out_step * 128;
-    xy_out += (size_t)blockIdx.y * Bt.out_step * 2;
-    if (scale_ori_out) scale_ori_out += (size_t)blockIdx.y * Bt.out_step * 2;
-    n_out += (size_t)blockIdx.y * Bt.n_out_step;
-  }
-  int n = *n_keys;
-  if (n > key_cap) n = key_cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n < out_cap ? n : out_cap;
-  for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    __shared__ int cnt_s;
-    if (threadIdx.x == 0) cnt_s = 0;
-    __syncthreads();
-    const unsigned long long mine = keys[i].order;
-    int c = 0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) c += keys[j].order > mine;  // keys are distinct
-    if (c) atomicAdd(&cnt_s, c);
-    __syncthreads();
-    const int dst = cnt_s;  // number of keys generated after this one
+    const int dst = rank[ki];   // number of keys generated after this one
     if (dst < out_cap) {
-      for (int t = threadIdx.x; t < 128; t += blockDim.x) desc_out[(size_t)dst * 128 + t] = desc_in[(size_t)i * 128 + t];
-      if (threadIdx.x == 0) {
-        xy_out[2 * dst] = geo_in[4 * (size_t)i];
-        xy_out[2 * dst + 1] = geo_in[4 * (size_t)i + 1];
+      if (tid < 128) desc_out[(size_t)dst * 128 + tid] = d;
+      if (tid == 0) {
+        const float fscale = O.fscale;
+        xy_out[2 * dst] = __fmul_rn(fscale, fcol);   // coord2D = (col, row), FEAT_SIFT_CPU.hpp:103-104
+        xy_out[2 * dst + 1] = __fmul_rn(fscale, frow);
         if (scale_ori_out) {
-          scale_ori_out[2 * dst] = geo_in[4 * (size_t)i + 2];
-          scale_ori_out[2 * dst + 1] = geo_in[4 * (size_t)i + 3];
+          scale_ori_out[2 * dst] = __fmul_rn(fscale, fSize);
+          scale_ori_out[2 * dst + 1] = ang;
         }
       }
     }
-    __syncthreads();
+    __syncthreads();   // the next key rewrites the rows and the lists
   }
 }
 
@@ -1110,8 +1388,7 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
     O.owner = own;
     own += px;
   }
-  hipMemsetAsync(B.owner, 0xFF, B.owner_elems * sizeof(unsigned int) * n, s);
-  hipMemsetAsync(B.counters, 0, 4 * sizeof(int32_t) * n, s);
+  // (the counters are cleared by prepare_kernel, the owner map by grad_ori_kernel: three fill launches less per image)
 
   const SiftOctave& O0 = P.oct[0];
   const dim3 tb(256);
@@ -1122,7 +1399,8 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
   const bool init_fused = init_blur && (t0.n >> 1) <= BT_MAXW;
   // the prepared image goes to the scratch image when the fused blur can write octave 0's first level from there
   hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
-                     init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols, imgs, init_fused ? Bt.tmp_step : Bt.pyr_step);
+                     init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols, imgs, init_fused ? Bt.tmp_step : Bt.pyr_step,
+                     B.counters);
   if (init_fused) {
     BlurJobs J;
     J.n = 1;
@@ -1266,17 +1544,28 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
       G.begin[o * kScales + i + 1] = G.begin[o * kScales + i] + G.tiles_x[o] * ((plan.rows[o] + 3) / 4);
   }
   const dim3 g2(G.begin[G.n], un);
-  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G, (size_t)Bt.pyr_step);
-  hipLaunchKernelGGL(detect_kernel, g2, tb2, 0, s, P, G, B.cand, B.counters + 0, B.cand_cap, B.counters + 2, Bt);
+  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G, Bt);
+  DetectGrid DG;
+  DG.n = plan.n_octaves;
+  DG.begin[0] = 0;
+  for (int o = 0; o < plan.n_octaves; ++o) {   // the scanned region: 5 pixels inside every border (:925)
+    const int w = plan.cols[o] - 10, h = plan.rows[o] - 10;
+    DG.tiles_x[o] = w > 0 ? (w + DT_X - 1) / DT_X : 0;
+    DG.begin[o + 1] = DG.begin[o] + (w > 0 && h > 0 ? DG.tiles_x[o] * ((h + DT_Y - 1) / DT_Y) : 0);
+  }
+  if (DG.begin[DG.n] > 0)
+    hipLaunchKernelGGL(detect_kernel, dim3(DG.begin[DG.n], un), dim3(DT_THREADS), 0, s, P, DG, B.cand, B.counters + 0,
+                       B.cand_cap, B.counters + 2, Bt);
   // (the per-key kernels loop over the keys: a batch's images share the chip, fewer workgroups per image)
   const unsigned per = n > 4 ? 4 : 1;
   hipLaunchKernelGGL(orient_kernel, dim3(4096 / per, un), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
                      (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2, Bt);
-  hipLaunchKernelGGL(describe_kernel, dim3(2048 / per, un), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
-                     (const int32_t*)(B.counters + 1), B.key_cap, B.desc_tmp, B.geo_tmp, Bt);
-  hipLaunchKernelGGL(order_kernel, dim3(1024 / per, un), dim3(64), 0, s, (const SiftKey*)B.keys,
-                     (const int32_t*)(B.counters + 1), B.key_cap, (const float*)B.desc_tmp, (const float*)B.geo_tmp,
-                     out_cap, desc_out, xy_out, scale_ori_out, n_out, Bt);
+  int32_t* const rank = reinterpret_cast<int32_t*>(B.geo_tmp);   // [key_cap] places per image
+  hipLaunchKernelGGL(rank_kernel, dim3(128 / per, un), dim3(RK_KEYS * RK_SEGS), 0, s, (const SiftKey*)B.keys,
+                     (const int32_t*)(B.counters + 1), B.key_cap, out_cap, rank, n_out, Bt);
+  hipLaunchKernelGGL(describe_kernel, dim3(4096 / per, un), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
+                     (const int32_t*)(B.counters + 1), B.key_cap, (const int32_t*)rank, out_cap, desc_out, xy_out,
+                     scale_ori_out, Bt);
 }
 
 }  // namespace
