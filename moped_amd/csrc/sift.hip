@@ -385,7 +385,7 @@ __global__ void half_kernel(const float* __restrict__ src, int scols, float* __r
 // launches than in arithmetic: one workgroup runs the whole rest of the blur chain -- every level of
 // every remaining octave and the subsampling between them -- out of LDS, with the same per-pixel
 // loops (taps in ascending order, replicated edges).
-constexpr int SMALL_OCTAVE_PX = 80 * 60;
+constexpr int SMALL_OCTAVE_PX = 40 * 30;
 struct Taps5 {
   Taps t[kScales + 2];
 };
@@ -554,18 +554,20 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
 // blocks as there are tiles (the small octaves' slices were almost all empty blocks).
 struct SiftGrid {
   int begin[SIFT_MAX_OCTAVES * kScales + 1];
-  int tiles_x[SIFT_MAX_OCTAVES];
-  int n;   // slices
+  int tiles_x[SIFT_MAX_OCTAVES];   // of octave o_first + i
+  int n;                           // slices
+  int o_first;                     // the launch covers octaves o_first .. o_first + n / kScales - 1
 };
 __device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index, int& bx, int& by) {
   const int b = blockIdx.x;
   int z = 0;
   while (z + 1 < G.n && b >= G.begin[z + 1]) ++z;   // (most blocks belong to the first slices: one or two steps)
-  o = z / kScales;
+  const int oi = z / kScales;
+  o = G.o_first + oi;
   index = 1 + z % kScales;
   const int t = b - G.begin[z];
-  bx = t % G.tiles_x[o];
-  by = t / G.tiles_x[o];
+  bx = t % G.tiles_x[oi];
+  by = t / G.tiles_x[oi];
   return b < G.begin[G.n];
 }
 
@@ -662,9 +664,9 @@ __device__ float fit_quadratic(float* X, const float* p0, const float* p1, const
 // walks up to five pixels away.
 constexpr int DT_X = 64, DT_Y = 8, DT_W = DT_X + 2, DT_H = DT_Y + 2, DT_THREADS = 256;
 struct DetectGrid {
-  int begin[SIFT_MAX_OCTAVES + 1];   // first block of octave o
+  int begin[SIFT_MAX_OCTAVES + 1];   // first block of octave o_first + i
   int tiles_x[SIFT_MAX_OCTAVES];
-  int n;
+  int n, o_first;
 };
 __global__ __launch_bounds__(DT_THREADS) void detect_kernel(SiftPyramid P, DetectGrid G, SiftCandidate* __restrict__ cand,
                                                             int32_t* __restrict__ n_cand, int cap,
@@ -675,12 +677,13 @@ __global__ __launch_bounds__(DT_THREADS) void detect_kernel(SiftPyramid P, Detec
   overflow += 4 * blockIdx.y;
   const int b = blockIdx.x;
   if (b >= G.begin[G.n]) return;
-  int o = 0;
-  while (o + 1 < G.n && b >= G.begin[o + 1]) ++o;
+  int oi = 0;
+  while (oi + 1 < G.n && b >= G.begin[oi + 1]) ++oi;
+  const int o = G.o_first + oi;
   const SiftOctave& O = P.oct[o];
   const int rows = O.rows, cols = O.cols;
-  const int t = b - G.begin[o];
-  const int c0 = 5 + (t % G.tiles_x[o]) * DT_X, r0 = 5 + (t / G.tiles_x[o]) * DT_Y;
+  const int t = b - G.begin[oi];
+  const int c0 = 5 + (t % G.tiles_x[oi]) * DT_X, r0 = 5 + (t / G.tiles_x[oi]) * DT_Y;
   __shared__ float S[kScales + 2][DT_H][DT_W + 1];
   const int tid = threadIdx.x;
   {
@@ -782,14 +785,20 @@ __global__ __launch_bounds__(DT_THREADS) void detect_kernel(SiftPyramid P, Detec
 }
 
 // ---- orientation (AssignOriHist, :1274-1382) ---------------------------------------------------
-// One wavefront per candidate.  Samples are visited 64 at a time in raster order; lane b < 36
-// owns histogram bin b and adds the chunk's contributions to it in that order, so every bin
+// One wavefront per candidate.  Samples are visited 64 at a time in raster order and listed in LDS; lane b < 36
+// owns histogram bin b and adds the list's contributions to it in that order, so every bin
 // sums exactly like the serial loop.
+constexpr int OR_CAP = 1728;   // samples per pass: the largest window of the shipped constants has 41 x 41 = 1 681
+struct OrientLds {
+  __attribute__((aligned(16))) float val[OR_CAP + 4];
+  __attribute__((aligned(4))) unsigned char bin[OR_CAP + 4];
+};
 __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCandidate* __restrict__ cand,
                                                     const int32_t* __restrict__ n_cand, int cand_cap,
                                                     SiftKey* __restrict__ keys, int32_t* __restrict__ n_keys,
                                                     int key_cap, int32_t* __restrict__ overflow, SiftBatch Bt) {
   const int lane = threadIdx.x;
+  __shared__ OrientLds L;
   const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
   cand += (size_t)blockIdx.y * Bt.cand_step;
   keys += (size_t)blockIdx.y * Bt.key_step;
@@ -814,10 +823,9 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
     const int win = (int)__fmul_rn(__fmul_rn(fSize, 1.5f), 3.0f);
     const int side = 2 * win + 1, total = side * side;
     float h = 0.f;  // lane's bin
-    // The window's samples 64 at a time, folded into the bins one after the other in raster order (the serial code's
-    // order per bin).  All batches' gradient / orientation values are fetched FIRST -- batch by batch every fetch was
-    // two dependent trips to L2 / HBM in front of a few hundred cycles of folding (0.048 ms per frame, most of it
-    // waiting); windows of more than OR_MAXB batches (fSize > 3.9) finish with fetches of their own.
+    // All batches' gradient / orientation values are fetched FIRST -- batch by batch every fetch was two dependent trips
+    // to L2 / HBM in front of a few hundred cycles of work (0.048 ms per frame, most of it waiting); windows of more than
+    // OR_MAXB batches (fSize > 3.9) finish with fetches of their own.
     constexpr int OR_MAXB = 20;
     float gv[OR_MAXB], ov[OR_MAXB];
 #pragma unroll
@@ -833,9 +841,13 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
         }
       }
     }
-    auto fold = [&](int s, float g, float ori, bool fetched) {
-      int bin = -1;
-      float val = 0.f;
+    // The window's samples 64 at a time: every lane's (bin, weighted magnitude), the ones that count packed into a list in
+    // LDS in raster order (one ballot per 64); then lane b < 36 walks the whole list and adds the entries of bin b -- the
+    // serial code's order per bin.  (Until round 5 the wavefront folded every sample into its bin one after the other with
+    // two readlanes each: ~7 instructions per sample on all lanes against 4 here, 57 us at 2 700 candidates.)
+    auto sample = [&](int s, float g, float ori, bool fetched, int& bin, float& val) {
+      bin = -1;
+      val = 0.f;
       if (s < total) {
         const int r = rowstart - win + s / side, c = colstart - win + s % side;
         if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
@@ -854,21 +866,55 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
           }
         }
       }
-      unsigned long long m = __ballot(bin >= 0);
-      while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int b = __builtin_amdgcn_readlane(bin, src);
-        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), src));
-        if (lane == b) h = __fadd_rn(h, x);
-      }
     };
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int s0 = 0; s0 < total; s0 += OR_CAP) {   // (windows of more than OR_CAP samples -- none with the shipped constants -- in parts)
+      int n_list = 0;
+      const int s1 = min(total, s0 + OR_CAP);
+      auto push = [&](int bin, float val) {
+        const unsigned long long m = __ballot(bin >= 0);
+        if (bin >= 0) {
+          const int at = n_list + __popcll(m & lt);
+          L.val[at] = val;
+          L.bin[at] = (unsigned char)bin;
+        }
+        n_list += __popcll(m);
+      };
+      if (s0 == 0) {
 #pragma unroll
-    for (int b = 0; b < OR_MAXB; ++b) {
-      if (b * 64 >= total) break;
-      fold(b * 64 + lane, gv[b], ov[b], true);
+        for (int b = 0; b < OR_MAXB; ++b) {
+          if (b * 64 >= s1) break;
+          int bin;
+          float val;
+          sample(b * 64 + lane, gv[b], ov[b], true, bin, val);
+          push(bin, val);
+        }
+      }
+      for (int base = s0 == 0 ? OR_MAXB * 64 : s0; base < s1; base += 64) {
+        int bin;
+        float val;
+        sample(base + lane, 0.f, 0.f, false, bin, val);
+        push(bin, val);
+      }
+      if (lane < 4) {   // the list's last group of four, padded with entries of no bin
+        const int at = n_list + lane;
+        L.val[at] = 0.f;
+        L.bin[at] = 255;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < n_list; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&L.val[i]);
+        const unsigned bb = *reinterpret_cast<const unsigned*>(&L.bin[i]);
+        // (adding +0 where the entry belongs to another bin leaves h as it is: the magnitudes are positive)
+        h = __fadd_rn(h, (int)(bb & 255u) == lane ? v.x : 0.f);
+        h = __fadd_rn(h, (int)((bb >> 8) & 255u) == lane ? v.y : 0.f);
+        h = __fadd_rn(h, (int)((bb >> 16) & 255u) == lane ? v.z : 0.f);
+        h = __fadd_rn(h, (int)(bb >> 24) == lane ? v.w : 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    for (int base = OR_MAXB * 64; base < total; base += 64) fold(base + lane, 0.f, 0.f, false);
     // SmoothHistogram x 6 (:1395-1408): every new bin is (previous + own) + next of the OLD values (the serial
     // loop carries the old left neighbour along and has not reached the right one yet; bin 35 closes the ring
     // with the old bin 0 and its own, shorter, constant), so the 36 lanes smooth their bins side by side.
@@ -1008,6 +1054,14 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
   s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
   return s;
 }
+#ifdef SIFT_PROF   // phase timing build (make EXTRA=-DSIFT_PROF): cycles of lane 0 of the first ([0..9]) and of the last wavefront
+// ([10..19]) of describe_kernel's workgroups, summed over keys: 0 setup + rows, 1 fetch, 2 sample arithmetic, 3 masks + sizes,
+// 4 list writes, 5 waiting at the step's barrier, 6 B, 7 normalisation + output; [8] keys, [9] steps
+__device__ unsigned long long g_sift_prof[32];
+#define DPF(k) do { if (prof_on) { const unsigned long long now_ = clock64(); prof_acc[k] += now_ - prof_t; prof_t = now_; } } while (0)
+#else
+#define DPF(k) do { } while (0)
+#endif
 #ifndef MH_DESC_WAVES
 #define MH_DESC_WAVES 4
 #endif
@@ -1024,6 +1078,7 @@ struct DescLds {
   float val[2][DESC_WAVES][512];
   int rowbeg[DESC_MAX_SIDE + 1];                // samples in front of window row i
   short rowlo[DESC_MAX_SIDE];                   // first column (window coordinates) of row i's interval
+  unsigned char chunkrow[DESC_MAX_SIDE * DESC_MAX_SIDE / 64];   // window row of sample 64 c
   float sq[128];
   float scal;
 };
@@ -1051,6 +1106,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
+#ifdef SIFT_PROF
+  const bool prof_on = lane == 0 && (wave == 0 || wave == DESC_WAVES - 1);
+  unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = clock64();
+#endif
   for (int ki = blockIdx.x; ki < n; ki += gridDim.x) {
     const SiftKey k = keys[ki];
     const SiftOctave& O = P.oct[k.octave];
@@ -1089,11 +1148,22 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
           sum += __builtin_amdgcn_readlane(incl, 63);
         }
         if (lane == 0) L.rowbeg[side] = sum;
+        wave_sync();
+        // the row of every 64th sample: a lane finds its sample's row from there without walking the rows (four
+        // wavefronts share the walk, so a lane moves 256 samples = 6 - 12 rows per step: the walk -- dependent LDS
+        // reads in a divergent loop -- was the longest phase of a step, SIFT_PROF)
+        for (int base = 0; base < side; base += 64) {
+          const int rr = base + lane;
+          if (rr < side) {
+            const int b0 = L.rowbeg[rr], b1 = L.rowbeg[rr + 1];
+            for (int c = (b0 + 63) >> 6; (c << 6) < b1; ++c) L.chunkrow[c] = (unsigned char)rr;
+          }
+        }
       }
       __syncthreads();
       total = L.rowbeg[side];
     }
-    int rho = 0;   // the lane's row cursor
+    DPF(0);
     // sample t of the walk: its window row / column, and its two values when its pixel exists
     struct Sample {
       bool have;
@@ -1104,6 +1174,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
       Sample q{false, 0, 0, 0.f, 0.f};
       if (t >= total) return q;
       if (compact) {
+        // the row of the chunk's first sample, then at most a few rows on (four bounds read at once; rows of fewer than 16
+        // samples -- the rotated square's corners -- go on one by one)
+        int rho = L.chunkrow[t >> 6];
+        const int b1 = L.rowbeg[rho + 1], b2 = L.rowbeg[min(rho + 2, side)], b3 = L.rowbeg[min(rho + 3, side)],
+                  b4 = L.rowbeg[min(rho + 4, side)];
+        rho += (int)(t >= b1) + (int)(t >= b2) + (int)(t >= b3) + (int)(t >= b4);
         while (t >= L.rowbeg[rho + 1]) ++rho;
         q.row = rho - win;
         q.col = (int)L.rowlo[rho] + (t - L.rowbeg[rho]);
@@ -1149,6 +1225,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
           nb = no & 7;   // the bins wrap: orientation 2 pi falls into bin 8 = bin 0
         }
       }
+      DPF(2);
       // the 16 masks: rows of cells in lanes 0..3, columns in 4..7, bins in 8..15
       {
         const int nrk = ok ? nr : -100, nck = ok ? nc : -100;
@@ -1184,6 +1261,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
         if (lane == 63) offs[128] = (uint16_t)incl;
       }
       wave_sync();
+      DPF(3);
       if (ok) {
         const float rg0 = __fmul_rn(mag, __fsub_rn(1.f, rf)), rg1 = __fmul_rn(mag, rf);   // rows nr, nr + 1
         const float cfm = __fsub_rn(1.f, cf), ofm = __fsub_rn(1.f, of);
@@ -1207,19 +1285,23 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
           }
         }
       }
+      DPF(4);
     };
     const int per_step = 64 * DESC_WAVES;
     const int n_steps = (total + per_step - 1) / per_step;
     // step i's sample of this lane: t = i per_step + tid (raster order over the wavefronts, then the lanes)
     Sample cur = fetch(tid), nxt = fetch(per_step + tid);
     float acc = 0.f;
+    DPF(1);
     if (n_steps > 0) phase_a(cur, 0);
     for (int i = 0; i < n_steps; ++i) {
       __syncthreads();   // step i's lists are written, step i - 1's are read: step i + 1 may overwrite those
+      DPF(5);
       if (i + 1 < n_steps) {
         cur = nxt;
         nxt = fetch((i + 2) * per_step + tid);
       }
+      DPF(1);
       // ---- B ----
       if (tid < 128) {
         const int buf = i & 1;
@@ -1259,6 +1341,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
         }
 #endif
       }
+      DPF(6);
       if (i + 1 < n_steps) phase_a(cur, (i + 1) & 1);
     }
     // NormalizeVec, clamp at 0.2, NormalizeVec again if anything was clamped (:1497-1527); the squares are summed in the
@@ -1303,7 +1386,18 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
       }
     }
     __syncthreads();   // the next key rewrites the rows and the lists
+    DPF(7);
+#ifdef SIFT_PROF
+    if (prof_on) {
+      prof_acc[8] += 1;
+      prof_acc[9] += n_steps;
+    }
+#endif
   }
+#ifdef SIFT_PROF
+  if (prof_on)
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_sift_prof[(wave == 0 ? 0 : 10) + i], prof_acc[i]);
+#endif
 }
 
 // GaussianBlur's kernel (:470-506), on the host with libm's expf like the reference.
@@ -1442,6 +1536,48 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
       o_small = o;
       break;
     }
+  // gradients / orientations, then extrema, of octaves [o_lo, o_hi) on stream st
+  auto grad_detect = [&](int o_lo, int o_hi, hipStream_t st) {
+    if (o_hi <= o_lo) return;
+    const dim3 tb2(64, 4);
+    SiftGrid G;
+    G.n = (o_hi - o_lo) * kScales;
+    G.o_first = o_lo;
+    G.begin[0] = 0;
+    for (int o = o_lo; o < o_hi; ++o) {
+      const int oi = o - o_lo;
+      G.tiles_x[oi] = (plan.cols[o] + 63) / 64;
+      for (int i = 0; i < kScales; ++i)
+        G.begin[oi * kScales + i + 1] = G.begin[oi * kScales + i] + G.tiles_x[oi] * ((plan.rows[o] + 3) / 4);
+    }
+    hipLaunchKernelGGL(grad_ori_kernel, dim3(G.begin[G.n], un), tb2, 0, st, P, G, Bt);
+    DetectGrid DG;
+    DG.n = o_hi - o_lo;
+    DG.o_first = o_lo;
+    DG.begin[0] = 0;
+    for (int o = o_lo; o < o_hi; ++o) {   // the scanned region: 5 pixels inside every border (:925)
+      const int oi = o - o_lo, w = plan.cols[o] - 10, h = plan.rows[o] - 10;
+      DG.tiles_x[oi] = w > 0 ? (w + DT_X - 1) / DT_X : 0;
+      DG.begin[oi + 1] = DG.begin[oi] + (w > 0 && h > 0 ? DG.tiles_x[oi] * ((h + DT_Y - 1) / DT_Y) : 0);
+    }
+    if (DG.begin[DG.n] > 0)
+      hipLaunchKernelGGL(detect_kernel, dim3(DG.begin[DG.n], un), dim3(DT_THREADS), 0, st, P, DG, B.cand, B.counters + 0,
+                         B.cand_cap, B.counters + 2, Bt);
+  };
+  // The small octaves' blur chain, one workgroup per image.  (Round 5 tried it -- with the small octaves' gradients and
+  // extrema -- on a stream of its own beside the last large octave's last two levels and the large octaves' gradients and
+  // extrema, which need nothing of it: one image alone gained 13 us of the 58, the event hand-over between the streams
+  // costs the rest, and sixteen contexts with two streams each share the hardware queues: 0.13 -> 0.26 ms per image with
+  // four in flight.  One stream.)
+  auto small_chain = [&](bool with_half) {
+    if (with_half) {   // the first small octave's level 0
+      const SiftOctave& O = P.oct[o_small - 1];
+      const SiftOctave& N = P.oct[o_small];
+      hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
+                         N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
+    }
+    hipLaunchKernelGGL(small_octaves_kernel, dim3(un), dim3(1024), 0, s, P, o_small, T5, (size_t)Bt.pyr_step);
+  };
   bool jobs_ok = true;   // every level's kernel fits the tile kernel's halo
   for (int i = 0; i < kScales + 2; ++i) jobs_ok = jobs_ok && (T5.t[i].n >> 1) <= BT_MAXW;
   if (jobs_ok) {
@@ -1504,14 +1640,9 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
           launch_jobs(a, nullptr);
         }
       }
-      if (!next && o + 1 < plan.n_octaves) {   // the first small octave's level 0
-        const SiftOctave& O = P.oct[o];
-        const SiftOctave& N = P.oct[o + 1];
-        hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
-                           N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
-      }
     }
-  } else
+    if (o_small < plan.n_octaves) small_chain(true);
+  } else {
   for (int o = 0; o < o_small; ++o) {
     const SiftOctave& O = P.oct[o];
     for (int i = 1; i < kScales + 3; ++i) {   // OctaveKeypoints (:410-438)
@@ -1532,30 +1663,9 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
                          N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
     }
   }
-  if (o_small < plan.n_octaves)
-    hipLaunchKernelGGL(small_octaves_kernel, dim3(un), dim3(1024), 0, s, P, o_small, T5, (size_t)Bt.pyr_step);
-  const dim3 tb2(64, 4);
-  SiftGrid G;
-  G.n = plan.n_octaves * kScales;
-  G.begin[0] = 0;
-  for (int o = 0; o < plan.n_octaves; ++o) {
-    G.tiles_x[o] = (plan.cols[o] + 63) / 64;
-    for (int i = 0; i < kScales; ++i)
-      G.begin[o * kScales + i + 1] = G.begin[o * kScales + i] + G.tiles_x[o] * ((plan.rows[o] + 3) / 4);
+    if (o_small < plan.n_octaves) small_chain(false);   // (the loop above launched the half-size copy itself)
   }
-  const dim3 g2(G.begin[G.n], un);
-  hipLaunchKernelGGL(grad_ori_kernel, g2, tb2, 0, s, P, G, Bt);
-  DetectGrid DG;
-  DG.n = plan.n_octaves;
-  DG.begin[0] = 0;
-  for (int o = 0; o < plan.n_octaves; ++o) {   // the scanned region: 5 pixels inside every border (:925)
-    const int w = plan.cols[o] - 10, h = plan.rows[o] - 10;
-    DG.tiles_x[o] = w > 0 ? (w + DT_X - 1) / DT_X : 0;
-    DG.begin[o + 1] = DG.begin[o] + (w > 0 && h > 0 ? DG.tiles_x[o] * ((h + DT_Y - 1) / DT_Y) : 0);
-  }
-  if (DG.begin[DG.n] > 0)
-    hipLaunchKernelGGL(detect_kernel, dim3(DG.begin[DG.n], un), dim3(DT_THREADS), 0, s, P, DG, B.cand, B.counters + 0,
-                       B.cand_cap, B.counters + 2, Bt);
+  grad_detect(0, plan.n_octaves, s);
   // (the per-key kernels loop over the keys: a batch's images share the chip, fewer workgroups per image)
   const unsigned per = n > 4 ? 4 : 1;
   hipLaunchKernelGGL(orient_kernel, dim3(4096 / per, un), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
@@ -1606,3 +1716,14 @@ void launch_sift_batch(const uint8_t* const* gray, int n, int width, int height,
 }
 
 }  // namespace mh
+
+#ifdef SIFT_PROF
+extern "C" int mh_debug_sift_prof(unsigned long long out[32], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mh::g_sift_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mh::g_sift_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
