@@ -75,7 +75,6 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap, in
   st->B.images = images;
   rc |= alloc(ctx, st->B.cand, (size_t)st->B.cand_cap * ni);
   rc |= alloc(ctx, st->B.keys, (size_t)cap * ni);
-  rc |= alloc(ctx, st->B.geo_tmp, (size_t)cap * ni);   // (int32 places, one per key)
   rc |= alloc(ctx, st->B.counters, 4 * ni);
   rc |= alloc(ctx, st->gray, (size_t)width * height);
   rc |= alloc(ctx, st->desc, (size_t)cap * 128);

@@ -65,8 +65,8 @@ struct SiftBuffers {
   int cand_cap;
   SiftKey* keys;
   int key_cap;
-  float* desc_tmp;          // (unused since round 5: describe_kernel writes a descriptor at its place in the list)
-  float* geo_tmp;           // [key_cap] int32: a key's place in the reference's list order (rank_kernel)
+  float* desc_tmp;          // (both unused since round 5: describe_kernel finds a key's place in the list itself and
+  float* geo_tmp;           //  writes the descriptor there)
   int32_t* counters;        // [4]: candidates, keys, overflow flag, -
   int images;               // every array above holds this many images' worth, one after the other
 };

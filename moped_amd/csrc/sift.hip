@@ -40,6 +40,20 @@ constexpr float kInitSigma = 1.6f;    // :109
 // FEAT_SIFT_CPU.hpp:91 (pixel * 1./255. in double) and SiftDoubleSize (:363-380).
 __device__ __forceinline__ float to_unit(uint8_t g) { return (float)((double)(float)g * 1. / 255.); }
 
+// pixel (r, c) of the image GetKeypoints starts from: the frame itself or SiftDoubleSize's (:363-380) 2x - 2 version of it
+__device__ __forceinline__ float prepared_px(const uint8_t* __restrict__ gray, int w, int double_size, int r, int c) {
+  if (!double_size) return to_unit(gray[(size_t)r * w + c]);
+  const int i = r >> 1, j = c >> 1;
+  const float a = to_unit(gray[(size_t)i * w + j]);
+  if ((r & 1) == 0 && (c & 1) == 0) return a;
+  if ((r & 1) == 1 && (c & 1) == 0) return __fmul_rn(0.5f, __fadd_rn(a, to_unit(gray[(size_t)(i + 1) * w + j])));
+  if ((r & 1) == 0) return __fmul_rn(0.5f, __fadd_rn(a, to_unit(gray[(size_t)i * w + j + 1])));
+  const float b = to_unit(gray[(size_t)i * w + j + 1]);
+  const float d = to_unit(gray[(size_t)(i + 1) * w + j]);
+  const float e = to_unit(gray[(size_t)(i + 1) * w + j + 1]);
+  return __fmul_rn(0.25f, __fadd_rn(__fadd_rn(__fadd_rn(a, b), d), e));
+}
+
 // blockIdx.z = image of a batch (SiftImages: its pixels; its output `out_step` floats behind the image's before it)
 __global__ void prepare_kernel(const uint8_t* __restrict__ gray, int w, int h, int double_size,
                                float* __restrict__ out, int orows, int ocols, SiftImages imgs, size_t out_step,
@@ -53,26 +67,7 @@ __global__ void prepare_kernel(const uint8_t* __restrict__ gray, int w, int h, i
     gray = imgs.gray[blockIdx.z];
     out += blockIdx.z * out_step;
   }
-  if (!double_size) {
-    out[(size_t)r * ocols + c] = to_unit(gray[(size_t)r * w + c]);
-    return;
-  }
-  const int i = r >> 1, j = c >> 1;
-  const float a = to_unit(gray[(size_t)i * w + j]);
-  float v;
-  if ((r & 1) == 0 && (c & 1) == 0) {
-    v = a;
-  } else if ((r & 1) == 1 && (c & 1) == 0) {
-    v = __fmul_rn(0.5f, __fadd_rn(a, to_unit(gray[(size_t)(i + 1) * w + j])));
-  } else if ((r & 1) == 0) {
-    v = __fmul_rn(0.5f, __fadd_rn(a, to_unit(gray[(size_t)i * w + j + 1])));
-  } else {
-    const float b = to_unit(gray[(size_t)i * w + j + 1]);
-    const float d = to_unit(gray[(size_t)(i + 1) * w + j]);
-    const float e = to_unit(gray[(size_t)(i + 1) * w + j + 1]);
-    v = __fmul_rn(0.25f, __fadd_rn(__fadd_rn(__fadd_rn(a, b), d), e));
-  }
-  out[(size_t)r * ocols + c] = v;
+  out[(size_t)r * ocols + c] = prepared_px(gray, w, double_size, r, c);
 }
 
 // ---- blur ---------------------------------------------------------------------------------
@@ -468,7 +463,7 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
       so_put_padded(cur, cs, cols, r, c, v);
     };
     const float* src0 = O.gaus[0] + off;
-    if (o > o_first) {   // HalfImageSize (:390-408) of the previous octave's image `kScales`
+    if (o > 0) {   // HalfImageSize (:390-408) of the previous octave's image `kScales` (the first small octave's too: no launch of its own)
       const SiftOctave& V = P.oct[o - 1];
       const float* src = V.gaus[kScales] + off;
       float* dst = O.gaus[0] + off;
@@ -966,56 +961,6 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
   }
 }
 
-// ---- order: the reference's list = generation order reversed (every key is pushed on the
-// front of a linked list, :1432, :944-952) -------------------------------------------------------
-// A key's place in the list = the number of keys generated after it.  64 keys per workgroup of 16 wavefronts, the other
-// keys' generation words staged through LDS and every wavefront comparing a sixteenth of them with its lane's key (all
-// lanes read the same words: a broadcast).  (Until round 5 one workgroup per key walked all keys in global memory and
-// then copied the key's descriptor to its place: 49 us at 3 240 keys; now describe_kernel writes each descriptor where
-// it belongs.)
-constexpr int RK_KEYS = 64, RK_SEGS = 16, RK_TILE = 4096;
-__global__ __launch_bounds__(RK_KEYS* RK_SEGS) void rank_kernel(const SiftKey* __restrict__ keys,
-                                                                const int32_t* __restrict__ n_keys, int key_cap, int out_cap,
-                                                                int32_t* __restrict__ rank, int32_t* __restrict__ n_out,
-                                                                SiftBatch Bt) {
-  keys += (size_t)blockIdx.y * Bt.key_step;   // image of a batch
-  n_keys += 4 * blockIdx.y;
-  rank += (size_t)blockIdx.y * Bt.key_step;
-  n_out += (size_t)blockIdx.y * Bt.n_out_step;
-  int n = *n_keys;
-  if (n > key_cap) n = key_cap;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n < out_cap ? n : out_cap;
-  __shared__ __attribute__((aligned(16))) unsigned long long tile[RK_TILE];
-  __shared__ int cnt_s[RK_SEGS][RK_KEYS];
-  const int lane = threadIdx.x & (RK_KEYS - 1), seg = threadIdx.x / RK_KEYS;
-  for (int base = blockIdx.x * RK_KEYS; base < n; base += gridDim.x * RK_KEYS) {
-    const int i = base + lane;
-    const unsigned long long mine = i < n ? keys[i].order : ~0ull;
-    int c = 0;
-    for (int t0 = 0; t0 < n; t0 += RK_TILE) {
-      const int m = min(RK_TILE, n - t0);
-      __syncthreads();
-      for (int j = threadIdx.x; j < RK_TILE; j += RK_KEYS * RK_SEGS) tile[j] = j < m ? keys[t0 + j].order : 0ull;   // (0: greater than nothing)
-      __syncthreads();
-      // wavefront `seg` takes the words 8 seg .. 8 seg + 7 of every 128: eight independent reads per step
-      for (int j = 8 * seg; j < m; j += 8 * RK_SEGS) {
-        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(tile + j);
-        const ulonglong2 a = q[0], b = q[1], d = q[2], e = q[3];
-        c += (int)(a.x > mine) + (int)(a.y > mine) + (int)(b.x > mine) + (int)(b.y > mine) + (int)(d.x > mine) +
-             (int)(d.y > mine) + (int)(e.x > mine) + (int)(e.y > mine);   // keys are distinct
-      }
-    }
-    cnt_s[seg][lane] = c;
-    __syncthreads();
-    if (seg == 0 && i < n) {
-      int r = 0;
-#pragma unroll
-      for (int g = 0; g < RK_SEGS; ++g) r += cnt_s[g][lane];
-      rank[i] = r;
-    }
-  }
-}
-
 // ---- descriptor (MakeKeypointSample / KeySample / AddSample / PlaceInIndex, :1424-1668) ---------
 // One workgroup of DESC_WAVES wavefronts per key.  The reference adds a sample's (up to eight) contributions to the
 // descriptor entries it touches one sample after the other in raster order; the 128 entries are independent of each
@@ -1037,7 +982,10 @@ __global__ __launch_bounds__(RK_KEYS* RK_SEGS) void rank_kernel(const SiftKey* _
 //      products in the same order as the serial code, and nothing else (no entry is visited that is not added).
 // The lists are double-buffered -- step i + 1's A runs beside step i's B, ONE workgroup barrier per step -- and a
 // sample's gradient / orientation values are requested a step before they are used.  The descriptor goes straight to
-// its place in the reference's list order (rank_kernel).
+// its place in the reference's list: generation order reversed (every key is pushed on the front of a linked list, :1432,
+// :944-952), so a key's place = the number of keys generated after it, which the key's workgroup counts itself (n / 256
+// generation words per thread; until round 5 an order kernel ranked the keys -- one workgroup per key walking all keys --
+// and copied every descriptor to its place: 49 us at 3 240 keys).
 // History (per 640x480 frame of ~600 keys): every wavefront folding all samples of its key with readlanes 0.28 ms;
 // per-cell lists that four lanes per cell filter by bin 0.14; 256 samples per step out of the window's whole square, 24
 // ballots, two barriers per step 0.1 (197 us at 3 240 keys); one wavefront per key with the interval walk: slower (225
@@ -1081,10 +1029,11 @@ struct DescLds {
   unsigned char chunkrow[DESC_MAX_SIDE * DESC_MAX_SIDE / 64];   // window row of sample 64 c
   float sq[128];
   float scal;
+  int later[DESC_WAVES];                        // keys generated after this one, counted by wavefront w
 };
 __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel(SiftPyramid P, const SiftKey* __restrict__ keys,
-                                                      const int32_t* __restrict__ n_keys, int key_cap,
-                                                      const int32_t* __restrict__ rank, int out_cap,
+                                                      const int32_t* __restrict__ n_keys, int key_cap, int out_cap,
+                                                      int32_t* __restrict__ n_out,
                                                       float* __restrict__ desc_out /* [place][128] */,
                                                       float* __restrict__ xy_out /* [place][2] col,row */,
                                                       float* __restrict__ scale_ori_out /* [place][2] or null */,
@@ -1092,7 +1041,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
   const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
   keys += (size_t)blockIdx.y * Bt.key_step;
   n_keys += 4 * blockIdx.y;
-  rank += (size_t)blockIdx.y * Bt.key_step;
+  n_out += (size_t)blockIdx.y * Bt.n_out_step;
   desc_out += (size_t)blockIdx.y * Bt.out_step * 128;
   xy_out += (size_t)blockIdx.y * Bt.out_step * 2;
   if (scale_ori_out) scale_ori_out += (size_t)blockIdx.y * Bt.out_step * 2;
@@ -1100,6 +1049,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int n = *n_keys;
   if (n > key_cap) n = key_cap;
+  if (blockIdx.x == 0 && tid == 0) *n_out = n < out_cap ? n : out_cap;
   const unsigned long long lt = (1ull << lane) - 1ull;
   // LDS written by one lane of a wavefront and read by another of the same wavefront
   auto wave_sync = [&]() {
@@ -1129,8 +1079,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
     // -- is walked whole, a sample's row and column by division)
     const bool compact = side <= DESC_MAX_SIDE;
     int total = side * side;
-    if (compact) {
-      if (wave == 0) {
+    {   // the key's place in the list (keys are distinct)
+      int later = 0;
+      for (int j = tid; j < n; j += 64 * DESC_WAVES) later += (int)(keys[j].order > k.order);
+      later = wave_incl_scan(later);
+      if (lane == 63) L.later[wave] = later;
+    }
+    {
+      if (compact && wave == 0) {
         int sum = 0;
         for (int base = 0; base < side; base += 64) {
           const int rr = base + lane;
@@ -1161,7 +1117,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
         }
       }
       __syncthreads();
-      total = L.rowbeg[side];
+      if (compact) total = L.rowbeg[side];
     }
     DPF(0);
     // sample t of the walk: its window row / column, and its two values when its pixel exists
@@ -1372,7 +1328,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
       const int any = __syncthreads_or(clamp ? 1 : 0);
       if (!any) break;
     }
-    const int dst = rank[ki];   // number of keys generated after this one
+    int dst = 0;   // number of keys generated after this one
+#pragma unroll
+    for (int w = 0; w < DESC_WAVES; ++w) dst += L.later[w];
     if (dst < out_cap) {
       if (tid < 128) desc_out[(size_t)dst * 128 + tid] = d;
       if (tid == 0) {
@@ -1491,7 +1449,9 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
   const bool init_blur = kInitSigma > fnew;   // :325-327
   const Taps t0 = init_blur ? make_taps(sqrtf(kInitSigma * kInitSigma - fnew * fnew)) : Taps{};
   const bool init_fused = init_blur && (t0.n >> 1) <= BT_MAXW;
-  // the prepared image goes to the scratch image when the fused blur can write octave 0's first level from there
+  // the prepared image goes to the scratch image when the fused blur can write octave 0's first level from there.  (Round 5
+  // tried the first blur on the frame's pixels directly -- prepared_px in its staging: the staging's loads no longer go
+  // out together, every blur launch of the chain paid for it, 132 -> 175 us.)
   hipLaunchKernelGGL(prepare_kernel, grid_for(O0.rows, O0.cols), tb, 0, s, gray, width, height, double_size,
                      init_fused ? B.tmp : O0.gaus[0], O0.rows, O0.cols, imgs, init_fused ? Bt.tmp_step : Bt.pyr_step,
                      B.counters);
@@ -1569,13 +1529,7 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
   // extrema, which need nothing of it: one image alone gained 13 us of the 58, the event hand-over between the streams
   // costs the rest, and sixteen contexts with two streams each share the hardware queues: 0.13 -> 0.26 ms per image with
   // four in flight.  One stream.)
-  auto small_chain = [&](bool with_half) {
-    if (with_half) {   // the first small octave's level 0
-      const SiftOctave& O = P.oct[o_small - 1];
-      const SiftOctave& N = P.oct[o_small];
-      hipLaunchKernelGGL(half_kernel, grid_for(N.rows, N.cols), tb, 0, s, (const float*)O.gaus[kScales], O.cols,
-                         N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
-    }
+  auto small_chain = [&]() {
     hipLaunchKernelGGL(small_octaves_kernel, dim3(un), dim3(1024), 0, s, P, o_small, T5, (size_t)Bt.pyr_step);
   };
   bool jobs_ok = true;   // every level's kernel fits the tile kernel's halo
@@ -1641,7 +1595,7 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
         }
       }
     }
-    if (o_small < plan.n_octaves) small_chain(true);
+    if (o_small < plan.n_octaves) small_chain();
   } else {
   for (int o = 0; o < o_small; ++o) {
     const SiftOctave& O = P.oct[o];
@@ -1663,19 +1617,15 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
                          N.gaus[0], N.rows, N.cols, (size_t)Bt.pyr_step);
     }
   }
-    if (o_small < plan.n_octaves) small_chain(false);   // (the loop above launched the half-size copy itself)
+    if (o_small < plan.n_octaves) small_chain();   // (the loop above wrote the half-size copy already: the same numbers again)
   }
   grad_detect(0, plan.n_octaves, s);
   // (the per-key kernels loop over the keys: a batch's images share the chip, fewer workgroups per image)
   const unsigned per = n > 4 ? 4 : 1;
   hipLaunchKernelGGL(orient_kernel, dim3(4096 / per, un), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
                      (const int32_t*)(B.counters + 0), B.cand_cap, B.keys, B.counters + 1, B.key_cap, B.counters + 2, Bt);
-  int32_t* const rank = reinterpret_cast<int32_t*>(B.geo_tmp);   // [key_cap] places per image
-  hipLaunchKernelGGL(rank_kernel, dim3(128 / per, un), dim3(RK_KEYS * RK_SEGS), 0, s, (const SiftKey*)B.keys,
-                     (const int32_t*)(B.counters + 1), B.key_cap, out_cap, rank, n_out, Bt);
   hipLaunchKernelGGL(describe_kernel, dim3(4096 / per, un), dim3(64 * DESC_WAVES), 0, s, P, (const SiftKey*)B.keys,
-                     (const int32_t*)(B.counters + 1), B.key_cap, (const int32_t*)rank, out_cap, desc_out, xy_out,
-                     scale_ori_out, Bt);
+                     (const int32_t*)(B.counters + 1), B.key_cap, out_cap, n_out, desc_out, xy_out, scale_ori_out, Bt);
 }
 
 }  // namespace
