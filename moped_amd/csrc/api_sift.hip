@@ -14,6 +14,7 @@ struct SiftState {
   uint8_t* gray = nullptr;       // staging for host-pointer calls
   float *desc = nullptr, *xy = nullptr, *scale_ori = nullptr;
   int32_t* n_dev = nullptr;
+  unsigned int own_epoch = 0;    // B.own_epoch points here
 };
 
 namespace {
@@ -70,6 +71,7 @@ int ensure_sift(mh_ctx* ctx, int width, int height, int double_size, int cap, in
   rc |= alloc(ctx, st->B.tmp, (size_t)st->plan.rows0 * st->plan.cols0 * ni);
   rc |= alloc(ctx, st->B.owner, owner * ni);
   st->B.owner_elems = owner;
+  st->B.own_epoch = &st->own_epoch;
   st->B.cand_cap = 4 * cap;
   st->B.key_cap = cap;
   st->B.images = images;

@@ -5,16 +5,14 @@
 namespace mh {
 
 constexpr int SIFT_MAX_OCTAVES = 8;
-constexpr int SIFT_IMAGES_PER_OCTAVE = 17;  // 6 Gaussian + 5 DoG + 3 gradient + 3 orientation
+constexpr int SIFT_IMAGES_PER_OCTAVE = 11;  // 6 Gaussian + 5 DoG (gradient magnitude / orientation: computed per sample)
 
 struct SiftOctave {
   int rows, cols;
   float fscale;             // octave pixel -> original image pixel (0.5 for the doubled image, :318)
   float* gaus[6];
   float* dog[5];
-  float* grad[3];           // of gaus[1..3]
-  float* ori[3];
-  unsigned int* owner;      // per pixel: generation key of the extremum that owns it (0xFFFFFFFF = free)
+  unsigned int* owner;      // per pixel: epoch prefix | generation key of the extremum that owns it (SiftBatch::own_prefix)
 };
 
 struct SiftPyramid {
@@ -43,6 +41,11 @@ struct SiftBatch {
   int cand_step = 0, key_step = 0;                               // candidates / keys (counters: 4 words per image)
   int out_step = 0, n_out_step = 0;
   int n = 1;
+  // The owner map is never cleared between images: a claim is `own_prefix | key` with a prefix that goes DOWN from image
+  // to image, claims go in with atomicMin, so every claim of this image lies below everything older; a word whose prefix
+  // is not this image's is free.  (When the prefixes run out -- every 2^(32 - key bits) images -- the map is filled with
+  // ones again.)
+  unsigned int own_prefix = 0;
 };
 struct SiftImages {
   const uint8_t* gray[MH_MAX_BATCH];
@@ -69,6 +72,7 @@ struct SiftBuffers {
   float* geo_tmp;           //  writes the descriptor there)
   int32_t* counters;        // [4]: candidates, keys, overflow flag, -
   int images;               // every array above holds this many images' worth, one after the other
+  unsigned int* own_epoch;  // host word: the prefix counter of the owner map (SiftBatch::own_prefix); starts at 0 = fill first
 };
 
 // Octave sizes of GetKeypoints' loop (:344-348).  Returns the number of octaves.

@@ -544,51 +544,33 @@ __global__ __launch_bounds__(1024) void small_octaves_kernel(SiftPyramid P, int 
 }
 
 // ---- gradient / orientation (GradOriImages, :959-992) ---------------------------------------
-// The per-pixel kernels over all (octave, level) images run on ONE flat grid of 64 x 4 tiles: slice z = octave * kScales
-// + level - 1 owns the blocks [begin[z], begin[z + 1]) -- a 3-D grid sized for octave 0 launched six times as many
-// blocks as there are tiles (the small octaves' slices were almost all empty blocks).
-struct SiftGrid {
-  int begin[SIFT_MAX_OCTAVES * kScales + 1];
-  int tiles_x[SIFT_MAX_OCTAVES];   // of octave o_first + i
-  int n;                           // slices
-  int o_first;                     // the launch covers octaves o_first .. o_first + n / kScales - 1
+// gradient magnitude and orientation of pixel (i, j) of a Gaussian level, as GradOriImages stores them (:959-992):
+// central differences, one-sided and doubled on the border rows / columns.  Computed where a key's window asks for them
+// (orient_kernel, describe_kernel) -- until round 5 a kernel of its own wrote both for every pixel of three levels per
+// octave: six of an octave's seventeen images, 59 MB per 640x480 frame, for the few hundred thousand samples the keys read.
+struct GradTaps {   // the four neighbours' offsets and the border factor
+  size_t a, b, u, d;
+  bool edge_c, edge_r;
 };
-__device__ __forceinline__ bool sift_tile(const SiftGrid& G, int& o, int& index, int& bx, int& by) {
-  const int b = blockIdx.x;
-  int z = 0;
-  while (z + 1 < G.n && b >= G.begin[z + 1]) ++z;   // (most blocks belong to the first slices: one or two steps)
-  const int oi = z / kScales;
-  o = G.o_first + oi;
-  index = 1 + z % kScales;
-  const int t = b - G.begin[z];
-  bx = t % G.tiles_x[oi];
-  by = t / G.tiles_x[oi];
-  return b < G.begin[G.n];
+__device__ __forceinline__ GradTaps grad_taps(int rows, int cols, int i, int j) {
+  GradTaps t;
+  const int jm = j > 0 ? j - 1 : 0, jp = j < cols - 1 ? j + 1 : cols - 1;
+  const int im = i > 0 ? i - 1 : 0, ip = i < rows - 1 ? i + 1 : rows - 1;
+  t.a = (size_t)i * cols + jm;
+  t.b = (size_t)i * cols + jp;
+  t.u = (size_t)im * cols + j;
+  t.d = (size_t)ip * cols + j;
+  t.edge_c = j == 0 || j == cols - 1;
+  t.edge_r = i == 0 || i == rows - 1;
+  return t;
 }
-
-__global__ void grad_ori_kernel(SiftPyramid P, SiftGrid G, SiftBatch Bt) {
-  const size_t off = blockIdx.y * Bt.pyr_step;   // image of a batch
-  int o, index, bx, by;
-  if (!sift_tile(G, o, index, bx, by)) return;
-  const SiftOctave& O = P.oct[o];
-  const int rows = O.rows, cols = O.cols;
-  const int j = bx * blockDim.x + threadIdx.x;
-  const int i = by * blockDim.y + threadIdx.y;
-  if (j >= cols || i >= rows) return;
-  const float* im = O.gaus[index] + off;
-  const float* p = im + (size_t)i * cols;
-  float dc, dr;
-  if (j == 0) dc = __fmul_rn(2.0f, __fsub_rn(p[1], p[0]));
-  else if (j == cols - 1) dc = __fmul_rn(2.0f, __fsub_rn(p[j], p[j - 1]));
-  else dc = __fsub_rn(p[j + 1], p[j - 1]);
-  if (i == 0) dr = __fmul_rn(2.0f, __fsub_rn(p[j], p[cols + j]));
-  else if (i == rows - 1) dr = __fmul_rn(2.0f, __fsub_rn(p[-cols + j], p[j]));
-  else dr = __fsub_rn(p[-cols + j], p[cols + j]);
-  const size_t at = (size_t)i * cols + j;
-  (O.grad[index - 1] + off)[at] = sqrtf(__fadd_rn(__fmul_rn(dc, dc), __fmul_rn(dr, dr)));
-  (O.ori[index - 1] + off)[at] = atan2f(dr, dc);
-  if (index == 1) (O.owner + blockIdx.y * Bt.own_step)[at] = 0xFFFFFFFFu;   // nobody owns the pixel yet (detect_kernel)
+__device__ __forceinline__ void grad_of(float a, float b, float u, float d, bool edge_c, bool edge_r, float& dc, float& dr) {
+  dc = __fsub_rn(b, a);   // p[j + 1] - p[j - 1]; on a border column 2 (p[1] - p[0]) / 2 (p[j] - p[j - 1])
+  if (edge_c) dc = __fmul_rn(2.0f, dc);
+  dr = __fsub_rn(u, d);   // p[i - 1] - p[i + 1]; on a border row 2 (p[i] - p[i + 1]) / 2 (p[i - 1] - p[i])
+  if (edge_r) dr = __fmul_rn(2.0f, dr);
 }
+__device__ __forceinline__ float grad_mag(float dc, float dr) { return sqrtf(__fadd_rn(__fmul_rn(dc, dc), __fmul_rn(dr, dr))); }
 
 // ---- detection ------------------------------------------------------------------------------
 __device__ void solve3(float* Y, float* H) {  // SolveLinearSystem (:1235-1272), dim = 3
@@ -759,7 +741,7 @@ __global__ __launch_bounds__(DT_THREADS) void detect_kernel(SiftPyramid P, Detec
       }
       if (!(fabsf(X[0]) <= 1.5f && fabsf(X[1]) <= 1.5f && fabsf(X[2]) <= 1.5f && fabsf(val) >= peak_thresh)) continue;
       const unsigned key = (unsigned)(index - 1) * (unsigned)(rows * cols) + (unsigned)(r * cols + c);
-      atomicMin(&(O.owner + blockIdx.y * Bt.own_step)[(size_t)rr * cols + cc], key);
+      atomicMin(&(O.owner + blockIdx.y * Bt.own_step)[(size_t)rr * cols + cc], Bt.own_prefix | key);   // (SiftBatch::own_prefix)
       const int at = atomicAdd(n_cand, 1);
       if (at >= cap) {
         *overflow = 1;
@@ -806,9 +788,8 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
     const SiftCandidate k = cand[ci];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
-    if ((O.owner + blockIdx.y * Bt.own_step)[(size_t)k.r * cols + k.c] != k.key) continue;  // another extremum got this pixel first
-    const float* grad = O.grad[k.index - 1] + off;
-    const float* orim = O.ori[k.index - 1] + off;
+    if ((O.owner + blockIdx.y * Bt.own_step)[(size_t)k.r * cols + k.c] != (Bt.own_prefix | k.key)) continue;  // another extremum got this pixel first
+    const float* im = O.gaus[k.index] + off;   // gradients of the key's Gaussian level (grad_of)
     const float fSize = __fmul_rn(kInitSigma, powf(2.0f, __fdiv_rn(__fadd_rn((float)k.index, k.x0), (float)kScales)));
     const float frow = __fadd_rn((float)k.r, k.x1), fcol = __fadd_rn((float)k.c, k.x2);
     const int rowstart = (int)__fadd_rn(frow, 0.5f), colstart = (int)__fadd_rn(fcol, 0.5f);
@@ -821,38 +802,51 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
     // All batches' gradient / orientation values are fetched FIRST -- batch by batch every fetch was two dependent trips
     // to L2 / HBM in front of a few hundred cycles of work (0.048 ms per frame, most of it waiting); windows of more than
     // OR_MAXB batches (fSize > 3.9) finish with fetches of their own.
-    constexpr int OR_MAXB = 20;
-    float gv[OR_MAXB], ov[OR_MAXB];
+    constexpr int OR_MAXB = 12;
+    float dcv[OR_MAXB], drv[OR_MAXB];   // a sample's column / row difference (zero: no sample)
+    {
+      float pa[OR_MAXB], pb[OR_MAXB], pu[OR_MAXB], pd[OR_MAXB];
+      unsigned edges = 0;
 #pragma unroll
-    for (int b = 0; b < OR_MAXB; ++b) {
-      gv[b] = 0.f;
-      ov[b] = 0.f;
-      const int s = b * 64 + lane;
-      if (s < total) {
-        const int r = rowstart - win + s / side, c = colstart - win + s % side;
-        if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
-          gv[b] = grad[(size_t)r * cols + c];
-          ov[b] = orim[(size_t)r * cols + c];
+      for (int b = 0; b < OR_MAXB; ++b) {
+        pa[b] = pb[b] = pu[b] = pd[b] = 0.f;
+        const int s = b * 64 + lane;
+        if (s < total) {
+          const int r = rowstart - win + s / side, c = colstart - win + s % side;
+          if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
+            const GradTaps t = grad_taps(rows, cols, r, c);
+            pa[b] = im[t.a];
+            pb[b] = im[t.b];
+            pu[b] = im[t.u];
+            pd[b] = im[t.d];
+            edges |= (t.edge_c ? 1u : 0u) << (2 * b) | (t.edge_r ? 2u : 0u) << (2 * b);
+          }
         }
       }
+#pragma unroll
+      for (int b = 0; b < OR_MAXB; ++b) grad_of(pa[b], pb[b], pu[b], pd[b], (edges >> (2 * b)) & 1u, (edges >> (2 * b)) & 2u, dcv[b], drv[b]);
     }
     // The window's samples 64 at a time: every lane's (bin, weighted magnitude), the ones that count packed into a list in
     // LDS in raster order (one ballot per 64); then lane b < 36 walks the whole list and adds the entries of bin b -- the
     // serial code's order per bin.  (Until round 5 the wavefront folded every sample into its bin one after the other with
     // two readlanes each: ~7 instructions per sample on all lanes against 4 here, 57 us at 2 700 candidates.)
-    auto sample = [&](int s, float g, float ori, bool fetched, int& bin, float& val) {
+    auto sample = [&](int s, float gdc, float gdr, bool fetched, int& bin, float& val) {
       bin = -1;
       val = 0.f;
       if (s < total) {
         const int r = rowstart - win + s / side, c = colstart - win + s % side;
         if (r >= 0 && r < rows - 2 && c >= 0 && c < cols - 2) {
-          if (!fetched) g = grad[(size_t)r * cols + c];
+          if (!fetched) {
+            const GradTaps t = grad_taps(rows, cols, r, c);
+            grad_of(im[t.a], im[t.b], im[t.u], im[t.d], t.edge_c, t.edge_r, gdc, gdr);
+          }
+          const float g = grad_mag(gdc, gdr);
           if (g > 0) {
             const float dr = __fsub_rn((float)r, frow), dc = __fsub_rn((float)c, fcol);
             const float rad2 = __fadd_rn(__fmul_rn(dr, dr), __fmul_rn(dc, dc));
             if (__fadd_rn((float)(win * win), 0.5f) > rad2) {
               const float w = expf(__fmul_rn(rad2, fexpmult));
-              if (!fetched) ori = orim[(size_t)r * cols + c];
+              const float ori = atan2f(gdr, gdc);
               bin = (int)__fadd_rn(__fmul_rn(ori, fbinmult), fbinadd);
               if (bin > 36) bin = 0;
               if (bin == 36) bin = 35;
@@ -881,7 +875,7 @@ __global__ __launch_bounds__(64) void orient_kernel(SiftPyramid P, const SiftCan
           if (b * 64 >= s1) break;
           int bin;
           float val;
-          sample(b * 64 + lane, gv[b], ov[b], true, bin, val);
+          sample(b * 64 + lane, dcv[b], drv[b], true, bin, val);
           push(bin, val);
         }
       }
@@ -1064,8 +1058,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
     const SiftKey k = keys[ki];
     const SiftOctave& O = P.oct[k.octave];
     const int rows = O.rows, cols = O.cols;
-    const float* grad = O.grad[k.index - 1] + off;
-    const float* orim = O.ori[k.index - 1] + off;
+    const float* im = O.gaus[k.index] + off;   // gradients of the key's Gaussian level (grad_of)
     const float fSize = k.fsize, frow = k.frow, fcol = k.fcol, ang = k.ori;
     const int rowstart = (int)__fadd_rn(frow, 0.5f), colstart = (int)__fadd_rn(fcol, 0.5f);
     const float sinang = sinf(ang), cosang = cosf(ang);
@@ -1122,12 +1115,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
     DPF(0);
     // sample t of the walk: its window row / column, and its two values when its pixel exists
     struct Sample {
-      bool have;
+      bool have, edge_c, edge_r;
       int row, col;
-      float g, o;
+      float a, b, u, d;   // the pixel's left / right / upper / lower neighbour
     };
     auto fetch = [&](int t) -> Sample {
-      Sample q{false, 0, 0, 0.f, 0.f};
+      Sample q{false, false, false, 0, 0, 0.f, 0.f, 0.f, 0.f};
       if (t >= total) return q;
       if (compact) {
         // the row of the chunk's first sample, then at most a few rows on (four bounds read at once; rows of fewer than 16
@@ -1146,8 +1139,13 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
       const int r = rowstart + q.row, c = colstart + q.col;
       if (r >= 0 && r < rows && c >= 0 && c < cols) {
         q.have = true;
-        q.g = grad[(size_t)r * cols + c];
-        q.o = orim[(size_t)r * cols + c];
+        const GradTaps t = grad_taps(rows, cols, r, c);
+        q.a = im[t.a];
+        q.b = im[t.b];
+        q.u = im[t.u];
+        q.d = im[t.d];
+        q.edge_c = t.edge_c;
+        q.edge_r = t.edge_r;
       }
       return q;
     };
@@ -1167,8 +1165,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES, MH_DESC_MINW) void describe_kernel
         if (rx > -0.9999f && rx < 3.9999f && cx > -0.9999f && cx < 3.9999f) {
           ok = true;
           const float e = expf(__fmul_rn(-0.125f, __fadd_rn(__fmul_rn(rpos, rpos), __fmul_rn(cpos, cpos))));
-          mag = __fmul_rn(q.g, e);
-          float oo = __fsub_rn(q.o, ang);
+          float gdc, gdr;
+          grad_of(q.a, q.b, q.u, q.d, q.edge_c, q.edge_r, gdc, gdr);
+          mag = __fmul_rn(grad_mag(gdc, gdr), e);
+          float oo = __fsub_rn(atan2f(gdr, gdc), ang);
           while (oo > 2 * kPi) oo = __fsub_rn(oo, 2 * kPi);
           while (oo < 0) oo = __fadd_rn(oo, 2 * kPi);
           const float oribin = __fmul_rn(oo, 8.0f / (2 * (float)kPi));   // PlaceInIndex
@@ -1435,12 +1435,21 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
     const size_t px = (size_t)O.rows * O.cols;
     for (int i = 0; i < kScales + 3; ++i, p += px) O.gaus[i] = p;
     for (int i = 0; i < kScales + 2; ++i, p += px) O.dog[i] = p;
-    for (int i = 0; i < kScales; ++i, p += px) O.grad[i] = p;
-    for (int i = 0; i < kScales; ++i, p += px) O.ori[i] = p;
     O.owner = own;
     own += px;
   }
-  // (the counters are cleared by prepare_kernel, the owner map by grad_ori_kernel: three fill launches less per image)
+  // (the counters are cleared by prepare_kernel; the owner map is not cleared at all: SiftBatch::own_prefix)
+  {
+    unsigned key_bits = 1;
+    while (key_bits < 32 && (1ull << key_bits) < (unsigned long long)kScales * plan.rows[0] * plan.cols[0]) ++key_bits;
+    const unsigned n_prefix = key_bits >= 31 ? 1u : 1u << (32 - key_bits);   // (a key is below kScales rows cols of octave 0)
+    if (*B.own_epoch == 0 || n_prefix == 1) {
+      hipMemsetAsync(B.owner, 0xFF, B.owner_elems * sizeof(unsigned int) * B.images, s);
+      *B.own_epoch = n_prefix;
+    }
+    --*B.own_epoch;
+    Bt.own_prefix = key_bits >= 32 ? 0u : *B.own_epoch << key_bits;
+  }
 
   const SiftOctave& O0 = P.oct[0];
   const dim3 tb(256);
@@ -1496,21 +1505,9 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
       o_small = o;
       break;
     }
-  // gradients / orientations, then extrema, of octaves [o_lo, o_hi) on stream st
-  auto grad_detect = [&](int o_lo, int o_hi, hipStream_t st) {
+  // extrema of octaves [o_lo, o_hi) on stream st
+  auto detect = [&](int o_lo, int o_hi, hipStream_t st) {
     if (o_hi <= o_lo) return;
-    const dim3 tb2(64, 4);
-    SiftGrid G;
-    G.n = (o_hi - o_lo) * kScales;
-    G.o_first = o_lo;
-    G.begin[0] = 0;
-    for (int o = o_lo; o < o_hi; ++o) {
-      const int oi = o - o_lo;
-      G.tiles_x[oi] = (plan.cols[o] + 63) / 64;
-      for (int i = 0; i < kScales; ++i)
-        G.begin[oi * kScales + i + 1] = G.begin[oi * kScales + i] + G.tiles_x[oi] * ((plan.rows[o] + 3) / 4);
-    }
-    hipLaunchKernelGGL(grad_ori_kernel, dim3(G.begin[G.n], un), tb2, 0, st, P, G, Bt);
     DetectGrid DG;
     DG.n = o_hi - o_lo;
     DG.o_first = o_lo;
@@ -1619,7 +1616,7 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
   }
     if (o_small < plan.n_octaves) small_chain();   // (the loop above wrote the half-size copy already: the same numbers again)
   }
-  grad_detect(0, plan.n_octaves, s);
+  detect(0, plan.n_octaves, s);
   // (the per-key kernels loop over the keys: a batch's images share the chip, fewer workgroups per image)
   const unsigned per = n > 4 ? 4 : 1;
   hipLaunchKernelGGL(orient_kernel, dim3(4096 / per, un), dim3(64), 0, s, P, (const SiftCandidate*)B.cand,
