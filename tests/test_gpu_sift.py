@@ -114,3 +114,23 @@ def test_hip_sift_flat_image_and_capacity(ctx):
     tiny = np.zeros((6, 6), np.uint8)
     with pytest.raises(capi.MhError):
         ctx.sift(tiny)
+
+
+def test_owner_map_is_never_cleared_across_1100_images(ctx):
+    """The per-pixel owner map (which extremum got a pixel first, libsiftfast's s_MaxMinArray) is not cleared between
+    images: a claim is `epoch prefix | generation key`, the prefix goes down from image to image and claims go in with
+    atomicMin (SiftBatch::own_prefix, csrc/sift.h).  A doubled 640x480 frame leaves 10 bits of prefix: after 1 024 images
+    the map is filled again.  Two different frames alternate through more than one such cycle -- a stale claim that
+    survived would cost the other frame a keypoint -- and every result must be, bit for bit, the frame's first one."""
+    fr = [int(x) for x in GOLD["frames"]]
+    a, b = GOLD[f"gray{fr[0]}"], GOLD[f"gray{fr[-1]}"]
+    first = {}
+    for i in range(1100):
+        which = i & 1
+        xy, so, d = ctx.sift(b if which else a)
+        if which not in first:
+            first[which] = (xy.copy(), so.copy(), d.copy())
+            assert len(xy) > 300
+        elif i % 37 < 2 or i > 1015:          # (every call runs; a sample of them is compared, all of them around the refill)
+            fx, fs, fd = first[which]
+            assert np.array_equal(xy, fx) and np.array_equal(so, fs) and np.array_equal(d.view(np.uint32), fd.view(np.uint32)), i
