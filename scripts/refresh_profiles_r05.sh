@@ -122,7 +122,13 @@ if has feat; then
   timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 > $out/r05_image_frame_bench.txt 2>&1
   timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 8 >> $out/r05_image_frame_bench.txt 2>&1
   timeout -k 10 300 python3 scripts/image_frame_bench.py 20 16 2000 16 >> $out/r05_image_frame_bench.txt 2>&1
-  cat $out/r05_sift_size_probe.txt; grep -v amdgpu $out/r05_image_frame_bench.txt | grep "image->"
+  # the batch path's kernels (16 slots x 16 images) and the FEAT stages' HBM traffic (counter passes of their own)
+  cd /tmp && rm -rf /tmp/ifb
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ifb -- python3 $root/scripts/image_frame_bench.py 20 16 2000 16 > /dev/null 2>&1
+  cp $(find /tmp/ifb -name "*kernel_stats.csv" | head -1) $out/r05_image_batch16_kernel_stats.csv
+  cd $root
+  bash scripts/pmc_feat.sh $out/r05_feat_traffic.txt > /dev/null
+  cat $out/r05_sift_size_probe.txt; grep -v amdgpu $out/r05_image_frame_bench.txt | grep "image->"; cat $out/r05_feat_traffic.txt
 fi
 if has stress; then
   # (the 2 x 1000-scene frame stress of round 5 runs as two calls of its own: gpurun_out/r05_frame_stress_{a,b}.txt)

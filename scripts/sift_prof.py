@@ -1,4 +1,6 @@
-"""Phase cycle counts of describe_kernel over one image alone (needs a build with EXTRA=-DSIFT_PROF; MH_LIB_PATH).
+"""Phase tick counts (clock64; read them as shares of a key's time: the tick is not calibrated against the kernel's
+duration and the build costs 21 more registers) of describe_kernel over one image alone (needs a build with
+EXTRA=-DSIFT_PROF; MH_LIB_PATH).
 usage: sift_prof.py [textured|bundled]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
