@@ -971,6 +971,14 @@ def main():
         if job.n_vis != args.n_vis:
             job.load_frames(args.n_vis)
 
+    # ---- image in, objects out (the next row in front of the path: FEAT on the device) ----
+    if world == 1 and not args.no_secondary and not (args.depth_kind or args.moped3d_frontend) and not args.no_adaptive:
+        arm_watchdog(wd)
+        try:
+            out["image_to_objects"] = image_to_objects_leg(args)
+        except Exception as e:    # a reported extra: the line survives, the failure is in it
+            out["image_to_objects"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- secondary partitions / workloads in the same line (all ranks take part) ----
     if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
         sec_steps = max(1, args.secondary_steps)
@@ -1051,6 +1059,90 @@ def main():
         job.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
+    """SURVEY 8(f) N2 in front of the path: 8-bit 640x480 frames in, objects out -- FEAT (SIFT, csrc/sift.hip: what
+    FEAT_SIFT_CPU::process does, moped2/libmoped/src/feat/FEAT_SIFT_CPU.hpp:78-112), MATCH .. FILTER2 on the device,
+    `batch` images per launch sequence (mh_frame_enqueue_image_batch), `slots` contexts in flight.  The frames are the
+    reference's bundled test frames (tests/golden/sift_ref_frames.npz, ~590 keypoints each); the DB is the synthetic
+    one plus frame 0's own keypoints as a planar model, so every frame of the pool that shows it yields an object.
+    Images resident in HBM, like the descriptors of the judged line."""
+    import torch
+    from moped_amd import capi, synth
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "sift_ref_frames.npz"))
+    K, CAM0 = synth.K_DEFAULT, synth.CAM_IDENTITY
+    dev = torch.device("cuda:0")
+    db = synth.make_db(args.models, 5000)
+    c0 = capi.Context(0)
+    xy, _, desc = c0.sift(gold["gray0"])
+    z = np.float32(0.8)
+    xyz = np.stack([(xy[:, 0] - K[2]) / K[0] * z, (xy[:, 1] - K[3]) / K[1] * z, np.full(len(xy), z)], 1).astype(np.float32)
+    all_desc = c0.normalize(np.concatenate([db.desc, desc]))
+    all_xyz = np.concatenate([db.xyz, xyz])
+    model_of = np.concatenate([db.model_of, np.full(len(xy), args.models, np.int32)])
+    c0.close()
+    ctxs, streams = [], []
+    try:
+        for i in range(slots):
+            c = capi.Context(0)
+            st = torch.cuda.Stream(device=dev)
+            c.set_stream(st.cuda_stream)
+            if i == 0:
+                c.db_upload(all_desc, model_of, all_xyz, args.models + 1)
+            else:
+                c.db_share(ctxs[0])
+            c.reserve(1024 * batch)
+            ctxs.append(c)
+            streams.append(st)
+        imgs = [torch.from_numpy(gold[f"gray{int(f)}"]).to(dev) for f in gold["frames"]]
+        h, w = gold["gray0"].shape
+        prm = capi.default_frame_params()
+        cam = capi.make_cam(K, CAM0)
+        torch.cuda.synchronize()
+
+        def go(k):
+            for g in range(k // batch):
+                ptrs = [imgs[(g * batch + j) % len(imgs)].data_ptr() for j in range(batch)]
+                ctxs[g % slots].frame_enqueue_image_batch(ptrs, w, h, True, 1024, K, CAM0, prm,
+                                                         [g * batch + j + 1 for j in range(batch)], _cam_struct=cam)
+        go(2 * slots * batch)
+        for c in ctxs:
+            c.frame_fetch_slot(0)
+        frames = max(slots * batch, frames // (slots * batch) * slots * batch)
+        t0 = time.perf_counter()
+        go(frames)
+        for st in streams:
+            st.synchronize()
+        dt = time.perf_counter() - t0
+        n_obj, best = [], []
+        for j in range(batch):    # the last batch's frames: frame 0's object where frame 0 is the image
+            objs, _ = ctxs[(frames // batch - 1) % slots].frame_fetch_slot(j)
+            n_obj.append(len(objs))
+            best.append(int(objs[np.argmax(objs["score"])]["model"]) if len(objs) else -1)
+        # SIFT alone, one image at a time
+        c = ctxs[0]
+        cap = 4096
+        d_, xy_, cnt = (torch.empty((cap, 128), device=dev), torch.empty((cap, 2), device=dev),
+                        torch.zeros(1, dtype=torch.int32, device=dev))
+        for _ in range(20):
+            c.sift_dev(imgs[0].data_ptr(), w, h, True, d_.data_ptr(), xy_.data_ptr(), 0, cap, cnt.data_ptr())
+        streams[0].synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            c.sift_dev(imgs[0].data_ptr(), w, h, True, d_.data_ptr(), xy_.data_ptr(), 0, cap, cnt.data_ptr())
+        streams[0].synchronize()
+        sift_ms = (time.perf_counter() - t0) / 200 * 1e3
+        return {"value": round(frames / dt, 1), "unit": "frames/s", "frames": frames, "slots": slots,
+                "images_per_launch_sequence": batch, "image": "640x480 8-bit, doubled (ScaleOrigin -1)",
+                "keypoints_per_image": int(cnt.item()), "objects_per_frame_last_batch": n_obj,
+                "frames_of_the_last_batch_whose_best_object_is_the_planted_model": int(sum(b == args.models for b in best)),
+                "sift_alone_ms": round(sift_ms, 4),
+                "what": "FEAT(SIFT) + MATCH + CLUSTER + POSE + FILTER + POSE2 + FILTER2 on the device from the image; "
+                        "data: the reference's bundled test frames, DB = the synthetic models + frame 0's keypoints as a planar model"}
+    finally:
+        for c in ctxs[1:] + ctxs[:1]:
+            c.close()
 
 
 def host_side_figures(args, db, frames):
