@@ -126,3 +126,17 @@ def test_batch_of_images_equals_the_images_alone(scene):
     c.frame_enqueue_image(imgs[0].data_ptr(), w, h, True, CAP, K, CAM0, prm, seed=40)
     again, _ = c.frame_fetch()
     assert again.tobytes() == alone[0][0].tobytes()
+
+
+def test_bench_image_leg_finds_the_planted_model_in_every_frame():
+    """bench.py's `image_to_objects` leg (what the driver's line reports for FEAT in front of the path): a small run of it
+    -- two slots, batches of 16 images -- must find the planar model planted from frame 0's keypoints in every frame of
+    the last batch, as its best object."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.image_to_objects_leg(argparse.Namespace(models=5), frames=64, slots=2, batch=16)
+    assert r["value"] > 0 and r["frames"] == 64 and r["keypoints_per_image"] > 300
+    assert r["frames_of_the_last_batch_whose_best_object_is_the_planted_model"] == 16
+    assert all(n >= 1 for n in r["objects_per_frame_last_batch"]) and 0 < r["sift_alone_ms"] < 5
