@@ -21,8 +21,8 @@ namespace {
 
 void free_sift(SiftState* st) {
   if (!st) return;
-  void* ptrs[] = {st->B.pyramid, st->B.tmp, st->B.owner, st->B.cand,     st->B.keys, st->B.desc_tmp,
-                  st->B.geo_tmp, st->B.counters, st->gray, st->desc, st->xy,     st->scale_ori, st->n_dev};
+  void* ptrs[] = {st->B.pyramid, st->B.tmp, st->B.owner, st->B.cand, st->B.keys, st->B.counters,
+                  st->gray,      st->desc,  st->xy,      st->scale_ori, st->n_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete st;

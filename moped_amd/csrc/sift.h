@@ -68,8 +68,6 @@ struct SiftBuffers {
   int cand_cap;
   SiftKey* keys;
   int key_cap;
-  float* desc_tmp;          // (both unused since round 5: describe_kernel finds a key's place in the list itself and
-  float* geo_tmp;           //  writes the descriptor there)
   int32_t* counters;        // [4]: candidates, keys, overflow flag, -
   int images;               // every array above holds this many images' worth, one after the other
   unsigned int* own_epoch;  // host word: the prefix counter of the owner map (SiftBatch::own_prefix); starts at 0 = fill first

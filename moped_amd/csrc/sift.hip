@@ -288,10 +288,10 @@ __device__ __forceinline__ void blur_tile_fixed(const BlurJob& job, const float*
       if (r >= rows || c >= cols) continue;
       const size_t at = (size_t)r * cols + c;
       const float* old = in_s + ((y + W) >> 1) * (2 * IN_WP) + 2 * (x + W) + ((y + W) & 1);   // the source pixel (and its right neighbour: + 2)
-      job.dst[at] = acc[o].x;
+      if (job.dst) job.dst[at] = acc[o].x;   // (an octave's last level is read by nobody: only its DoG is kept)
       if (job.dog) job.dog[at] = __fsub_rn(old[0], acc[o].x);
       if (c + 1 < cols) {
-        job.dst[at + 1] = acc[o].y;
+        if (job.dst) job.dst[at + 1] = acc[o].y;
         if (job.dog) job.dog[at + 1] = __fsub_rn(old[2], acc[o].y);
       }
     }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
   BlurJob job = J.j[jn];
   if (blockIdx.y) {   // image of a batch
     job.src += blockIdx.y * job.src_step;
-    job.dst += blockIdx.y * job.pyr_step;
+    if (job.dst) job.dst += blockIdx.y * job.pyr_step;
     if (job.dog) job.dog += blockIdx.y * job.pyr_step;
     if (job.half_dst) job.half_dst += blockIdx.y * job.pyr_step;
   }
@@ -356,10 +356,10 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
     for (int j = 0; j < t.n; ++j) a = a + *reinterpret_cast<const v2f*>(col + j * BT_X) * v2f{t.k[j], t.k[j]};
     const size_t o = (size_t)r * cols + c;
     const float* old = in_s + (y + w) * in_w + (x + w);
-    job.dst[o] = a.x;
+    if (job.dst) job.dst[o] = a.x;
     if (job.dog) job.dog[o] = __fsub_rn(old[0], a.x);
     if (c + 1 < cols) {
-      job.dst[o + 1] = a.y;
+      if (job.dst) job.dst[o + 1] = a.y;
       if (job.dog) job.dog[o + 1] = __fsub_rn(old[1], a.y);
     }
   }
@@ -1538,7 +1538,7 @@ void launch_sift_images(const uint8_t* const* grays, int n, int width, int heigh
       BlurJob b;
       b.rows = O.rows;
       b.cols = O.cols;
-      b.dst = O.gaus[i];
+      b.dst = i == kScales + 2 ? nullptr : O.gaus[i];   // (the last level: nobody reads it, its DoG is all that is kept)
       b.dog = O.dog[i - 1];
       b.taps = i - 1;
       b.tiles_x = (O.cols + BT_X - 1) / BT_X;
