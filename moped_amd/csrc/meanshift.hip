@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
   // whose number -- counted through the frames -- is its own modulo the grid.  The workgroup that finishes a frame's
   // last model lays the frame's cluster table out (a frame with nothing to cluster: workgroup frame mod grid).
   __shared__ unsigned long long busy[MS_WAVES];
+  __shared__ int lay_s[MS_WAVES];
   const int G = (int)gridDim.x;
   const int n_frames = fbx.n > 1 ? fbx.n : 1;
   int rank = 0;   // models with work, counted through the frames of the launch
@@ -1099,34 +1100,62 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
     bool last = false;
     if (mine > 0) last = frame_work_done(ticket, (unsigned)mine, (unsigned)n_busy);
     else if (n_busy == 0) last = (int)blockIdx.x == f % G;
-    if (!last || threadIdx.x != 0) continue;
-    if (feedback) feedback[f] = n_busy;   // what the next launches size their grids by
+    if (!last) continue;   // (`last` is the same in every thread of the workgroup)
+    if (threadIdx.x == 0 && feedback) feedback[f] = n_busy;   // what the next launches size their grids by
+    // The frame's cluster table in (model, emission) order, by the whole workgroup: thread mm reads model mm's cluster
+    // count, a prefix sum over the models gives its clusters their places.  (One thread walking the models -- two or
+    // three dependent global loads per model, a store between them -- kept the workgroup that finished the frame's
+    // longest problem another ~15 us on a 20-model frame: the tail of CLUSTER's 103 us in a frame alone.)
     int32_t* cl_model = frame_ptr(cl_model0, a);
     int32_t* cl_begin = frame_ptr(cl_begin0, a);
     int32_t* cl_count = frame_ptr(cl_count0, a);
-    int k = 0;
-    for (int mm = 0; mm < n_models; ++mm) {
-      const int bb = model_off[mm];
-      const int nn = model_off[mm + 1] - bb;
+    int k0 = 0;
+    for (int c0 = 0; c0 < n_models; c0 += MS_THREADS) {
+      const int mm = c0 + threadIdx.x;
+      int nc = 0, bb = 0;
+      if (mm < n_models) {
+        bb = model_off[mm];
+        const int nn = model_off[mm + 1] - bb;
+        const bool work = nn > 0 && nn >= min_pts;
+        nc = work ? ncl[mm] : 0;          // (a model without work was never clustered)
+        if (!work) ncl[mm] = 0;
+      }
+      int incl = nc;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += up;
+      }
+      __syncthreads();   // (lay_s of the chunk before)
+      if ((threadIdx.x & 63) == 63) lay_s[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < MS_WAVES; ++w) {
+        const int c = lay_s[w];
+        if (w < (int)(threadIdx.x >> 6)) before += c;
+        total += c;
+      }
+      const int first = k0 + before + incl - nc;
       const int32_t* st = cl_start + bb + mm;
-      const int nc = (nn > 0 && nn >= min_pts) ? ncl[mm] : 0;   // (a model without work was never clustered)
-      if (!(nn > 0 && nn >= min_pts)) ncl[mm] = 0;
       for (int c = 0; c < nc; ++c) {
-        if (k >= max_clusters) {
-          atomicOr(&counts->error, ERR_CLUSTER_CAP);
-          break;
-        }
+        const int k = first + c;
+        if (k >= max_clusters) break;     // (the table is full: ERR_CLUSTER_CAP below)
         cl_model[k] = mm / models_div;
         cl_begin[k] = bb + st[c];
         cl_count[k] = st[c + 1] - st[c];
-        ++k;
       }
+      k0 += total;
     }
-    counts->n_clusters = k;
-    *frame_ptr(n_clusters_out0, a) = k;
-    if (snap0) {
-      snap0[4 * f] = counts->n_matches;
-      snap0[4 * f + 1] = k;
+    if (threadIdx.x == 0) {
+      if (k0 > max_clusters) atomicOr(&counts->error, ERR_CLUSTER_CAP);
+      const int k = k0 < max_clusters ? k0 : max_clusters;
+      counts->n_clusters = k;
+      *frame_ptr(n_clusters_out0, a) = k;
+      if (snap0) {
+        snap0[4 * f] = counts->n_matches;
+        snap0[4 * f + 1] = k;
+      }
     }
   }
 }
