@@ -215,6 +215,57 @@ __device__ __forceinline__ bool frame_work_done(unsigned int* ticket, unsigned i
   if (last) __threadfence();   // acquire: everybody else's results
   return last;
 }
+// The frame's cluster table in (model, emission) order -- the order POSE walks `clusters[model]`
+// (POSE_RANSAC_LM_DIFF_REPROJECTION_CPU.hpp:276-280) -- written by the WHOLE workgroup that closes the frame's CLUSTER
+// step: thread mm reads model mm's cluster count (zero, and stored as zero, for a model `work(points)` says was never
+// clustered), a prefix sum over the models gives its clusters their places; clusters past `max_clusters` are dropped.
+// Returns the number of clusters the models hold (the caller reports more than max_clusters as ERR_CLUSTER_CAP).  All
+// threads call it; lay_s: blockDim.x / 64 words of LDS.  (One thread walking the models -- two or three dependent global
+// loads per model, a store between them -- kept the closing workgroup ~15 us longer on a 20-model frame.)
+template <typename WorkFn>
+__device__ __forceinline__ int layout_cluster_table(int n_models, const int32_t* __restrict__ model_off, int32_t* ncl,
+                                                    const int32_t* cl_start, int models_div, int max_clusters,
+                                                    int32_t* __restrict__ cl_model, int32_t* __restrict__ cl_begin,
+                                                    int32_t* __restrict__ cl_count, int* lay_s, WorkFn work) {
+  const int n_waves = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  int k0 = 0;
+  for (int c0 = 0; c0 < n_models; c0 += (int)blockDim.x) {
+    const int mm = c0 + (int)threadIdx.x;
+    int nc = 0, bb = 0;
+    if (mm < n_models) {
+      bb = model_off[mm];
+      const bool w = work(model_off[mm + 1] - bb);
+      nc = w ? ncl[mm] : 0;
+      if (!w) ncl[mm] = 0;
+    }
+    int incl = nc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    __syncthreads();   // (lay_s of the chunk before)
+    if (lane == 63) lay_s[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const int c = lay_s[w];
+      if (w < wave) before += c;
+      total += c;
+    }
+    const int first = k0 + before + incl - nc;
+    const int32_t* st = cl_start + bb + mm;
+    for (int c = 0; c < nc; ++c) {
+      const int k = first + c;
+      if (k >= max_clusters) break;
+      cl_model[k] = mm / models_div;
+      cl_begin[k] = bb + st[c];
+      cl_count[k] = st[c + 1] - st[c];
+    }
+    k0 += total;
+  }
+  return k0;
+}
 #endif
 
 // Depth map of the frame as moped3d holds it (moped3d/moped3d.cpp:279-333): 4 floats per pixel

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(LK_THREADS) void linkage_models_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LkLds& L = *reinterpret_cast<LkLds*>(smem);
   __shared__ unsigned long long busy[LK_THREADS / 64];
+  __shared__ int lay_s[LK_THREADS / 64];
   const int G = (int)gridDim.x;
   const int n_frames = fbx.n > 1 ? fbx.n : 1;
   int rank = 0;   // models with work, counted through the frames of the launch
@@ -478,34 +479,22 @@ __global__ __launch_bounds__(LK_THREADS) void linkage_models_kernel(
     bool last = false;
     if (mine > 0) last = frame_work_done(ticket, (unsigned)mine, (unsigned)n_busy);
     else if (n_busy == 0) last = (int)blockIdx.x == f % G;
-    if (!last || threadIdx.x != 0) continue;
-    if (feedback) feedback[f] = n_busy;   // what the next launches size their grids by
-    int32_t* cl_model = frame_ptr(cl_model0, a);
-    int32_t* cl_begin = frame_ptr(cl_begin0, a);
-    int32_t* cl_count = frame_ptr(cl_count0, a);
-    int k = 0;
-    for (int mm = 0; mm < n_models; ++mm) {
-      const int bb = model_off[mm];
-      const bool work = model_off[mm + 1] - bb > P.min_pts;
-      const int32_t* st = cl_start + bb + mm;
-      const int nc = work ? ncl[mm] : 0;   // (a model without work was never clustered)
-      if (!work) ncl[mm] = 0;
-      for (int c = 0; c < nc; ++c) {
-        if (k >= max_clusters) {
-          atomicOr(&counts->error, ERR_CLUSTER_CAP);
-          break;
-        }
-        cl_model[k] = mm;
-        cl_begin[k] = bb + st[c];
-        cl_count[k] = st[c + 1] - st[c];
-        ++k;
+    if (!last) continue;   // (`last` is the same in every thread of the workgroup)
+    if (threadIdx.x == 0 && feedback) feedback[f] = n_busy;   // what the next launches size their grids by
+    // the frame's cluster table, by the whole workgroup (layout_cluster_table, common.h)
+    const int min_pts = P.min_pts;
+    const int k0 = layout_cluster_table(n_models, model_off, ncl, cl_start, 1, max_clusters, frame_ptr(cl_model0, a),
+                                        frame_ptr(cl_begin0, a), frame_ptr(cl_count0, a), lay_s,
+                                        [min_pts](int nn) { return nn > min_pts; });   // (a model without work was never clustered)
+    if (threadIdx.x == 0) {
+      if (k0 > max_clusters) atomicOr(&counts->error, ERR_CLUSTER_CAP);
+      const int k = k0 < max_clusters ? k0 : max_clusters;
+      counts->n_clusters = k;
+      *frame_ptr(n_clusters_out0, a) = k;
+      if (snap0) {
+        snap0[4 * f] = counts->n_matches;
+        snap0[4 * f + 1] = k;
       }
-    }
-    counts->n_clusters = k;
-    *frame_ptr(n_clusters_out0, a) = k;
-    if (snap0) {
-      snap0[4 * f] = counts->n_matches;
-      snap0[4 * f + 1] = k;
     }
   }
 }

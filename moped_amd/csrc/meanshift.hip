@@ -1102,51 +1102,10 @@ __global__ __launch_bounds__(MS_THREADS) void meanshift_models_kernel(
     else if (n_busy == 0) last = (int)blockIdx.x == f % G;
     if (!last) continue;   // (`last` is the same in every thread of the workgroup)
     if (threadIdx.x == 0 && feedback) feedback[f] = n_busy;   // what the next launches size their grids by
-    // The frame's cluster table in (model, emission) order, by the whole workgroup: thread mm reads model mm's cluster
-    // count, a prefix sum over the models gives its clusters their places.  (One thread walking the models -- two or
-    // three dependent global loads per model, a store between them -- kept the workgroup that finished the frame's
-    // longest problem another ~15 us on a 20-model frame: the tail of CLUSTER's 103 us in a frame alone.)
-    int32_t* cl_model = frame_ptr(cl_model0, a);
-    int32_t* cl_begin = frame_ptr(cl_begin0, a);
-    int32_t* cl_count = frame_ptr(cl_count0, a);
-    int k0 = 0;
-    for (int c0 = 0; c0 < n_models; c0 += MS_THREADS) {
-      const int mm = c0 + threadIdx.x;
-      int nc = 0, bb = 0;
-      if (mm < n_models) {
-        bb = model_off[mm];
-        const int nn = model_off[mm + 1] - bb;
-        const bool work = nn > 0 && nn >= min_pts;
-        nc = work ? ncl[mm] : 0;          // (a model without work was never clustered)
-        if (!work) ncl[mm] = 0;
-      }
-      int incl = nc;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if ((int)(threadIdx.x & 63) >= d) incl += up;
-      }
-      __syncthreads();   // (lay_s of the chunk before)
-      if ((threadIdx.x & 63) == 63) lay_s[threadIdx.x >> 6] = incl;
-      __syncthreads();
-      int before = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < MS_WAVES; ++w) {
-        const int c = lay_s[w];
-        if (w < (int)(threadIdx.x >> 6)) before += c;
-        total += c;
-      }
-      const int first = k0 + before + incl - nc;
-      const int32_t* st = cl_start + bb + mm;
-      for (int c = 0; c < nc; ++c) {
-        const int k = first + c;
-        if (k >= max_clusters) break;     // (the table is full: ERR_CLUSTER_CAP below)
-        cl_model[k] = mm / models_div;
-        cl_begin[k] = bb + st[c];
-        cl_count[k] = st[c + 1] - st[c];
-      }
-      k0 += total;
-    }
+    // the frame's cluster table, by the whole workgroup (layout_cluster_table, common.h)
+    const int k0 = layout_cluster_table(n_models, model_off, ncl, cl_start, models_div, max_clusters, frame_ptr(cl_model0, a),
+                                        frame_ptr(cl_begin0, a), frame_ptr(cl_count0, a), lay_s,
+                                        [min_pts](int nn) { return nn > 0 && nn >= min_pts; });   // fewer points than MinPts: never clustered
     if (threadIdx.x == 0) {
       if (k0 > max_clusters) atomicOr(&counts->error, ERR_CLUSTER_CAP);
       const int k = k0 < max_clusters ? k0 : max_clusters;
