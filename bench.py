@@ -1169,7 +1169,9 @@ def host_side_figures(args, db, frames):
                 if r.returncode == 0 and lines:
                     d = json.loads(lines[-1])
                     out["cpp_host"] = d
-                    out["single_frame_latency_ms"] = d["single_frame_latency_ms"]
+                    out["single_frame_latency_ms"] = d["single_frame_latency_ms"]   # descriptors from pinned host memory: PCIe inside the clock
+                    if "single_frame_latency_resident_ms" in d:
+                        out["single_frame_latency_resident_ms"] = d["single_frame_latency_resident_ms"]   # descriptors in HBM, like `value`
                 else:
                     out["cpp_host"] = {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:

@@ -245,16 +245,33 @@ int main(int argc, char** argv) {
   }
   std::sort(lat.begin(), lat.end());
   const double lat_ms = 1e3 * lat[lat.size() / 2];
+  // ... and with the descriptors already in HBM (the convention of the throughput figure above: the 1.5 MB of a frame's
+  // descriptors do not cross PCIe inside the clock; the frame's working copy is made on the device because
+  // mh_frame_enqueue normalises in place)
+  lat.clear();
+  for (int i = 0; i < 60; ++i) {
+    const int fi = i % n_frames;
+    CK_HIP(hipMemcpyAsync(work[0], d_pristine + fd * fi, fd * 4, hipMemcpyDeviceToDevice, stream[0]));
+    CK_HIP(hipStreamSynchronize(stream[0]));
+    const double t0 = now_s();
+    CK_MH(ctx[0], mh_frame_enqueue(ctx[0], work[0], d_uv + fu * fi, Q, &cam, &prm, 77 + i));
+    int32_t n = 0, counts[4];
+    CK_MH(ctx[0], mh_frame_fetch(ctx[0], &objs[0], (int)objs.size(), &n, counts));
+    if (i >= 10) lat.push_back(now_s() - t0);
+  }
+  std::sort(lat.begin(), lat.end());
+  const double lat_res_ms = 1e3 * lat[lat.size() / 2];
   const double opf = frames_counted ? (double)objects_counted / frames_counted : 0.0;
   if (json)
     std::printf("{\"host\": \"moped_hip_bench (C++, C ABI only)\", \"slots\": %d, \"frames_per_batch\": %d, \"steps\": %d, "
-                "\"frames_per_step\": %d, \"fps_resident\": %.2f, \"fps_pinned_host\": %.2f, \"single_frame_latency_ms\": %.4f, "
+                "\"frames_per_step\": %d, \"fps_resident\": %.2f, \"fps_pinned_host\": %.2f, \"single_frame_latency_ms\": %.4f, \"single_frame_latency_resident_ms\": %.4f, "
                 "\"results_delivered\": \"every frame\", \"frames_delivered\": %ld, \"objects_per_frame\": %.3f, "
                 "\"min_objects_per_frame\": %ld, \"max_objects_per_frame\": %ld, \"models\": %d, \"rows\": %d, \"queries\": %d}\n",
-                slots, B, steps, groups * B, fps[0], fps[1], lat_ms, frames_counted, opf, min_per_frame, max_per_frame, nm, N, Q);
+                slots, B, steps, groups * B, fps[0], fps[1], lat_ms, lat_res_ms, frames_counted, opf, min_per_frame, max_per_frame, nm, N, Q);
   else
     std::printf("slots %d x %d frames: %.0f frames/s (inputs in HBM), %.0f frames/s (descriptors from pinned host memory); one "
-                "frame alone %.3f ms; %.2f objects per frame\n", slots, B, fps[0], fps[1], lat_ms, opf);
+                "frame alone %.3f ms from pinned host memory, %.3f ms with its descriptors in HBM; %.2f objects per frame\n", slots, B, fps[0],
+                fps[1], lat_ms, lat_res_ms, opf);
   for (int s = 0; s < slots; ++s) {
     hipFree(work[s]);
     hipHostFree(block[s]);
