@@ -240,7 +240,14 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
       }
       old_of[k] = o;
       fb.obj_model[k] = model;
-      for (int j = 0; j < 7; ++j) fb.obj_pose[7 * k + j] = fb.obj_pose[7 * o + j];
+      {   // (the seven words requested together: copied one by one, every store waited for its load -- seven trips to L2
+          // per kept object in a single thread, ~3.5 us each time an object moved)
+        float pz[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) pz[j] = fb.obj_pose[7 * o + j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) fb.obj_pose[7 * k + j] = pz[j];
+      }
       fb.obj_score[k] = score;
       fb.obj_npts[k] = sz;
       fb.obj_valid[k] = 1;
@@ -288,22 +295,23 @@ __device__ __forceinline__ void filter_finish(FilterLds& S, const FilterBuffers&
   // ---- result block {int32 n; int32 pad[3]; mh_object[n]} (list order) ----
   if (tail.result && tid == 0) {
     mh_object* out = reinterpret_cast<mh_object*>(tail.result + 16);
-    for (int r = 0; r < kept; ++r) {
+    FrameHostBlock* const h = (tail.host && tail.host_seq) ? tail.host : nullptr;   // one frame alone: the same straight into the
+    for (int r = 0; r < kept; ++r) {                                                 // host's page-locked block (no copies at fetch)
       mh_object ob;
       ob.model = fb.obj_model[r];
+#pragma unroll
       for (int j = 0; j < 7; ++j) ob.pose[j] = fb.obj_pose[7 * r + j];
       ob.score = fb.obj_score[r];
       ob.n_points = fb.obj_npts[r];
       out[r] = ob;
+      if (h && r < FRAME_HOST_OBJECTS) h->objects[r] = ob;   // (from the registers: not read back from the result block)
     }
     reinterpret_cast<int32_t*>(tail.result)[0] = kept;
     reinterpret_cast<int32_t*>(tail.result)[1] = counts->error;   // sticky capacity flags of this frame
-    if (tail.host && tail.host_seq) {   // one frame alone: the same straight into the host's page-locked block (no copies at fetch)
-      FrameHostBlock* h = tail.host;
+    if (h) {
       h->head[0] = kept;
       h->head[1] = counts->error;
       h->head[2] = h->head[3] = 0;
-      for (int r = 0; r < kept && r < FRAME_HOST_OBJECTS; ++r) h->objects[r] = out[r];
       for (int i = 0; i < 4; ++i) h->snap[i] = tail.snap_all ? tail.snap_all[i] : 0;
       h->error = counts->error;
       __threadfence_system();
