@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NORM_THREADS) void normalize_kernel(float* __restri
   if (blockIdx.y) {   // image of a batch: its n rows, its count word
     desc += (size_t)blockIdx.y * n * DIM;
     norm_out += (size_t)blockIdx.y * n;
-    n_dev += blockIdx.y;
+    if (n_dev) n_dev += blockIdx.y;
   }
   if (n_dev) n = min(n, *n_dev);   // row count known only on the device (features extracted there)
   const int rows = min(NORM_ROWS, n - (int)row0);
