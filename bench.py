@@ -976,8 +976,12 @@ def main():
         arm_watchdog(wd)
         try:
             out["image_to_objects"] = image_to_objects_leg(args)
+            arm_watchdog(wd)
+            t = image_to_objects_leg(args, frames=1024, image="textured")   # the config's keypoint count
+            out["image_to_objects"]["at_3240_keypoints"] = {k: t[k] for k in ("value", "unit", "frames", "keypoints_per_image", "sift_alone_ms",
+                                                                               "objects_per_frame_last_batch", "image")}
         except Exception as e:    # a reported extra: the line survives, the failure is in it
-            out["image_to_objects"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out.setdefault("image_to_objects", {})["error"] = f"{type(e).__name__}: {e}"[:300]
 
     # ---- secondary partitions / workloads in the same line (all ranks take part) ----
     if not args.no_secondary and not (args.depth_kind or args.moped3d_frontend):
@@ -1061,13 +1065,15 @@ def main():
         dist.destroy_process_group()
 
 
-def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
+def image_to_objects_leg(args, frames=2048, slots=16, batch=16, image="bundled"):
     """SURVEY 8(f) N2 in front of the path: 8-bit 640x480 frames in, objects out -- FEAT (SIFT, csrc/sift.hip: what
     FEAT_SIFT_CPU::process does, moped2/libmoped/src/feat/FEAT_SIFT_CPU.hpp:78-112), MATCH .. FILTER2 on the device,
     `batch` images per launch sequence (mh_frame_enqueue_image_batch), `slots` contexts in flight.  The frames are the
     reference's bundled test frames (tests/golden/sift_ref_frames.npz, ~590 keypoints each); the DB is the synthetic
     one plus frame 0's own keypoints as a planar model, so every frame of the pool that shows it yields an object.
-    Images resident in HBM, like the descriptors of the judged line."""
+    Images resident in HBM, like the descriptors of the judged line.  image="textured": synth.textured_image -- ~3 240
+    keypoints, the keypoint count BASELINE.json's config names -- with the keypoints of its centre as the planar model (all
+    3 240 in one model are past what CLUSTER / POSE reserve per model)."""
     import torch
     from moped_amd import capi, synth
     gold = np.load(os.path.join(ROOT, "tests", "golden", "sift_ref_frames.npz"))
@@ -1075,7 +1081,14 @@ def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
     dev = torch.device("cuda:0")
     db = synth.make_db(args.models, 5000)
     c0 = capi.Context(0)
-    xy, _, desc = c0.sift(gold["gray0"])
+    textured = image == "textured"
+    pool = [synth.textured_image(0)] if textured else [gold[f"gray{int(f)}"] for f in gold["frames"]]
+    cap = 4096 if textured else 1024
+    xy, _, desc = c0.sift(pool[0])
+    if textured:
+        hh, ww = pool[0].shape
+        keep = (np.abs(xy[:, 0] - ww / 2) < 110) & (np.abs(xy[:, 1] - hh / 2) < 90)
+        xy, desc = xy[keep], desc[keep]
     z = np.float32(0.8)
     xyz = np.stack([(xy[:, 0] - K[2]) / K[0] * z, (xy[:, 1] - K[3]) / K[1] * z, np.full(len(xy), z)], 1).astype(np.float32)
     all_desc = c0.normalize(np.concatenate([db.desc, desc]))
@@ -1092,11 +1105,11 @@ def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
                 c.db_upload(all_desc, model_of, all_xyz, args.models + 1)
             else:
                 c.db_share(ctxs[0])
-            c.reserve(1024 * batch)
+            c.reserve(cap * batch)
             ctxs.append(c)
             streams.append(st)
-        imgs = [torch.from_numpy(gold[f"gray{int(f)}"]).to(dev) for f in gold["frames"]]
-        h, w = gold["gray0"].shape
+        imgs = [torch.from_numpy(np.ascontiguousarray(g)).to(dev) for g in pool]
+        h, w = pool[0].shape
         prm = capi.default_frame_params()
         cam = capi.make_cam(K, CAM0)
         torch.cuda.synchronize()
@@ -1104,7 +1117,7 @@ def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
         def go(k):
             for g in range(k // batch):
                 ptrs = [imgs[(g * batch + j) % len(imgs)].data_ptr() for j in range(batch)]
-                ctxs[g % slots].frame_enqueue_image_batch(ptrs, w, h, True, 1024, K, CAM0, prm,
+                ctxs[g % slots].frame_enqueue_image_batch(ptrs, w, h, True, cap, K, CAM0, prm,
                                                          [g * batch + j + 1 for j in range(batch)], _cam_struct=cam)
         go(2 * slots * batch)
         for c in ctxs:
@@ -1134,12 +1147,13 @@ def image_to_objects_leg(args, frames=2048, slots=16, batch=16):
         streams[0].synchronize()
         sift_ms = (time.perf_counter() - t0) / 200 * 1e3
         return {"value": round(frames / dt, 1), "unit": "frames/s", "frames": frames, "slots": slots,
-                "images_per_launch_sequence": batch, "image": "640x480 8-bit, doubled (ScaleOrigin -1)",
+                "images_per_launch_sequence": batch,
+                "image": "640x480 8-bit, doubled (ScaleOrigin -1): " + ("synth.textured_image" if textured else "the reference's bundled test frames"),
                 "keypoints_per_image": int(cnt.item()), "objects_per_frame_last_batch": n_obj,
                 "frames_of_the_last_batch_whose_best_object_is_the_planted_model": int(sum(b == args.models for b in best)),
                 "sift_alone_ms": round(sift_ms, 4),
                 "what": "FEAT(SIFT) + MATCH + CLUSTER + POSE + FILTER + POSE2 + FILTER2 on the device from the image; "
-                        "data: the reference's bundled test frames, DB = the synthetic models + frame 0's keypoints as a planar model"}
+                        "DB = the synthetic models + the first image's keypoints (the textured image: those of its centre) as a planar model"}
     finally:
         for c in ctxs[1:] + ctxs[:1]:
             c.close()
