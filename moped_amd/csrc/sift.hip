@@ -365,6 +365,10 @@ __global__ __launch_bounds__(BT_THREADS) void blur_jobs_kernel(BlurJobs J) {
   }
 }
 
+// (Round 5 also tried the tile blur as persistent workgroups -- a workgroup walking its job's tiles over all images of a
+// batch, the next tile's source pixels requested while the current tile's passes run: the prefetch registers beside the
+// passes' windows took the kernel from 81 to 154 registers, three wavefronts per SIMD instead of six, and the chain from
+// 636 to 811 us per batch of 16 images.  One tile per workgroup.)
 // HalfImageSize (:390-408)
 __global__ void half_kernel(const float* __restrict__ src, int scols, float* __restrict__ dst, int rows, int cols,
                             size_t pyr_step) {
